@@ -1,0 +1,239 @@
+#!/usr/bin/env python
+"""Benchmark of the DRR render path on MI355X: DRRs/s, forward + backward (pose and voxel gradient).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one batch: render B poses of a 512^3 volume onto a 256^2
+detector through DRR.forward (trilinear, n_points=500) and backpropagate a weighted sum to the pose
+parameters AND to the voxels.  Workload = BASELINE.json configs[1] ("Single 512^3 CT, trilinear
+fwd+bwd, 256x256 detector, batch_size=116 on 1xMI355X"); synthetic seeded phantom and poses
+(SURVEY.md section 8d).  With N > 1 each rank renders its own B poses of a replicated volume (weak
+scaling; the unit -- a pose -- is independent) and the rendered DRRs are all-gathered over RCCL.
+
+Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel, timed live with HIP events
+on the launch stream; `cpu_baseline` is the oracle (the torch-ops restatement of the reference's CPU
+render path) timed on this host on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+import torch.distributed as dist
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s measured copy peak
+HBM_COPY_GBS = 6290.0
+TAP_BYTES_PER_SAMPLE = 32   # 8 taps x 4 B; the voxel backward accumulates into the same 8
+
+
+def deepfluoro_poses(batch, seed):
+    from xvr_amd.training import get_random_pose
+
+    g = torch.Generator().manual_seed(seed)
+    # ranges of scripts/deepfluoro/train/de_novo.sh:24-29
+    return get_random_pose(135.0, 225.0, -45.0, 45.0, -15.0, 15.0, -150.0, 150.0, 450.0, 1000.0, -150.0, 150.0,
+                           batch, generator=g)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=116)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--det", type=int, default=256)
+    ap.add_argument("--n-points", type=int, default=500)
+    ap.add_argument("--renderer", default="trilinear", choices=["trilinear", "siddon"])
+    ap.add_argument("--no-voxel-grad", action="store_true", help="pose-only backward")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rays", type=int, default=16384, help="rays of one DRR rendered by the CPU baseline")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run for N>1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from xvr_amd import renderers
+    from xvr_amd.data import make_phantom, read
+    from xvr_amd.drr import DRR
+    from xvr_amd.pose import convert
+
+    B, H = args.batch, args.det
+    vol, _ = make_phantom(args.size, n_ellipsoids=64, seed=0, device=dev)
+    subject = read(vol, orientation="AP")
+    delx = 1.08821875 * 256 / H  # scripts/v1-submission/pelvis/train/patient_specific.sh:31-33
+    kw = {"n_points": args.n_points} if args.renderer == "trilinear" else {}
+    drr = DRR(subject, 1020.0, H, delx, renderer=args.renderer, reverse_x_axis=False).to(dev)
+    density = drr.density.clone().requires_grad_(not args.no_voxel_grad)
+    pose0 = deepfluoro_poses(B, seed=rank)
+    rot, xyz = pose0.convert("euler_angles", "ZXY")
+    rot = rot.to(dev).requires_grad_(True)
+    xyz = xyz.to(dev).requires_grad_(True)
+    w = torch.rand(B, 1, H, H, device=dev)
+    gathered = torch.empty(world * B, 1, H, H, device=dev) if world > 1 else None
+
+    def step():
+        density.grad = None
+        rot.grad = None
+        xyz.grad = None
+        pose = convert(rot, xyz, parameterization="euler_angles", convention="ZXY")
+        source, target = drr.detector(pose, None)
+        img = drr.render(density, source, target, **kw)
+        img = drr.reshape_transform(img, batch_size=B)
+        handle = None
+        if world > 1:  # the exchange step of the path: every rank gets every rendered DRR (RCCL over xGMI)
+            handle = dist.all_gather_into_tensor(gathered, img.detach(), async_op=True)
+        (img * w).sum().backward()
+        if handle is not None:
+            handle.wait()
+        return img
+
+    # algorithmic work of one step, counted by the kernel itself (samples that touch the volume /
+    # voxel segments traversed)
+    with torch.no_grad():
+        work = torch.zeros(1, dtype=torch.int64, device=dev)
+        pose = convert(rot, xyz, parameterization="euler_angles", convention="ZXY")
+        s, t = drr.detector(pose, None)
+        L = (t - s).norm(dim=-1).unsqueeze(1)
+        spec = drr.renderer._spec(**kw)
+        renderers.render(density.detach(), drr.affine_inverse(s), drr.affine_inverse(t), L, spec,
+                         ray_grid_w=H, work=work)
+        units = int(work.item())
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    renderers.PROFILER = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    events, renderers.PROFILER = renderers.PROFILER, None
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = tmax.item()
+
+    # per-kernel launch durations from the HIP events recorded on the launch stream
+    per_kernel = {}
+    for name, e0, e1 in events:
+        per_kernel.setdefault(name, []).append(e0.elapsed_time(e1))
+    kernels = {k: {"launches": len(v), "avg_ms": sum(v) / len(v)} for k, v in per_kernel.items()}
+    dominant = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"])
+    bytes_per_unit = TAP_BYTES_PER_SAMPLE if args.renderer == "trilinear" else 4
+    for k, v in kernels.items():
+        tapk = k.startswith(args.renderer)  # the elementwise from-jacobian kernel does no taps
+        v["algorithmic_GBps"] = (units * bytes_per_unit / (v["avg_ms"] * 1e-3) / 1e9) if tapk else None
+    dom = kernels[dominant]
+    nominal_units = B * H * H * (args.n_points if args.renderer == "trilinear" else 0)
+    roofline = {
+        "bound": "hbm", "kernel": dominant,
+        "achieved": dom["algorithmic_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": (dom["algorithmic_GBps"] or 0.0) / HBM_PEAK_GBS,
+        "frac_of_measured_copy_peak": (dom["algorithmic_GBps"] or 0.0) / HBM_COPY_GBS,
+        "traffic": None,  # HBM bytes per launch from rocprofv3 PMC passes: see profiles/ and DESIGN.md
+        "units_per_launch": units, "unit_name": "volume-touching samples" if args.renderer == "trilinear" else "voxel segments",
+        "bytes_per_unit": bytes_per_unit, "avg_launch_ms": dom["avg_ms"],
+        "nominal_units_per_launch": nominal_units or None,
+    }
+
+    result = {
+        "metric": "DRRs/sec (fwd+bwd) 512³ CT→256² detector; achieved HBM GB/s vs peak",
+        "value": world * B * args.steps / elapsed, "unit": "DRRs/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": f"single {args.size}^3 CT, {args.renderer} fwd+bwd(pose{'' if args.no_voxel_grad else '+voxel'}), "
+                        f"{H}x{H} detector, batch_size={B} per GPU"
+                        + (f", n_points={args.n_points}" if args.renderer == "trilinear" else ""),
+            "global_batch": world * B, "parallelism": f"pose-sharded x{world}, replicated volume, all-gather of DRRs"
+            if world > 1 else "single GPU",
+        },
+        "roofline": roofline, "kernels": kernels,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(vol, drr, rot, xyz, spec, args)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(vol, drr, rot, xyz, spec, args):
+    """The oracle (torch-ops restatement of the reference's CPU render path: linspace -> grid_sample ->
+    sum, autograd backward to pose and voxels) on this host's cores, on a bounded sample: the first
+    `cpu_rays` rays of pose 0 of the same workload, scaled to whole DRRs."""
+    import dataclasses
+
+    from oracle.diffdrr_restated import RenderSpec as OSpec, render as oracle_render
+    from xvr_amd.pose import convert
+
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    H = args.det
+    nrays = min(args.cpu_rays, H * H)
+    with torch.no_grad():
+        pose = convert(rot[:1].detach(), xyz[:1].detach(), parameterization="euler_angles", convention="ZXY")
+        s, t = drr.detector(pose, None)
+        L = (t - s).norm(dim=-1).unsqueeze(1)
+        s, t = drr.affine_inverse(s), drr.affine_inverse(t)
+    # a centred block of detector rows (the border rows would miss the volume and flatter the CPU)
+    r0 = (H * H - nrays) // 2
+    vol_c = vol.detach().cpu().requires_grad_(not args.no_voxel_grad)
+    s_c = s.cpu().requires_grad_(True)
+    t_c = t[:, r0:r0 + nrays].cpu().requires_grad_(True)
+    L_c = L[..., r0:r0 + nrays].cpu()
+    ospec = OSpec(**dataclasses.asdict(spec))
+
+    def run():
+        out = oracle_render(vol_c, s_c, t_c, L_c, ospec, chunk=4096)
+        out.sum().backward()
+
+    run()  # warm-up (page in the volume, thread pool)
+    vol_c.grad = None
+    t0 = time.perf_counter()
+    reps = 0
+    while reps < 1 or (time.perf_counter() - t0 < 10.0 and reps < 8):
+        run()
+        vol_c.grad = None
+        reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {
+        "value": (nrays / (H * H)) / dt, "unit": "DRRs/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": f"{nrays} centre rays of one {H}x{H} DRR of the same workload, fwd+bwd, {reps} reps of {dt:.2f} s "
+                  f"(torch {torch.__version__} CPU ops, {ncores} threads, {model})",
+    }
+
+
+if __name__ == "__main__":
+    main()

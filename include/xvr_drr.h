@@ -1,0 +1,122 @@
+/*
+ * xvr_drr.h -- C ABI of the MI355X (gfx950) differentiable-DRR render library, libxvr_drr.so.
+ *
+ * This is the drop-in boundary for the one hot path this project accelerates: the renderer call
+ * that xvr makes through diffdrr (the reference is pure Python and has no FFI of its own, so each
+ * entry point cites the Python interface it replaces):
+ *
+ *     img = drr.renderer(volume, source, target, img, mask=seg)      -> [B, C, n]
+ *         /root/reference/src/xvr/model/trainer.py:288   (training, called directly)
+ *         /root/reference/src/xvr/registrar/base.py:249  (registration, via Registration -> DRR.forward)
+ *     loss.backward() through that call
+ *         /root/reference/src/xvr/model/trainer.py:223, /root/reference/src/xvr/registrar/base.py:252
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 (caller-owned, contiguous, not retained past the call);
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued on it, nothing synchronises;
+ *   - coordinates are voxel-index space (the caller already applied the CT's inverse affine,
+ *     trainer.py:285); `raylen` is the world-mm length of each ray computed BEFORE that affine
+ *     (trainer.py:284);
+ *   - layouts: volume/mask [D0][D1][D2] (D2 fastest; coordinate axis i indexes volume axis i),
+ *     source [B][3] (one per pose; the reference's [B,1,3]), target [B][n][3], raylen [B][n],
+ *     out / grad_out [B][C][n], C = 1 without a mask, else max(label)+1;
+ *   - return value: 0 = ok, negative = error (XVR_DRR_E_*); xvr_drr_last_error() gives the text.
+ *     Nothing aborts: xvr's trainer swallows exceptions per step and continues (trainer.py:171-175).
+ */
+#ifndef XVR_DRR_H
+#define XVR_DRR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XVR_DRR_ABI_VERSION 1
+
+#define XVR_DRR_OK 0
+#define XVR_DRR_E_ARG (-1)     /* bad argument (null pointer, non-positive size, unsupported combo) */
+#define XVR_DRR_E_LAUNCH (-2)  /* hipLaunch / hipMemsetAsync failed; see xvr_drr_last_error()       */
+#define XVR_DRR_E_UNSUPPORTED (-3)
+
+#define XVR_DRR_JAC_STRIDE 8 /* floats per ray in the jacobian buffer */
+
+/*
+ * Numerical convention of a render (every constant that could not be pinned against
+ * diffdrr==0.6.0 is explicit; see SURVEY.md Appendix A and DESIGN.md "Semantics").
+ */
+typedef struct xvr_drr_spec {
+    float a[3], b[3];      /* sampling index along axis i = a[i] * x + b[i]  (grid_sample's un-normalisation
+                              of u = 2 (x + voxel_shift) / dims - 1)                                       */
+    float lo[3], hi[3];    /* bounding planes of the volume in x: -voxel_shift, shape - voxel_shift        */
+    float plane0[3];       /* siddon: plane i of axis k sits at x = i + plane0[k]  (= -voxel_shift)         */
+    float eps;             /* added to (target - source)                                                   */
+    /* trilinear */
+    int32_t n_points;      /* samples per ray                                                              */
+    float near_, far_;     /* alphas = linspace(near, far, n_points)                                       */
+    float inv_denom;       /* out = raylen * sum * inv_denom   (1/n_points or 1/(n_points-1))              */
+    int32_t clip_to_volume;/* 0: alphas span source->target; 1: rescaled per ray to [alphamin, alphamax]   */
+    /* launch shaping (performance only, never changes results) */
+    int32_t ray_grid_w;    /* >0: the n rays form an (n / ray_grid_w) x ray_grid_w row-major detector and
+                              lanes are mapped to 8x8 pixel tiles; 0: rays are mapped linearly             */
+} xvr_drr_spec;
+
+int xvr_drr_abi_version(void);
+const char* xvr_drr_last_error(void);
+
+/*
+ * Trilinear ray-marching forward.  Replaces Trilinear.forward(volume, source, target, img, mask=...).
+ *   mask     nullable; float labels, same shape as volume.
+ *   jac      nullable [B][n][8]; only with C == 1.  Per ray: {out / raylen, d out/d source[3],
+ *            d out/d target[3], 0}.  Filled in the same sweep (no second gather), consumed by
+ *            xvr_drr_backward_from_jac.
+ *   work     nullable device uint64: incremented by the number of samples that touched the volume
+ *            (the kernel's own count of algorithmic work, for the roofline).
+ */
+int xvr_drr_trilinear_forward(const float* volume, const float* mask, int D0, int D1, int D2, int C,
+                              const float* source, const float* target, const float* raylen,
+                              int B, int n, const xvr_drr_spec* spec,
+                              float* out, float* jac, unsigned long long* work, void* stream);
+
+/*
+ * Trilinear backward by re-marching (needed for grad_volume, and for the pose gradient when C > 1).
+ * Replaces autograd through grid_sample (grid gradient -> pose, input gradient -> voxels).
+ *   grad_volume  nullable [D0][D1][D2]; ACCUMULATED into (caller zeroes it).
+ *   grad_source  nullable [B][3]; ACCUMULATED into (caller zeroes it) -- the sum over a pose's rays.
+ *   grad_target  nullable [B][n][3]; written.
+ *   grad_raylen  nullable [B][n]; written.
+ *   grad_source/grad_target must be both null or both non-null.
+ */
+int xvr_drr_trilinear_backward(const float* volume, const float* mask, int D0, int D1, int D2, int C,
+                               const float* source, const float* target, const float* raylen,
+                               int B, int n, const xvr_drr_spec* spec, const float* grad_out,
+                               float* grad_volume, float* grad_source, float* grad_target,
+                               float* grad_raylen, void* stream);
+
+/* Siddon exact ray tracing, same contract.  Replaces Siddon.forward(volume, source, target, img, mask=...).
+ *   work counts voxel segments traversed. */
+int xvr_drr_siddon_forward(const float* volume, const float* mask, int D0, int D1, int D2, int C,
+                           const float* source, const float* target, const float* raylen,
+                           int B, int n, const xvr_drr_spec* spec,
+                           float* out, float* jac, unsigned long long* work, void* stream);
+
+int xvr_drr_siddon_backward(const float* volume, const float* mask, int D0, int D1, int D2, int C,
+                            const float* source, const float* target, const float* raylen,
+                            int B, int n, const xvr_drr_spec* spec, const float* grad_out,
+                            float* grad_volume, float* grad_source, float* grad_target,
+                            float* grad_raylen, void* stream);
+
+/*
+ * Pose-side backward from the jacobian saved by a forward call (C == 1): an elementwise product
+ * with grad_out [B][1][n] plus a wave-level reduction of grad_source over each pose's rays.
+ *   grad_source [B][3] is ACCUMULATED into (caller zeroes it); grad_target [B][n][3] and
+ *   grad_raylen [B][n] (nullable) are written.
+ */
+int xvr_drr_backward_from_jac(const float* jac, const float* grad_out, int B, int n,
+                              float* grad_source, float* grad_target, float* grad_raylen,
+                              void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XVR_DRR_H */

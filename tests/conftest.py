@@ -1,0 +1,51 @@
+import dataclasses
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+def to_oracle_spec(spec):
+    """xvr_amd.spec.RenderSpec -> oracle RenderSpec (two independent definitions, same fields)."""
+    from oracle.diffdrr_restated import RenderSpec as OSpec
+
+    return OSpec(**dataclasses.asdict(spec))
+
+
+def make_case(shape=(20, 24, 28), height=12, width=10, sdd=400.0, delx=6.0, n_labels=3, seed=0,
+              rot=((170.0, 10.0, 5.0), (20.0, -20.0, -8.0)), xyz=((5.0, 300.0, -4.0), (-3.0, 200.0, 6.0)),
+              spacing=(1.0, 1.0, 1.0)):
+    """A small seeded render case in the renderer's own input space (voxel-index source/target)."""
+    from oracle.diffdrr_restated import _apply, rays_from_pose
+    from xvr_amd.pose import convert
+
+    g = torch.Generator().manual_seed(seed)
+    vol = torch.rand(*shape, generator=g)
+    mask = (torch.rand(*shape, generator=g) * n_labels).floor()
+    affine = torch.diag(torch.tensor([*spacing, 1.0]))
+    affine[:3, 3] = -(affine[:3, :3] @ ((torch.tensor(shape, dtype=torch.float32) - 1) / 2))
+    pose = convert(torch.tensor(rot), torch.tensor(xyz), parameterization="euler_angles",
+                   convention="ZXY", degrees=True)
+    src, tgt = rays_from_pose(pose.matrix, height, width, sdd, delx, delx, 0.0, 0.0)
+    img = (tgt - src).norm(dim=-1).unsqueeze(1)
+    affinv = torch.linalg.inv(affine)[None]
+    return dict(volume=vol, mask=mask, source=_apply(affinv, src), target=_apply(affinv, tgt), img=img,
+                affine=affine, pose=pose, height=height, width=width, sdd=sdd, delx=delx)

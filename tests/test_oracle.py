@@ -1,0 +1,198 @@
+"""CPU tests of the oracle itself: analytic known-answer tests, torch-ops restatement vs the
+independent float64 scalar restatement, and the committed golden fixtures.
+
+Parity of the oracle against the real diffdrr==0.6.0 is UNPINNED (see oracle/diffdrr_restated.py);
+these tests pin it against geometry (closed forms) and against regressions instead.
+"""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import make_case
+from oracle import scalar
+from oracle.diffdrr_restated import RenderSpec, drr_from_pose, index_map, render, siddon, trilinear
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+
+
+def _axis_rays(shape, axis, offsets, shift, length=200.0):
+    """Rays parallel to `axis` through in-plane points `offsets` (list of (u, v) in x-coordinates)."""
+    S = shape
+    src = []
+    tgt = []
+    others = [a for a in range(3) if a != axis]
+    for (u, v) in offsets:
+        s = [0.0, 0.0, 0.0]
+        t = [0.0, 0.0, 0.0]
+        s[axis], t[axis] = -50.0, -50.0 + length
+        s[others[0]] = t[others[0]] = u
+        s[others[1]] = t[others[1]] = v
+        src.append(s)
+        tgt.append(t)
+    src = torch.tensor(src)[:, None, :]
+    tgt = torch.tensor(tgt)[:, None, :]
+    img = (tgt - src).norm(dim=-1).unsqueeze(1)
+    return src, tgt, img
+
+
+@pytest.mark.parametrize("shift", [0.0, 0.5])
+@pytest.mark.parametrize("axis", [0, 1, 2])
+def test_siddon_uniform_box_is_chord_length(axis, shift):
+    """KAT: uniform density rho -> rho * chord length (mm), exactly, for Siddon."""
+    shape = (10, 12, 14)
+    rho = 0.75
+    vol = torch.full(shape, rho)
+    src, tgt, img = _axis_rays(shape, axis, [(3.3, 4.1), (5.0, 6.49)], shift)
+    spec = RenderSpec(renderer="siddon", voxel_shift=shift)
+    out = siddon(vol, src, tgt, img, spec)
+    assert torch.allclose(out, torch.full_like(out, rho * shape[axis]), rtol=1e-5)
+    out64 = scalar.render(vol, src, tgt, img, spec)
+    assert np.allclose(out64, rho * shape[axis], rtol=1e-9)
+
+
+def test_siddon_diagonal_chord():
+    """KAT: the body diagonal of a uniform cube has length sqrt(3) * N."""
+    N = 16
+    vol = torch.ones(N, N, N)
+    spec = RenderSpec(renderer="siddon", voxel_shift=0.5)
+    src = torch.tensor([[[-20.5, -20.5, -20.5]]])
+    tgt = torch.tensor([[[40.5, 40.5, 40.5]]]) + torch.tensor([0.0, 1e-3, 2e-3])  # avoid exact triple ties
+    img = (tgt - src).norm(dim=-1).unsqueeze(1)
+    out64 = scalar.render(vol, src, tgt, img, spec)
+    assert abs(out64.item() - np.sqrt(3) * N) < 1e-2
+    out = siddon(vol, src, tgt, img, spec)
+    assert abs(out.item() - np.sqrt(3) * N) < 1e-2
+
+
+def test_ray_missing_the_volume_is_zero():
+    vol = torch.rand(8, 8, 8)
+    src = torch.tensor([[[-30.0, 20.0, 3.0]]])
+    tgt = torch.tensor([[[40.0, 21.0, 3.0]]])
+    img = (tgt - src).norm(dim=-1).unsqueeze(1)
+    for r in ("siddon", "trilinear"):
+        spec = RenderSpec(renderer=r, n_points=50)
+        assert render(vol, src, tgt, img, spec).abs().max() == 0
+        assert np.abs(scalar.render(vol, src, tgt, img, spec)).max() == 0
+
+
+def test_siddon_single_hot_voxel():
+    """KAT: one hot voxel -> value * (length of the ray inside that voxel)."""
+    vol = torch.zeros(9, 9, 9)
+    vol[4, 5, 3] = 2.0
+    spec = RenderSpec(renderer="siddon", voxel_shift=0.5)
+    src, tgt, img = _axis_rays(vol.shape, 0, [(5.2, 2.9), (5.2, 3.6)], 0.5)  # second ray is in voxel z=4
+    out = scalar.render(vol, src, tgt, img, spec)
+    assert np.allclose(out.ravel(), [2.0, 0.0], atol=1e-12)
+
+
+def test_siddon_source_inside_volume_is_clamped():
+    """KAT: with the source inside the volume the integral starts at alpha = 0 (per-ray clamp)."""
+    vol = torch.full((10, 10, 10), 0.5)
+    spec = RenderSpec(renderer="siddon", voxel_shift=0.0)
+    src = torch.tensor([[[2.25, 5.0, 5.0]]])
+    tgt = torch.tensor([[[30.0, 5.0, 5.0]]])
+    img = (tgt - src).norm(dim=-1).unsqueeze(1)
+    want = 0.5 * (10 - 2.25)
+    assert abs(scalar.render(vol, src, tgt, img, spec).item() - want) < 1e-7  # eps=1e-8 in (t - s)
+    assert abs(siddon(vol, src, tgt, img, spec).item() - want) < 1e-4
+
+
+def test_trilinear_uniform_interior_segment():
+    """KAT: in a uniform volume every interior sample reads rho, so out = rho * L * (#inside)/N."""
+    vol = torch.full((40, 12, 12), 0.25)
+    spec = RenderSpec(renderer="trilinear", n_points=101, voxel_shift=0.5)
+    src = torch.tensor([[[-30.0, 5.3, 6.1]]])
+    tgt = torch.tensor([[[70.0, 5.3, 6.1]]])  # x_k = -30 + k, k = 0..100
+    img = (tgt - src).norm(dim=-1).unsqueeze(1)
+    # index = x (shift 0.5): weight-1 samples for 0 <= x <= 39 -> 40 samples; x = -1, 40 read only padding
+    want = 0.25 * 100.0 * 40 / 101
+    assert abs(scalar.render(vol, src, tgt, img, spec).item() - want) < 1e-7  # eps=1e-8 in (t - s)
+    assert abs(trilinear(vol, src, tgt, img, spec).item() - want) < 1e-3
+
+
+def test_mask_channels_sum_to_unmasked():
+    c = make_case()
+    for r in ("siddon", "trilinear"):
+        spec = RenderSpec(renderer=r, n_points=40)
+        a = render(c["volume"], c["source"], c["target"], c["img"], spec)
+        b = render(c["volume"], c["source"], c["target"], c["img"], spec, c["mask"])
+        assert b.shape[1] == 3
+        assert torch.allclose(b.sum(1, keepdim=True), a, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(renderer="trilinear", n_points=30),
+    dict(renderer="trilinear", n_points=30, voxel_shift=0.0, align_corners=True, norm_dims_offset=-1),
+    dict(renderer="trilinear", n_points=30, clip_to_volume=True),
+    dict(renderer="siddon"),
+    dict(renderer="siddon", voxel_shift=0.0),
+    dict(renderer="siddon", per_ray_clamp=False),
+])
+def test_torch_restatement_matches_scalar_float64(kw):
+    c = make_case(seed=3)
+    spec = RenderSpec(**kw)
+    a = render(c["volume"], c["source"], c["target"], c["img"], spec).double().numpy()
+    b = scalar.render(c["volume"], c["source"], c["target"], c["img"], spec)
+    assert np.abs(a - b).max() <= 2e-5 * np.abs(b).max()
+
+
+def test_literal_and_per_ray_siddon_agree_when_endpoints_are_outside():
+    c = make_case(seed=5)
+    a = render(c["volume"], c["source"], c["target"], c["img"], RenderSpec(renderer="siddon", per_ray_clamp=True))
+    b = render(c["volume"], c["source"], c["target"], c["img"], RenderSpec(renderer="siddon", per_ray_clamp=False))
+    assert torch.allclose(a, b, rtol=1e-5, atol=1e-5)
+
+
+def test_linearity_in_the_volume():
+    c = make_case(seed=7)
+    v2 = torch.rand_like(c["volume"])
+    for r in ("siddon", "trilinear"):
+        spec = RenderSpec(renderer=r, n_points=25)
+        f = lambda v: render(v, c["source"], c["target"], c["img"], spec)  # noqa: E731
+        assert torch.allclose(f(2.0 * c["volume"] + 3.0 * v2), 2.0 * f(c["volume"]) + 3.0 * f(v2), rtol=1e-4, atol=1e-4)
+
+
+def test_index_map_exactness():
+    a, b = index_map((7, 9, 11), RenderSpec(voxel_shift=0.5))
+    assert torch.allclose(a, torch.ones(3, dtype=a.dtype)) and torch.allclose(b, torch.zeros(3, dtype=b.dtype))
+    a, b = index_map((7, 9, 11), RenderSpec(voxel_shift=0.0))
+    assert torch.allclose(b, torch.full((3,), -0.5, dtype=b.dtype))
+
+
+def test_drr_from_pose_plumbing_c1_shape():
+    """configs[0] plumbing: DeepFluoro-like geometry, trilinear, batch 4, CPU (small phantom)."""
+    from xvr_amd.data import make_phantom
+    from xvr_amd.pose import convert
+
+    vol, _ = make_phantom(32, seed=1)
+    affine = torch.diag(torch.tensor([8.0, 8.0, 8.0, 1.0]))
+    affine[:3, 3] = -8.0 * 15.5
+    rot = torch.tensor([[180.0, 0, 0], [170.0, 10, 5], [200.0, -10, 0], [150.0, 0, 10]])
+    xyz = torch.tensor([[0.0, 700.0, 0]] * 4)
+    pose = convert(rot, xyz, parameterization="euler_angles", convention="ZXY", degrees=True)
+    out = drr_from_pose(vol, affine, pose.matrix, 16, 16, 1020.0, 17.4, 17.4, 0.0, 0.0,
+                        RenderSpec(renderer="trilinear", n_points=100))
+    assert out.shape == (4, 1, 16, 16)
+    assert (out > 0).float().mean() > 0.3
+
+
+@pytest.mark.parametrize("name", sorted(p.stem for p in GOLDEN.glob("*.npz")))
+def test_golden_fixtures(name):
+    """The committed vectors (inputs + expected outputs + expected gradients) reproduce."""
+    d = np.load(GOLDEN / f"{name}.npz")
+    kw = {}
+    for k, v in zip(d["spec_keys"], d["spec_vals"]):
+        v = str(v)
+        kw[str(k)] = v if k in ("renderer", "step_mode") else (v == "True" if v in ("True", "False") else (float(v) if "." in v else int(v)))
+    spec = RenderSpec(**kw)
+    t = lambda k: torch.from_numpy(d[k])  # noqa: E731
+    for tag, mask in (("nomask", None), ("mask", t("mask"))):
+        vol, src, tgt, img = (t(k).clone().requires_grad_(True) for k in ("volume", "source", "target", "img"))
+        out = render(vol, src, tgt, img, spec, mask)
+        assert torch.allclose(out, t(f"out_{tag}"), rtol=1e-5, atol=1e-5)
+        (out * t(f"w_{tag}")).sum().backward()
+        for g, k in ((vol, "gvol"), (src, "gsrc"), (tgt, "gtgt"), (img, "gimg")):
+            want = t(f"{k}_{tag}")
+            assert torch.allclose(g.grad, want, rtol=1e-4, atol=1e-4 * max(1.0, want.abs().max().item())), k

@@ -1,0 +1,76 @@
+import math
+
+import pytest
+import torch
+
+from xvr_amd.pose import (N_ANGULAR_COMPONENTS, RigidTransform, convert, euler_angles_to_matrix,
+                          make_matrix, matrix_to_euler_angles)
+
+
+def _random_pose(n=5, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    rot = (torch.rand(n, 3, generator=g) - 0.5) * 2.0
+    xyz = (torch.rand(n, 3, generator=g) - 0.5) * 400
+    return convert(rot, xyz, parameterization="euler_angles", convention="ZXY")
+
+
+def test_euler_zxy_is_rz_rx_ry():
+    a = torch.tensor([[0.3, -0.2, 0.5]])
+    R = euler_angles_to_matrix(a, "ZXY")[0]
+    cz, sz, cx, sx, cy, sy = math.cos(.3), math.sin(.3), math.cos(-.2), math.sin(-.2), math.cos(.5), math.sin(.5)
+    Rz = torch.tensor([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1.0]])
+    Rx = torch.tensor([[1.0, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = torch.tensor([[cy, 0, sy], [0, 1.0, 0], [-sy, 0, cy]])
+    assert torch.allclose(R, Rz @ Rx @ Ry, atol=1e-6)
+    assert torch.allclose(matrix_to_euler_angles(R[None], "ZXY"), a, atol=1e-6)
+
+
+def test_convert_orbits_the_isocentre():
+    """Fixed xyz = (0, sid, 0) with varying gantry angles must orbit: |source| constant and the
+    optical axis through the origin (pins x_world = R (x_cam + t); xray.py:77-90, inference.py:51-55)."""
+    sid = 700.0
+    for yaw in (0.0, 45.0, 180.0, 270.0):
+        T = convert(torch.tensor([[yaw, 10.0, 0.0]]), torch.tensor([[0.0, sid, 0.0]]),
+                    parameterization="euler_angles", convention="ZXY", degrees=True)
+        src = T(torch.zeros(1, 1, 3))[0, 0]
+        far = T(torch.tensor([[[0.0, -2 * sid, 0.0]]]))[0, 0]  # a point down the camera's -y axis
+        assert abs(src.norm().item() - sid) < 1e-3
+        assert torch.allclose(src + far, torch.zeros(3), atol=1e-3)  # symmetric about the origin
+
+
+@pytest.mark.parametrize("param", sorted(N_ANGULAR_COMPONENTS))
+def test_convert_round_trip(param):
+    T = _random_pose()
+    conv = "ZXY" if param == "euler_angles" else None
+    rot, xyz = T.convert(param, conv)
+    assert rot.shape[-1] == N_ANGULAR_COMPONENTS[param]
+    T2 = convert(rot, xyz, parameterization=param, convention=conv)
+    assert torch.allclose(T2.matrix, T.matrix, atol=2e-4)
+
+
+def test_compose_order_and_inverse():
+    A, B = _random_pose(3, 1), _random_pose(3, 2)
+    x = torch.randn(3, 7, 3)
+    assert torch.allclose(A.compose(B)(x), B(A(x)), atol=1e-3)
+    assert torch.allclose(A.compose(A.inverse()).matrix, torch.eye(4).expand(3, 4, 4), atol=1e-4)
+    assert torch.allclose((A @ B).matrix, A.matrix @ B.matrix)
+    assert len(A[torch.tensor([True, False, True])]) == 2 and len(A[0]) == 1
+
+
+def test_make_matrix_and_grad_flow():
+    rot = torch.zeros(2, 3, requires_grad=True)
+    xyz = torch.tensor([[0.0, 500.0, 0.0], [1.0, 2.0, 3.0]], requires_grad=True)
+    T = convert(rot, xyz, parameterization="euler_angles", convention="ZXY")
+    T(torch.ones(1, 4, 3)).sum().backward()
+    assert rot.grad is not None and xyz.grad is not None and torch.isfinite(rot.grad).all()
+    M = make_matrix(torch.eye(3)[None], torch.tensor([[1.0, 2.0, 3.0]]))
+    assert torch.equal(M[0, :3, 3], torch.tensor([1.0, 2.0, 3.0])) and M[0, 3, 3] == 1
+
+
+def test_quaternion_adjugate_head_is_differentiable():
+    rot = torch.randn(4, 10, requires_grad=True)
+    T = convert(rot, torch.zeros(4, 3), parameterization="quaternion_adjugate")
+    R = T.matrix[:, :3, :3]
+    assert torch.allclose(R @ R.transpose(-1, -2), torch.eye(3).expand(4, 3, 3), atol=1e-5)
+    R.sum().backward()
+    assert torch.isfinite(rot.grad).all()

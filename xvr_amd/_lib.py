@@ -1,0 +1,89 @@
+"""ctypes binding of libxvr_drr.so (include/xvr_drr.h).  No CPU fallback: if the HIP library cannot
+be loaded, every render call raises."""
+
+from __future__ import annotations
+
+import ctypes
+from pathlib import Path
+
+from .build import LIB, build_library, is_stale
+
+ABI_VERSION = 1
+JAC_STRIDE = 8
+
+
+class CSpec(ctypes.Structure):
+    _fields_ = [
+        ("a", ctypes.c_float * 3),
+        ("b", ctypes.c_float * 3),
+        ("lo", ctypes.c_float * 3),
+        ("hi", ctypes.c_float * 3),
+        ("plane0", ctypes.c_float * 3),
+        ("eps", ctypes.c_float),
+        ("n_points", ctypes.c_int32),
+        ("near_", ctypes.c_float),
+        ("far_", ctypes.c_float),
+        ("inv_denom", ctypes.c_float),
+        ("clip_to_volume", ctypes.c_int32),
+        ("ray_grid_w", ctypes.c_int32),
+    ]
+
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_FWD = [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, ctypes.POINTER(CSpec), _P, _P, _P, _P]
+_BWD = [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, ctypes.POINTER(CSpec), _P, _P, _P, _P, _P, _P]
+
+EXPORTS = {
+    "xvr_drr_abi_version": ([], ctypes.c_int),
+    "xvr_drr_last_error": ([], ctypes.c_char_p),
+    "xvr_drr_trilinear_forward": (_FWD, ctypes.c_int),
+    "xvr_drr_trilinear_backward": (_BWD, ctypes.c_int),
+    "xvr_drr_siddon_forward": (_FWD, ctypes.c_int),
+    "xvr_drr_siddon_backward": (_BWD, ctypes.c_int),
+    "xvr_drr_backward_from_jac": ([_P, _P, _I, _I, _P, _P, _P, _P], ctypes.c_int),
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def library_path() -> Path:
+    return LIB
+
+
+def load(build_if_missing: bool = True) -> ctypes.CDLL:
+    """Load (building first if the sources are newer and hipcc is present) libxvr_drr.so."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if build_if_missing and is_stale():
+        try:
+            build_library()
+        except RuntimeError as e:
+            if not LIB.exists():
+                raise HipLibraryError(f"libxvr_drr.so is missing and could not be built: {e}") from e
+    if not LIB.exists():
+        raise HipLibraryError(f"{LIB} not found; run `python -m xvr_amd.build` (needs hipcc)")
+    try:
+        lib = ctypes.CDLL(str(LIB))
+    except OSError as e:
+        raise HipLibraryError(f"cannot load {LIB}: {e}") from e
+    for name, (argtypes, restype) in EXPORTS.items():
+        fn = getattr(lib, name, None)
+        if fn is None:
+            raise HipLibraryError(f"{LIB} does not export {name}")
+        fn.argtypes, fn.restype = argtypes, restype
+    if lib.xvr_drr_abi_version() != ABI_VERSION:
+        raise HipLibraryError(f"ABI mismatch: library {lib.xvr_drr_abi_version()} != binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().xvr_drr_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")

@@ -1,0 +1,822 @@
+// MI355X (gfx950 / CDNA4) differentiable-DRR kernels + the C ABI of include/xvr_drr.h.
+//
+// One lane = one ray; one 64-lane wavefront = an 8x8 pixel tile of one pose's detector, so the 64
+// rays of a wave form a narrow frustum and, because every ray of a pose samples the SAME alpha_k
+// (alphas = linspace(near, far, n_points) is shared), the wave's 64 samples at step k lie on a small
+// planar patch: their 8 x 64 taps fall into a few hundred bytes of neighbouring voxel rows and are
+// served by the CU's L1 / the XCD's L2 rather than HBM.  Workgroups (4 waves = a 16x16 pixel tile)
+// are renumbered so that each XCD works through whole poses (its L2 then holds one frustum at a time).
+//
+// No MFMA anywhere: this is gather + interpolate, not a contraction.
+//
+// Semantics are those of oracle/diffdrr_restated.py (the restated diffdrr==0.6.0 algorithm; every
+// unpinned constant arrives through xvr_drr_spec).  Reference call sites being replaced:
+//   /root/reference/src/xvr/model/trainer.py:288   drr.renderer(volume, source, target, img, mask=seg)
+//   /root/reference/src/xvr/registrar/base.py:249,252   reg() ... loss.backward()
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "xvr_drr.h"
+
+namespace {
+
+constexpr int WG = 256;  // 4 wavefronts
+
+thread_local char g_err[512] = "";
+
+struct RenderArgs {
+    const float* __restrict__ volume;
+    const float* __restrict__ mask;
+    int D0, D1, D2, C;
+    const float* __restrict__ source;
+    const float* __restrict__ target;
+    const float* __restrict__ raylen;
+    int B, n;
+    xvr_drr_spec sp;
+    int grid_w, grid_h, tiles_x, blocks_per_pose;
+    float* __restrict__ out;
+    float* __restrict__ jac;
+    unsigned long long* work;
+    const float* __restrict__ gout;
+    float* gvol;
+    float* gsrc;
+    float* __restrict__ gtgt;
+    float* __restrict__ glen;
+};
+
+struct __attribute__((packed, aligned(4))) fpair {
+    float x, y;
+};
+
+__device__ __forceinline__ fpair load_pair(const float* p) { return *reinterpret_cast<const fpair*>(p); }
+
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ unsigned wave_sum_u(unsigned v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ __forceinline__ void atomic_add_f32(float* p, float v) {
+    // hardware fp32 add at the L2 / memory side (no CAS loop); agent scope so that XCDs agree
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Blocks are dispatched round-robin over the 8 XCDs (block i -> XCD i % 8, observed, speed only).
+// Renumber so that XCD x works on one contiguous range of logical blocks, i.e. on whole poses:
+// its private 4 MiB L2 then serves the neighbouring tiles of one frustum instead of 8 different ones.
+__device__ __forceinline__ unsigned xcd_remap(unsigned i, unsigned nb) {
+    unsigned q = nb >> 3, rem = nb & 7u;
+    unsigned x = i & 7u, j = i >> 3;
+    return x * q + (x < rem ? x : rem) + j;
+}
+
+__device__ __forceinline__ bool map_ray(const RenderArgs& A, int& b, int& r) {
+    unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+    b = (int)(lb / (unsigned)A.blocks_per_pose);
+    int t = (int)(lb - (unsigned)b * (unsigned)A.blocks_per_pose);
+    int tid = threadIdx.x;
+    if (A.grid_w > 0) {
+        int ty = t / A.tiles_x, tx = t - ty * A.tiles_x;
+        int w = tid >> 6, l = tid & 63;
+        int px = tx * 16 + (w & 1) * 8 + (l & 7);
+        int py = ty * 16 + (w >> 1) * 8 + (l >> 3);
+        r = py * A.grid_w + px;
+        return px < A.grid_w && py < A.grid_h;
+    }
+    r = t * WG + tid;
+    return r < A.n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-ray setup shared by all kernels
+// ---------------------------------------------------------------------------------------------
+struct Ray {
+    float s[3], d[3], L;
+    float amin, amax;   // slab test against the volume's bounding planes, clamped to [0, 1]
+    int ax_in, ax_out;  // axis whose plane gives amin / amax; -1 when clamped to 0 / 1
+    bool valid;
+};
+
+__device__ __forceinline__ void ray_setup(const RenderArgs& A, int b, int r, bool valid, Ray& R) {
+    R.valid = valid;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) R.s[i] = A.source[3 * b + i];
+    float t[3] = {R.s[0], R.s[1], R.s[2]};
+    R.L = 0.f;
+    if (valid) {
+        const float* tp = A.target + ((size_t)b * A.n + r) * 3;
+        t[0] = tp[0];
+        t[1] = tp[1];
+        t[2] = tp[2];
+        R.L = A.raylen[(size_t)b * A.n + r];
+    }
+    float lo = -INFINITY, hi = INFINITY;
+    int ain = -1, aout = -1;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        R.d[i] = (t[i] - R.s[i]) + A.sp.eps;
+        float a0 = (A.sp.lo[i] - R.s[i]) / R.d[i];
+        float a1 = (A.sp.hi[i] - R.s[i]) / R.d[i];
+        float mn = fminf(a0, a1), mx = fmaxf(a0, a1);
+        if (mn > lo) { lo = mn; ain = i; }
+        if (mx < hi) { hi = mx; aout = i; }
+    }
+    if (!(lo > 0.f)) { lo = 0.f; ain = -1; }
+    if (!(hi < 1.f)) { hi = 1.f; aout = -1; }
+    R.amin = lo;
+    R.amax = hi;
+    R.ax_in = ain;
+    R.ax_out = aout;
+}
+
+// ---------------------------------------------------------------------------------------------
+// trilinear taps: grid_sample(mode="bilinear", padding_mode="zeros") on the index point (px,py,pz)
+// ---------------------------------------------------------------------------------------------
+struct Taps {
+    int base[4];        // element offsets of rows (x0,y0) (x0,y1) (x1,y0) (x1,y1), at z = zc
+    float wx0, wx1, wy0, wy1;  // interpolation weights (0 where the corner is outside)
+    float sx0, sx1, sy0, sy1;  // d/dx, d/dy weights (-1/+1, 0 where the corner is outside)
+    float pz0, pz1, qz0, qz1;  // weights / d/dz weights on the loaded (zc, zc+1) pair
+};
+
+__device__ __forceinline__ void make_taps(float px, float py, float pz, int D0, int D1, int D2, Taps& T) {
+    float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+    int ix = (int)fx, iy = (int)fy, iz = (int)fz;
+    float tx = px - fx, ty = py - fy, tz = pz - fz;
+    bool x0 = (unsigned)ix < (unsigned)D0, x1 = (unsigned)(ix + 1) < (unsigned)D0;
+    bool y0 = (unsigned)iy < (unsigned)D1, y1 = (unsigned)(iy + 1) < (unsigned)D1;
+    T.wx0 = x0 ? 1.f - tx : 0.f;
+    T.wx1 = x1 ? tx : 0.f;
+    T.wy0 = y0 ? 1.f - ty : 0.f;
+    T.wy1 = y1 ? ty : 0.f;
+    T.sx0 = x0 ? -1.f : 0.f;
+    T.sx1 = x1 ? 1.f : 0.f;
+    T.sy0 = y0 ? -1.f : 0.f;
+    T.sy1 = y1 ? 1.f : 0.f;
+    int cx0 = min(max(ix, 0), D0 - 1), cx1 = min(max(ix + 1, 0), D0 - 1);
+    int cy0 = min(max(iy, 0), D1 - 1), cy1 = min(max(iy + 1, 0), D1 - 1);
+    // the two z taps are adjacent in memory: one 8-byte load of (zc, zc+1), zc clamped so the pair
+    // is always inside the row; sh says where the wanted pair (iz, iz+1) sits relative to it.
+    int zc = min(max(iz, 0), D2 - 2);
+    int sh = iz - zc;
+    T.pz0 = sh == 0 ? 1.f - tz : (sh == -1 ? tz : 0.f);
+    T.pz1 = sh == 0 ? tz : (sh == 1 ? 1.f - tz : 0.f);
+    T.qz0 = sh == 0 ? -1.f : (sh == -1 ? 1.f : 0.f);
+    T.qz1 = sh == 0 ? 1.f : (sh == 1 ? -1.f : 0.f);
+    T.base[0] = (cx0 * D1 + cy0) * D2 + zc;
+    T.base[1] = (cx0 * D1 + cy1) * D2 + zc;
+    T.base[2] = (cx1 * D1 + cy0) * D2 + zc;
+    T.base[3] = (cx1 * D1 + cy1) * D2 + zc;
+}
+
+__device__ __forceinline__ int nearest_label(const float* __restrict__ mask, float px, float py, float pz,
+                                             int D0, int D1, int D2, int C) {
+    int lx = (int)rintf(px), ly = (int)rintf(py), lz = (int)rintf(pz);
+    bool inb = (unsigned)lx < (unsigned)D0 && (unsigned)ly < (unsigned)D1 && (unsigned)lz < (unsigned)D2;
+    int lab = inb ? (int)mask[(lx * D1 + ly) * D2 + lz] : 0;
+    return min(max(lab, 0), C - 1);
+}
+
+// torch.linspace(near, far, N)[k] (symmetric evaluation, as ATen computes it)
+__device__ __forceinline__ float linspace_at(int k, int N, float near_, float far_, float step) {
+    return (k < N / 2) ? fmaf(step, (float)k, near_) : far_ - step * (float)(N - 1 - k);
+}
+
+struct KRange {
+    int lo, hi;
+};
+
+// Range of sample indices whose 8 taps can touch the volume (exact outside: those samples read only
+// zero padding and contribute exactly 0, so skipping them changes nothing).
+__device__ __forceinline__ KRange tri_krange(const RenderArgs& A, const Ray& R, bool clip, float step) {
+    KRange K = {INT32_MAX, INT32_MIN};  // empty
+    if (!R.valid) return K;
+    const int N = A.sp.n_points;
+    if (clip) {
+        if (R.amax > R.amin) { K.lo = 0; K.hi = N - 1; }
+        return K;
+    }
+    float ain = -INFINITY, aout = INFINITY;
+    const int S[3] = {A.D0, A.D1, A.D2};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float xlo = (-1.f - A.sp.b[i]) / A.sp.a[i];
+        float xhi = ((float)S[i] - A.sp.b[i]) / A.sp.a[i];
+        float a0 = (xlo - R.s[i]) / R.d[i], a1 = (xhi - R.s[i]) / R.d[i];
+        ain = fmaxf(ain, fminf(a0, a1));
+        aout = fminf(aout, fmaxf(a0, a1));
+    }
+    if (!(aout >= ain)) return K;
+    float fN = (float)N;
+    float klo = fminf(fmaxf((ain - A.sp.near_) / step - 1.f, 0.f), fN);
+    float khi = fminf(fmaxf((aout - A.sp.near_) / step + 1.f, -1.f), fN - 1.f);
+    K.lo = (int)ceilf(klo);
+    K.hi = (int)floorf(khi);
+    return K;
+}
+
+// =============================================================================================
+// trilinear forward (+ optional per-ray jacobian in the same sweep)
+// =============================================================================================
+template <bool JAC, bool MASK, bool CLIP>
+__global__ __launch_bounds__(WG) void k_trilinear_fwd(RenderArgs A) {
+    extern __shared__ float lds[];  // MASK: per-lane channel accumulators [C][WG]
+    int b, r;
+    const bool valid = map_ray(A, b, r);
+    const int tid = threadIdx.x;
+    Ray R;
+    ray_setup(A, b, r, valid, R);
+    const int N = A.sp.n_points;
+    const float step = N > 1 ? (A.sp.far_ - A.sp.near_) / (float)(N - 1) : 0.f;
+    const KRange K = tri_krange(A, R, CLIP, step);
+    const int kbeg = __builtin_amdgcn_readfirstlane(wave_min_i(K.lo));
+    const int kend = __builtin_amdgcn_readfirstlane(wave_max_i(K.hi));
+    const float span = fmaxf(R.amax - R.amin, 0.f);
+    const float* __restrict__ vol = A.volume;
+    const int D0 = A.D0, D1 = A.D1, D2 = A.D2;
+
+    if (MASK) {
+        for (int c = 0; c < A.C; ++c) lds[c * WG + tid] = 0.f;
+    }
+    float S = 0.f;
+    float G[3] = {0.f, 0.f, 0.f}, H[3] = {0.f, 0.f, 0.f};
+    float E0 = 0.f, E1 = 0.f;
+    unsigned cnt = 0;
+    const float adx = A.sp.a[0] * R.d[0], ady = A.sp.a[1] * R.d[1], adz = A.sp.a[2] * R.d[2];
+
+    for (int k = kbeg; k <= kend; ++k) {
+        if (k < K.lo || k > K.hi) continue;
+        const float u = linspace_at(k, N, A.sp.near_, A.sp.far_, step);
+        const float al = CLIP ? fmaf(u, R.amax - R.amin, R.amin) : u;
+        const float px = fmaf(A.sp.a[0], fmaf(al, R.d[0], R.s[0]), A.sp.b[0]);
+        const float py = fmaf(A.sp.a[1], fmaf(al, R.d[1], R.s[1]), A.sp.b[1]);
+        const float pz = fmaf(A.sp.a[2], fmaf(al, R.d[2], R.s[2]), A.sp.b[2]);
+        Taps T;
+        make_taps(px, py, pz, D0, D1, D2, T);
+        const fpair P0 = load_pair(vol + T.base[0]);
+        const fpair P1 = load_pair(vol + T.base[1]);
+        const fpair P2 = load_pair(vol + T.base[2]);
+        const fpair P3 = load_pair(vol + T.base[3]);
+        const float v0 = fmaf(T.pz1, P0.y, T.pz0 * P0.x), v1 = fmaf(T.pz1, P1.y, T.pz0 * P1.x);
+        const float v2 = fmaf(T.pz1, P2.y, T.pz0 * P2.x), v3 = fmaf(T.pz1, P3.y, T.pz0 * P3.x);
+        const float r0 = fmaf(T.wy1, v1, T.wy0 * v0), r1 = fmaf(T.wy1, v3, T.wy0 * v2);
+        const float v = fmaf(T.wx1, r1, T.wx0 * r0);
+        ++cnt;
+        if (MASK) {
+            const int lab = nearest_label(A.mask, px, py, pz, D0, D1, D2, A.C);
+            lds[lab * WG + tid] += v;
+        } else {
+            S += v;
+        }
+        if (JAC) {
+            const float d0 = fmaf(T.qz1, P0.y, T.qz0 * P0.x), d1 = fmaf(T.qz1, P1.y, T.qz0 * P1.x);
+            const float d2 = fmaf(T.qz1, P2.y, T.qz0 * P2.x), d3 = fmaf(T.qz1, P3.y, T.qz0 * P3.x);
+            const float gz = fmaf(T.wx1, fmaf(T.wy1, d3, T.wy0 * d2), T.wx0 * fmaf(T.wy1, d1, T.wy0 * d0));
+            const float gx = fmaf(T.sx1, r1, T.sx0 * r0);
+            const float gy = fmaf(T.wx1, fmaf(T.sy1, v3, T.sy0 * v2), T.wx0 * fmaf(T.sy1, v1, T.sy0 * v0));
+            G[0] += gx; G[1] += gy; G[2] += gz;
+            H[0] = fmaf(al, gx, H[0]); H[1] = fmaf(al, gy, H[1]); H[2] = fmaf(al, gz, H[2]);
+            if (CLIP) {
+                const float gd = fmaf(gx, adx, fmaf(gy, ady, gz * adz));
+                E0 = fmaf(gd, 1.f - u, E0);
+                E1 = fmaf(gd, u, E1);
+            }
+        }
+    }
+
+    const float base_scale = R.L * A.sp.inv_denom;
+    const float scale = CLIP ? base_scale * span : base_scale;
+    if (valid) {
+        if (MASK) {
+            for (int c = 0; c < A.C; ++c) A.out[((size_t)b * A.C + c) * A.n + r] = lds[c * WG + tid] * scale;
+        } else {
+            A.out[(size_t)b * A.n + r] = S * scale;
+        }
+        if (JAC) {
+            float js[3], jt[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                jt[i] = scale * A.sp.a[i] * H[i];
+                js[i] = scale * A.sp.a[i] * (G[i] - H[i]);
+            }
+            if (CLIP) {
+                const float dmin = base_scale * (-S + span * E0), dmax = base_scale * (S + span * E1);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    if (R.ax_in == i && span > 0.f) {
+                        js[i] += dmin * (R.amin - 1.f) / R.d[i];
+                        jt[i] += dmin * (-R.amin) / R.d[i];
+                    }
+                    if (R.ax_out == i && span > 0.f) {
+                        js[i] += dmax * (R.amax - 1.f) / R.d[i];
+                        jt[i] += dmax * (-R.amax) / R.d[i];
+                    }
+                }
+            }
+            float4* jp = reinterpret_cast<float4*>(A.jac + ((size_t)b * A.n + r) * XVR_DRR_JAC_STRIDE);
+            jp[0] = make_float4(S * (CLIP ? A.sp.inv_denom * span : A.sp.inv_denom), js[0], js[1], js[2]);
+            jp[1] = make_float4(jt[0], jt[1], jt[2], 0.f);
+        }
+    }
+    if (A.work) {
+        unsigned tot = wave_sum_u(cnt);
+        if ((tid & 63) == 0 && tot) atomicAdd(A.work, (unsigned long long)tot);
+    }
+}
+
+// =============================================================================================
+// trilinear backward by re-marching: pose gradient (GPOSE) and/or voxel gradient (GVOL)
+// =============================================================================================
+template <bool MASK, bool CLIP, bool GPOSE, bool GVOL>
+__global__ __launch_bounds__(WG) void k_trilinear_bwd(RenderArgs A) {
+    extern __shared__ float lds[];  // MASK: per-lane upstream gradient per channel [C][WG]
+    int b, r;
+    const bool valid = map_ray(A, b, r);
+    const int tid = threadIdx.x;
+    Ray R;
+    ray_setup(A, b, r, valid, R);
+    const int N = A.sp.n_points;
+    const float step = N > 1 ? (A.sp.far_ - A.sp.near_) / (float)(N - 1) : 0.f;
+    const KRange K = tri_krange(A, R, CLIP, step);
+    const int kbeg = __builtin_amdgcn_readfirstlane(wave_min_i(K.lo));
+    const int kend = __builtin_amdgcn_readfirstlane(wave_max_i(K.hi));
+    const float span = fmaxf(R.amax - R.amin, 0.f);
+    const float* __restrict__ vol = A.volume;
+    const int D0 = A.D0, D1 = A.D1, D2 = A.D2;
+    const float base_scale = R.L * A.sp.inv_denom;
+    const float scale = CLIP ? base_scale * span : base_scale;
+
+    float g0 = 0.f;
+    if (MASK) {
+        for (int c = 0; c < A.C; ++c) lds[c * WG + tid] = valid ? A.gout[((size_t)b * A.C + c) * A.n + r] : 0.f;
+    } else if (valid) {
+        g0 = A.gout[(size_t)b * A.n + r];
+    }
+    float SV = 0.f;
+    float G[3] = {0.f, 0.f, 0.f}, H[3] = {0.f, 0.f, 0.f};
+    float E0 = 0.f, E1 = 0.f;
+    const float adx = A.sp.a[0] * R.d[0], ady = A.sp.a[1] * R.d[1], adz = A.sp.a[2] * R.d[2];
+
+    for (int k = kbeg; k <= kend; ++k) {
+        if (k < K.lo || k > K.hi) continue;
+        const float u = linspace_at(k, N, A.sp.near_, A.sp.far_, step);
+        const float al = CLIP ? fmaf(u, R.amax - R.amin, R.amin) : u;
+        const float px = fmaf(A.sp.a[0], fmaf(al, R.d[0], R.s[0]), A.sp.b[0]);
+        const float py = fmaf(A.sp.a[1], fmaf(al, R.d[1], R.s[1]), A.sp.b[1]);
+        const float pz = fmaf(A.sp.a[2], fmaf(al, R.d[2], R.s[2]), A.sp.b[2]);
+        Taps T;
+        make_taps(px, py, pz, D0, D1, D2, T);
+        float gk = g0;
+        if (MASK) gk = lds[nearest_label(A.mask, px, py, pz, D0, D1, D2, A.C) * WG + tid];
+        if (GVOL) {
+            const float c = gk * scale;
+            if (c != 0.f) {
+                const float w00 = c * T.wx0 * T.wy0, w01 = c * T.wx0 * T.wy1;
+                const float w10 = c * T.wx1 * T.wy0, w11 = c * T.wx1 * T.wy1;
+                const float w[4] = {w00, w01, w10, w11};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float a0 = w[q] * T.pz0, a1 = w[q] * T.pz1;
+                    if (a0 != 0.f) atomic_add_f32(A.gvol + T.base[q], a0);
+                    if (a1 != 0.f) atomic_add_f32(A.gvol + T.base[q] + 1, a1);
+                }
+            }
+        }
+        if (GPOSE) {
+            const fpair P0 = load_pair(vol + T.base[0]);
+            const fpair P1 = load_pair(vol + T.base[1]);
+            const fpair P2 = load_pair(vol + T.base[2]);
+            const fpair P3 = load_pair(vol + T.base[3]);
+            const float v0 = fmaf(T.pz1, P0.y, T.pz0 * P0.x), v1 = fmaf(T.pz1, P1.y, T.pz0 * P1.x);
+            const float v2 = fmaf(T.pz1, P2.y, T.pz0 * P2.x), v3 = fmaf(T.pz1, P3.y, T.pz0 * P3.x);
+            const float r0 = fmaf(T.wy1, v1, T.wy0 * v0), r1 = fmaf(T.wy1, v3, T.wy0 * v2);
+            const float v = fmaf(T.wx1, r1, T.wx0 * r0);
+            const float d0 = fmaf(T.qz1, P0.y, T.qz0 * P0.x), d1 = fmaf(T.qz1, P1.y, T.qz0 * P1.x);
+            const float d2 = fmaf(T.qz1, P2.y, T.qz0 * P2.x), d3 = fmaf(T.qz1, P3.y, T.qz0 * P3.x);
+            const float gz = gk * fmaf(T.wx1, fmaf(T.wy1, d3, T.wy0 * d2), T.wx0 * fmaf(T.wy1, d1, T.wy0 * d0));
+            const float gx = gk * fmaf(T.sx1, r1, T.sx0 * r0);
+            const float gy = gk * fmaf(T.wx1, fmaf(T.sy1, v3, T.sy0 * v2), T.wx0 * fmaf(T.sy1, v1, T.sy0 * v0));
+            SV = fmaf(gk, v, SV);
+            G[0] += gx; G[1] += gy; G[2] += gz;
+            H[0] = fmaf(al, gx, H[0]); H[1] = fmaf(al, gy, H[1]); H[2] = fmaf(al, gz, H[2]);
+            if (CLIP) {
+                const float gd = fmaf(gx, adx, fmaf(gy, ady, gz * adz));
+                E0 = fmaf(gd, 1.f - u, E0);
+                E1 = fmaf(gd, u, E1);
+            }
+        }
+    }
+
+    if (GPOSE) {
+        float js[3], jt[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            jt[i] = scale * A.sp.a[i] * H[i];
+            js[i] = scale * A.sp.a[i] * (G[i] - H[i]);
+        }
+        if (CLIP) {
+            const float dmin = base_scale * (-SV + span * E0), dmax = base_scale * (SV + span * E1);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                if (R.ax_in == i && span > 0.f) {
+                    js[i] += dmin * (R.amin - 1.f) / R.d[i];
+                    jt[i] += dmin * (-R.amin) / R.d[i];
+                }
+                if (R.ax_out == i && span > 0.f) {
+                    js[i] += dmax * (R.amax - 1.f) / R.d[i];
+                    jt[i] += dmax * (-R.amax) / R.d[i];
+                }
+            }
+        }
+        if (!valid) js[0] = js[1] = js[2] = 0.f;
+        if (valid) {
+            float* tp = A.gtgt + ((size_t)b * A.n + r) * 3;
+            tp[0] = jt[0]; tp[1] = jt[1]; tp[2] = jt[2];
+            if (A.glen) A.glen[(size_t)b * A.n + r] = SV * (CLIP ? A.sp.inv_denom * span : A.sp.inv_denom);
+        }
+        // grad_source is shared by all rays of the pose: wave butterfly, then one atomic per wave
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float tot = wave_sum_f(js[i]);
+            if ((tid & 63) == 0 && tot != 0.f) atomic_add_f32(A.gsrc + 3 * b + i, tot);
+        }
+    }
+}
+
+// =============================================================================================
+// pose-side backward from the saved jacobian (C == 1): elementwise + wave reduction
+// =============================================================================================
+__global__ __launch_bounds__(WG) void k_backward_from_jac(const float* __restrict__ jac, const float* __restrict__ gout,
+                                                         int n, float* gsrc, float* __restrict__ gtgt,
+                                                         float* __restrict__ glen) {
+    const int b = blockIdx.y;
+    const int r = blockIdx.x * WG + threadIdx.x;
+    float js[3] = {0.f, 0.f, 0.f};
+    if (r < n) {
+        const size_t ray = (size_t)b * n + r;
+        const float g = gout[ray];
+        const float4* jp = reinterpret_cast<const float4*>(jac + ray * XVR_DRR_JAC_STRIDE);
+        const float4 j0 = jp[0], j1 = jp[1];
+        js[0] = g * j0.y; js[1] = g * j0.z; js[2] = g * j0.w;
+        float* tp = gtgt + ray * 3;
+        tp[0] = g * j1.x; tp[1] = g * j1.y; tp[2] = g * j1.z;
+        if (glen) glen[ray] = g * j0.x;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float tot = wave_sum_f(js[i]);
+        if ((threadIdx.x & 63) == 0 && tot != 0.f) atomic_add_f32(gsrc + 3 * b + i, tot);
+    }
+}
+
+// =============================================================================================
+// Siddon: exact traversal as an incremental merge of the three per-axis plane-crossing sequences
+// (no sort, no materialised alpha list).  MODE 0: forward; 1: forward + jacobian; 2: backward.
+// =============================================================================================
+struct SidState {
+    float inv_d[3];
+    int ip[3];      // index of the next plane to be crossed on each axis
+    int stp[3];     // +1 / -1
+    float an[3];    // alpha of that plane (INF when the axis has no further plane)
+};
+
+__device__ __forceinline__ float sid_alpha(const RenderArgs& A, const Ray& R, const SidState& st, int i, int S) {
+    const int p = st.ip[i];
+    if (p < 0 || p > S) return INFINITY;
+    return (((float)p + A.sp.plane0[i]) - R.s[i]) * st.inv_d[i];
+}
+
+template <int MODE, bool MASK, bool GPOSE, bool GVOL>
+__global__ __launch_bounds__(WG) void k_siddon(RenderArgs A) {
+    extern __shared__ float lds[];  // MASK: fwd -> channel accumulators, bwd -> upstream gradients
+    int b, r;
+    const bool valid = map_ray(A, b, r);
+    const int tid = threadIdx.x;
+    Ray R;
+    ray_setup(A, b, r, valid, R);
+    const float* __restrict__ vol = A.volume;
+    const int D0 = A.D0, D1 = A.D1, D2 = A.D2;
+    const int Sz[3] = {D0, D1, D2};
+    constexpr bool BWD = MODE == 2;
+    constexpr bool DERIV = MODE == 1 || (BWD && GPOSE);
+
+    float g0 = 1.f;
+    if (MASK) {
+        for (int c = 0; c < A.C; ++c)
+            lds[c * WG + tid] = (BWD && valid) ? A.gout[((size_t)b * A.C + c) * A.n + r] : 0.f;
+    } else if (BWD) {
+        g0 = valid ? A.gout[(size_t)b * A.n + r] : 0.f;
+    }
+
+    const float alo = R.amin, ahi = R.amax;
+    bool live = valid && (ahi > alo);
+    SidState st;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        st.inv_d[i] = 1.f / R.d[i];
+        const float f = fmaf(alo, R.d[i], R.s[i]) - A.sp.plane0[i];  // position in plane-index units
+        if (R.d[i] > 0.f) { st.stp[i] = 1; st.ip[i] = (int)floorf(f) + 1; }
+        else { st.stp[i] = -1; st.ip[i] = (int)ceilf(f) - 1; }
+        st.an[i] = live ? sid_alpha(A, R, st, i, Sz[i]) : INFINITY;
+        // a plane at or behind the entry point (fp noise) is skipped
+        if (live && st.an[i] <= alo) {
+            st.ip[i] += st.stp[i];
+            st.an[i] = sid_alpha(A, R, st, i, Sz[i]);
+        }
+    }
+
+    float acc = 0.f;                 // sum V * dalpha (C==1 fwd) / sum g V dalpha (bwd)
+    float As[3] = {0.f, 0.f, 0.f};   // sum dW (alpha-1)/d  per axis
+    float At[3] = {0.f, 0.f, 0.f};   // sum dW (-alpha)/d   per axis
+    float Wprev = 0.f;
+    int ax_prev = R.ax_in;           // axis of the crossing that opened the current segment (-1: none)
+    float ac = alo;
+    unsigned cnt = 0;
+    const int max_iter = D0 + D1 + D2 + 8;
+
+    for (int it = 0; it < max_iter; ++it) {
+        if (!live) break;
+        float an = fminf(fminf(st.an[0], st.an[1]), fminf(st.an[2], ahi));
+        const float mid = 0.5f * (ac + an);
+        const float px = fmaf(A.sp.a[0], fmaf(mid, R.d[0], R.s[0]), A.sp.b[0]);
+        const float py = fmaf(A.sp.a[1], fmaf(mid, R.d[1], R.s[1]), A.sp.b[1]);
+        const float pz = fmaf(A.sp.a[2], fmaf(mid, R.d[2], R.s[2]), A.sp.b[2]);
+        const int ix = (int)rintf(px), iy = (int)rintf(py), iz = (int)rintf(pz);
+        const bool inb = (unsigned)ix < (unsigned)D0 && (unsigned)iy < (unsigned)D1 && (unsigned)iz < (unsigned)D2;
+        const int off = inb ? (ix * D1 + iy) * D2 + iz : 0;
+        const float v = inb ? vol[off] : 0.f;
+        const float seg = an - ac;
+        int lab = 0;
+        if (MASK) lab = inb ? min(max((int)A.mask[off], 0), A.C - 1) : 0;
+        float W = v;
+        if (BWD) {
+            const float gk = MASK ? lds[lab * WG + tid] : g0;
+            W = gk * v;
+            if (GVOL && inb) {
+                const float c = gk * R.L * seg;
+                if (c != 0.f) atomic_add_f32(A.gvol + off, c);
+            }
+            acc = fmaf(W, seg, acc);
+        } else if (MASK) {
+            lds[lab * WG + tid] = fmaf(v, seg, lds[lab * WG + tid]);
+        } else {
+            acc = fmaf(v, seg, acc);
+        }
+        if (inb) ++cnt;
+        if (DERIV) {
+            const float dW = Wprev - W;  // d out / d alpha at the crossing that opened this segment
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float m = (ax_prev == i) ? dW * st.inv_d[i] : 0.f;
+                As[i] = fmaf(m, ac - 1.f, As[i]);
+                At[i] = fmaf(m, -ac, At[i]);
+            }
+            Wprev = W;
+        }
+        if (an >= ahi) {
+            if (DERIV) {  // exit crossing: the next segment has W = 0
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const float m = (R.ax_out == i) ? W * st.inv_d[i] : 0.f;
+                    As[i] = fmaf(m, ahi - 1.f, As[i]);
+                    At[i] = fmaf(m, -ahi, At[i]);
+                }
+            }
+            live = false;
+        } else {
+            int ax = -1;
+#pragma unroll
+            for (int i = 2; i >= 0; --i) {
+                if (st.an[i] <= an) {
+                    st.ip[i] += st.stp[i];
+                    st.an[i] = sid_alpha(A, R, st, i, Sz[i]);
+                    ax = i;
+                }
+            }
+            ax_prev = ax;
+            ac = an;
+        }
+    }
+
+    if (!BWD) {
+        if (valid) {
+            if (MASK) {
+                for (int c = 0; c < A.C; ++c) A.out[((size_t)b * A.C + c) * A.n + r] = lds[c * WG + tid] * R.L;
+            } else {
+                A.out[(size_t)b * A.n + r] = acc * R.L;
+            }
+            if (MODE == 1) {
+                float4* jp = reinterpret_cast<float4*>(A.jac + ((size_t)b * A.n + r) * XVR_DRR_JAC_STRIDE);
+                jp[0] = make_float4(acc, R.L * As[0], R.L * As[1], R.L * As[2]);
+                jp[1] = make_float4(R.L * At[0], R.L * At[1], R.L * At[2], 0.f);
+            }
+        }
+        if (A.work) {
+            unsigned tot = wave_sum_u(cnt);
+            if ((tid & 63) == 0 && tot) atomicAdd(A.work, (unsigned long long)tot);
+        }
+    } else if (GPOSE) {
+        float js[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) js[i] = valid ? R.L * As[i] : 0.f;
+        if (valid) {
+            float* tp = A.gtgt + ((size_t)b * A.n + r) * 3;
+            tp[0] = R.L * At[0]; tp[1] = R.L * At[1]; tp[2] = R.L * At[2];
+            if (A.glen) A.glen[(size_t)b * A.n + r] = acc;
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float tot = wave_sum_f(js[i]);
+            if ((tid & 63) == 0 && tot != 0.f) atomic_add_f32(A.gsrc + 3 * b + i, tot);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+int fail(int code, const char* msg) {
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
+
+int check_common(const float* volume, int D0, int D1, int D2, int C, const float* source, const float* target,
+                 const float* raylen, int B, int n, const xvr_drr_spec* sp) {
+    if (!volume || !source || !target || !raylen || !sp) return fail(XVR_DRR_E_ARG, "null pointer argument");
+    if (D0 < 2 || D1 < 2 || D2 < 2) return fail(XVR_DRR_E_ARG, "every volume dimension must be >= 2");
+    if ((long long)D0 * D1 * D2 >= (1LL << 31)) return fail(XVR_DRR_E_UNSUPPORTED, "volume has >= 2^31 voxels");
+    if (B <= 0 || n <= 0) return fail(XVR_DRR_E_ARG, "B and n must be positive");
+    if (C < 1 || C > 128) return fail(XVR_DRR_E_ARG, "C must be in [1, 128]");
+    for (int i = 0; i < 3; ++i)
+        if (!(sp->a[i] > 0.f)) return fail(XVR_DRR_E_ARG, "spec.a must be positive");
+    if (sp->ray_grid_w < 0 || (sp->ray_grid_w > 0 && n % sp->ray_grid_w != 0))
+        return fail(XVR_DRR_E_ARG, "ray_grid_w must divide n");
+    return XVR_DRR_OK;
+}
+
+void fill_args(RenderArgs& A, const float* volume, const float* mask, int D0, int D1, int D2, int C,
+               const float* source, const float* target, const float* raylen, int B, int n,
+               const xvr_drr_spec* sp) {
+    A = RenderArgs{};
+    A.volume = volume; A.mask = mask;
+    A.D0 = D0; A.D1 = D1; A.D2 = D2; A.C = C;
+    A.source = source; A.target = target; A.raylen = raylen;
+    A.B = B; A.n = n; A.sp = *sp;
+    A.grid_w = sp->ray_grid_w;
+    if (A.grid_w > 0) {
+        A.grid_h = n / A.grid_w;
+        A.tiles_x = (A.grid_w + 15) / 16;
+        A.blocks_per_pose = A.tiles_x * ((A.grid_h + 15) / 16);
+    } else {
+        A.grid_h = 0; A.tiles_x = 0;
+        A.blocks_per_pose = (n + WG - 1) / WG;
+    }
+}
+
+template <typename Kern>
+int launch(Kern kern, const RenderArgs& A, size_t lds_bytes, void* stream) {
+    const long long nblocks = (long long)A.B * A.blocks_per_pose;
+    if (nblocks >= (1LL << 31)) return fail(XVR_DRR_E_UNSUPPORTED, "grid too large");
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(WG), lds_bytes, (hipStream_t)stream, A);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
+    return XVR_DRR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int xvr_drr_abi_version(void) { return XVR_DRR_ABI_VERSION; }
+const char* xvr_drr_last_error(void) { return g_err; }
+
+int xvr_drr_trilinear_forward(const float* volume, const float* mask, int D0, int D1, int D2, int C,
+                              const float* source, const float* target, const float* raylen, int B, int n,
+                              const xvr_drr_spec* sp, float* out, float* jac, unsigned long long* work,
+                              void* stream) {
+    int rc = check_common(volume, D0, D1, D2, C, source, target, raylen, B, n, sp);
+    if (rc) return rc;
+    if (!out) return fail(XVR_DRR_E_ARG, "out is null");
+    if (sp->n_points < 1) return fail(XVR_DRR_E_ARG, "n_points must be >= 1");
+    if (!(sp->far_ >= sp->near_)) return fail(XVR_DRR_E_ARG, "far must be >= near");
+    if (!mask && C != 1) return fail(XVR_DRR_E_ARG, "C must be 1 without a mask");
+    if (jac && mask) return fail(XVR_DRR_E_UNSUPPORTED, "jacobian output is only available without a mask");
+    RenderArgs A;
+    fill_args(A, volume, mask, D0, D1, D2, C, source, target, raylen, B, n, sp);
+    A.out = out; A.jac = jac; A.work = work;
+    const bool clip = sp->clip_to_volume != 0;
+    const size_t lds = mask ? (size_t)C * WG * sizeof(float) : 0;
+    if (mask) return clip ? launch(k_trilinear_fwd<false, true, true>, A, lds, stream)
+                          : launch(k_trilinear_fwd<false, true, false>, A, lds, stream);
+    if (jac) return clip ? launch(k_trilinear_fwd<true, false, true>, A, 0, stream)
+                         : launch(k_trilinear_fwd<true, false, false>, A, 0, stream);
+    return clip ? launch(k_trilinear_fwd<false, false, true>, A, 0, stream)
+                : launch(k_trilinear_fwd<false, false, false>, A, 0, stream);
+}
+
+int xvr_drr_trilinear_backward(const float* volume, const float* mask, int D0, int D1, int D2, int C,
+                               const float* source, const float* target, const float* raylen, int B, int n,
+                               const xvr_drr_spec* sp, const float* grad_out, float* grad_volume,
+                               float* grad_source, float* grad_target, float* grad_raylen, void* stream) {
+    int rc = check_common(volume, D0, D1, D2, C, source, target, raylen, B, n, sp);
+    if (rc) return rc;
+    if (!grad_out) return fail(XVR_DRR_E_ARG, "grad_out is null");
+    if (sp->n_points < 1) return fail(XVR_DRR_E_ARG, "n_points must be >= 1");
+    if (!mask && C != 1) return fail(XVR_DRR_E_ARG, "C must be 1 without a mask");
+    if ((grad_source == nullptr) != (grad_target == nullptr))
+        return fail(XVR_DRR_E_ARG, "grad_source and grad_target must be requested together");
+    if (grad_raylen && !grad_target) return fail(XVR_DRR_E_ARG, "grad_raylen needs grad_source/grad_target");
+    const bool gpose = grad_target != nullptr, gvol = grad_volume != nullptr;
+    if (!gpose && !gvol) return XVR_DRR_OK;
+    RenderArgs A;
+    fill_args(A, volume, mask, D0, D1, D2, C, source, target, raylen, B, n, sp);
+    A.gout = grad_out; A.gvol = grad_volume; A.gsrc = grad_source; A.gtgt = grad_target; A.glen = grad_raylen;
+    const bool clip = sp->clip_to_volume != 0;
+    const size_t lds = mask ? (size_t)C * WG * sizeof(float) : 0;
+#define TRI_BWD(M, CL)                                                                         \
+    (gpose ? (gvol ? launch(k_trilinear_bwd<M, CL, true, true>, A, lds, stream)                \
+                   : launch(k_trilinear_bwd<M, CL, true, false>, A, lds, stream))              \
+           : launch(k_trilinear_bwd<M, CL, false, true>, A, lds, stream))
+    if (mask) return clip ? TRI_BWD(true, true) : TRI_BWD(true, false);
+    return clip ? TRI_BWD(false, true) : TRI_BWD(false, false);
+#undef TRI_BWD
+}
+
+int xvr_drr_siddon_forward(const float* volume, const float* mask, int D0, int D1, int D2, int C,
+                           const float* source, const float* target, const float* raylen, int B, int n,
+                           const xvr_drr_spec* sp, float* out, float* jac, unsigned long long* work,
+                           void* stream) {
+    int rc = check_common(volume, D0, D1, D2, C, source, target, raylen, B, n, sp);
+    if (rc) return rc;
+    if (!out) return fail(XVR_DRR_E_ARG, "out is null");
+    if (!mask && C != 1) return fail(XVR_DRR_E_ARG, "C must be 1 without a mask");
+    if (jac && mask) return fail(XVR_DRR_E_UNSUPPORTED, "jacobian output is only available without a mask");
+    RenderArgs A;
+    fill_args(A, volume, mask, D0, D1, D2, C, source, target, raylen, B, n, sp);
+    A.out = out; A.jac = jac; A.work = work;
+    const size_t lds = mask ? (size_t)C * WG * sizeof(float) : 0;
+    if (mask) return launch(k_siddon<0, true, false, false>, A, lds, stream);
+    if (jac) return launch(k_siddon<1, false, false, false>, A, 0, stream);
+    return launch(k_siddon<0, false, false, false>, A, 0, stream);
+}
+
+int xvr_drr_siddon_backward(const float* volume, const float* mask, int D0, int D1, int D2, int C,
+                            const float* source, const float* target, const float* raylen, int B, int n,
+                            const xvr_drr_spec* sp, const float* grad_out, float* grad_volume,
+                            float* grad_source, float* grad_target, float* grad_raylen, void* stream) {
+    int rc = check_common(volume, D0, D1, D2, C, source, target, raylen, B, n, sp);
+    if (rc) return rc;
+    if (!grad_out) return fail(XVR_DRR_E_ARG, "grad_out is null");
+    if (!mask && C != 1) return fail(XVR_DRR_E_ARG, "C must be 1 without a mask");
+    if ((grad_source == nullptr) != (grad_target == nullptr))
+        return fail(XVR_DRR_E_ARG, "grad_source and grad_target must be requested together");
+    if (grad_raylen && !grad_target) return fail(XVR_DRR_E_ARG, "grad_raylen needs grad_source/grad_target");
+    const bool gpose = grad_target != nullptr, gvol = grad_volume != nullptr;
+    if (!gpose && !gvol) return XVR_DRR_OK;
+    RenderArgs A;
+    fill_args(A, volume, mask, D0, D1, D2, C, source, target, raylen, B, n, sp);
+    A.gout = grad_out; A.gvol = grad_volume; A.gsrc = grad_source; A.gtgt = grad_target; A.glen = grad_raylen;
+    const size_t lds = mask ? (size_t)C * WG * sizeof(float) : 0;
+#define SID_BWD(M)                                                                      \
+    (gpose ? (gvol ? launch(k_siddon<2, M, true, true>, A, lds, stream)                 \
+                   : launch(k_siddon<2, M, true, false>, A, lds, stream))               \
+           : launch(k_siddon<2, M, false, true>, A, lds, stream))
+    return mask ? SID_BWD(true) : SID_BWD(false);
+#undef SID_BWD
+}
+
+int xvr_drr_backward_from_jac(const float* jac, const float* grad_out, int B, int n, float* grad_source,
+                              float* grad_target, float* grad_raylen, void* stream) {
+    if (!jac || !grad_out || !grad_source || !grad_target) return fail(XVR_DRR_E_ARG, "null pointer argument");
+    if (B <= 0 || n <= 0) return fail(XVR_DRR_E_ARG, "B and n must be positive");
+    dim3 grid((unsigned)((n + WG - 1) / WG), (unsigned)B);
+    hipLaunchKernelGGL(k_backward_from_jac, grid, dim3(WG), 0, (hipStream_t)stream, jac, grad_out, n,
+                       grad_source, grad_target, grad_raylen);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
+    return XVR_DRR_OK;
+}
+
+}  // extern "C"

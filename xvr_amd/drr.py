@@ -1,0 +1,139 @@
+"""``DRR`` module: the drop-in for ``diffdrr.drr.DRR`` as xvr uses it.
+
+Reference call sites honoured here:
+* construction ``DRR(subject, sdd, height, delx, width, dely, x0, y0, reverse_x_axis=, renderer=,
+  voxel_shift=...)``                       /root/reference/src/xvr/renderer/load.py:32-44,
+                                           /root/reference/src/xvr/model/utils.py:154-171
+* buffers ``density / mask / volume / center``, ``affine_inverse``, ``detector``, ``renderer``,
+  ``reshape_transform``                    /root/reference/src/xvr/model/trainer.py:251-256,279-304
+* ``drr(pose)``                            /root/reference/src/xvr/registrar/base.py:249,315,317
+* ``set_intrinsics_`` / ``rescale_detector_``  /root/reference/src/xvr/registrar/base.py:155,212
+* ``perspective_projection`` / ``inverse_projection``  /root/reference/src/xvr/metrics/evaluator.py:19-25
+"""
+
+from __future__ import annotations
+
+import torch
+
+from .data import Subject
+from .detector import Detector, make_reorient
+from .pose import RigidTransform, convert
+from .renderers import Siddon, Trilinear
+
+__all__ = ["DRR"]
+
+
+class DRR(torch.nn.Module):
+    def __init__(self, subject: Subject, sdd: float, height: int, delx: float, width: int | None = None,
+                 dely: float | None = None, x0: float = 0.0, y0: float = 0.0, reshape: bool = True,
+                 reverse_x_axis: bool = True, renderer: str = "siddon", voxel_shift: float = 0.5,
+                 **renderer_kwargs):
+        super().__init__()
+        width = height if width is None else width
+        dely = delx if dely is None else dely
+        self.detector = Detector(sdd, height, width, delx, dely, x0, y0,
+                                 reorient=make_reorient(subject.orientation), reverse_x_axis=reverse_x_axis)
+        self.subject = subject
+        affine = torch.as_tensor(subject.affine, dtype=torch.float32)
+        self.register_buffer("_affine", affine[None].clone())
+        self.register_buffer("_affine_inverse", torch.linalg.inv(affine)[None])
+        density = subject.density if subject.density is not None else subject.volume
+        self.register_buffer("density", density.to(torch.float32).contiguous())
+        if subject.mask is not None:
+            self.register_buffer("mask", subject.mask.to(torch.float32).contiguous())
+        if renderer == "siddon":
+            self.renderer = Siddon(voxel_shift=voxel_shift, **renderer_kwargs)
+        elif renderer == "trilinear":
+            self.renderer = Trilinear(voxel_shift=voxel_shift, **renderer_kwargs)
+        else:
+            raise ValueError(f"renderer must be 'siddon' or 'trilinear', got {renderer!r}")
+        self.reshape = reshape
+        self._sync_ray_grid()
+
+    def _sync_ray_grid(self):
+        self.renderer.ray_grid = (self.detector.height, self.detector.width)
+
+    @property
+    def affine(self) -> RigidTransform:
+        return RigidTransform(self._affine)
+
+    @property
+    def affine_inverse(self) -> RigidTransform:
+        return RigidTransform(self._affine_inverse)
+
+    def reshape_transform(self, img, batch_size):
+        if self.reshape:
+            img = img.view(batch_size, -1, self.detector.height, self.detector.width)
+        return img
+
+    # ------------------------------------------------------------------ rendering
+    def forward(self, *args, parameterization=None, convention=None, calibration=None,
+                mask_to_channels=False, **kwargs):
+        """``drr(pose)`` with a RigidTransform, or ``drr(rot, xyz, parameterization=, convention=)``."""
+        pose = args[0] if parameterization is None else convert(
+            *args, parameterization=parameterization, convention=convention)
+        source, target = self.detector(pose, calibration)
+        img = self.render(self.density, source, target, mask_to_channels, **kwargs)
+        return self.reshape_transform(img, batch_size=len(pose))
+
+    def render(self, density, source, target, mask_to_channels=False, **kwargs):
+        img = (target - source).norm(dim=-1).unsqueeze(1)        # world-mm length of every ray
+        source = self.affine_inverse(source)                      # world -> voxel index coordinates
+        target = self.affine_inverse(target)
+        kwargs["mask"] = self.mask if mask_to_channels else None
+        return self.renderer(density, source, target, img, **kwargs)
+
+    # ------------------------------------------------------------------ intrinsics
+    def set_intrinsics_(self, sdd=None, delx=None, dely=None, x0=None, y0=None, height=None, width=None):
+        d = self.detector
+        self.detector = Detector(
+            d.sdd if sdd is None else sdd,
+            d.height if height is None else height,
+            d.width if width is None else width,
+            d.delx if delx is None else delx,
+            d.dely if dely is None else dely,
+            -d.x0 if x0 is None else x0,   # the calibration stores x0/y0 as given; the properties negate
+            -d.y0 if y0 is None else y0,
+            reorient=d._reorient, reverse_x_axis=d.reverse_x_axis,
+        ).to(self._affine.device)
+        self._sync_ray_grid()
+
+    def rescale_detector_(self, scale: float):
+        d = self.detector
+        self.set_intrinsics_(height=int(d.height * scale), width=int(d.width * scale),
+                             delx=d.delx / scale, dely=d.dely / scale)
+
+    # ------------------------------------------------------------------ point projection
+    # Exact inverses of Detector.forward's pixel -> world map (pixel (row, col) has plane
+    # coefficients t = row - H/2 + 0.5, s = +/-(col - W/2 + 0.5) for even sizes).
+    def _pixel_offsets(self):
+        d = self.detector
+        h_off = 1.0 if d.height % 2 else 0.5
+        w_off = 1.0 if d.width % 2 else 0.5
+        return (-d.height // 2) + h_off, (-d.width // 2) + w_off
+
+    def perspective_projection(self, pose: RigidTransform, pts: torch.Tensor) -> torch.Tensor:
+        """World points [B|1, P, 3] -> detector pixel coordinates [B, P, 2] as (col, row)."""
+        d = self.detector
+        cam = d.reorient.compose(pose).inverse()(pts)
+        C = d._calibration
+        u = cam[..., 0] * (C[2, 2] / cam[..., 2])
+        v = cam[..., 1] * (C[2, 2] / cam[..., 2])
+        t = (u - C[0, 3]) / C[0, 0]
+        s = (v - C[1, 3]) / C[1, 1]
+        if d.reverse_x_axis:
+            s = -s
+        t0, s0 = self._pixel_offsets()
+        return torch.stack([s - s0, t - t0], dim=-1)
+
+    def inverse_projection(self, pose: RigidTransform, pts: torch.Tensor) -> torch.Tensor:
+        """Detector pixel coordinates [B, P, 2] (col, row) -> world points on the detector plane."""
+        d = self.detector
+        t0, s0 = self._pixel_offsets()
+        s = pts[..., 0] + s0
+        t = pts[..., 1] + t0
+        if d.reverse_x_axis:
+            s = -s
+        C = d._calibration
+        cam = torch.stack([t * C[0, 0] + C[0, 3], s * C[1, 1] + C[1, 3], torch.full_like(s, C[2, 2].item())], dim=-1)
+        return d.reorient.compose(pose)(cam)

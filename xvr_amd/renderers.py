@@ -1,0 +1,248 @@
+"""``Siddon`` / ``Trilinear`` renderer modules over the HIP library (the hot call of the path).
+
+Drop-in for the object xvr reaches as ``drr.renderer`` and calls as
+
+    img = self.drr.renderer(tmp, source, target, img, mask=seg)      # -> [B, C, n]
+
+(/root/reference/src/xvr/model/trainer.py:288; constructed from ``renderer="siddon"|"trilinear"``
+at /root/reference/src/xvr/renderer/load.py:32-44, ``voxel_shift`` forwarded from
+/root/reference/src/xvr/registrar/base.py:61).  Same argument meaning as the reference:
+``volume[D0,D1,D2]``, ``source[B,1,3]`` and ``target[B,n,3]`` in voxel-index coordinates,
+``img[B,1,n]`` = world-mm ray length; differentiable w.r.t. ``source``/``target``/``img`` (-> pose) and
+``volume`` (-> voxels).
+
+There is NO CPU path: tensors must live on the GPU and libxvr_drr.so must load, otherwise the call
+raises (python exceptions only -- the reference's trainer catches them per step,
+/root/reference/src/xvr/model/trainer.py:171-175).
+"""
+
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+from .spec import RenderSpec
+
+__all__ = ["Siddon", "Trilinear", "render", "make_cspec"]
+
+
+def make_cspec(shape, spec: RenderSpec, ray_grid_w: int = 0) -> _lib.CSpec:
+    spec.validate()
+    a, b = spec.index_map(shape)
+    c = _lib.CSpec()
+    for i in range(3):
+        c.a[i], c.b[i] = a[i], b[i]
+        c.lo[i] = -spec.voxel_shift
+        c.hi[i] = shape[i] - spec.voxel_shift
+        c.plane0[i] = -spec.voxel_shift
+    c.eps = spec.eps
+    c.n_points = spec.n_points
+    c.near_, c.far_ = spec.near, spec.far
+    c.inv_denom = 1.0 / (spec.n_points if spec.step_mode == "n_points" else spec.n_points - 1)
+    c.clip_to_volume = int(spec.clip_to_volume)
+    c.ray_grid_w = int(ray_grid_w)
+    return c
+
+
+# When set to a list, every C-ABI launch is bracketed by HIP events recorded on the launch stream and
+# (name, start, end) is appended -- bench.py uses this to time the kernels live (no effect otherwise).
+PROFILER = None
+
+
+def _timed(name, fn, *args):
+    if PROFILER is None:
+        return fn(*args)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = fn(*args)
+    e1.record()
+    PROFILER.append((name, e0, e1))
+    return rc
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _check_gpu_f32(name, t):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{name} is on {t.device}: the DRR renderer is a HIP kernel and has no CPU path; move it to the GPU"
+        )
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32 (got {t.dtype}); xvr casts the DRR module to float32")
+
+
+class _Render(torch.autograd.Function):
+    """forward: one fused sweep (with the per-ray jacobian when a pose gradient may be needed);
+    backward: elementwise-from-jacobian for the pose, a re-march with scatter for the voxels."""
+
+    @staticmethod
+    def forward(ctx, volume, source, target, img, mask, spec: RenderSpec, ray_grid_w: int, C: int, work):
+        lib = _lib.load()
+        D0, D1, D2 = volume.shape
+        B, n, _ = target.shape
+        vol_c = volume.contiguous()
+        src_c = source.reshape(B, 3).contiguous()
+        tgt_c = target.contiguous()
+        len_c = img.reshape(B, n).contiguous()
+        msk_c = mask.contiguous() if mask is not None else None
+        cs = make_cspec((D0, D1, D2), spec, ray_grid_w)
+        need_pose = any(ctx.needs_input_grad[1:4])
+        use_jac = need_pose and mask is None
+        out = torch.empty(B, C, n, device=volume.device, dtype=torch.float32)
+        jac = torch.empty(B, n, _lib.JAC_STRIDE, device=volume.device, dtype=torch.float32) if use_jac else None
+        fn = lib.xvr_drr_trilinear_forward if spec.renderer == "trilinear" else lib.xvr_drr_siddon_forward
+        rc = _timed(f"{spec.renderer}_forward" + ("+jac" if use_jac else ""), fn,
+                    _ptr(vol_c), _ptr(msk_c), D0, D1, D2, C, _ptr(src_c), _ptr(tgt_c), _ptr(len_c), B, n,
+                    ctypes.byref(cs), _ptr(out), _ptr(jac), _ptr(work), _stream())
+        _lib.check(rc, f"xvr_drr_{spec.renderer}_forward")
+        ctx.spec, ctx.ray_grid_w, ctx.C = spec, ray_grid_w, C
+        ctx.src_shape, ctx.img_shape = source.shape, img.shape
+        ctx.save_for_backward(vol_c, src_c, tgt_c, len_c, msk_c, jac)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        vol_c, src_c, tgt_c, len_c, msk_c, jac = ctx.saved_tensors
+        spec, C = ctx.spec, ctx.C
+        D0, D1, D2 = vol_c.shape
+        B, n, _ = tgt_c.shape
+        dev = vol_c.device
+        gout = gout.contiguous()
+        need_vol = ctx.needs_input_grad[0]
+        need_pose = any(ctx.needs_input_grad[1:4])
+        gvol = torch.zeros_like(vol_c) if need_vol else None
+        gsrc = gtgt = glen = None
+        if need_pose:
+            gsrc = torch.zeros(B, 3, device=dev, dtype=torch.float32)
+            gtgt = torch.empty(B, n, 3, device=dev, dtype=torch.float32)
+            glen = torch.empty(B, n, device=dev, dtype=torch.float32)
+        from_jac = need_pose and jac is not None
+        if from_jac:
+            rc = _timed("backward_from_jac", lib.xvr_drr_backward_from_jac,
+                        _ptr(jac), _ptr(gout), B, n, _ptr(gsrc), _ptr(gtgt), _ptr(glen), _stream())
+            _lib.check(rc, "xvr_drr_backward_from_jac")
+        if need_vol or (need_pose and not from_jac):
+            cs = make_cspec((D0, D1, D2), spec, ctx.ray_grid_w)
+            fn = lib.xvr_drr_trilinear_backward if spec.renderer == "trilinear" else lib.xvr_drr_siddon_backward
+            pose_here = need_pose and not from_jac
+            tag = ("pose" if pose_here else "") + ("+vol" if need_vol else "")
+            rc = _timed(f"{spec.renderer}_backward[{tag.strip('+')}]", fn,
+                        _ptr(vol_c), _ptr(msk_c), D0, D1, D2, C, _ptr(src_c), _ptr(tgt_c), _ptr(len_c), B, n,
+                        ctypes.byref(cs), _ptr(gout), _ptr(gvol),
+                        _ptr(gsrc) if pose_here else None, _ptr(gtgt) if pose_here else None,
+                        _ptr(glen) if pose_here else None, _stream())
+            _lib.check(rc, f"xvr_drr_{spec.renderer}_backward")
+        g_source = gsrc.reshape(ctx.src_shape) if need_pose and ctx.needs_input_grad[1] else None
+        g_target = gtgt if need_pose and ctx.needs_input_grad[2] else None
+        g_img = glen.reshape(ctx.img_shape) if need_pose and ctx.needs_input_grad[3] else None
+        return gvol, g_source, g_target, g_img, None, None, None, None, None
+
+
+def render(volume, source, target, img, spec: RenderSpec, mask=None, ray_grid_w: int = 0, n_channels=None, work=None):
+    """Functional form.  ``work``: optional cuda uint64/int64 scalar the kernel adds its count of
+    volume-touching samples (trilinear) or voxel segments (siddon) to."""
+    for name, t in (("volume", volume), ("source", source), ("target", target), ("img", img)):
+        _check_gpu_f32(name, t)
+    if volume.dim() != 3:
+        raise ValueError(f"volume must be [D0, D1, D2], got {tuple(volume.shape)}")
+    if target.dim() != 3 or target.shape[-1] != 3:
+        raise ValueError(f"target must be [B, n, 3], got {tuple(target.shape)}")
+    B, n, _ = target.shape
+    if source.numel() != B * 3:
+        raise ValueError(f"source must be [B, 1, 3] (one X-ray source per pose), got {tuple(source.shape)}")
+    if img.numel() != B * n:
+        raise ValueError(f"img must be [B, 1, n] ray lengths, got {tuple(img.shape)}")
+    if mask is not None:
+        _check_gpu_f32("mask", mask)
+        if mask.shape != volume.shape:
+            raise ValueError("mask and volume must have the same shape")
+        C = int(n_channels) if n_channels is not None else int(mask.max().item()) + 1
+    else:
+        C = 1
+    if ray_grid_w and n % ray_grid_w:
+        ray_grid_w = 0
+    return _Render.apply(volume, source, target, img, mask, spec, int(ray_grid_w), C, work)
+
+
+class _RendererBase(torch.nn.Module):
+    renderer_name = ""
+
+    def __init__(self, voxel_shift: float = 0.5, eps: float = 1e-8,
+                 filter_intersections_outside_volume: bool = True, **spec_overrides):
+        super().__init__()
+        self.voxel_shift = voxel_shift
+        self.eps = eps
+        self.filter_intersections_outside_volume = filter_intersections_outside_volume
+        self.spec_overrides = dict(spec_overrides)
+        # (H, W) of the detector whose rays this module is fed, set by DRR; lets the kernels map
+        # wavefronts to 8x8 pixel tiles.  Purely a launch-shaping hint.
+        self.ray_grid = None
+        self._label_cache = (None, None, None)
+
+    def _spec(self, **kw) -> RenderSpec:
+        base = dict(renderer=self.renderer_name, voxel_shift=self.voxel_shift, eps=self.eps,
+                    filter_intersections_outside_volume=self.filter_intersections_outside_volume)
+        base.update(self.spec_overrides)
+        base.update(kw)
+        return RenderSpec(**base)
+
+    def _n_channels(self, mask):
+        if mask is None:
+            return None
+        key = (mask.data_ptr(), mask._version)
+        if self._label_cache[:2] != key:
+            self._label_cache = (*key, int(mask.max().item()) + 1)
+        return self._label_cache[2]
+
+    def _grid_w(self, n):
+        if self.ray_grid is not None and self.ray_grid[0] * self.ray_grid[1] == n:
+            return int(self.ray_grid[1])
+        return 0
+
+
+class Trilinear(_RendererBase):
+    """Trilinear ray-marching: ``n_points`` samples at ``linspace(near, far)`` along source->target."""
+
+    renderer_name = "trilinear"
+
+    def __init__(self, near: float = 0.0, far: float = 1.0, mode: str = "bilinear",
+                 filter_intersections_outside_volume: bool = True, voxel_shift: float = 0.5,
+                 eps: float = 1e-8, **spec_overrides):
+        if mode != "bilinear":
+            raise NotImplementedError("Trilinear supports mode='bilinear' only")
+        super().__init__(voxel_shift, eps, filter_intersections_outside_volume, **spec_overrides)
+        self.near, self.far, self.mode = near, far, mode
+
+    def forward(self, volume, source, target, img, n_points: int = 500, align_corners: bool = False, mask=None):
+        spec = self._spec(near=self.near, far=self.far, n_points=n_points, align_corners=align_corners)
+        return render(volume, source, target, img, spec, mask, self._grid_w(target.shape[1]), self._n_channels(mask))
+
+
+class Siddon(_RendererBase):
+    """Siddon's exact ray tracing (nearest-voxel lookup per plane-to-plane segment)."""
+
+    renderer_name = "siddon"
+
+    def __init__(self, mode: str = "nearest", stop_gradients_through_grid_sample: bool = False,
+                 filter_intersections_outside_volume: bool = True, voxel_shift: float = 0.5,
+                 eps: float = 1e-8, **spec_overrides):
+        if mode != "nearest":
+            raise NotImplementedError("Siddon supports mode='nearest' only")
+        super().__init__(voxel_shift, eps, filter_intersections_outside_volume, **spec_overrides)
+        self.mode = mode
+        self.stop_gradients_through_grid_sample = stop_gradients_through_grid_sample
+
+    def forward(self, volume, source, target, img, align_corners: bool = False, mask=None):
+        spec = self._spec(align_corners=align_corners)
+        if self.stop_gradients_through_grid_sample:
+            volume = volume.detach()
+        return render(volume, source, target, img, spec, mask, self._grid_w(target.shape[1]), self._n_channels(mask))

@@ -1,0 +1,60 @@
+"""Numerical convention of a render (host side).
+
+diffdrr==0.6.0, which defines these constants for the reference, is not available here
+(SURVEY.md F2-F4): every one of them is therefore an explicit, documented knob rather than a
+hard-coded guess.  Defaults are the self-consistent geometry
+described in DESIGN.md ("Semantics"); the recalled upstream variants are one keyword away.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, replace
+
+
+@dataclass(frozen=True)
+class RenderSpec:
+    renderer: str = "trilinear"  # "trilinear" | "siddon"
+    voxel_shift: float = 0.5     # integer coordinate = voxel corner (0.0) or centre (0.5)
+    eps: float = 1e-8            # added to (target - source)
+    align_corners: bool = False  # grid_sample's flag
+    norm_dims_offset: int = 0    # xyz normalised with shape + offset (recalled upstream: +1 siddon, -1 trilinear)
+    # trilinear
+    n_points: int = 500
+    near: float = 0.0
+    far: float = 1.0
+    step_mode: str = "n_points"  # out = L * sum / n_points   |  "n_minus_1": / (n_points - 1)
+    clip_to_volume: bool = False  # rescale alphas per ray to [alphamin, alphamax]
+    # siddon (the HIP traversal is per ray by construction)
+    per_ray_clamp: bool = True
+    filter_intersections_outside_volume: bool = True
+
+    def with_(self, **kw) -> "RenderSpec":
+        return replace(self, **kw)
+
+    def validate(self) -> None:
+        if self.renderer not in ("trilinear", "siddon"):
+            raise ValueError(f"renderer must be 'trilinear' or 'siddon', got {self.renderer!r}")
+        if self.step_mode not in ("n_points", "n_minus_1"):
+            raise ValueError(f"unknown step_mode {self.step_mode!r}")
+        if self.n_points < 1 or (self.step_mode == "n_minus_1" and self.n_points < 2):
+            raise ValueError("n_points too small")
+        if not self.far >= self.near:
+            raise ValueError("far must be >= near")
+        if self.renderer == "siddon" and not self.per_ray_clamp:
+            raise NotImplementedError(
+                "per_ray_clamp=False (the literal batch-filtered sort formulation) is an oracle-only "
+                "mode: a per-ray traversal cannot reproduce a batch-dependent column filter"
+            )
+
+    def index_map(self, shape):
+        """(a, b) per axis with sampling index = a * x + b (see oracle/diffdrr_restated.py::index_map)."""
+        a, b = [], []
+        for S in shape:
+            dims = S + self.norm_dims_offset
+            if self.align_corners:
+                a.append((S - 1) / dims)
+                b.append(self.voxel_shift * (S - 1) / dims)
+            else:
+                a.append(S / dims)
+                b.append(self.voxel_shift * S / dims - 0.5)
+        return a, b

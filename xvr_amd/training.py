@@ -1,0 +1,49 @@
+"""The render-side pieces of xvr's training step (the callers immediately around the hot call).
+
+* ``get_random_pose``  -- /root/reference/src/xvr/model/sampler.py:5-38
+* ``render_samples``   -- /root/reference/src/xvr/model/trainer.py:279-304 (the exploded 4-call
+  sequence detector -> ray length -> affine_inverse -> renderer -> reshape, then the foreground
+  mask / keep test with thresholds 0.10 / 0.05)
+"""
+
+from __future__ import annotations
+
+import torch
+
+from .pose import convert
+
+
+def _uniform(low, high, n, circle_shift=False, generator=None):
+    x = (high - low) * torch.rand(n, 1, generator=generator) + low
+    if circle_shift:
+        x = ((x + 180) % 360) - 180
+    return x
+
+
+def get_random_pose(alphamin, alphamax, betamin, betamax, gammamin, gammamax, txmin, txmax, tymin, tymax,
+                    tzmin, tzmax, batch_size, generator=None):
+    """A batch of random poses: uniform Euler-ZXY angles (degrees) and translations (mm)."""
+    rot = torch.concat([_uniform(alphamin, alphamax, batch_size, True, generator),
+                        _uniform(betamin, betamax, batch_size, True, generator),
+                        _uniform(gammamin, gammamax, batch_size, True, generator)], dim=1)
+    xyz = torch.concat([_uniform(txmin, txmax, batch_size, generator=generator),
+                        _uniform(tymin, tymax, batch_size, generator=generator),
+                        _uniform(tzmin, tzmax, batch_size, generator=generator)], dim=1)
+    return convert(rot, xyz, parameterization="euler_angles", convention="ZXY", degrees=True)
+
+
+def render_samples(drr, volume, seg, affinv, pose, img_threshold=0.10, mask_threshold=0.05):
+    """-> (img [B,1,H,W], mask [B,C,H,W] bool, keep [B] bool)."""
+    source, target = drr.detector(pose, None)
+    img = (target - source).norm(dim=-1).unsqueeze(1)
+    source, target = affinv(source), affinv(target)
+    img = drr.renderer(volume, source, target, img, mask=seg)
+    img = drr.reshape_transform(img, batch_size=len(pose))
+    mask = img > 0
+    img = img.sum(dim=1, keepdim=True)
+    if mask.shape[1] == 1:
+        keep = mask.to(img).flatten(1).mean(1) > img_threshold
+    else:
+        keep = mask[:, 1:].sum(dim=1, keepdim=True)
+        keep = (keep > 0).to(img).flatten(1).mean(1) > mask_threshold
+    return img, mask, keep
