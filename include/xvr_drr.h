@@ -26,6 +26,7 @@
 #ifndef XVR_DRR_H
 #define XVR_DRR_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -64,6 +65,9 @@ typedef struct xvr_drr_spec {
 int xvr_drr_abi_version(void);
 const char* xvr_drr_last_error(void);
 
+/* Bytes of scratch the backward entry points want for the XCD-private voxel scatter (8 volumes). */
+size_t xvr_drr_backward_workspace_bytes(int D0, int D1, int D2);
+
 /*
  * Trilinear ray-marching forward.  Replaces Trilinear.forward(volume, source, target, img, mask=...).
  *   mask     nullable; float labels, same shape as volume.
@@ -86,12 +90,18 @@ int xvr_drr_trilinear_forward(const float* volume, const float* mask, int D0, in
  *   grad_target  nullable [B][n][3]; written.
  *   grad_raylen  nullable [B][n]; written.
  *   grad_source/grad_target must be both null or both non-null.
+ *   workspace    nullable device scratch of xvr_drr_backward_workspace_bytes() bytes, 16-B aligned.
+ *                With it the voxel scatter runs XCD-privately: each of the 8 XCDs adds into its own
+ *                copy of the gradient volume with atomics that execute in that XCD's L2, and the
+ *                copies are folded into grad_volume afterwards (MI355X has 288 GB; 8 x 512 MiB is
+ *                cheap).  Without it the scatter falls back to memory-side (agent-scope) atomics --
+ *                same result up to float summation order, several times slower.
  */
 int xvr_drr_trilinear_backward(const float* volume, const float* mask, int D0, int D1, int D2, int C,
                                const float* source, const float* target, const float* raylen,
                                int B, int n, const xvr_drr_spec* spec, const float* grad_out,
                                float* grad_volume, float* grad_source, float* grad_target,
-                               float* grad_raylen, void* stream);
+                               float* grad_raylen, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Siddon exact ray tracing, same contract.  Replaces Siddon.forward(volume, source, target, img, mask=...).
  *   work counts voxel segments traversed. */
@@ -104,7 +114,7 @@ int xvr_drr_siddon_backward(const float* volume, const float* mask, int D0, int 
                             const float* source, const float* target, const float* raylen,
                             int B, int n, const xvr_drr_spec* spec, const float* grad_out,
                             float* grad_volume, float* grad_source, float* grad_target,
-                            float* grad_raylen, void* stream);
+                            float* grad_raylen, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * Pose-side backward from the jacobian saved by a forward call (C == 1): an elementwise product

@@ -32,11 +32,12 @@ class CSpec(ctypes.Structure):
 _P = ctypes.c_void_p
 _I = ctypes.c_int
 _FWD = [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, ctypes.POINTER(CSpec), _P, _P, _P, _P]
-_BWD = [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, ctypes.POINTER(CSpec), _P, _P, _P, _P, _P, _P]
+_BWD = [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, ctypes.POINTER(CSpec), _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]
 
 EXPORTS = {
     "xvr_drr_abi_version": ([], ctypes.c_int),
     "xvr_drr_last_error": ([], ctypes.c_char_p),
+    "xvr_drr_backward_workspace_bytes": ([_I, _I, _I], ctypes.c_size_t),
     "xvr_drr_trilinear_forward": (_FWD, ctypes.c_int),
     "xvr_drr_trilinear_backward": (_BWD, ctypes.c_int),
     "xvr_drr_siddon_forward": (_FWD, ctypes.c_int),

@@ -41,6 +41,8 @@ struct RenderArgs {
     unsigned long long* work;
     const float* __restrict__ gout;
     float* gvol;
+    float* gvol_ws;   // XCD-private accumulators [8][nvox] (nullable)
+    long long nvox;
     float* gsrc;
     float* __restrict__ gtgt;
     float* __restrict__ glen;
@@ -74,8 +76,29 @@ __device__ __forceinline__ unsigned wave_sum_u(unsigned v) {
 }
 
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) {
-    // hardware fp32 add at the L2 / memory side (no CAS loop); agent scope so that XCDs agree
+    // hardware fp32 add (no CAS loop); agent scope: the 8 XCD L2s are not coherent with each other,
+    // so this executes at the memory side -- correct from any XCD, but one fabric transaction each.
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The same add executed IN the issuing XCD's L2 (no sc1 bit).  Only legal on memory that no other
+// XCD touches during the launch: the XCD-private accumulator selected by xcc_id() below.
+__device__ __forceinline__ void atomic_add_f32_l2(float* p, float v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// Physical XCD (XCC) this wave runs on, read from the hardware register -- NOT inferred from the
+// block id, so the choice of accumulator is correct under any dispatch order / placement.
+__device__ __forceinline__ unsigned xcc_id() {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 7u;
+}
+
+template <bool L2>
+__device__ __forceinline__ void scatter_add(float* p, float v) {
+    if (L2) atomic_add_f32_l2(p, v);
+    else atomic_add_f32(p, v);
 }
 
 // Blocks are dispatched round-robin over the 8 XCDs (block i -> XCD i % 8, observed, speed only).
@@ -344,7 +367,7 @@ __global__ __launch_bounds__(WG) void k_trilinear_fwd(RenderArgs A) {
 // =============================================================================================
 // trilinear backward by re-marching: pose gradient (GPOSE) and/or voxel gradient (GVOL)
 // =============================================================================================
-template <bool MASK, bool CLIP, bool GPOSE, bool GVOL>
+template <bool MASK, bool CLIP, bool GPOSE, bool GVOL, bool XCDP>
 __global__ __launch_bounds__(WG) void k_trilinear_bwd(RenderArgs A) {
     extern __shared__ float lds[];  // MASK: per-lane upstream gradient per channel [C][WG]
     int b, r;
@@ -369,6 +392,7 @@ __global__ __launch_bounds__(WG) void k_trilinear_bwd(RenderArgs A) {
     } else if (valid) {
         g0 = A.gout[(size_t)b * A.n + r];
     }
+    float* const gv = (GVOL && XCDP) ? A.gvol_ws + (size_t)xcc_id() * (size_t)A.nvox : A.gvol;
     float SV = 0.f;
     float G[3] = {0.f, 0.f, 0.f}, H[3] = {0.f, 0.f, 0.f};
     float E0 = 0.f, E1 = 0.f;
@@ -394,8 +418,8 @@ __global__ __launch_bounds__(WG) void k_trilinear_bwd(RenderArgs A) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float a0 = w[q] * T.pz0, a1 = w[q] * T.pz1;
-                    if (a0 != 0.f) atomic_add_f32(A.gvol + T.base[q], a0);
-                    if (a1 != 0.f) atomic_add_f32(A.gvol + T.base[q] + 1, a1);
+                    if (a0 != 0.f) scatter_add<XCDP>(gv + T.base[q], a0);
+                    if (a1 != 0.f) scatter_add<XCDP>(gv + T.base[q] + 1, a1);
                 }
             }
         }
@@ -503,7 +527,7 @@ __device__ __forceinline__ float sid_alpha(const RenderArgs& A, const Ray& R, co
     return (((float)p + A.sp.plane0[i]) - R.s[i]) * st.inv_d[i];
 }
 
-template <int MODE, bool MASK, bool GPOSE, bool GVOL>
+template <int MODE, bool MASK, bool GPOSE, bool GVOL, bool XCDP>
 __global__ __launch_bounds__(WG) void k_siddon(RenderArgs A) {
     extern __shared__ float lds[];  // MASK: fwd -> channel accumulators, bwd -> upstream gradients
     int b, r;
@@ -525,6 +549,7 @@ __global__ __launch_bounds__(WG) void k_siddon(RenderArgs A) {
         g0 = valid ? A.gout[(size_t)b * A.n + r] : 0.f;
     }
 
+    float* const gv = (MODE == 2 && GVOL && XCDP) ? A.gvol_ws + (size_t)xcc_id() * (size_t)A.nvox : A.gvol;
     const float alo = R.amin, ahi = R.amax;
     bool live = valid && (ahi > alo);
     SidState st;
@@ -571,7 +596,7 @@ __global__ __launch_bounds__(WG) void k_siddon(RenderArgs A) {
             W = gk * v;
             if (GVOL && inb) {
                 const float c = gk * R.L * seg;
-                if (c != 0.f) atomic_add_f32(A.gvol + off, c);
+                if (c != 0.f) scatter_add<XCDP>(gv + off, c);
             }
             acc = fmaf(W, seg, acc);
         } else if (MASK) {
@@ -649,6 +674,28 @@ __global__ __launch_bounds__(WG) void k_siddon(RenderArgs A) {
     }
 }
 
+// gvol[i] += sum over the 8 XCD-private accumulators (streaming, 16 B per lane)
+__global__ __launch_bounds__(WG) void k_reduce_xcd(const float* __restrict__ ws, float* __restrict__ gvol,
+                                                   long long nvox) {
+    const long long n4 = nvox >> 2;
+    const long long stride = (long long)gridDim.x * WG;
+    for (long long i = (long long)blockIdx.x * WG + threadIdx.x; i < n4; i += stride) {
+        float4 acc = reinterpret_cast<const float4*>(gvol)[i];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float4 v = reinterpret_cast<const float4*>(ws + (size_t)c * nvox)[i];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        reinterpret_cast<float4*>(gvol)[i] = acc;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (nvox & 3)) {
+        const long long i = (n4 << 2) + threadIdx.x;
+        float acc = gvol[i];
+        for (int c = 0; c < 8; ++c) acc += ws[(size_t)c * nvox + i];
+        gvol[i] = acc;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -705,9 +752,37 @@ int launch(Kern kern, const RenderArgs& A, size_t lds_bytes, void* stream) {
     return XVR_DRR_OK;
 }
 
+// XCD-private scatter: zero the 8 accumulators, run the scatter kernel, fold them into grad_volume.
+bool use_xcd_private(void* workspace, size_t workspace_bytes, long long nvox) {
+    return workspace && workspace_bytes >= (size_t)8 * (size_t)nvox * sizeof(float) &&
+           (reinterpret_cast<uintptr_t>(workspace) & 15u) == 0 && (nvox & 3) == 0;
+}
+
+int xcd_prepare(RenderArgs& A, void* workspace, void* stream) {
+    A.gvol_ws = static_cast<float*>(workspace);
+    hipError_t e = hipMemsetAsync(workspace, 0, (size_t)8 * (size_t)A.nvox * sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
+    return XVR_DRR_OK;
+}
+
+int xcd_reduce(const RenderArgs& A, void* stream) {
+    const long long n4 = A.nvox >> 2;
+    const unsigned blocks = (unsigned)((n4 + WG - 1) / WG < 8192 ? (n4 + WG - 1) / WG : 8192);
+    hipLaunchKernelGGL(k_reduce_xcd, dim3(blocks ? blocks : 1), dim3(WG), 0, (hipStream_t)stream, A.gvol_ws, A.gvol,
+                       A.nvox);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
+    return XVR_DRR_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+size_t xvr_drr_backward_workspace_bytes(int D0, int D1, int D2) {
+    if (D0 <= 0 || D1 <= 0 || D2 <= 0) return 0;
+    return (size_t)8 * (size_t)D0 * (size_t)D1 * (size_t)D2 * sizeof(float);
+}
 
 int xvr_drr_abi_version(void) { return XVR_DRR_ABI_VERSION; }
 const char* xvr_drr_last_error(void) { return g_err; }
@@ -739,7 +814,8 @@ int xvr_drr_trilinear_forward(const float* volume, const float* mask, int D0, in
 int xvr_drr_trilinear_backward(const float* volume, const float* mask, int D0, int D1, int D2, int C,
                                const float* source, const float* target, const float* raylen, int B, int n,
                                const xvr_drr_spec* sp, const float* grad_out, float* grad_volume,
-                               float* grad_source, float* grad_target, float* grad_raylen, void* stream) {
+                               float* grad_source, float* grad_target, float* grad_raylen, void* workspace,
+                               size_t workspace_bytes, void* stream) {
     int rc = check_common(volume, D0, D1, D2, C, source, target, raylen, B, n, sp);
     if (rc) return rc;
     if (!grad_out) return fail(XVR_DRR_E_ARG, "grad_out is null");
@@ -755,13 +831,20 @@ int xvr_drr_trilinear_backward(const float* volume, const float* mask, int D0, i
     A.gout = grad_out; A.gvol = grad_volume; A.gsrc = grad_source; A.gtgt = grad_target; A.glen = grad_raylen;
     const bool clip = sp->clip_to_volume != 0;
     const size_t lds = mask ? (size_t)C * WG * sizeof(float) : 0;
-#define TRI_BWD(M, CL)                                                                         \
-    (gpose ? (gvol ? launch(k_trilinear_bwd<M, CL, true, true>, A, lds, stream)                \
-                   : launch(k_trilinear_bwd<M, CL, true, false>, A, lds, stream))              \
-           : launch(k_trilinear_bwd<M, CL, false, true>, A, lds, stream))
-    if (mask) return clip ? TRI_BWD(true, true) : TRI_BWD(true, false);
-    return clip ? TRI_BWD(false, true) : TRI_BWD(false, false);
+    A.nvox = (long long)D0 * D1 * D2;
+    const bool xp = gvol && use_xcd_private(workspace, workspace_bytes, A.nvox);
+    if (xp && (rc = xcd_prepare(A, workspace, stream))) return rc;
+#define TRI_BWD3(M, CL, X)                                                                     \
+    (gpose ? (gvol ? launch(k_trilinear_bwd<M, CL, true, true, X>, A, lds, stream)             \
+                   : launch(k_trilinear_bwd<M, CL, true, false, false>, A, lds, stream))       \
+           : launch(k_trilinear_bwd<M, CL, false, true, X>, A, lds, stream))
+#define TRI_BWD(M, CL) (xp ? TRI_BWD3(M, CL, true) : TRI_BWD3(M, CL, false))
+    if (mask) rc = clip ? TRI_BWD(true, true) : TRI_BWD(true, false);
+    else rc = clip ? TRI_BWD(false, true) : TRI_BWD(false, false);
 #undef TRI_BWD
+#undef TRI_BWD3
+    if (rc) return rc;
+    return xp ? xcd_reduce(A, stream) : XVR_DRR_OK;
 }
 
 int xvr_drr_siddon_forward(const float* volume, const float* mask, int D0, int D1, int D2, int C,
@@ -777,15 +860,16 @@ int xvr_drr_siddon_forward(const float* volume, const float* mask, int D0, int D
     fill_args(A, volume, mask, D0, D1, D2, C, source, target, raylen, B, n, sp);
     A.out = out; A.jac = jac; A.work = work;
     const size_t lds = mask ? (size_t)C * WG * sizeof(float) : 0;
-    if (mask) return launch(k_siddon<0, true, false, false>, A, lds, stream);
-    if (jac) return launch(k_siddon<1, false, false, false>, A, 0, stream);
-    return launch(k_siddon<0, false, false, false>, A, 0, stream);
+    if (mask) return launch(k_siddon<0, true, false, false, false>, A, lds, stream);
+    if (jac) return launch(k_siddon<1, false, false, false, false>, A, 0, stream);
+    return launch(k_siddon<0, false, false, false, false>, A, 0, stream);
 }
 
 int xvr_drr_siddon_backward(const float* volume, const float* mask, int D0, int D1, int D2, int C,
                             const float* source, const float* target, const float* raylen, int B, int n,
                             const xvr_drr_spec* sp, const float* grad_out, float* grad_volume,
-                            float* grad_source, float* grad_target, float* grad_raylen, void* stream) {
+                            float* grad_source, float* grad_target, float* grad_raylen, void* workspace,
+                            size_t workspace_bytes, void* stream) {
     int rc = check_common(volume, D0, D1, D2, C, source, target, raylen, B, n, sp);
     if (rc) return rc;
     if (!grad_out) return fail(XVR_DRR_E_ARG, "grad_out is null");
@@ -799,12 +883,19 @@ int xvr_drr_siddon_backward(const float* volume, const float* mask, int D0, int 
     fill_args(A, volume, mask, D0, D1, D2, C, source, target, raylen, B, n, sp);
     A.gout = grad_out; A.gvol = grad_volume; A.gsrc = grad_source; A.gtgt = grad_target; A.glen = grad_raylen;
     const size_t lds = mask ? (size_t)C * WG * sizeof(float) : 0;
-#define SID_BWD(M)                                                                      \
-    (gpose ? (gvol ? launch(k_siddon<2, M, true, true>, A, lds, stream)                 \
-                   : launch(k_siddon<2, M, true, false>, A, lds, stream))               \
-           : launch(k_siddon<2, M, false, true>, A, lds, stream))
-    return mask ? SID_BWD(true) : SID_BWD(false);
+    A.nvox = (long long)D0 * D1 * D2;
+    const bool xp = gvol && use_xcd_private(workspace, workspace_bytes, A.nvox);
+    if (xp && (rc = xcd_prepare(A, workspace, stream))) return rc;
+#define SID_BWD3(M, X)                                                                  \
+    (gpose ? (gvol ? launch(k_siddon<2, M, true, true, X>, A, lds, stream)              \
+                   : launch(k_siddon<2, M, true, false, false>, A, lds, stream))        \
+           : launch(k_siddon<2, M, false, true, X>, A, lds, stream))
+#define SID_BWD(M) (xp ? SID_BWD3(M, true) : SID_BWD3(M, false))
+    rc = mask ? SID_BWD(true) : SID_BWD(false);
 #undef SID_BWD
+#undef SID_BWD3
+    if (rc) return rc;
+    return xp ? xcd_reduce(A, stream) : XVR_DRR_OK;
 }
 
 int xvr_drr_backward_from_jac(const float* jac, const float* grad_out, int B, int n, float* grad_source,

@@ -79,6 +79,24 @@ def _check_gpu_f32(name, t):
         raise TypeError(f"{name} must be float32 (got {t.dtype}); xvr casts the DRR module to float32")
 
 
+# Scratch for the XCD-private voxel scatter (8 gradient volumes), one per (device, shape), reused across
+# calls on the same stream; set XCD_PRIVATE_SCATTER = False to force the memory-side atomics path.
+XCD_PRIVATE_SCATTER = True
+_WORKSPACES = {}
+
+
+def _workspace(lib, shape, device):
+    if not XCD_PRIVATE_SCATTER:
+        return None, 0
+    nbytes = lib.xvr_drr_backward_workspace_bytes(*shape)
+    key = (device, nbytes)
+    ws = _WORKSPACES.get(key)
+    if ws is None:
+        _WORKSPACES.clear()  # keep at most one (a new volume shape replaces the old scratch)
+        ws = _WORKSPACES[key] = torch.empty(nbytes // 4, device=device, dtype=torch.float32)
+    return ws, nbytes
+
+
 class _Render(torch.autograd.Function):
     """forward: one fused sweep (with the per-ray jacobian when a pose gradient may be needed);
     backward: elementwise-from-jacobian for the pose, a re-march with scatter for the voxels."""
@@ -134,12 +152,13 @@ class _Render(torch.autograd.Function):
             cs = make_cspec((D0, D1, D2), spec, ctx.ray_grid_w)
             fn = lib.xvr_drr_trilinear_backward if spec.renderer == "trilinear" else lib.xvr_drr_siddon_backward
             pose_here = need_pose and not from_jac
+            ws, ws_bytes = (_workspace(lib, (D0, D1, D2), dev) if need_vol else (None, 0))
             tag = ("pose" if pose_here else "") + ("+vol" if need_vol else "")
             rc = _timed(f"{spec.renderer}_backward[{tag.strip('+')}]", fn,
                         _ptr(vol_c), _ptr(msk_c), D0, D1, D2, C, _ptr(src_c), _ptr(tgt_c), _ptr(len_c), B, n,
                         ctypes.byref(cs), _ptr(gout), _ptr(gvol),
                         _ptr(gsrc) if pose_here else None, _ptr(gtgt) if pose_here else None,
-                        _ptr(glen) if pose_here else None, _stream())
+                        _ptr(glen) if pose_here else None, _ptr(ws), ws_bytes, _stream())
             _lib.check(rc, f"xvr_drr_{spec.renderer}_backward")
         g_source = gsrc.reshape(ctx.src_shape) if need_pose and ctx.needs_input_grad[1] else None
         g_target = gtgt if need_pose and ctx.needs_input_grad[2] else None
