@@ -65,8 +65,8 @@ typedef struct xvr_drr_spec {
 int xvr_drr_abi_version(void);
 const char* xvr_drr_last_error(void);
 
-/* Bytes of scratch the backward entry points want for the XCD-private voxel scatter (8 volumes). */
-size_t xvr_drr_backward_workspace_bytes(int D0, int D1, int D2);
+/* Bytes of device scratch the backward entry points can use (see `workspace` below). */
+size_t xvr_drr_backward_workspace_bytes(int B, int n, int D0, int D1, int D2);
 
 /*
  * Trilinear ray-marching forward.  Replaces Trilinear.forward(volume, source, target, img, mask=...).
@@ -90,12 +90,12 @@ int xvr_drr_trilinear_forward(const float* volume, const float* mask, int D0, in
  *   grad_target  nullable [B][n][3]; written.
  *   grad_raylen  nullable [B][n]; written.
  *   grad_source/grad_target must be both null or both non-null.
- *   workspace    nullable device scratch of xvr_drr_backward_workspace_bytes() bytes, 16-B aligned.
- *                With it the voxel scatter runs XCD-privately: each of the 8 XCDs adds into its own
- *                copy of the gradient volume with atomics that execute in that XCD's L2, and the
- *                copies are folded into grad_volume afterwards (MI355X has 288 GB; 8 x 512 MiB is
- *                cheap).  Without it the scatter falls back to memory-side (agent-scope) atomics --
- *                same result up to float summation order, several times slower.
+ *   workspace    nullable device scratch of xvr_drr_backward_workspace_bytes(B, n, D0, D1, D2) bytes, 16-B aligned.
+ *                With it, and when the rays are a detector lattice (spec.ray_grid_w > 1, no mask, no
+ *                clip_to_volume), grad_volume is computed by an atomic-free voxel-driven gather (the
+ *                exact transpose of the forward, deterministic).  Otherwise -- or when the kernel finds
+ *                on the device that the targets are not a lattice -- it falls back to a scatter with
+ *                fp32 atomics: same result up to summation order, an order of magnitude slower on MI355X.
  */
 int xvr_drr_trilinear_backward(const float* volume, const float* mask, int D0, int D1, int D2, int C,
                                const float* source, const float* target, const float* raylen,

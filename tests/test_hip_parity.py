@@ -121,28 +121,65 @@ def test_backward_matches_oracle_autograd(kw, masked):
         _close(h, r, FWD_TOL if name == "out" else GRAD_TOL, name)
 
 
-@pytest.mark.parametrize("renderer", ["trilinear", "siddon"])
-@pytest.mark.parametrize("shape", [(20, 24, 28), (9, 11, 13)], ids=["nvox%4==0", "odd-nvox"])
-def test_xcd_private_scatter_equals_memory_side_atomics(renderer, shape):
-    """grad_volume through the XCD-private accumulators (L2-scope atomics + 8-way fold) must equal
-    the agent-scope fallback, and both must match the oracle.  (An odd voxel count forces the
-    fallback inside the library even when a workspace is offered.)"""
+@pytest.mark.parametrize("kw", [
+    dict(n_points=70), dict(n_points=33, voxel_shift=0.0, step_mode="n_minus_1"),
+    dict(n_points=50, norm_dims_offset=-1), dict(n_points=40, near=0.2, far=0.9), dict(n_points=1),
+], ids=_id)
+@pytest.mark.parametrize("hw", [(24, 24), (17, 33), (2, 2)])
+def test_voxel_gather_equals_atomic_scatter_and_oracle(kw, hw):
+    """grad_volume by the atomic-free voxel-driven gather must equal the atomic scatter fallback
+    (same weights, different summation order) and match autograd through the oracle."""
     from xvr_amd import renderers
     from xvr_amd.spec import RenderSpec
 
-    spec = RenderSpec(renderer=renderer, n_points=70)
-    case = make_case(seed=17, shape=shape, height=24, width=24, delx=1.5)
-    w = torch.rand(2, 1, 24 * 24, generator=torch.Generator().manual_seed(5))
+    spec = RenderSpec(renderer="trilinear", **kw)
+    case = make_case(seed=17, shape=(20, 24, 28), height=hw[0], width=hw[1], delx=1.5 * 24 / max(hw))
+    w = torch.rand(2, 1, hw[0] * hw[1], generator=torch.Generator().manual_seed(5))
     grads = []
     for flag in (True, False):
-        renderers.XCD_PRIVATE_SCATTER = flag
+        renderers.VOXEL_GATHER = flag
         try:
-            grads.append(_hip_render(case, spec, grid_w=24, grads=True, w=w)[1])
+            grads.append(_hip_render(case, spec, grid_w=hw[1], grads=True, w=w)[1])
         finally:
-            renderers.XCD_PRIVATE_SCATTER = True
+            renderers.VOXEL_GATHER = True
     ref = _oracle_render(case, spec, grads=True, w=w)[1]
-    _close(grads[0], grads[1], 1e-5, "xcd-private vs agent-scope")
-    _close(grads[0], ref, GRAD_TOL, "xcd-private vs oracle")
+    _close(grads[0], grads[1], 2e-5, "gather vs scatter")
+    _close(grads[0], ref, GRAD_TOL, "gather vs oracle")
+
+
+def test_voxel_gather_declines_non_lattice_rays_on_device():
+    """Targets that are not a planar lattice (here: shuffled) must take the scatter fallback, decided
+    on the device, and still give the right gradient."""
+    from xvr_amd.spec import RenderSpec
+
+    spec = RenderSpec(renderer="trilinear", n_points=60)
+    case = make_case(seed=18, height=16, width=16, delx=2.0)
+    perm = torch.randperm(256, generator=torch.Generator().manual_seed(1))
+    case["target"] = case["target"][:, perm].contiguous()
+    case["img"] = case["img"][..., perm].contiguous()
+    w = torch.rand(2, 1, 256, generator=torch.Generator().manual_seed(6))
+    hip = _hip_render(case, spec, grid_w=16, grads=True, w=w)
+    ref = _oracle_render(case, spec, grads=True, w=w)
+    _close(hip[1], ref[1], GRAD_TOL, "grad_volume on shuffled rays")
+
+
+def test_voxel_gather_with_source_inside_the_volume():
+    """alpha_0 = 0 puts sample 0 of EVERY ray on the source: the gather must credit all of them."""
+    from xvr_amd.renderers import render
+    from xvr_amd.spec import RenderSpec
+
+    spec = RenderSpec(renderer="trilinear", n_points=30)
+    vol = torch.rand(12, 12, 12)
+    src = torch.tensor([[[5.3, 6.2, 4.9]]])
+    ii, jj = torch.meshgrid(torch.arange(6.0), torch.arange(5.0), indexing="ij")
+    tgt = (torch.tensor([40.0, -3.0, -2.0]) + ii[..., None] * torch.tensor([0.0, 2.0, 0.3]) + jj[..., None] * torch.tensor([0.0, -0.2, 2.5])).reshape(1, 30, 3)
+    img = (tgt - src).norm(dim=-1).unsqueeze(1)
+    case = dict(volume=vol, source=src, target=tgt, img=img)
+    w = torch.rand(1, 1, 30, generator=torch.Generator().manual_seed(7))
+    hip = _hip_render(case, spec, grid_w=5, grads=True, w=w)
+    ref = _oracle_render(case, spec, grads=True, w=w)
+    _close(hip[0], ref[0], FWD_TOL, "out")
+    _close(hip[1], ref[1], GRAD_TOL, "grad_volume")
 
 
 @pytest.mark.parametrize("renderer", ["trilinear", "siddon"])
@@ -356,18 +393,27 @@ def test_full_size_linearity_adjoint_and_oracle_spot_check(renderer):
 
 def test_full_size_pose_gradient_matches_finite_differences():
     """d loss / d (rot, xyz) through DRR.forward at 512^3 -> 256^2, vs central differences of the
-    HIP forward itself (size-independent check of the fused jacobian + the pose chain)."""
+    HIP forward itself (size-independent check of the fused jacobian + the pose chain).  Finite
+    differences need a smooth problem, so the volume is a sum of wide Gaussians and the image weights
+    are smooth; the loss is summed in float64 (fp32 summation noise would be amplified by 1/(2h))."""
+    from xvr_amd.data import read
+    from xvr_amd.drr import DRR
     from xvr_amd.pose import convert
 
-    vol, drrs, _ = _full_size_setup()
-    drr = drrs["trilinear"]
-    w = torch.rand(1, 1, 256, 256, device="cuda")
+    ax = torch.arange(512, dtype=torch.float32, device="cuda")
+    vol = torch.zeros(512, 512, 512, device="cuda")
+    for cx, cy, cz, sg, rho in ((200.0, 260.0, 250.0, 60.0, 1.0), (330.0, 220.0, 300.0, 45.0, 0.7), (256.0, 300.0, 180.0, 80.0, 0.5)):
+        vol += rho * (torch.exp(-((ax - cx) / sg) ** 2)[:, None, None] * torch.exp(-((ax - cy) / sg) ** 2)[None, :, None]
+                      * torch.exp(-((ax - cz) / sg) ** 2)[None, None, :])
+    drr = DRR(read(vol.cpu(), orientation="AP"), 1020.0, 256, 1.08821875, renderer="trilinear", reverse_x_axis=False).cuda()
+    u = torch.linspace(0, 1, 256, device="cuda", dtype=torch.float64)
+    w = (0.6 + 0.4 * torch.cos(3.0 * u))[:, None] * (0.5 + 0.5 * torch.sin(2.0 * u + 0.3))[None, :]
     rot0 = torch.tensor([[3.05, 0.1, -0.05]], device="cuda")
     xyz0 = torch.tensor([[10.0, 720.0, -15.0]], device="cuda")
 
     def loss(rot, xyz):
         pose = convert(rot, xyz, parameterization="euler_angles", convention="ZXY")
-        return (drr(pose) * w).sum()
+        return (drr(pose).double() * w).sum()
 
     rot, xyz = rot0.clone().requires_grad_(True), xyz0.clone().requires_grad_(True)
     loss(rot, xyz).backward()
@@ -379,10 +425,7 @@ def test_full_size_pose_gradient_matches_finite_differences():
                 fd = (loss(rot0 + e, xyz0) - loss(rot0 - e, xyz0)).item() / (2 * h)
             else:
                 fd = (loss(rot0, xyz0 + e) - loss(rot0, xyz0 - e)).item() / (2 * h)
-            # the render is only piecewise smooth in the pose (trilinear kinks, rays entering/leaving):
-            # central differences agree with the analytic gradient to ~1 % of the gradient's scale
-            scale = max(abs(fd), abs(g).max().item() if p is rot0 else abs(g).max().item())
-            assert abs(g[0, i].item() - fd) <= 0.02 * scale, (i, g[0, i].item(), fd)
+            assert abs(g[0, i].item() - fd) <= 0.01 * max(abs(fd), 0.05 * abs(g).max().item()), (i, g[0, i].item(), fd)
 
 
 # ----------------------------------------------------------------------------------------------

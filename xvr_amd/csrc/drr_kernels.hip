@@ -24,6 +24,11 @@ namespace {
 
 constexpr int WG = 256;  // 4 wavefronts
 
+// voxel-driven gather (see k_trilinear_gather_vol)
+constexpr float GATHER_DEV_TOL = 0.02f;     // max lattice deviation, in units of the pixel pitch
+constexpr float GATHER_WIN_MARGIN = 0.05f;  // extra half-width (pixels) of the candidate window
+constexpr float GATHER_K_SLACK = 1e-3f;
+
 thread_local char g_err[512] = "";
 
 struct RenderArgs {
@@ -41,8 +46,7 @@ struct RenderArgs {
     unsigned long long* work;
     const float* __restrict__ gout;
     float* gvol;
-    float* gvol_ws;   // XCD-private accumulators [8][nvox] (nullable)
-    long long nvox;
+    const unsigned* skip_unless_flag_gt;  // nullable: run the scatter only if *flag > GATHER_DEV_TOL
     float* gsrc;
     float* __restrict__ gtgt;
     float* __restrict__ glen;
@@ -76,29 +80,8 @@ __device__ __forceinline__ unsigned wave_sum_u(unsigned v) {
 }
 
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) {
-    // hardware fp32 add (no CAS loop); agent scope: the 8 XCD L2s are not coherent with each other,
-    // so this executes at the memory side -- correct from any XCD, but one fabric transaction each.
+    // hardware fp32 add at the L2 / memory side (no CAS loop); agent scope so that XCDs agree
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// The same add executed IN the issuing XCD's L2 (no sc1 bit).  Only legal on memory that no other
-// XCD touches during the launch: the XCD-private accumulator selected by xcc_id() below.
-__device__ __forceinline__ void atomic_add_f32_l2(float* p, float v) {
-    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
-// Physical XCD (XCC) this wave runs on, read from the hardware register -- NOT inferred from the
-// block id, so the choice of accumulator is correct under any dispatch order / placement.
-__device__ __forceinline__ unsigned xcc_id() {
-    unsigned v;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
-    return v & 7u;
-}
-
-template <bool L2>
-__device__ __forceinline__ void scatter_add(float* p, float v) {
-    if (L2) atomic_add_f32_l2(p, v);
-    else atomic_add_f32(p, v);
 }
 
 // Blocks are dispatched round-robin over the 8 XCDs (block i -> XCD i % 8, observed, speed only).
@@ -367,9 +350,11 @@ __global__ __launch_bounds__(WG) void k_trilinear_fwd(RenderArgs A) {
 // =============================================================================================
 // trilinear backward by re-marching: pose gradient (GPOSE) and/or voxel gradient (GVOL)
 // =============================================================================================
-template <bool MASK, bool CLIP, bool GPOSE, bool GVOL, bool XCDP>
+template <bool MASK, bool CLIP, bool GPOSE, bool GVOL>
 __global__ __launch_bounds__(WG) void k_trilinear_bwd(RenderArgs A) {
     extern __shared__ float lds[];  // MASK: per-lane upstream gradient per channel [C][WG]
+    // fallback role: when a gather launch precedes this one, run only if it declined (rays not a lattice)
+    if (A.skip_unless_flag_gt && !(*A.skip_unless_flag_gt > __float_as_uint(GATHER_DEV_TOL))) return;
     int b, r;
     const bool valid = map_ray(A, b, r);
     const int tid = threadIdx.x;
@@ -392,7 +377,6 @@ __global__ __launch_bounds__(WG) void k_trilinear_bwd(RenderArgs A) {
     } else if (valid) {
         g0 = A.gout[(size_t)b * A.n + r];
     }
-    float* const gv = (GVOL && XCDP) ? A.gvol_ws + (size_t)xcc_id() * (size_t)A.nvox : A.gvol;
     float SV = 0.f;
     float G[3] = {0.f, 0.f, 0.f}, H[3] = {0.f, 0.f, 0.f};
     float E0 = 0.f, E1 = 0.f;
@@ -418,8 +402,8 @@ __global__ __launch_bounds__(WG) void k_trilinear_bwd(RenderArgs A) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float a0 = w[q] * T.pz0, a1 = w[q] * T.pz1;
-                    if (a0 != 0.f) scatter_add<XCDP>(gv + T.base[q], a0);
-                    if (a1 != 0.f) scatter_add<XCDP>(gv + T.base[q] + 1, a1);
+                    if (a0 != 0.f) atomic_add_f32(A.gvol + T.base[q], a0);
+                    if (a1 != 0.f) atomic_add_f32(A.gvol + T.base[q] + 1, a1);
                 }
             }
         }
@@ -484,6 +468,296 @@ __global__ __launch_bounds__(WG) void k_trilinear_bwd(RenderArgs A) {
     }
 }
 
+
+// =============================================================================================
+// Voxel gradient of the trilinear renderer WITHOUT atomics: a voxel-driven exact adjoint.
+//
+// fp32 atomics are the wrong tool on this chip (measured, profiles/r01_microbench_atomics.txt:
+// ~20 G scattered global atomic line-ops/s whatever the scope, ~190 G/s for LDS ds_add_f32
+// chip-wide), and the scatter has 8 of them per sample.  Instead one thread OWNS one voxel v and
+// gathers every sample that touches it.  Because a pose's rays end on a planar H x W lattice and all
+// rays share alpha_k, the samples of step k form a planar patch, so the few (pixel, step) pairs whose
+// sample lies inside v's unit box are found by projecting v onto the detector:
+//     alpha_v = n.(x_v - s)/h,  pixel (i*, j*) = G.(s + (x_v - s)/alpha_k - T00)
+// with a conservative window around (k*, i*, j*).  Each candidate's sample position is recomputed
+// with the SAME fmaf sequence as the forward from the SAME target array, so its weight
+// prod(1 - |p - v|) is bit-identical to the forward's interpolation weight: this is the exact
+// transpose of the forward gather, up to summation order -- and it is deterministic.
+// =============================================================================================
+
+struct PoseLattice {  // per pose, 32 floats
+    float s[3], dalpha;    // source; half-range of alpha over a voxel's unit box
+    float nh[3], nh_norm;  // alpha_v = nh . (x_v - s)
+    float gc[3], gc0;      // column  j* = gc0 + (gc . w) / alpha
+    float gr[3], gr0;      // row     i* = gr0 + (gr . w) / alpha
+    float hwc, hwr, gc_norm, gr_norm;  // window half-widths (pixels) at alpha = 1; |gc|, |gr|
+    float st[3], pad0;     // T00 + eps - s
+    float ec[3], pad1;     // lattice step per column
+    float er[3], pad2;     // lattice step per row
+};
+
+struct GatherArgs {
+    const float* __restrict__ source;
+    const float* __restrict__ target;
+    const float* __restrict__ raylen;
+    const float* __restrict__ gout;
+    int B, n, W, H;
+    int D0, D1, D2;
+    xvr_drr_spec sp;
+    unsigned* flag;          // max lattice deviation (float bits), written by k_gather_prep
+    PoseLattice* poses;
+    float4* q;               // [B][n] = (target.xyz, gout * raylen * inv_denom)
+    unsigned* cull;          // [bricks][words] bit p set = pose p can touch the brick
+    int words;               // ceil(B / 32)
+    float* gvol;
+};
+
+__device__ __forceinline__ void cross3(const float* a, const float* b, float* o) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+__device__ __forceinline__ float dot3(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+// one block per (pose, 256 rays): packs q, measures how far the targets are from an exact lattice,
+// and (block 0 of each pose) derives the pose's projection constants.
+__global__ __launch_bounds__(WG) void k_gather_prep(GatherArgs G) {
+    const int b = blockIdx.y;
+    const int r = blockIdx.x * WG + threadIdx.x;
+    const float* T = G.target + (size_t)b * G.n * 3;
+    float t00[3], ec[3], er[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        t00[i] = T[i];
+        ec[i] = (T[(size_t)(G.W - 1) * 3 + i] - t00[i]) / (float)(G.W - 1);
+        er[i] = (T[(size_t)(G.H - 1) * G.W * 3 + i] - t00[i]) / (float)(G.H - 1);
+    }
+    const float pitch = fminf(sqrtf(dot3(ec, ec)), sqrtf(dot3(er, er)));
+    float dev = 0.f;
+    if (r < G.n) {
+        const int i = r / G.W, j = r - i * G.W;
+        const float tx = T[(size_t)r * 3], ty = T[(size_t)r * 3 + 1], tz = T[(size_t)r * 3 + 2];
+        dev = fmaxf(fabsf(tx - (t00[0] + j * ec[0] + i * er[0])),
+                    fmaxf(fabsf(ty - (t00[1] + j * ec[1] + i * er[1])), fabsf(tz - (t00[2] + j * ec[2] + i * er[2]))));
+        dev = pitch > 0.f ? dev / pitch : INFINITY;
+        if (!(dev == dev)) dev = INFINITY;
+        const float c = G.gout[(size_t)b * G.n + r] * G.raylen[(size_t)b * G.n + r] * G.sp.inv_denom;
+        G.q[(size_t)b * G.n + r] = make_float4(tx, ty, tz, c);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dev = fmaxf(dev, __shfl_xor(dev, o));
+    if ((threadIdx.x & 63) == 0 && dev > 0.f) atomicMax(G.flag, __float_as_uint(dev));
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        PoseLattice P = {};
+        float s[3], nrm[3], st[3], ts[3], tmp[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            s[i] = G.source[3 * b + i];
+            ts[i] = (t00[i] + G.sp.eps) - s[i];  // T00e - s
+            st[i] = -ts[i];
+        }
+        cross3(ec, er, nrm);
+        const float h = dot3(nrm, ts);  // n . (T00 - s)
+        cross3(er, nrm, tmp);
+        const float dc = dot3(ec, tmp);
+        float gc[3] = {tmp[0] / dc, tmp[1] / dc, tmp[2] / dc};
+        cross3(nrm, ec, tmp);
+        const float dr = dot3(er, tmp);
+        float gr[3] = {tmp[0] / dr, tmp[1] / dr, tmp[2] / dr};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            P.s[i] = s[i];
+            P.nh[i] = nrm[i] / h;
+            P.gc[i] = gc[i];
+            P.gr[i] = gr[i];
+            P.st[i] = ts[i];
+            P.ec[i] = ec[i];
+            P.er[i] = er[i];
+            P.dalpha += fabsf(P.nh[i]) / G.sp.a[i];
+            P.hwc += fabsf(gc[i]) / G.sp.a[i];
+            P.hwr += fabsf(gr[i]) / G.sp.a[i];
+        }
+        P.nh_norm = sqrtf(dot3(P.nh, P.nh));
+        P.gc_norm = sqrtf(dot3(gc, gc));
+        P.gr_norm = sqrtf(dot3(gr, gr));
+        P.gc0 = dot3(gc, st);
+        P.gr0 = dot3(gr, st);
+        const float chk = P.dalpha + P.hwc + P.hwr + P.gc0 + P.gr0;
+        if (!(chk == chk) || !(fabsf(chk) < 1e30f) || h == 0.f) atomicMax(G.flag, __float_as_uint(INFINITY));
+        G.poses[b] = P;
+    }
+}
+
+// bricks of 4 x 8 x 8 voxels (x, y, z): one workgroup of the gather kernel each
+__device__ __forceinline__ void brick_coords(int blk, int D1, int D2, int& bx, int& by, int& bz) {
+    const int nz = (D2 + 7) >> 3, ny = (D1 + 7) >> 3;
+    bz = blk % nz; blk /= nz;
+    by = blk % ny; bx = blk / ny;
+}
+
+// one thread per (brick, pose): can any sample of the pose fall inside the brick grown by one voxel?
+// (bounding sphere against the pose's sample pyramid, conservative).  32 poses per word.
+__global__ __launch_bounds__(WG) void k_gather_cull(GatherArgs G, int nbricks) {
+    const int brick = blockIdx.x * (WG / 32) + (threadIdx.x >> 5);
+    const int lane = threadIdx.x & 31;
+    if (brick >= nbricks) return;
+    int bx, by, bz;
+    brick_coords(brick, G.D1, G.D2, bx, by, bz);
+    const float c[3] = {bx * 4 + 1.5f, by * 8 + 3.5f, bz * 8 + 3.5f};
+    // half extents (2,4,4) + 0.5 (voxel centres -> faces) + 1 (interpolation support), in x units
+    const float hx = 3.f / G.sp.a[0], hy = 5.f / G.sp.a[1], hz = 5.f / G.sp.a[2];
+    const float R = sqrtf(hx * hx + hy * hy + hz * hz);
+    for (int wd = 0; wd < G.words; ++wd) {
+        const int p = wd * 32 + lane;
+        bool hit = false;
+        if (p < G.B) {
+            const PoseLattice& P = G.poses[p];
+            float w[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) w[i] = (c[i] - G.sp.b[i]) / G.sp.a[i] - P.s[i];
+            const float av = dot3(P.nh, w), da = R * P.nh_norm;
+            const float amin = av - da, amax = av + da;
+            if (amax >= G.sp.near_ && amin <= G.sp.far_) {
+                if (amin <= 1e-6f) {
+                    hit = true;  // the sphere reaches the source plane: no perspective bound, keep
+                } else {
+                    const float inv = 1.f / av;
+                    const float jc = fmaf(dot3(P.gc, w), inv, P.gc0), ic = fmaf(dot3(P.gr, w), inv, P.gr0);
+                    // a point of the sphere moves the pixel by at most R |g| / alpha (lateral) plus the
+                    // centre's own shift |j - gc0| * da / alpha (depth), with alpha >= amin
+                    const float ia = 1.f / amin;
+                    const float rj = (R * P.gc_norm + fabsf(jc - P.gc0) * da) * ia + 1.f;
+                    const float ri = (R * P.gr_norm + fabsf(ic - P.gr0) * da) * ia + 1.f;
+                    hit = jc + rj >= 0.f && jc - rj <= (float)(G.W - 1) && ic + ri >= 0.f && ic - ri <= (float)(G.H - 1);
+                }
+            }
+        }
+        const unsigned long long m = __ballot(hit);
+        const unsigned bits = (threadIdx.x & 32) ? (unsigned)(m >> 32) : (unsigned)m;
+        if (lane == 0) G.cull[(size_t)brick * G.words + wd] = bits;
+    }
+}
+
+// one thread = one voxel; a workgroup = a 4 x 8 x 8 brick (x, y, z), so its candidates share pixels
+__global__ __launch_bounds__(WG) void k_trilinear_gather_vol(GatherArgs G) {
+    if (*G.flag > __float_as_uint(GATHER_DEV_TOL)) return;  // not a lattice: the scatter kernel runs instead
+    int bx, by, bz;
+    brick_coords(blockIdx.x, G.D1, G.D2, bx, by, bz);
+    const int tid = threadIdx.x;
+    const int vx = bx * 4 + (tid >> 6), vy = by * 8 + ((tid >> 3) & 7), vz = bz * 8 + (tid & 7);
+    const bool inb = vx < G.D0 && vy < G.D1 && vz < G.D2;
+    const float fv[3] = {(float)vx, (float)vy, (float)vz};
+    float xv[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) xv[i] = (fv[i] - G.sp.b[i]) / G.sp.a[i];
+    const int N = G.sp.n_points;
+    const float near_ = G.sp.near_, far_ = G.sp.far_;
+    const float step = N > 1 ? (far_ - near_) / (float)(N - 1) : 0.f;
+    const float inv_step = step > 0.f ? 1.f / step : 0.f;
+    const float eps = G.sp.eps;
+    const float a0 = G.sp.a[0], a1 = G.sp.a[1], a2 = G.sp.a[2];
+    const float b0 = G.sp.b[0], b1 = G.sp.b[1], b2 = G.sp.b[2];
+    const float jmargin = GATHER_DEV_TOL + 0.01f;
+    float acc = 0.f;
+
+    for (int wd = 0; wd < G.words; ++wd) {
+        unsigned bits = G.cull[(size_t)blockIdx.x * G.words + wd];  // uniform: scalar load
+        while (bits) {
+            const int p = wd * 32 + __builtin_ctz(bits);
+            bits &= bits - 1;
+            const PoseLattice& P = G.poses[p];
+            const float s0 = P.s[0], s1 = P.s[1], s2 = P.s[2];
+            const float w0 = xv[0] - s0, w1 = xv[1] - s1, w2 = xv[2] - s2;
+            const float av = P.nh[0] * w0 + P.nh[1] * w1 + P.nh[2] * w2;
+            int klo, khi;
+            if (step > 0.f) {
+                const float k0 = (av - P.dalpha - near_) * inv_step, k1 = (av + P.dalpha - near_) * inv_step;
+                klo = (int)ceilf(fmaxf(k0 - GATHER_K_SLACK, 0.f));
+                khi = (int)floorf(fminf(k1 + GATHER_K_SLACK, (float)(N - 1)));
+            } else {
+                klo = 0;
+                khi = (fabsf(av - near_) <= P.dalpha) ? 0 : -1;
+            }
+            if (!inb || !(av == av)) khi = -1;
+            const float grw = P.gr[0] * w0 + P.gr[1] * w1 + P.gr[2] * w2;
+            const float4* __restrict__ q = G.q + (size_t)p * G.n;
+            for (int k = klo; k <= khi; ++k) {
+                const float al = linspace_at(k, N, near_, far_, step);
+                if (al > 1e-12f) {
+                    const float inv = 1.f / al;
+                    const float ic = fmaf(grw, inv, P.gr0);
+                    const float hi = fmaf(P.hwr, inv, GATHER_WIN_MARGIN);
+                    const int ilo = (int)ceilf(fmaxf(ic - hi, 0.f));
+                    const int ihi = (int)floorf(fminf(ic + hi, (float)(G.H - 1)));
+                    // lattice model of the sample positions relative to v: Q0 + i Ur + j Uc (index space).
+                    // Used ONLY to find which pixels to visit; weights come from the real targets below.
+                    const float ucx = al * a0 * P.ec[0], ucy = al * a1 * P.ec[1], ucz = al * a2 * P.ec[2];
+                    const float urx = al * a0 * P.er[0], ury = al * a1 * P.er[1], urz = al * a2 * P.er[2];
+                    const float q0x = fmaf(a0, fmaf(al, P.st[0], s0), b0) - fv[0];
+                    const float q0y = fmaf(a1, fmaf(al, P.st[1], s1), b1) - fv[1];
+                    const float q0z = fmaf(a2, fmaf(al, P.st[2], s2), b2) - fv[2];
+                    const float rx = 1.f / ucx, ry = 1.f / ucy, rz = 1.f / ucz;
+                    const bool dx = fabsf(ucx) < 1e-9f, dy = fabsf(ucy) < 1e-9f, dz = fabsf(ucz) < 1e-9f;
+                    for (int i = ilo; i <= ihi; ++i) {
+                        const float fi = (float)i;
+                        const float qx = fmaf(fi, urx, q0x), qy = fmaf(fi, ury, q0y), qz = fmaf(fi, urz, q0z);
+                        // exact j-interval on this row where |q + j Uc| < 1 on all three axes
+                        float lo = -INFINITY, hiJ = INFINITY;
+                        {
+                            const float t0 = (-1.f - qx) * rx, t1 = (1.f - qx) * rx;
+                            const float l = dx ? (fabsf(qx) < 1.f ? -INFINITY : INFINITY) : fminf(t0, t1);
+                            const float h = dx ? (fabsf(qx) < 1.f ? INFINITY : -INFINITY) : fmaxf(t0, t1);
+                            lo = fmaxf(lo, l); hiJ = fminf(hiJ, h);
+                        }
+                        {
+                            const float t0 = (-1.f - qy) * ry, t1 = (1.f - qy) * ry;
+                            const float l = dy ? (fabsf(qy) < 1.f ? -INFINITY : INFINITY) : fminf(t0, t1);
+                            const float h = dy ? (fabsf(qy) < 1.f ? INFINITY : -INFINITY) : fmaxf(t0, t1);
+                            lo = fmaxf(lo, l); hiJ = fminf(hiJ, h);
+                        }
+                        {
+                            const float t0 = (-1.f - qz) * rz, t1 = (1.f - qz) * rz;
+                            const float l = dz ? (fabsf(qz) < 1.f ? -INFINITY : INFINITY) : fminf(t0, t1);
+                            const float h = dz ? (fabsf(qz) < 1.f ? INFINITY : -INFINITY) : fmaxf(t0, t1);
+                            lo = fmaxf(lo, l); hiJ = fminf(hiJ, h);
+                        }
+                        const int jlo = (int)ceilf(fmaxf(lo - jmargin, 0.f));
+                        const int jhi = (int)floorf(fminf(hiJ + jmargin, (float)(G.W - 1)));
+                        const float4* __restrict__ row = q + (size_t)i * G.W;
+                        for (int j = jlo; j <= jhi; ++j) {
+                            const float4 t = row[j];
+                            const float px = fmaf(a0, fmaf(al, (t.x - s0) + eps, s0), b0);
+                            const float py = fmaf(a1, fmaf(al, (t.y - s1) + eps, s1), b1);
+                            const float pz = fmaf(a2, fmaf(al, (t.z - s2) + eps, s2), b2);
+                            const float ux = fmaxf(1.f - fabsf(px - fv[0]), 0.f);
+                            const float uy = fmaxf(1.f - fabsf(py - fv[1]), 0.f);
+                            const float uz = fmaxf(1.f - fabsf(pz - fv[2]), 0.f);
+                            acc = fmaf(ux * uy * uz, t.w, acc);
+                        }
+                    }
+                } else {
+                    // alpha_k = 0: every ray's sample sits on the source; all pixels are candidates for the
+                    // voxels whose unit box contains it (a source inside the volume only)
+                    const bool hit = fabsf(fmaf(a0, s0, b0) - fv[0]) < 1.f && fabsf(fmaf(a1, s1, b1) - fv[1]) < 1.f &&
+                                     fabsf(fmaf(a2, s2, b2) - fv[2]) < 1.f;
+                    const int cnt = hit ? G.n : 0;
+                    for (int r = 0; r < cnt; ++r) {
+                        const float4 t = q[r];
+                        const float px = fmaf(a0, fmaf(al, (t.x - s0) + eps, s0), b0);
+                        const float py = fmaf(a1, fmaf(al, (t.y - s1) + eps, s1), b1);
+                        const float pz = fmaf(a2, fmaf(al, (t.z - s2) + eps, s2), b2);
+                        const float ux = fmaxf(1.f - fabsf(px - fv[0]), 0.f);
+                        const float uy = fmaxf(1.f - fabsf(py - fv[1]), 0.f);
+                        const float uz = fmaxf(1.f - fabsf(pz - fv[2]), 0.f);
+                        acc = fmaf(ux * uy * uz, t.w, acc);
+                    }
+                }
+            }
+        }
+    }
+    if (inb && acc != 0.f) G.gvol[((size_t)vx * G.D1 + vy) * G.D2 + vz] += acc;
+}
+
 // =============================================================================================
 // pose-side backward from the saved jacobian (C == 1): elementwise + wave reduction
 // =============================================================================================
@@ -527,7 +801,7 @@ __device__ __forceinline__ float sid_alpha(const RenderArgs& A, const Ray& R, co
     return (((float)p + A.sp.plane0[i]) - R.s[i]) * st.inv_d[i];
 }
 
-template <int MODE, bool MASK, bool GPOSE, bool GVOL, bool XCDP>
+template <int MODE, bool MASK, bool GPOSE, bool GVOL>
 __global__ __launch_bounds__(WG) void k_siddon(RenderArgs A) {
     extern __shared__ float lds[];  // MASK: fwd -> channel accumulators, bwd -> upstream gradients
     int b, r;
@@ -549,7 +823,6 @@ __global__ __launch_bounds__(WG) void k_siddon(RenderArgs A) {
         g0 = valid ? A.gout[(size_t)b * A.n + r] : 0.f;
     }
 
-    float* const gv = (MODE == 2 && GVOL && XCDP) ? A.gvol_ws + (size_t)xcc_id() * (size_t)A.nvox : A.gvol;
     const float alo = R.amin, ahi = R.amax;
     bool live = valid && (ahi > alo);
     SidState st;
@@ -596,7 +869,7 @@ __global__ __launch_bounds__(WG) void k_siddon(RenderArgs A) {
             W = gk * v;
             if (GVOL && inb) {
                 const float c = gk * R.L * seg;
-                if (c != 0.f) scatter_add<XCDP>(gv + off, c);
+                if (c != 0.f) atomic_add_f32(A.gvol + off, c);
             }
             acc = fmaf(W, seg, acc);
         } else if (MASK) {
@@ -674,28 +947,6 @@ __global__ __launch_bounds__(WG) void k_siddon(RenderArgs A) {
     }
 }
 
-// gvol[i] += sum over the 8 XCD-private accumulators (streaming, 16 B per lane)
-__global__ __launch_bounds__(WG) void k_reduce_xcd(const float* __restrict__ ws, float* __restrict__ gvol,
-                                                   long long nvox) {
-    const long long n4 = nvox >> 2;
-    const long long stride = (long long)gridDim.x * WG;
-    for (long long i = (long long)blockIdx.x * WG + threadIdx.x; i < n4; i += stride) {
-        float4 acc = reinterpret_cast<const float4*>(gvol)[i];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const float4 v = reinterpret_cast<const float4*>(ws + (size_t)c * nvox)[i];
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-        }
-        reinterpret_cast<float4*>(gvol)[i] = acc;
-    }
-    if (blockIdx.x == 0 && threadIdx.x < (nvox & 3)) {
-        const long long i = (n4 << 2) + threadIdx.x;
-        float acc = gvol[i];
-        for (int c = 0; c < 8; ++c) acc += ws[(size_t)c * nvox + i];
-        gvol[i] = acc;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -752,36 +1003,24 @@ int launch(Kern kern, const RenderArgs& A, size_t lds_bytes, void* stream) {
     return XVR_DRR_OK;
 }
 
-// XCD-private scatter: zero the 8 accumulators, run the scatter kernel, fold them into grad_volume.
-bool use_xcd_private(void* workspace, size_t workspace_bytes, long long nvox) {
-    return workspace && workspace_bytes >= (size_t)8 * (size_t)nvox * sizeof(float) &&
-           (reinterpret_cast<uintptr_t>(workspace) & 15u) == 0 && (nvox & 3) == 0;
-}
-
-int xcd_prepare(RenderArgs& A, void* workspace, void* stream) {
-    A.gvol_ws = static_cast<float*>(workspace);
-    hipError_t e = hipMemsetAsync(workspace, 0, (size_t)8 * (size_t)A.nvox * sizeof(float), (hipStream_t)stream);
-    if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
-    return XVR_DRR_OK;
-}
-
-int xcd_reduce(const RenderArgs& A, void* stream) {
-    const long long n4 = A.nvox >> 2;
-    const unsigned blocks = (unsigned)((n4 + WG - 1) / WG < 8192 ? (n4 + WG - 1) / WG : 8192);
-    hipLaunchKernelGGL(k_reduce_xcd, dim3(blocks ? blocks : 1), dim3(WG), 0, (hipStream_t)stream, A.gvol_ws, A.gvol,
-                       A.nvox);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
-    return XVR_DRR_OK;
+// workspace layout of the gather path:
+//   [flag, 256 B][PoseLattice x B, 256-aligned][float4 x B*n][cull words: bricks x ceil(B/32)]
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+long long n_bricks(int D0, int D1, int D2) { return (long long)((D0 + 3) / 4) * ((D1 + 7) / 8) * ((D2 + 7) / 8); }
+size_t ws_pose_off() { return 256; }
+size_t ws_q_off(int B) { return 256 + align256((size_t)B * sizeof(PoseLattice)); }
+size_t ws_cull_off(int B, int n) { return ws_q_off(B) + align256((size_t)B * (size_t)n * sizeof(float4)); }
+size_t ws_bytes(int B, int n, int D0, int D1, int D2) {
+    return ws_cull_off(B, n) + (size_t)n_bricks(D0, D1, D2) * (size_t)((B + 31) / 32) * sizeof(unsigned);
 }
 
 }  // namespace
 
 extern "C" {
 
-size_t xvr_drr_backward_workspace_bytes(int D0, int D1, int D2) {
-    if (D0 <= 0 || D1 <= 0 || D2 <= 0) return 0;
-    return (size_t)8 * (size_t)D0 * (size_t)D1 * (size_t)D2 * sizeof(float);
+size_t xvr_drr_backward_workspace_bytes(int B, int n, int D0, int D1, int D2) {
+    if (B <= 0 || n <= 0 || D0 <= 0 || D1 <= 0 || D2 <= 0) return 0;
+    return ws_bytes(B, n, D0, D1, D2);
 }
 
 int xvr_drr_abi_version(void) { return XVR_DRR_ABI_VERSION; }
@@ -831,20 +1070,53 @@ int xvr_drr_trilinear_backward(const float* volume, const float* mask, int D0, i
     A.gout = grad_out; A.gvol = grad_volume; A.gsrc = grad_source; A.gtgt = grad_target; A.glen = grad_raylen;
     const bool clip = sp->clip_to_volume != 0;
     const size_t lds = mask ? (size_t)C * WG * sizeof(float) : 0;
-    A.nvox = (long long)D0 * D1 * D2;
-    const bool xp = gvol && use_xcd_private(workspace, workspace_bytes, A.nvox);
-    if (xp && (rc = xcd_prepare(A, workspace, stream))) return rc;
-#define TRI_BWD3(M, CL, X)                                                                     \
-    (gpose ? (gvol ? launch(k_trilinear_bwd<M, CL, true, true, X>, A, lds, stream)             \
-                   : launch(k_trilinear_bwd<M, CL, true, false, false>, A, lds, stream))       \
-           : launch(k_trilinear_bwd<M, CL, false, true, X>, A, lds, stream))
-#define TRI_BWD(M, CL) (xp ? TRI_BWD3(M, CL, true) : TRI_BWD3(M, CL, false))
-    if (mask) rc = clip ? TRI_BWD(true, true) : TRI_BWD(true, false);
-    else rc = clip ? TRI_BWD(false, true) : TRI_BWD(false, false);
+
+    // Voxel gradient by the atomic-free voxel-driven gather when the rays are a detector lattice
+    // (no mask, no per-ray alpha rescaling); the scatter kernel stays as the general fallback and is
+    // launched right behind it, reading the lattice flag on the device (no host sync).
+    const int gw = sp->ray_grid_w, gh = gw > 0 ? n / gw : 0;
+    const bool gather = gvol && !mask && !clip && gw > 1 && gh > 1 && workspace &&
+                        workspace_bytes >= ws_bytes(B, n, D0, D1, D2) && (reinterpret_cast<uintptr_t>(workspace) & 15u) == 0;
+    if (gather) {
+        char* ws = static_cast<char*>(workspace);
+        GatherArgs G = {};
+        G.source = source; G.target = target; G.raylen = raylen; G.gout = grad_out;
+        G.B = B; G.n = n; G.W = gw; G.H = gh; G.D0 = D0; G.D1 = D1; G.D2 = D2; G.sp = *sp;
+        G.flag = reinterpret_cast<unsigned*>(ws);
+        G.poses = reinterpret_cast<PoseLattice*>(ws + ws_pose_off());
+        G.q = reinterpret_cast<float4*>(ws + ws_q_off(B));
+        G.cull = reinterpret_cast<unsigned*>(ws + ws_cull_off(B, n));
+        G.words = (B + 31) / 32;
+        G.gvol = grad_volume;
+        hipError_t e = hipMemsetAsync(G.flag, 0, 16, (hipStream_t)stream);
+        if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
+        hipLaunchKernelGGL(k_gather_prep, dim3((unsigned)((n + WG - 1) / WG), (unsigned)B), dim3(WG), 0,
+                           (hipStream_t)stream, G);
+        const long long bricks = n_bricks(D0, D1, D2);
+        if (bricks >= (1LL << 31)) return fail(XVR_DRR_E_UNSUPPORTED, "grid too large");
+        hipLaunchKernelGGL(k_gather_cull, dim3((unsigned)((bricks + WG / 32 - 1) / (WG / 32))), dim3(WG), 0,
+                           (hipStream_t)stream, G, (int)bricks);
+        hipLaunchKernelGGL(k_trilinear_gather_vol, dim3((unsigned)bricks), dim3(WG), 0, (hipStream_t)stream, G);
+        e = hipGetLastError();
+        if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
+        if (gpose) {  // the pose part does not depend on how the voxel part is done
+            RenderArgs Ap = A;
+            Ap.gvol = nullptr;
+            rc = launch(k_trilinear_bwd<false, false, true, false>, Ap, 0, stream);
+            if (rc) return rc;
+        }
+        RenderArgs Av = A;
+        Av.gsrc = nullptr; Av.gtgt = nullptr; Av.glen = nullptr;
+        Av.skip_unless_flag_gt = G.flag;
+        return launch(k_trilinear_bwd<false, false, false, true>, Av, 0, stream);
+    }
+#define TRI_BWD(M, CL)                                                                         \
+    (gpose ? (gvol ? launch(k_trilinear_bwd<M, CL, true, true>, A, lds, stream)                \
+                   : launch(k_trilinear_bwd<M, CL, true, false>, A, lds, stream))              \
+           : launch(k_trilinear_bwd<M, CL, false, true>, A, lds, stream))
+    if (mask) return clip ? TRI_BWD(true, true) : TRI_BWD(true, false);
+    return clip ? TRI_BWD(false, true) : TRI_BWD(false, false);
 #undef TRI_BWD
-#undef TRI_BWD3
-    if (rc) return rc;
-    return xp ? xcd_reduce(A, stream) : XVR_DRR_OK;
 }
 
 int xvr_drr_siddon_forward(const float* volume, const float* mask, int D0, int D1, int D2, int C,
@@ -860,9 +1132,9 @@ int xvr_drr_siddon_forward(const float* volume, const float* mask, int D0, int D
     fill_args(A, volume, mask, D0, D1, D2, C, source, target, raylen, B, n, sp);
     A.out = out; A.jac = jac; A.work = work;
     const size_t lds = mask ? (size_t)C * WG * sizeof(float) : 0;
-    if (mask) return launch(k_siddon<0, true, false, false, false>, A, lds, stream);
-    if (jac) return launch(k_siddon<1, false, false, false, false>, A, 0, stream);
-    return launch(k_siddon<0, false, false, false, false>, A, 0, stream);
+    if (mask) return launch(k_siddon<0, true, false, false>, A, lds, stream);
+    if (jac) return launch(k_siddon<1, false, false, false>, A, 0, stream);
+    return launch(k_siddon<0, false, false, false>, A, 0, stream);
 }
 
 int xvr_drr_siddon_backward(const float* volume, const float* mask, int D0, int D1, int D2, int C,
@@ -870,6 +1142,7 @@ int xvr_drr_siddon_backward(const float* volume, const float* mask, int D0, int 
                             const xvr_drr_spec* sp, const float* grad_out, float* grad_volume,
                             float* grad_source, float* grad_target, float* grad_raylen, void* workspace,
                             size_t workspace_bytes, void* stream) {
+    (void)workspace; (void)workspace_bytes;  // reserved: the siddon voxel gradient still scatters
     int rc = check_common(volume, D0, D1, D2, C, source, target, raylen, B, n, sp);
     if (rc) return rc;
     if (!grad_out) return fail(XVR_DRR_E_ARG, "grad_out is null");
@@ -883,19 +1156,12 @@ int xvr_drr_siddon_backward(const float* volume, const float* mask, int D0, int 
     fill_args(A, volume, mask, D0, D1, D2, C, source, target, raylen, B, n, sp);
     A.gout = grad_out; A.gvol = grad_volume; A.gsrc = grad_source; A.gtgt = grad_target; A.glen = grad_raylen;
     const size_t lds = mask ? (size_t)C * WG * sizeof(float) : 0;
-    A.nvox = (long long)D0 * D1 * D2;
-    const bool xp = gvol && use_xcd_private(workspace, workspace_bytes, A.nvox);
-    if (xp && (rc = xcd_prepare(A, workspace, stream))) return rc;
-#define SID_BWD3(M, X)                                                                  \
-    (gpose ? (gvol ? launch(k_siddon<2, M, true, true, X>, A, lds, stream)              \
-                   : launch(k_siddon<2, M, true, false, false>, A, lds, stream))        \
-           : launch(k_siddon<2, M, false, true, X>, A, lds, stream))
-#define SID_BWD(M) (xp ? SID_BWD3(M, true) : SID_BWD3(M, false))
-    rc = mask ? SID_BWD(true) : SID_BWD(false);
+#define SID_BWD(M)                                                                      \
+    (gpose ? (gvol ? launch(k_siddon<2, M, true, true>, A, lds, stream)                 \
+                   : launch(k_siddon<2, M, true, false>, A, lds, stream))               \
+           : launch(k_siddon<2, M, false, true>, A, lds, stream))
+    return mask ? SID_BWD(true) : SID_BWD(false);
 #undef SID_BWD
-#undef SID_BWD3
-    if (rc) return rc;
-    return xp ? xcd_reduce(A, stream) : XVR_DRR_OK;
 }
 
 int xvr_drr_backward_from_jac(const float* jac, const float* grad_out, int B, int n, float* grad_source,

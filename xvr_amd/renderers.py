@@ -79,22 +79,21 @@ def _check_gpu_f32(name, t):
         raise TypeError(f"{name} must be float32 (got {t.dtype}); xvr casts the DRR module to float32")
 
 
-# Scratch for the XCD-private voxel scatter (8 gradient volumes), one per (device, shape), reused across
-# calls on the same stream; set XCD_PRIVATE_SCATTER = False to force the memory-side atomics path.
-XCD_PRIVATE_SCATTER = True
+# Device scratch for the backward pass (voxel-driven gather: packed rays + per-pose projection
+# constants), one buffer per device, grown on demand and reused across calls on the same stream.
+# VOXEL_GATHER = False withholds it, which forces the atomic scatter fallback (tests, A/B runs).
+VOXEL_GATHER = True
 _WORKSPACES = {}
 
 
-def _workspace(lib, shape, device):
-    if not XCD_PRIVATE_SCATTER:
+def _workspace(lib, B, n, shape, device):
+    if not VOXEL_GATHER:
         return None, 0
-    nbytes = lib.xvr_drr_backward_workspace_bytes(*shape)
-    key = (device, nbytes)
-    ws = _WORKSPACES.get(key)
-    if ws is None:
-        _WORKSPACES.clear()  # keep at most one (a new volume shape replaces the old scratch)
-        ws = _WORKSPACES[key] = torch.empty(nbytes // 4, device=device, dtype=torch.float32)
-    return ws, nbytes
+    nbytes = lib.xvr_drr_backward_workspace_bytes(B, n, *shape)
+    ws = _WORKSPACES.get(device)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = _WORKSPACES[device] = torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
+    return ws, ws.numel() * 4
 
 
 class _Render(torch.autograd.Function):
@@ -152,7 +151,7 @@ class _Render(torch.autograd.Function):
             cs = make_cspec((D0, D1, D2), spec, ctx.ray_grid_w)
             fn = lib.xvr_drr_trilinear_backward if spec.renderer == "trilinear" else lib.xvr_drr_siddon_backward
             pose_here = need_pose and not from_jac
-            ws, ws_bytes = (_workspace(lib, (D0, D1, D2), dev) if need_vol else (None, 0))
+            ws, ws_bytes = (_workspace(lib, B, n, (D0, D1, D2), dev) if need_vol else (None, 0))
             tag = ("pose" if pose_here else "") + ("+vol" if need_vol else "")
             rc = _timed(f"{spec.renderer}_backward[{tag.strip('+')}]", fn,
                         _ptr(vol_c), _ptr(msk_c), D0, D1, D2, C, _ptr(src_c), _ptr(tgt_c), _ptr(len_c), B, n,
