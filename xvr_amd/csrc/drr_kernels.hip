@@ -506,7 +506,7 @@ struct GatherArgs {
     xvr_drr_spec sp;
     unsigned* flag;          // max lattice deviation (float bits), written by k_gather_prep
     PoseLattice* poses;
-    float4* q;               // [B][n] = (target.xyz, gout * raylen * inv_denom)
+    float4* q;               // [B][n] = ((target - source) + eps, gout * raylen * inv_denom)
     unsigned* cull;          // [bricks][words] bit p set = pose p can touch the brick
     int words;               // ceil(B / 32)
     float* gvol;
@@ -542,7 +542,10 @@ __global__ __launch_bounds__(WG) void k_gather_prep(GatherArgs G) {
         dev = pitch > 0.f ? dev / pitch : INFINITY;
         if (!(dev == dev)) dev = INFINITY;
         const float c = G.gout[(size_t)b * G.n + r] * G.raylen[(size_t)b * G.n + r] * G.sp.inv_denom;
-        G.q[(size_t)b * G.n + r] = make_float4(tx, ty, tz, c);
+        // d exactly as the forward forms it, (t - s) + eps, so that the gather's fmaf chain below
+        // reproduces the forward's sample positions bit for bit
+        G.q[(size_t)b * G.n + r] = make_float4((tx - G.source[3 * b]) + G.sp.eps, (ty - G.source[3 * b + 1]) + G.sp.eps,
+                                               (tz - G.source[3 * b + 2]) + G.sp.eps, c);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) dev = fmaxf(dev, __shfl_xor(dev, o));
@@ -654,9 +657,9 @@ __global__ __launch_bounds__(WG) void k_trilinear_gather_vol(GatherArgs G) {
     const float near_ = G.sp.near_, far_ = G.sp.far_;
     const float step = N > 1 ? (far_ - near_) / (float)(N - 1) : 0.f;
     const float inv_step = step > 0.f ? 1.f / step : 0.f;
-    const float eps = G.sp.eps;
     const float a0 = G.sp.a[0], a1 = G.sp.a[1], a2 = G.sp.a[2];
     const float b0 = G.sp.b[0], b1 = G.sp.b[1], b2 = G.sp.b[2];
+    const float bv0 = b0 - fv[0], bv1 = b1 - fv[1], bv2 = b2 - fv[2];
     const float jmargin = GATHER_DEV_TOL + 0.01f;
     float acc = 0.f;
 
@@ -696,42 +699,33 @@ __global__ __launch_bounds__(WG) void k_trilinear_gather_vol(GatherArgs G) {
                     const float q0x = fmaf(a0, fmaf(al, P.st[0], s0), b0) - fv[0];
                     const float q0y = fmaf(a1, fmaf(al, P.st[1], s1), b1) - fv[1];
                     const float q0z = fmaf(a2, fmaf(al, P.st[2], s2), b2) - fv[2];
-                    const float rx = 1.f / ucx, ry = 1.f / ucy, rz = 1.f / ucz;
-                    const bool dx = fabsf(ucx) < 1e-9f, dy = fabsf(ucy) < 1e-9f, dz = fabsf(ucz) < 1e-9f;
+                    // reciprocal of the per-column step, clamped: an axis the row does not move along
+                    // (|uc| ~ 0) then yields (-huge, +huge) when |q| < 1 and an empty interval otherwise
+                    const float rx = fabsf(ucx) < 1e-9f ? 1e9f : 1.f / ucx;
+                    const float ry = fabsf(ucy) < 1e-9f ? 1e9f : 1.f / ucy;
+                    const float rz = fabsf(ucz) < 1e-9f ? 1e9f : 1.f / ucz;
                     for (int i = ilo; i <= ihi; ++i) {
                         const float fi = (float)i;
                         const float qx = fmaf(fi, urx, q0x), qy = fmaf(fi, ury, q0y), qz = fmaf(fi, urz, q0z);
-                        // exact j-interval on this row where |q + j Uc| < 1 on all three axes
-                        float lo = -INFINITY, hiJ = INFINITY;
-                        {
-                            const float t0 = (-1.f - qx) * rx, t1 = (1.f - qx) * rx;
-                            const float l = dx ? (fabsf(qx) < 1.f ? -INFINITY : INFINITY) : fminf(t0, t1);
-                            const float h = dx ? (fabsf(qx) < 1.f ? INFINITY : -INFINITY) : fmaxf(t0, t1);
-                            lo = fmaxf(lo, l); hiJ = fminf(hiJ, h);
-                        }
-                        {
-                            const float t0 = (-1.f - qy) * ry, t1 = (1.f - qy) * ry;
-                            const float l = dy ? (fabsf(qy) < 1.f ? -INFINITY : INFINITY) : fminf(t0, t1);
-                            const float h = dy ? (fabsf(qy) < 1.f ? INFINITY : -INFINITY) : fmaxf(t0, t1);
-                            lo = fmaxf(lo, l); hiJ = fminf(hiJ, h);
-                        }
-                        {
-                            const float t0 = (-1.f - qz) * rz, t1 = (1.f - qz) * rz;
-                            const float l = dz ? (fabsf(qz) < 1.f ? -INFINITY : INFINITY) : fminf(t0, t1);
-                            const float h = dz ? (fabsf(qz) < 1.f ? INFINITY : -INFINITY) : fmaxf(t0, t1);
-                            lo = fmaxf(lo, l); hiJ = fminf(hiJ, h);
-                        }
+                        // exact j-interval on this row where |q + j Uc| < 1 on all three axes:
+                        // j between (-1 - q) r and (1 - q) r per axis
+                        const float mx = -qx * rx, my = -qy * ry, mz = -qz * rz;
+                        const float ax_ = fabsf(rx), ay_ = fabsf(ry), az_ = fabsf(rz);
+                        const float lo = fmaxf(fmaxf(mx - ax_, my - ay_), mz - az_);
+                        const float hiJ = fminf(fminf(mx + ax_, my + ay_), mz + az_);
                         const int jlo = (int)ceilf(fmaxf(lo - jmargin, 0.f));
                         const int jhi = (int)floorf(fminf(hiJ + jmargin, (float)(G.W - 1)));
                         const float4* __restrict__ row = q + (size_t)i * G.W;
                         for (int j = jlo; j <= jhi; ++j) {
                             const float4 t = row[j];
-                            const float px = fmaf(a0, fmaf(al, (t.x - s0) + eps, s0), b0);
-                            const float py = fmaf(a1, fmaf(al, (t.y - s1) + eps, s1), b1);
-                            const float pz = fmaf(a2, fmaf(al, (t.z - s2) + eps, s2), b2);
-                            const float ux = fmaxf(1.f - fabsf(px - fv[0]), 0.f);
-                            const float uy = fmaxf(1.f - fabsf(py - fv[1]), 0.f);
-                            const float uz = fmaxf(1.f - fabsf(pz - fv[2]), 0.f);
+                            // p - v with the forward's fmaf chain (b - v is exact, and so is the fold
+                            // for every |p| < 2^23, so these are the forward's interpolation weights)
+                            const float px = fmaf(a0, fmaf(al, t.x, s0), bv0);
+                            const float py = fmaf(a1, fmaf(al, t.y, s1), bv1);
+                            const float pz = fmaf(a2, fmaf(al, t.z, s2), bv2);
+                            const float ux = fmaxf(1.f - fabsf(px), 0.f);
+                            const float uy = fmaxf(1.f - fabsf(py), 0.f);
+                            const float uz = fmaxf(1.f - fabsf(pz), 0.f);
                             acc = fmaf(ux * uy * uz, t.w, acc);
                         }
                     }
@@ -743,9 +737,9 @@ __global__ __launch_bounds__(WG) void k_trilinear_gather_vol(GatherArgs G) {
                     const int cnt = hit ? G.n : 0;
                     for (int r = 0; r < cnt; ++r) {
                         const float4 t = q[r];
-                        const float px = fmaf(a0, fmaf(al, (t.x - s0) + eps, s0), b0);
-                        const float py = fmaf(a1, fmaf(al, (t.y - s1) + eps, s1), b1);
-                        const float pz = fmaf(a2, fmaf(al, (t.z - s2) + eps, s2), b2);
+                        const float px = fmaf(a0, fmaf(al, t.x, s0), b0);
+                        const float py = fmaf(a1, fmaf(al, t.y, s1), b1);
+                        const float pz = fmaf(a2, fmaf(al, t.z, s2), b2);
                         const float ux = fmaxf(1.f - fabsf(px - fv[0]), 0.f);
                         const float uy = fmaxf(1.f - fabsf(py - fv[1]), 0.f);
                         const float uz = fmaxf(1.f - fabsf(pz - fv[2]), 0.f);
