@@ -183,8 +183,13 @@ def siddon(volume, source, target, img, spec: RenderSpec, mask=None):
     for ax in range(3):
         planes = torch.arange(shape[ax] + 1).to(source) - spec.voxel_shift
         per_axis.append((planes.expand(len(source), 1, -1) - source[..., ax : ax + 1]) / sdd[..., ax : ax + 1])
-    alphas = torch.sort(torch.cat(per_axis, dim=-1), dim=-1).values
     alphamin, alphamax = _alpha_minmax(source, target, shape, spec)
+    if spec.per_ray_clamp:
+        # the ends of the ray's own interval are segment boundaries too (they coincide with plane
+        # crossings unless the source/target lies inside the volume, where they cut the partial
+        # first/last segment that the column filter below would otherwise discard)
+        per_axis += [alphamin, torch.maximum(alphamax, alphamin)]
+    alphas = torch.sort(torch.cat(per_axis, dim=-1), dim=-1).values
     if spec.filter_intersections_outside_volume:
         alphas = _filter_columns(alphas, alphamin, alphamax)
     if spec.per_ray_clamp:

@@ -99,6 +99,22 @@ def test_siddon_source_inside_volume_is_clamped():
     assert abs(siddon(vol, src, tgt, img, spec).item() - want) < 1e-4
 
 
+def test_siddon_source_inside_oblique_rays_keeps_the_partial_first_segment():
+    """All rays start in the same voxel (same number of negative crossings): the torch restatement's
+    column filter must not discard the partial segment [0, first crossing]; float64 scalar agrees."""
+    g = torch.Generator().manual_seed(3)
+    vol = torch.rand(12, 12, 12, generator=g)
+    src = torch.tensor([[[5.3, 6.2, 4.9]]])
+    ii, jj = torch.meshgrid(torch.arange(6.0), torch.arange(5.0), indexing="ij")
+    tgt = (torch.tensor([40.0, -3.0, -2.0]) + ii[..., None] * torch.tensor([0.0, 2.0, 0.3])
+           + jj[..., None] * torch.tensor([0.0, -0.2, 2.5])).reshape(1, 30, 3)
+    img = (tgt - src).norm(dim=-1).unsqueeze(1)
+    spec = RenderSpec(renderer="siddon")
+    a = siddon(vol, src, tgt, img, spec).double().numpy()
+    b = scalar.render(vol, src, tgt, img, spec)
+    assert np.abs(a - b).max() <= 2e-5 * np.abs(b).max()
+
+
 def test_trilinear_uniform_interior_segment():
     """KAT: in a uniform volume every interior sample reads rho, so out = rho * L * (#inside)/N."""
     vol = torch.full((40, 12, 12), 0.25)

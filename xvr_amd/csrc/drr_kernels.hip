@@ -506,7 +506,10 @@ struct GatherArgs {
     xvr_drr_spec sp;
     unsigned* flag;          // max lattice deviation (float bits), written by k_gather_prep
     PoseLattice* poses;
-    float4* q;               // [B][n] = ((target - source) + eps, gout * raylen * inv_denom)
+    float4* q;               // trilinear: [B][n] = ((target - source) + eps, gout * raylen * inv_denom)
+                             // siddon:    [B][n] = (1 / ((target - source) + eps), gout * raylen)
+    float2* q2;              // siddon: [B][n] = (alpha_lo, alpha_hi) of the ray, as the forward clamps them
+    int siddon;
     unsigned* cull;          // [bricks][words] bit p set = pose p can touch the brick
     int words;               // ceil(B / 32)
     float* gvol;
@@ -544,8 +547,26 @@ __global__ __launch_bounds__(WG) void k_gather_prep(GatherArgs G) {
         const float c = G.gout[(size_t)b * G.n + r] * G.raylen[(size_t)b * G.n + r] * G.sp.inv_denom;
         // d exactly as the forward forms it, (t - s) + eps, so that the gather's fmaf chain below
         // reproduces the forward's sample positions bit for bit
-        G.q[(size_t)b * G.n + r] = make_float4((tx - G.source[3 * b]) + G.sp.eps, (ty - G.source[3 * b + 1]) + G.sp.eps,
-                                               (tz - G.source[3 * b + 2]) + G.sp.eps, c);
+        const float sx = G.source[3 * b], sy = G.source[3 * b + 1], sz = G.source[3 * b + 2];
+        const float ddx = (tx - sx) + G.sp.eps, ddy = (ty - sy) + G.sp.eps, ddz = (tz - sz) + G.sp.eps;
+        if (!G.siddon) {
+            G.q[(size_t)b * G.n + r] = make_float4(ddx, ddy, ddz, c);
+        } else {
+            // the ray's own integration interval, computed exactly as ray_setup() does for the forward
+            const float dd[3] = {ddx, ddy, ddz}, ss[3] = {sx, sy, sz};
+            float lo = -INFINITY, hi = INFINITY;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float a0 = (G.sp.lo[k] - ss[k]) / dd[k], a1 = (G.sp.hi[k] - ss[k]) / dd[k];
+                lo = fmaxf(lo, fminf(a0, a1));
+                hi = fminf(hi, fmaxf(a0, a1));
+            }
+            if (!(lo > 0.f)) lo = 0.f;
+            if (!(hi < 1.f)) hi = 1.f;
+            G.q[(size_t)b * G.n + r] = make_float4(1.f / ddx, 1.f / ddy, 1.f / ddz,
+                                                   G.gout[(size_t)b * G.n + r] * G.raylen[(size_t)b * G.n + r]);
+            G.q2[(size_t)b * G.n + r] = make_float2(lo, hi);
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) dev = fmaxf(dev, __shfl_xor(dev, o));
@@ -752,6 +773,78 @@ __global__ __launch_bounds__(WG) void k_trilinear_gather_vol(GatherArgs G) {
     if (inb && acc != 0.f) G.gvol[((size_t)vx * G.D1 + vy) * G.D2 + vz] += acc;
 }
 
+// Siddon voxel gradient as a gather (exact-geometry index map only: a = 1, b = shift - 1/2, so the
+// voxel a segment is credited to is the voxel whose box contains it).  d out / d V[v] for one ray is
+// L x (length of the ray inside v's box, clipped to the ray's own [alpha_lo, alpha_hi]); the box's
+// entry/exit alphas use the forward's expression ((plane + plane0) - s) * (1 / d), so they are the
+// very crossing values the forward traversal produced.
+__global__ __launch_bounds__(WG) void k_siddon_gather_vol(GatherArgs G) {
+    if (*G.flag > __float_as_uint(GATHER_DEV_TOL)) return;
+    int bx, by, bz;
+    brick_coords(blockIdx.x, G.D1, G.D2, bx, by, bz);
+    const int tid = threadIdx.x;
+    const int vx = bx * 4 + (tid >> 6), vy = by * 8 + ((tid >> 3) & 7), vz = bz * 8 + (tid & 7);
+    const bool inb = vx < G.D0 && vy < G.D1 && vz < G.D2;
+    // planes of the voxel's box and its centre, in x coordinates
+    const float p0x = (float)vx + G.sp.plane0[0], p0y = (float)vy + G.sp.plane0[1], p0z = (float)vz + G.sp.plane0[2];
+    const float p1x = (float)(vx + 1) + G.sp.plane0[0], p1y = (float)(vy + 1) + G.sp.plane0[1],
+                p1z = (float)(vz + 1) + G.sp.plane0[2];
+    const float cx = p0x + 0.5f, cy = p0y + 0.5f, cz = p0z + 0.5f;
+    float acc = 0.f;
+    for (int wd = 0; wd < G.words; ++wd) {
+        unsigned bits = G.cull[(size_t)blockIdx.x * G.words + wd];
+        while (bits) {
+            const int p = wd * 32 + __builtin_ctz(bits);
+            bits &= bits - 1;
+            const PoseLattice& P = G.poses[p];
+            const float s0 = P.s[0], s1 = P.s[1], s2 = P.s[2];
+            const float w0 = cx - s0, w1 = cy - s1, w2 = cz - s2;
+            const float av = P.nh[0] * w0 + P.nh[1] * w1 + P.nh[2] * w2;
+            const float da = 0.5f * P.dalpha;
+            const float amin = av - da, amax = av + da;
+            // pixel = g0 + N / alpha with N in [N0 - dN, N0 + dN], alpha in [amin, amax]
+            const float nj = P.gc[0] * w0 + P.gc[1] * w1 + P.gc[2] * w2, dnj = 0.5f * P.hwc;
+            const float ni = P.gr[0] * w0 + P.gr[1] * w1 + P.gr[2] * w2, dni = 0.5f * P.hwr;
+            int jlo = 0, jhi = -1, ilo = 0, ihi = -1;
+            if (inb && amin > 1e-6f && amax >= 0.f && amin <= 1.f) {
+                const float i0 = 1.f / amin, i1 = 1.f / amax;
+                const float ja = (nj - dnj) * i0, jb = (nj - dnj) * i1, jc = (nj + dnj) * i0, jd = (nj + dnj) * i1;
+                const float ia = (ni - dni) * i0, ib = (ni - dni) * i1, ic = (ni + dni) * i0, id = (ni + dni) * i1;
+                const float jmn = fminf(fminf(ja, jb), fminf(jc, jd)) + P.gc0 - GATHER_WIN_MARGIN;
+                const float jmx = fmaxf(fmaxf(ja, jb), fmaxf(jc, jd)) + P.gc0 + GATHER_WIN_MARGIN;
+                const float imn = fminf(fminf(ia, ib), fminf(ic, id)) + P.gr0 - GATHER_WIN_MARGIN;
+                const float imx = fmaxf(fmaxf(ia, ib), fmaxf(ic, id)) + P.gr0 + GATHER_WIN_MARGIN;
+                jlo = (int)ceilf(fmaxf(jmn, 0.f));
+                jhi = (int)floorf(fminf(jmx, (float)(G.W - 1)));
+                ilo = (int)ceilf(fmaxf(imn, 0.f));
+                ihi = (int)floorf(fminf(imx, (float)(G.H - 1)));
+            } else if (inb && amin <= 1e-6f && amax >= 0.f) {
+                // the box reaches the source plane: no perspective bound -- visit every ray
+                jhi = G.W - 1;
+                ihi = G.H - 1;
+            }
+            const float lx = p0x - s0, ly = p0y - s1, lz = p0z - s2;
+            const float hx = p1x - s0, hy = p1y - s1, hz = p1z - s2;
+            const float4* __restrict__ q = G.q + (size_t)p * G.n;
+            const float2* __restrict__ q2 = G.q2 + (size_t)p * G.n;
+            for (int i = ilo; i <= ihi; ++i) {
+                for (int j = jlo; j <= jhi; ++j) {
+                    const float4 t = q[(size_t)i * G.W + j];
+                    const float2 ab = q2[(size_t)i * G.W + j];
+                    const float x0 = lx * t.x, x1 = hx * t.x, y0 = ly * t.y, y1 = hy * t.y, z0 = lz * t.z, z1 = hz * t.z;
+                    float en = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+                    float ex = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+                    en = fmaxf(en, ab.x);
+                    ex = fminf(ex, ab.y);
+                    acc = fmaf(fmaxf(ex - en, 0.f), t.w, acc);
+                }
+            }
+        }
+    }
+    if (inb && acc != 0.f) G.gvol[((size_t)vx * G.D1 + vy) * G.D2 + vz] += acc;
+}
+
+
 // =============================================================================================
 // pose-side backward from the saved jacobian (C == 1): elementwise + wave reduction
 // =============================================================================================
@@ -798,6 +891,7 @@ __device__ __forceinline__ float sid_alpha(const RenderArgs& A, const Ray& R, co
 template <int MODE, bool MASK, bool GPOSE, bool GVOL>
 __global__ __launch_bounds__(WG) void k_siddon(RenderArgs A) {
     extern __shared__ float lds[];  // MASK: fwd -> channel accumulators, bwd -> upstream gradients
+    if (MODE == 2 && A.skip_unless_flag_gt && !(*A.skip_unless_flag_gt > __float_as_uint(GATHER_DEV_TOL))) return;
     int b, r;
     const bool valid = map_ray(A, b, r);
     const int tid = threadIdx.x;
@@ -1003,9 +1097,50 @@ size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 long long n_bricks(int D0, int D1, int D2) { return (long long)((D0 + 3) / 4) * ((D1 + 7) / 8) * ((D2 + 7) / 8); }
 size_t ws_pose_off() { return 256; }
 size_t ws_q_off(int B) { return 256 + align256((size_t)B * sizeof(PoseLattice)); }
-size_t ws_cull_off(int B, int n) { return ws_q_off(B) + align256((size_t)B * (size_t)n * sizeof(float4)); }
+size_t ws_q2_off(int B, int n) { return ws_q_off(B) + align256((size_t)B * (size_t)n * sizeof(float4)); }
+size_t ws_cull_off(int B, int n) { return ws_q2_off(B, n) + align256((size_t)B * (size_t)n * sizeof(float2)); }
 size_t ws_bytes(int B, int n, int D0, int D1, int D2) {
     return ws_cull_off(B, n) + (size_t)n_bricks(D0, D1, D2) * (size_t)((B + 31) / 32) * sizeof(unsigned);
+}
+
+// Set up the workspace and launch prep -> cull -> gather.  The caller launches the scatter fallback
+// (with skip_unless_flag_gt = the returned flag) right behind it.
+int launch_gather(bool siddon, const float* source, const float* target, const float* raylen, const float* grad_out,
+                  int B, int n, int gw, int D0, int D1, int D2, const xvr_drr_spec* sp, float* grad_volume,
+                  void* workspace, void* stream, unsigned** flag_out) {
+    char* ws = static_cast<char*>(workspace);
+    GatherArgs G = {};
+    G.source = source; G.target = target; G.raylen = raylen; G.gout = grad_out;
+    G.B = B; G.n = n; G.W = gw; G.H = n / gw; G.D0 = D0; G.D1 = D1; G.D2 = D2; G.sp = *sp;
+    G.flag = reinterpret_cast<unsigned*>(ws);
+    G.poses = reinterpret_cast<PoseLattice*>(ws + ws_pose_off());
+    G.q = reinterpret_cast<float4*>(ws + ws_q_off(B));
+    G.q2 = reinterpret_cast<float2*>(ws + ws_q2_off(B, n));
+    G.siddon = siddon ? 1 : 0;
+    G.cull = reinterpret_cast<unsigned*>(ws + ws_cull_off(B, n));
+    G.words = (B + 31) / 32;
+    G.gvol = grad_volume;
+    *flag_out = G.flag;
+    hipError_t e = hipMemsetAsync(G.flag, 0, 16, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
+    hipLaunchKernelGGL(k_gather_prep, dim3((unsigned)((n + WG - 1) / WG), (unsigned)B), dim3(WG), 0,
+                       (hipStream_t)stream, G);
+    const long long bricks = n_bricks(D0, D1, D2);
+    if (bricks >= (1LL << 31)) return fail(XVR_DRR_E_UNSUPPORTED, "grid too large");
+    hipLaunchKernelGGL(k_gather_cull, dim3((unsigned)((bricks + WG / 32 - 1) / (WG / 32))), dim3(WG), 0,
+                       (hipStream_t)stream, G, (int)bricks);
+    if (siddon) hipLaunchKernelGGL(k_siddon_gather_vol, dim3((unsigned)bricks), dim3(WG), 0, (hipStream_t)stream, G);
+    else hipLaunchKernelGGL(k_trilinear_gather_vol, dim3((unsigned)bricks), dim3(WG), 0, (hipStream_t)stream, G);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
+    return XVR_DRR_OK;
+}
+
+bool gather_usable(const xvr_drr_spec* sp, int n, void* workspace, size_t workspace_bytes, int B, int D0, int D1,
+                   int D2) {
+    const int gw = sp->ray_grid_w, gh = gw > 0 ? n / gw : 0;
+    return gw > 1 && gh > 1 && workspace && workspace_bytes >= ws_bytes(B, n, D0, D1, D2) &&
+           (reinterpret_cast<uintptr_t>(workspace) & 15u) == 0;
 }
 
 }  // namespace
@@ -1068,31 +1203,12 @@ int xvr_drr_trilinear_backward(const float* volume, const float* mask, int D0, i
     // Voxel gradient by the atomic-free voxel-driven gather when the rays are a detector lattice
     // (no mask, no per-ray alpha rescaling); the scatter kernel stays as the general fallback and is
     // launched right behind it, reading the lattice flag on the device (no host sync).
-    const int gw = sp->ray_grid_w, gh = gw > 0 ? n / gw : 0;
-    const bool gather = gvol && !mask && !clip && gw > 1 && gh > 1 && workspace &&
-                        workspace_bytes >= ws_bytes(B, n, D0, D1, D2) && (reinterpret_cast<uintptr_t>(workspace) & 15u) == 0;
+    const bool gather = gvol && !mask && !clip && gather_usable(sp, n, workspace, workspace_bytes, B, D0, D1, D2);
     if (gather) {
-        char* ws = static_cast<char*>(workspace);
-        GatherArgs G = {};
-        G.source = source; G.target = target; G.raylen = raylen; G.gout = grad_out;
-        G.B = B; G.n = n; G.W = gw; G.H = gh; G.D0 = D0; G.D1 = D1; G.D2 = D2; G.sp = *sp;
-        G.flag = reinterpret_cast<unsigned*>(ws);
-        G.poses = reinterpret_cast<PoseLattice*>(ws + ws_pose_off());
-        G.q = reinterpret_cast<float4*>(ws + ws_q_off(B));
-        G.cull = reinterpret_cast<unsigned*>(ws + ws_cull_off(B, n));
-        G.words = (B + 31) / 32;
-        G.gvol = grad_volume;
-        hipError_t e = hipMemsetAsync(G.flag, 0, 16, (hipStream_t)stream);
-        if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
-        hipLaunchKernelGGL(k_gather_prep, dim3((unsigned)((n + WG - 1) / WG), (unsigned)B), dim3(WG), 0,
-                           (hipStream_t)stream, G);
-        const long long bricks = n_bricks(D0, D1, D2);
-        if (bricks >= (1LL << 31)) return fail(XVR_DRR_E_UNSUPPORTED, "grid too large");
-        hipLaunchKernelGGL(k_gather_cull, dim3((unsigned)((bricks + WG / 32 - 1) / (WG / 32))), dim3(WG), 0,
-                           (hipStream_t)stream, G, (int)bricks);
-        hipLaunchKernelGGL(k_trilinear_gather_vol, dim3((unsigned)bricks), dim3(WG), 0, (hipStream_t)stream, G);
-        e = hipGetLastError();
-        if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
+        unsigned* flag = nullptr;
+        rc = launch_gather(false, source, target, raylen, grad_out, B, n, sp->ray_grid_w, D0, D1, D2, sp, grad_volume,
+                           workspace, stream, &flag);
+        if (rc) return rc;
         if (gpose) {  // the pose part does not depend on how the voxel part is done
             RenderArgs Ap = A;
             Ap.gvol = nullptr;
@@ -1101,7 +1217,7 @@ int xvr_drr_trilinear_backward(const float* volume, const float* mask, int D0, i
         }
         RenderArgs Av = A;
         Av.gsrc = nullptr; Av.gtgt = nullptr; Av.glen = nullptr;
-        Av.skip_unless_flag_gt = G.flag;
+        Av.skip_unless_flag_gt = flag;
         return launch(k_trilinear_bwd<false, false, false, true>, Av, 0, stream);
     }
 #define TRI_BWD(M, CL)                                                                         \
@@ -1136,7 +1252,7 @@ int xvr_drr_siddon_backward(const float* volume, const float* mask, int D0, int 
                             const xvr_drr_spec* sp, const float* grad_out, float* grad_volume,
                             float* grad_source, float* grad_target, float* grad_raylen, void* workspace,
                             size_t workspace_bytes, void* stream) {
-    (void)workspace; (void)workspace_bytes;  // reserved: the siddon voxel gradient still scatters
+
     int rc = check_common(volume, D0, D1, D2, C, source, target, raylen, B, n, sp);
     if (rc) return rc;
     if (!grad_out) return fail(XVR_DRR_E_ARG, "grad_out is null");
@@ -1150,6 +1266,26 @@ int xvr_drr_siddon_backward(const float* volume, const float* mask, int D0, int 
     fill_args(A, volume, mask, D0, D1, D2, C, source, target, raylen, B, n, sp);
     A.gout = grad_out; A.gvol = grad_volume; A.gsrc = grad_source; A.gtgt = grad_target; A.glen = grad_raylen;
     const size_t lds = mask ? (size_t)C * WG * sizeof(float) : 0;
+    // the gather needs the exact-geometry index map (voxel credited = voxel whose box holds the segment)
+    bool exact_geom = true;
+    for (int i = 0; i < 3; ++i)
+        exact_geom = exact_geom && fabsf(sp->a[i] - 1.f) < 1e-6f && fabsf(sp->b[i] + sp->plane0[i] + 0.5f) < 1e-6f;
+    if (gvol && !mask && exact_geom && gather_usable(sp, n, workspace, workspace_bytes, B, D0, D1, D2)) {
+        unsigned* flag = nullptr;
+        rc = launch_gather(true, source, target, raylen, grad_out, B, n, sp->ray_grid_w, D0, D1, D2, sp, grad_volume,
+                           workspace, stream, &flag);
+        if (rc) return rc;
+        if (gpose) {
+            RenderArgs Ap = A;
+            Ap.gvol = nullptr;
+            rc = launch(k_siddon<2, false, true, false>, Ap, 0, stream);
+            if (rc) return rc;
+        }
+        RenderArgs Av = A;
+        Av.gsrc = nullptr; Av.gtgt = nullptr; Av.glen = nullptr;
+        Av.skip_unless_flag_gt = flag;
+        return launch(k_siddon<2, false, false, true>, Av, 0, stream);
+    }
 #define SID_BWD(M)                                                                      \
     (gpose ? (gvol ? launch(k_siddon<2, M, true, true>, A, lds, stream)                 \
                    : launch(k_siddon<2, M, true, false>, A, lds, stream))               \
