@@ -17,6 +17,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "xvr_drr.h"
 
@@ -510,6 +511,7 @@ struct GatherArgs {
                              // siddon:    [B][n] = (1 / ((target - source) + eps), gout * raylen)
     float2* q2;              // siddon: [B][n] = (alpha_lo, alpha_hi) of the ray, as the forward clamps them
     int siddon;
+    int V;                   // voxels per lane and axis in the gather (1 or 2)
     unsigned* cull;          // [bricks][words] bit p set = pose p can touch the brick
     int words;               // ceil(B / 32)
     float* gvol;
@@ -612,9 +614,10 @@ __global__ __launch_bounds__(WG) void k_gather_prep(GatherArgs G) {
     }
 }
 
-// bricks of 4 x 8 x 8 voxels (x, y, z): one workgroup of the gather kernel each
-__device__ __forceinline__ void brick_coords(int blk, int D1, int D2, int& bx, int& by, int& bz) {
-    const int nz = (D2 + 7) >> 3, ny = (D1 + 7) >> 3;
+// A gather workgroup covers a brick of (4V) x (8V) x (8V) voxels (x, y, z); each of its 256 lanes
+// owns a V x V x V block (V = 1 or 2).
+__device__ __forceinline__ void brick_coords(int blk, int D1, int D2, int V, int& bx, int& by, int& bz) {
+    const int nz = (D2 + 8 * V - 1) / (8 * V), ny = (D1 + 8 * V - 1) / (8 * V);
     bz = blk % nz; blk /= nz;
     by = blk % ny; bx = blk / ny;
 }
@@ -626,10 +629,11 @@ __global__ __launch_bounds__(WG) void k_gather_cull(GatherArgs G, int nbricks) {
     const int lane = threadIdx.x & 31;
     if (brick >= nbricks) return;
     int bx, by, bz;
-    brick_coords(brick, G.D1, G.D2, bx, by, bz);
-    const float c[3] = {bx * 4 + 1.5f, by * 8 + 3.5f, bz * 8 + 3.5f};
-    // half extents (2,4,4) + 0.5 (voxel centres -> faces) + 1 (interpolation support), in x units
-    const float hx = 3.f / G.sp.a[0], hy = 5.f / G.sp.a[1], hz = 5.f / G.sp.a[2];
+    brick_coords(brick, G.D1, G.D2, G.V, bx, by, bz);
+    const float fV = (float)G.V;
+    const float c[3] = {bx * 4 * fV + 2.f * fV - 0.5f, by * 8 * fV + 4.f * fV - 0.5f, bz * 8 * fV + 4.f * fV - 0.5f};
+    // half extents (2,4,4) V - 0.5 (centres of the outer voxels) + 1 (interpolation support) + 0.5 (slack)
+    const float hx = (2.f * fV + 1.f) / G.sp.a[0], hy = (4.f * fV + 1.f) / G.sp.a[1], hz = (4.f * fV + 1.f) / G.sp.a[2];
     const float R = sqrtf(hx * hx + hy * hy + hz * hz);
     for (int wd = 0; wd < G.words; ++wd) {
         const int p = wd * 32 + lane;
@@ -662,27 +666,38 @@ __global__ __launch_bounds__(WG) void k_gather_cull(GatherArgs G, int nbricks) {
     }
 }
 
-// one thread = one voxel; a workgroup = a 4 x 8 x 8 brick (x, y, z), so its candidates share pixels
+// One lane owns a V x V x V block of voxels (V = 2: per-pose / per-step / per-row setup is paid once
+// for 8 voxels and the sample position is computed once per candidate); a workgroup covers a
+// (4V) x (8V) x (8V) brick so that its lanes' candidates share pixels.
+template <int V>
 __global__ __launch_bounds__(WG) void k_trilinear_gather_vol(GatherArgs G) {
     if (*G.flag > __float_as_uint(GATHER_DEV_TOL)) return;  // not a lattice: the scatter kernel runs instead
+    constexpr float HS = V == 2 ? 1.5f : 1.0f;  // half-size of the block's interpolation support
+    constexpr float CO = V == 2 ? 0.5f : 0.0f;  // block centre relative to its first voxel
     int bx, by, bz;
-    brick_coords(blockIdx.x, G.D1, G.D2, bx, by, bz);
+    brick_coords(blockIdx.x, G.D1, G.D2, V, bx, by, bz);
     const int tid = threadIdx.x;
-    const int vx = bx * 4 + (tid >> 6), vy = by * 8 + ((tid >> 3) & 7), vz = bz * 8 + (tid & 7);
+    const int vx = (bx * 4 + (tid >> 6)) * V, vy = (by * 8 + ((tid >> 3) & 7)) * V, vz = (bz * 8 + (tid & 7)) * V;
     const bool inb = vx < G.D0 && vy < G.D1 && vz < G.D2;
     const float fv[3] = {(float)vx, (float)vy, (float)vz};
-    float xv[3];
+    float xv[3];  // block centre in x coordinates
 #pragma unroll
-    for (int i = 0; i < 3; ++i) xv[i] = (fv[i] - G.sp.b[i]) / G.sp.a[i];
+    for (int i = 0; i < 3; ++i) xv[i] = (fv[i] + CO - G.sp.b[i]) / G.sp.a[i];
     const int N = G.sp.n_points;
     const float near_ = G.sp.near_, far_ = G.sp.far_;
     const float step = N > 1 ? (far_ - near_) / (float)(N - 1) : 0.f;
     const float inv_step = step > 0.f ? 1.f / step : 0.f;
     const float a0 = G.sp.a[0], a1 = G.sp.a[1], a2 = G.sp.a[2];
     const float b0 = G.sp.b[0], b1 = G.sp.b[1], b2 = G.sp.b[2];
+    // p - v for the first voxel of the block (b - v is exact, and so is folding it into the fmaf for
+    // every |p| < 2^23: these are the forward's interpolation weights); the second voxel gets its own
+    // constant so that its weight is formed by the same single fmaf
     const float bv0 = b0 - fv[0], bv1 = b1 - fv[1], bv2 = b2 - fv[2];
+    const float bw0 = bv0 - 1.f, bw1 = bv1 - 1.f, bw2 = bv2 - 1.f;
     const float jmargin = GATHER_DEV_TOL + 0.01f;
-    float acc = 0.f;
+    float acc[V * V * V];
+#pragma unroll
+    for (int i = 0; i < V * V * V; ++i) acc[i] = 0.f;
 
     for (int wd = 0; wd < G.words; ++wd) {
         unsigned bits = G.cull[(size_t)blockIdx.x * G.words + wd];  // uniform: scalar load
@@ -693,14 +708,15 @@ __global__ __launch_bounds__(WG) void k_trilinear_gather_vol(GatherArgs G) {
             const float s0 = P.s[0], s1 = P.s[1], s2 = P.s[2];
             const float w0 = xv[0] - s0, w1 = xv[1] - s1, w2 = xv[2] - s2;
             const float av = P.nh[0] * w0 + P.nh[1] * w1 + P.nh[2] * w2;
+            const float da = HS * P.dalpha;
             int klo, khi;
             if (step > 0.f) {
-                const float k0 = (av - P.dalpha - near_) * inv_step, k1 = (av + P.dalpha - near_) * inv_step;
+                const float k0 = (av - da - near_) * inv_step, k1 = (av + da - near_) * inv_step;
                 klo = (int)ceilf(fmaxf(k0 - GATHER_K_SLACK, 0.f));
                 khi = (int)floorf(fminf(k1 + GATHER_K_SLACK, (float)(N - 1)));
             } else {
                 klo = 0;
-                khi = (fabsf(av - near_) <= P.dalpha) ? 0 : -1;
+                khi = (fabsf(av - near_) <= da) ? 0 : -1;
             }
             if (!inb || !(av == av)) khi = -1;
             const float grw = P.gr[0] * w0 + P.gr[1] * w1 + P.gr[2] * w2;
@@ -710,28 +726,28 @@ __global__ __launch_bounds__(WG) void k_trilinear_gather_vol(GatherArgs G) {
                 if (al > 1e-12f) {
                     const float inv = 1.f / al;
                     const float ic = fmaf(grw, inv, P.gr0);
-                    const float hi = fmaf(P.hwr, inv, GATHER_WIN_MARGIN);
+                    const float hi = fmaf(HS * P.hwr, inv, GATHER_WIN_MARGIN);
                     const int ilo = (int)ceilf(fmaxf(ic - hi, 0.f));
                     const int ihi = (int)floorf(fminf(ic + hi, (float)(G.H - 1)));
-                    // lattice model of the sample positions relative to v: Q0 + i Ur + j Uc (index space).
-                    // Used ONLY to find which pixels to visit; weights come from the real targets below.
+                    // lattice model of the sample positions relative to the block centre, in index space:
+                    // Q0 + i Ur + j Uc.  Used ONLY to find which pixels to visit; the weights below come
+                    // from the real targets.
                     const float ucx = al * a0 * P.ec[0], ucy = al * a1 * P.ec[1], ucz = al * a2 * P.ec[2];
                     const float urx = al * a0 * P.er[0], ury = al * a1 * P.er[1], urz = al * a2 * P.er[2];
-                    const float q0x = fmaf(a0, fmaf(al, P.st[0], s0), b0) - fv[0];
-                    const float q0y = fmaf(a1, fmaf(al, P.st[1], s1), b1) - fv[1];
-                    const float q0z = fmaf(a2, fmaf(al, P.st[2], s2), b2) - fv[2];
+                    const float q0x = fmaf(a0, fmaf(al, P.st[0], s0), b0) - (fv[0] + CO);
+                    const float q0y = fmaf(a1, fmaf(al, P.st[1], s1), b1) - (fv[1] + CO);
+                    const float q0z = fmaf(a2, fmaf(al, P.st[2], s2), b2) - (fv[2] + CO);
                     // reciprocal of the per-column step, clamped: an axis the row does not move along
-                    // (|uc| ~ 0) then yields (-huge, +huge) when |q| < 1 and an empty interval otherwise
+                    // (|uc| ~ 0) then yields (-huge, +huge) when |q| < HS and an empty interval otherwise
                     const float rx = fabsf(ucx) < 1e-9f ? 1e9f : 1.f / ucx;
                     const float ry = fabsf(ucy) < 1e-9f ? 1e9f : 1.f / ucy;
                     const float rz = fabsf(ucz) < 1e-9f ? 1e9f : 1.f / ucz;
+                    const float ax_ = HS * fabsf(rx), ay_ = HS * fabsf(ry), az_ = HS * fabsf(rz);
                     for (int i = ilo; i <= ihi; ++i) {
                         const float fi = (float)i;
                         const float qx = fmaf(fi, urx, q0x), qy = fmaf(fi, ury, q0y), qz = fmaf(fi, urz, q0z);
-                        // exact j-interval on this row where |q + j Uc| < 1 on all three axes:
-                        // j between (-1 - q) r and (1 - q) r per axis
+                        // exact j-interval on this row where |q + j Uc| < HS on all three axes
                         const float mx = -qx * rx, my = -qy * ry, mz = -qz * rz;
-                        const float ax_ = fabsf(rx), ay_ = fabsf(ry), az_ = fabsf(rz);
                         const float lo = fmaxf(fmaxf(mx - ax_, my - ay_), mz - az_);
                         const float hiJ = fminf(fminf(mx + ax_, my + ay_), mz + az_);
                         const int jlo = (int)ceilf(fmaxf(lo - jmargin, 0.f));
@@ -739,38 +755,55 @@ __global__ __launch_bounds__(WG) void k_trilinear_gather_vol(GatherArgs G) {
                         const float4* __restrict__ row = q + (size_t)i * G.W;
                         for (int j = jlo; j <= jhi; ++j) {
                             const float4 t = row[j];
-                            // p - v with the forward's fmaf chain (b - v is exact, and so is the fold
-                            // for every |p| < 2^23, so these are the forward's interpolation weights)
-                            const float px = fmaf(a0, fmaf(al, t.x, s0), bv0);
-                            const float py = fmaf(a1, fmaf(al, t.y, s1), bv1);
-                            const float pz = fmaf(a2, fmaf(al, t.z, s2), bv2);
-                            const float ux = fmaxf(1.f - fabsf(px), 0.f);
-                            const float uy = fmaxf(1.f - fabsf(py), 0.f);
-                            const float uz = fmaxf(1.f - fabsf(pz), 0.f);
-                            acc = fmaf(ux * uy * uz, t.w, acc);
+                            const float ix = fmaf(al, t.x, s0), iy = fmaf(al, t.y, s1), iz = fmaf(al, t.z, s2);
+                            const float ux0 = fmaxf(1.f - fabsf(fmaf(a0, ix, bv0)), 0.f);
+                            const float uy0 = fmaxf(1.f - fabsf(fmaf(a1, iy, bv1)), 0.f);
+                            const float uz0 = fmaxf(1.f - fabsf(fmaf(a2, iz, bv2)), 0.f) * t.w;
+                            if (V == 1) {
+                                acc[0] = fmaf(ux0 * uy0, uz0, acc[0]);
+                            } else {
+                                const float ux1 = fmaxf(1.f - fabsf(fmaf(a0, ix, bw0)), 0.f);
+                                const float uy1 = fmaxf(1.f - fabsf(fmaf(a1, iy, bw1)), 0.f);
+                                const float uz1 = fmaxf(1.f - fabsf(fmaf(a2, iz, bw2)), 0.f) * t.w;
+                                const float p00 = ux0 * uy0, p01 = ux0 * uy1, p10 = ux1 * uy0, p11 = ux1 * uy1;
+                                acc[0] = fmaf(p00, uz0, acc[0]);
+                                acc[1 % (V * V * V)] = fmaf(p00, uz1, acc[1 % (V * V * V)]);
+                                acc[2 % (V * V * V)] = fmaf(p01, uz0, acc[2 % (V * V * V)]);
+                                acc[3 % (V * V * V)] = fmaf(p01, uz1, acc[3 % (V * V * V)]);
+                                acc[4 % (V * V * V)] = fmaf(p10, uz0, acc[4 % (V * V * V)]);
+                                acc[5 % (V * V * V)] = fmaf(p10, uz1, acc[5 % (V * V * V)]);
+                                acc[6 % (V * V * V)] = fmaf(p11, uz0, acc[6 % (V * V * V)]);
+                                acc[7 % (V * V * V)] = fmaf(p11, uz1, acc[7 % (V * V * V)]);
+                            }
                         }
                     }
                 } else {
                     // alpha_k = 0: every ray's sample sits on the source; all pixels are candidates for the
-                    // voxels whose unit box contains it (a source inside the volume only)
-                    const bool hit = fabsf(fmaf(a0, s0, b0) - fv[0]) < 1.f && fabsf(fmaf(a1, s1, b1) - fv[1]) < 1.f &&
-                                     fabsf(fmaf(a2, s2, b2) - fv[2]) < 1.f;
+                    // blocks whose support contains it (a source inside the volume only)
+                    const bool hit = fabsf(fmaf(a0, s0, b0) - (fv[0] + CO)) < HS && fabsf(fmaf(a1, s1, b1) - (fv[1] + CO)) < HS &&
+                                     fabsf(fmaf(a2, s2, b2) - (fv[2] + CO)) < HS;
                     const int cnt = hit ? G.n : 0;
                     for (int r = 0; r < cnt; ++r) {
                         const float4 t = q[r];
-                        const float px = fmaf(a0, fmaf(al, t.x, s0), b0);
-                        const float py = fmaf(a1, fmaf(al, t.y, s1), b1);
-                        const float pz = fmaf(a2, fmaf(al, t.z, s2), b2);
-                        const float ux = fmaxf(1.f - fabsf(px - fv[0]), 0.f);
-                        const float uy = fmaxf(1.f - fabsf(py - fv[1]), 0.f);
-                        const float uz = fmaxf(1.f - fabsf(pz - fv[2]), 0.f);
-                        acc = fmaf(ux * uy * uz, t.w, acc);
+                        const float ix = fmaf(al, t.x, s0), iy = fmaf(al, t.y, s1), iz = fmaf(al, t.z, s2);
+#pragma unroll
+                        for (int e = 0; e < V * V * V; ++e) {
+                            const float ox = (float)(e >> 2 & 1), oy = (float)(e >> 1 & 1), oz = (float)(e & 1);
+                            const float ux = fmaxf(1.f - fabsf(fmaf(a0, ix, bv0 - ox)), 0.f);
+                            const float uy = fmaxf(1.f - fabsf(fmaf(a1, iy, bv1 - oy)), 0.f);
+                            const float uz = fmaxf(1.f - fabsf(fmaf(a2, iz, bv2 - oz)), 0.f);
+                            acc[e] = fmaf(ux * uy * uz, t.w, acc[e]);
+                        }
                     }
                 }
             }
         }
     }
-    if (inb && acc != 0.f) G.gvol[((size_t)vx * G.D1 + vy) * G.D2 + vz] += acc;
+#pragma unroll
+    for (int e = 0; e < V * V * V; ++e) {
+        const int x = vx + (V == 2 ? (e >> 2 & 1) : 0), y = vy + (V == 2 ? (e >> 1 & 1) : 0), z = vz + (V == 2 ? (e & 1) : 0);
+        if (x < G.D0 && y < G.D1 && z < G.D2 && acc[e] != 0.f) G.gvol[((size_t)x * G.D1 + y) * G.D2 + z] += acc[e];
+    }
 }
 
 // Siddon voxel gradient as a gather (exact-geometry index map only: a = 1, b = shift - 1/2, so the
@@ -781,7 +814,7 @@ __global__ __launch_bounds__(WG) void k_trilinear_gather_vol(GatherArgs G) {
 __global__ __launch_bounds__(WG) void k_siddon_gather_vol(GatherArgs G) {
     if (*G.flag > __float_as_uint(GATHER_DEV_TOL)) return;
     int bx, by, bz;
-    brick_coords(blockIdx.x, G.D1, G.D2, bx, by, bz);
+    brick_coords(blockIdx.x, G.D1, G.D2, 1, bx, by, bz);
     const int tid = threadIdx.x;
     const int vx = bx * 4 + (tid >> 6), vy = by * 8 + ((tid >> 3) & 7), vz = bz * 8 + (tid & 7);
     const bool inb = vx < G.D0 && vy < G.D1 && vz < G.D2;
@@ -1094,7 +1127,17 @@ int launch(Kern kern, const RenderArgs& A, size_t lds_bytes, void* stream) {
 // workspace layout of the gather path:
 //   [flag, 256 B][PoseLattice x B, 256-aligned][float4 x B*n][cull words: bricks x ceil(B/32)]
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
-long long n_bricks(int D0, int D1, int D2) { return (long long)((D0 + 3) / 4) * ((D1 + 7) / 8) * ((D2 + 7) / 8); }
+long long n_bricks(int D0, int D1, int D2, int V = 1) {
+    return (long long)((D0 + 4 * V - 1) / (4 * V)) * ((D1 + 8 * V - 1) / (8 * V)) * ((D2 + 8 * V - 1) / (8 * V));
+}
+// voxels per lane and axis in the trilinear gather: 2 unless XVR_DRR_GATHER_BLOCK=1 (A/B switch)
+int gather_block() {
+    static const int v = [] {
+        const char* e = getenv("XVR_DRR_GATHER_BLOCK");
+        return (e && e[0] == '1') ? 1 : 2;
+    }();
+    return v;
+}
 size_t ws_pose_off() { return 256; }
 size_t ws_q_off(int B) { return 256 + align256((size_t)B * sizeof(PoseLattice)); }
 size_t ws_q2_off(int B, int n) { return ws_q_off(B) + align256((size_t)B * (size_t)n * sizeof(float4)); }
@@ -1117,6 +1160,7 @@ int launch_gather(bool siddon, const float* source, const float* target, const f
     G.q = reinterpret_cast<float4*>(ws + ws_q_off(B));
     G.q2 = reinterpret_cast<float2*>(ws + ws_q2_off(B, n));
     G.siddon = siddon ? 1 : 0;
+    G.V = siddon ? 1 : gather_block();
     G.cull = reinterpret_cast<unsigned*>(ws + ws_cull_off(B, n));
     G.words = (B + 31) / 32;
     G.gvol = grad_volume;
@@ -1125,12 +1169,13 @@ int launch_gather(bool siddon, const float* source, const float* target, const f
     if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
     hipLaunchKernelGGL(k_gather_prep, dim3((unsigned)((n + WG - 1) / WG), (unsigned)B), dim3(WG), 0,
                        (hipStream_t)stream, G);
-    const long long bricks = n_bricks(D0, D1, D2);
+    const long long bricks = n_bricks(D0, D1, D2, G.V);
     if (bricks >= (1LL << 31)) return fail(XVR_DRR_E_UNSUPPORTED, "grid too large");
     hipLaunchKernelGGL(k_gather_cull, dim3((unsigned)((bricks + WG / 32 - 1) / (WG / 32))), dim3(WG), 0,
                        (hipStream_t)stream, G, (int)bricks);
     if (siddon) hipLaunchKernelGGL(k_siddon_gather_vol, dim3((unsigned)bricks), dim3(WG), 0, (hipStream_t)stream, G);
-    else hipLaunchKernelGGL(k_trilinear_gather_vol, dim3((unsigned)bricks), dim3(WG), 0, (hipStream_t)stream, G);
+    else if (G.V == 2) hipLaunchKernelGGL(k_trilinear_gather_vol<2>, dim3((unsigned)bricks), dim3(WG), 0, (hipStream_t)stream, G);
+    else hipLaunchKernelGGL(k_trilinear_gather_vol<1>, dim3((unsigned)bricks), dim3(WG), 0, (hipStream_t)stream, G);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
     return XVR_DRR_OK;
