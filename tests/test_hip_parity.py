@@ -541,6 +541,70 @@ def test_render_samples_contract():
     _close(img1, img, FWD_TOL)
 
 
+def test_registration_c4_multiscale_refinement_and_first_step_parity():
+    """configs[3] in miniature: multiscale (mNCC + gradient-NCC) pose refinement.  (1) the first
+    iteration's similarity and its pose gradient match the oracle pipeline (CPU render + unfold NCC);
+    (2) the loop follows the reference schedule and pulls a perturbed pose back to the truth."""
+    from oracle import metrics_restated as mref
+    from oracle.diffdrr_restated import drr_from_pose
+    from xvr_amd.data import make_phantom, read
+    from xvr_amd.drr import DRR
+    from xvr_amd.metrics import DoubleGeodesicSE3
+    from xvr_amd.pose import convert
+    from xvr_amd.registrar import Registrar, parse_scales
+
+    assert parse_scales("8,4", 0, 2048) == [0.125, 2.0]
+    vol, _ = make_phantom(64, n_ellipsoids=10, seed=8)
+    sub = read(vol, spacing=(2.0, 2.0, 2.0), orientation="AP")
+    sdd, H, delx = 1020.0, 128, 1.4
+    drr = DRR(sub, sdd, H, delx, renderer="trilinear", reverse_x_axis=False, voxel_shift=0.0).cuda()
+    true_rot, true_xyz = torch.tensor([[3.10, 0.05, -0.03]]), torch.tensor([[4.0, 700.0, -6.0]])
+    true_pose = convert(true_rot, true_xyz, parameterization="euler_angles", convention="ZXY")
+    with torch.no_grad():
+        gt = drr(convert(true_rot, true_xyz, parameterization="euler_angles", convention="ZXY").cuda())
+    init_rot, init_xyz = true_rot + torch.tensor([[0.07, -0.05, 0.04]]), true_xyz + torch.tensor([[8.0, -12.0, 6.0]])
+    init_pose = convert(init_rot, init_xyz, parameterization="euler_angles", convention="ZXY")
+
+    # (1) first-step parity at the first pyramid level (128 -> 32 pixels)
+    reg = Registrar(drr, scales="4,2", n_itrs="60,40", patience=6, max_n_plateaus=2)
+    spec = to_oracle_spec(drr.renderer._spec(n_points=500))
+    h1, d1 = 32, delx * 4
+    r, t = init_rot.clone().requires_grad_(True), init_xyz.clone().requires_grad_(True)
+    pose_cpu = convert(r, t, parameterization="euler_angles", convention="ZXY")
+    pred_ref = drr_from_pose(vol, sub.affine, pose_cpu.matrix, h1, h1, sdd, d1, d1, 0.0, 0.0, spec, orientation="AP")
+    gt_ref = mref.xray_transforms(gt.cpu(), h1)
+    sim_ref = 0.5 * mref.multiscale_ncc(gt_ref, mref.xray_transforms(pred_ref, h1)) + 0.5 * mref.gradient_ncc(gt_ref, mref.xray_transforms(pred_ref, h1), 11, 0.0)
+    sim_ref.sum().backward()
+    from copy import deepcopy
+    from xvr_amd.metrics import XrayTransforms
+    from xvr_amd.registration import Registration
+    d = deepcopy(drr)
+    d.rescale_detector_(0.25)
+    rg = Registration(d, init_rot.cuda(), init_xyz.cuda(), "euler_angles", "ZXY")
+    tf = XrayTransforms(h1)
+    sim = reg.imagesim(tf(gt), tf(rg()))
+    sim.sum().backward()
+    assert abs(sim.item() - sim_ref.item()) < 2e-3, (sim.item(), sim_ref.item())
+    _close(rg.rotation.grad, r.grad, 2e-2, "d sim / d rot")
+    _close(rg.translation.grad, t.grad, 2e-2, "d sim / d xyz")
+
+    # (2) the loop
+    out = reg.run(gt, init_pose)
+    geo = DoubleGeodesicSE3(sdd)
+    err0 = geo(true_pose, init_pose)[2].item()
+    err1 = geo(true_pose, RigidTransform_cpu(out["final_pose"]))[2].item()
+    assert out["nccs"][-1] > out["nccs"][0] + 0.05
+    assert err1 < 0.35 * err0, (err0, err1)
+    assert out["drr"].detector.height == 64 and len(out["trajectory"]) == len(out["nccs"]) - 1
+    assert out["lrs"][0] == [1e-2, 1.0] and out["lrs"][-1][0] <= 1e-2 / 2
+
+
+def RigidTransform_cpu(pose):
+    from xvr_amd.pose import RigidTransform
+
+    return RigidTransform(pose.matrix.detach().cpu())
+
+
 def test_errors_are_python_exceptions():
     from xvr_amd.renderers import render
     from xvr_amd.spec import RenderSpec

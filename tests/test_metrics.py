@@ -1,0 +1,65 @@
+"""Box-filter NCC family (xvr_amd.metrics) against the literal unfold formulation (oracle)."""
+import pytest
+import torch
+
+from oracle import metrics_restated as ref
+from xvr_amd import metrics
+
+
+def _pair(seed=0, b=2, h=40, w=36):
+    g = torch.Generator().manual_seed(seed)
+    x1 = torch.rand(b, 1, h, w, generator=g) * 3 - 0.5
+    x2 = 0.6 * x1 + 0.4 * torch.rand(b, 1, h, w, generator=g)
+    x2[:, :, :8, :8] = 0.25  # a flat region: variance ~ 0, eps decides
+    return x1, x2
+
+
+@pytest.mark.parametrize("patch", [None, 5, 9])
+def test_ncc_matches_unfold_formulation(patch):
+    x1, x2 = _pair()
+    got = metrics.NormalizedCrossCorrelation2d(patch)(x1, x2)
+    want = ref.ncc(x1.double(), x2.double(), patch).float()
+    assert torch.allclose(got, want, atol=2e-5)
+
+
+def test_multiscale_and_gradient_ncc_match_and_differentiate():
+    x1, x2 = _pair(1)
+    m = metrics.MultiscaleNormalizedCrossCorrelation2d([None, 9], [0.5, 0.5])
+    assert torch.allclose(m(x1, x2), ref.multiscale_ncc(x1.double(), x2.double()).float(), atol=2e-5)
+    for sigma in (0.0, 1.5):
+        g = metrics.GradientNormalizedCrossCorrelation2d(11, sigma)
+        assert torch.allclose(g(x1, x2), ref.gradient_ncc(x1.double(), x2.double(), 11, sigma).float(), atol=2e-5)
+    # gradients agree with autograd through the unfold formulation
+    a = x2.clone().requires_grad_(True)
+    b = x2.double().clone().requires_grad_(True)
+    (0.5 * m(x1, a) + 0.5 * metrics.GradientNormalizedCrossCorrelation2d(11, 0.0)(x1, a)).sum().backward()
+    (0.5 * ref.multiscale_ncc(x1.double(), b) + 0.5 * ref.gradient_ncc(x1.double(), b, 11, 0.0)).sum().backward()
+    assert torch.allclose(a.grad, b.grad.float(), atol=1e-5 * b.grad.abs().max().item() + 1e-9)
+
+
+def test_ncc_of_identical_images_is_one_and_of_negated_is_minus_one():
+    x1, _ = _pair(2)
+    m = metrics.MultiscaleNormalizedCrossCorrelation2d([None, 9], [0.5, 0.5])
+    assert torch.allclose(m(x1, x1), torch.ones(2), atol=1e-3)
+    assert torch.allclose(m(x1, -x1), -torch.ones(2), atol=1e-3)
+    assert torch.allclose(m(x1, 2.5 * x1 + 0.7), torch.ones(2), atol=1e-3)  # affine invariance
+
+
+def test_xray_transforms_match_reference_lines():
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(1, 1, 64, 64, generator=g) * 900
+    t = metrics.XrayTransforms(16)
+    assert torch.allclose(t(x), ref.xray_transforms(x, 16), atol=1e-6)
+    same = metrics.XrayTransforms(64)(x)
+    assert torch.allclose(same, ((x - x.min()) / (x.max() - x.min() + 1e-6) - 0.15) / 0.1)
+
+
+def test_double_geodesic():
+    from xvr_amd.pose import convert
+
+    a = convert(torch.tensor([[0.0, 0.0, 0.0]]), torch.tensor([[0.0, 800.0, 0.0]]), parameterization="euler_angles", convention="ZXY")
+    b = convert(torch.tensor([[0.1, 0.0, 0.0]]), torch.tensor([[0.0, 800.0, 0.0]]), parameterization="euler_angles", convention="ZXY")
+    ang, tr, dbl = metrics.DoubleGeodesicSE3(1020.0)(a, b)
+    assert abs(ang.item() - 0.1 * 510.0) < 1e-2
+    assert abs(tr.item() - 2 * 800.0 * torch.sin(torch.tensor(0.05)).item()) < 1e-2
+    assert abs(dbl.item() - (ang.item() ** 2 + tr.item() ** 2) ** 0.5) < 1e-3

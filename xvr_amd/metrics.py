@@ -1,0 +1,139 @@
+"""Image-similarity metrics of the two outer loops (the step right after the renderer).
+
+Drop-ins for what xvr takes from ``diffdrr.metrics``:
+  MultiscaleNormalizedCrossCorrelation2d([None, 9], [0.5, 0.5])   /root/reference/src/xvr/registrar/base.py:119-121,
+                                                                   /root/reference/src/xvr/model/loss.py:16
+  GradientNormalizedCrossCorrelation2d(11, sigma)                  /root/reference/src/xvr/registrar/base.py:122
+  DoubleGeodesicSE3(sdd)                                           /root/reference/src/xvr/model/loss.py:18
+
+The reference's patch NCC unfolds every p x p patch into a channel ([b, (H-p+1)^2, p, p]: 81x the image
+at p = 9, 121x at p = 11) and z-scores each; here the same quantity is computed from five
+box filters -- mean(x1), mean(x2), mean(x1^2), mean(x2^2), mean(x1 x2) over every patch --
+
+    ncc_patch = (E[x1 x2] - mu1 mu2) / sqrt((var1 + eps)(var2 + eps)),   score = mean over patches,
+
+with the box sums accumulated in float64 (E[x^2] - mu^2 cancels catastrophically in fp32 on flat
+patches, where eps = 1e-5 decides the value).  Plain torch ops on the GPU, autograd-differentiable;
+checked against the literal unfold formulation in oracle/metrics_restated.py.
+"""
+
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from .pose import RigidTransform
+
+
+def _box_mean(x: torch.Tensor, p: int) -> torch.Tensor:
+    return F.avg_pool2d(x, kernel_size=p, stride=1)
+
+
+class NormalizedCrossCorrelation2d(torch.nn.Module):
+    def __init__(self, patch_size: int | None = None, eps: float = 1e-5):
+        super().__init__()
+        self.patch_size = patch_size
+        self.eps = eps
+
+    def forward(self, x1: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
+        assert x1.shape == x2.shape, "Input images must be the same size"
+        dt = x1.dtype
+        a, b = x1.double(), x2.double()
+        if self.patch_size is None:
+            mu1, mu2 = a.mean(dim=[-1, -2], keepdim=True), b.mean(dim=[-1, -2], keepdim=True)
+            d1, d2 = a - mu1, b - mu2
+            v1 = (d1 * d1).mean(dim=[-1, -2]) + self.eps
+            v2 = (d2 * d2).mean(dim=[-1, -2]) + self.eps
+            score = (d1 * d2).mean(dim=[-1, -2]) / (v1 * v2).sqrt()      # [b, c]
+            return score.mean(dim=1).to(dt)
+        p = self.patch_size
+        # centre globally first (NCC is shift invariant; keeps the box sums small)
+        a = a - a.mean(dim=[-1, -2], keepdim=True)
+        b = b - b.mean(dim=[-1, -2], keepdim=True)
+        m1, m2 = _box_mean(a, p), _box_mean(b, p)
+        v1 = (_box_mean(a * a, p) - m1 * m1).clamp_min(0) + self.eps
+        v2 = (_box_mean(b * b, p) - m2 * m2).clamp_min(0) + self.eps
+        cov = _box_mean(a * b, p) - m1 * m2
+        return (cov / (v1 * v2).sqrt()).mean(dim=[1, 2, 3]).to(dt)
+
+
+class MultiscaleNormalizedCrossCorrelation2d(torch.nn.Module):
+    def __init__(self, patch_sizes=(None,), patch_weights=(1.0,), eps: float = 1e-5):
+        super().__init__()
+        assert len(patch_sizes) == len(patch_weights), "Each scale must have a weight"
+        self.nccs = torch.nn.ModuleList([NormalizedCrossCorrelation2d(p, eps) for p in patch_sizes])
+        self.patch_weights = list(patch_weights)
+
+    def forward(self, x1, x2):
+        return sum(w * ncc(x1, x2) for w, ncc in zip(self.patch_weights, self.nccs))
+
+
+class Sobel(torch.nn.Module):
+    """Fixed 3x3 Sobel pair (2 output channels), optional 5x5 Gaussian pre-blur when sigma > 0."""
+
+    def __init__(self, sigma: float = 0.0):
+        super().__init__()
+        self.sigma = sigma
+        gx = torch.tensor([[1.0, 0.0, -1.0], [2.0, 0.0, -2.0], [1.0, 0.0, -1.0]])
+        gy = torch.tensor([[1.0, 2.0, 1.0], [0.0, 0.0, 0.0], [-1.0, -2.0, -1.0]])
+        self.register_buffer("weight", torch.stack([gx, gy]).unsqueeze(1))
+
+    def _blur(self, img):
+        x = torch.linspace(-2.0, 2.0, 5, dtype=img.dtype, device=img.device)
+        k = torch.exp(-0.5 * (x / self.sigma) ** 2)
+        k = k / k.sum()
+        c = img.shape[1]
+        img = F.pad(img, (2, 2, 2, 2), mode="reflect")
+        img = F.conv2d(img, k.view(1, 1, 1, 5).expand(c, 1, 1, 5), groups=c)
+        return F.conv2d(img, k.view(1, 1, 5, 1).expand(c, 1, 5, 1), groups=c)
+
+    def forward(self, img):
+        if self.sigma and self.sigma > 0:
+            img = self._blur(img)
+        return F.conv2d(img, self.weight.to(img), padding=1)
+
+
+class GradientNormalizedCrossCorrelation2d(NormalizedCrossCorrelation2d):
+    def __init__(self, patch_size: int | None = None, sigma: float = 1.0, **kwargs):
+        super().__init__(patch_size, **kwargs)
+        self.sobel = Sobel(sigma)
+
+    def forward(self, x1, x2):
+        return super().forward(self.sobel(x1), self.sobel(x2))
+
+
+class DoubleGeodesicSE3(torch.nn.Module):
+    """(angular, translational, double) geodesic distances between two batches of poses, in mm:
+    angular = sdd/2 * rotation angle, double = sqrt(angular^2 + translational^2 + eps)."""
+
+    def __init__(self, sdd: float, eps: float = 1e-6):
+        super().__init__()
+        self.sdd = sdd
+        self.eps = eps
+
+    def forward(self, pose_1: RigidTransform, pose_2: RigidTransform):
+        R = pose_1.matrix[..., :3, :3].transpose(-1, -2) @ pose_2.matrix[..., :3, :3]
+        cos = ((R.diagonal(dim1=-2, dim2=-1).sum(-1) - 1) / 2).clamp(-1 + 1e-7, 1 - 1e-7)
+        angular = 0.5 * self.sdd * torch.acos(cos)
+        trans = (pose_1.matrix[..., :3, 3] - pose_2.matrix[..., :3, 3]).norm(dim=-1)
+        return angular, trans, (angular.square() + trans.square() + self.eps).sqrt()
+
+
+class XrayTransforms(torch.nn.Module):
+    """Standardize (global min-max) -> Resize((h, w)) -> Normalize(mean, std), applied to every rendered
+    DRR each iteration (/root/reference/src/xvr/utils/preprocess.py:5-31; call sites
+    /root/reference/src/xvr/registrar/base.py:213-218,250, /root/reference/src/xvr/model/trainer.py:207,216).
+    ``equalize`` (the soft-histogram Equalize) is not provided this round."""
+
+    def __init__(self, height: int, width: int | None = None, mean: float = 0.15, std: float = 0.1, equalize: bool = False):
+        super().__init__()
+        if equalize:
+            raise NotImplementedError("Equalize is not provided in this round")
+        self.height, self.width = height, height if width is None else width
+        self.mean, self.std = mean, std
+
+    def forward(self, x):
+        x = (x - x.min()) / (x.max() - x.min() + 1e-6)
+        if tuple(x.shape[-2:]) != (self.height, self.width):
+            x = F.interpolate(x, size=(self.height, self.width), mode="bilinear", antialias=True, align_corners=False)
+        return (x - self.mean) / self.std

@@ -1,0 +1,123 @@
+"""Multiscale iterative pose refinement: the outer loop of ``xvr register`` around the render path.
+
+Mirrors ``_RegistrarBase.run`` / ``run_test_time_optimization``
+(/root/reference/src/xvr/registrar/base.py:125-292) without its file IO (DICOM parsing, pngs,
+parameters.pt) and without a pose-regressor initialiser -- the caller passes the target image, the
+detector intrinsics and an initial pose (what ``RegistrarFixed`` does,
+/root/reference/src/xvr/registrar/fixed.py:70-81).
+
+Schedule reproduced from the reference:
+* pyramid ratios from ``_parse_scales`` (base.py:402-407); ``rescale_detector_`` per stage (:212)
+* per stage Adam(maximize=True) with lr_rot / lr_xyz divided by prod 2^(stage-1) (:209,221-228),
+  ReduceLROnPlateau(factor 0.1, patience, threshold, mode="max") (:229-235)
+* loss = beta * mNCC([None, patch], [.5, .5]) + (1 - beta) * gradNCC(patch, sigma) on
+  XrayTransforms-ed images (:115-123, :250-251)
+* stop a stage after ``max_n_plateaus`` learning-rate drops, the initial lr counting as one (:238-239,270-278)
+
+What is NOT reproduced: the reference's 4+ device->host syncs per iteration (two ``loss.item()``, the
+pose -> euler -> ``tolist()``, two ``cuda.synchronize()``, base.py:246-267).  Only the plateau scheduler
+needs the loss on the host; the trajectory is kept on the device and copied once per stage.
+"""
+
+from __future__ import annotations
+
+import time
+from copy import deepcopy
+
+import torch
+
+from .drr import DRR
+from .metrics import (GradientNormalizedCrossCorrelation2d, MultiscaleNormalizedCrossCorrelation2d,
+                      XrayTransforms)
+from .pose import RigidTransform
+from .registration import Registration
+
+
+def parse_scales(scales, crop: int, height: int):
+    """Cumulative down-scaling factors -> per-stage ratios (base.py:402-407)."""
+    if isinstance(scales, str):
+        scales = scales.split(",")
+    pyramid = [1.0] + [float(x) * (height / (height + crop)) for x in scales]
+    return [pyramid[i] / pyramid[i + 1] for i in range(len(pyramid) - 1)]
+
+
+class Registrar:
+    def __init__(self, drr: DRR, scales="8", n_itrs="500", parameterization="euler_angles", convention="ZXY",
+                 lr_rot=1e-2, lr_xyz=1e0, patience=10, threshold=1e-4, max_n_plateaus=3, crop=0, equalize=False,
+                 mncc_patch_size=9, gncc_patch_size=11, sigma=0.0, beta=0.5, verbose=0):
+        self.drr = drr
+        self.scales = scales.split(",") if isinstance(scales, str) else [str(s) for s in scales]
+        self.n_itrs = [int(n) for n in (n_itrs.split(",") if isinstance(n_itrs, str) else n_itrs)]
+        assert len(self.scales) == len(self.n_itrs)
+        self.parameterization, self.convention = parameterization, convention
+        self.lr_rot, self.lr_xyz = lr_rot, lr_xyz
+        self.patience, self.threshold, self.max_n_plateaus = patience, threshold, max_n_plateaus
+        self.crop, self.equalize, self.verbose = crop, equalize, verbose
+        self.beta = beta
+        self.sim1 = MultiscaleNormalizedCrossCorrelation2d([None, mncc_patch_size], [0.5, 0.5])
+        self.sim2 = GradientNormalizedCrossCorrelation2d(gncc_patch_size, sigma)
+
+    def imagesim(self, x, y):
+        self.sim2.to(x.device)
+        return self.beta * self.sim1(x, y) + (1 - self.beta) * self.sim2(x, y)
+
+    def run(self, gt: torch.Tensor, init_pose: RigidTransform, intrinsics: dict | None = None):
+        """gt: [1,1,H,W] target image at full resolution.  Returns a dict with final_pose, ncc history,
+        per-iteration times, learning rates and the (r1,r2,r3,tx,ty,tz) trajectory."""
+        device = self.drr.density.device
+        *_, height, width = gt.shape
+        drr = deepcopy(self.drr)
+        if intrinsics is not None:
+            drr.set_intrinsics_(**{**intrinsics, "height": height, "width": width})
+        elif (drr.detector.height, drr.detector.width) != (height, width):
+            raise ValueError("gt and the DRR detector differ in size; pass intrinsics")
+        scales = parse_scales(self.scales, self.crop, height)
+        rot, xyz = init_pose.convert(self.parameterization, self.convention)
+        reg = Registration(drr, rot.to(device), xyz.to(device), self.parameterization, self.convention)
+        gt = gt.to(device)
+
+        traj, nccs, times, lrs = [], [], [0.0], [[self.lr_rot, self.lr_xyz]]
+        step_size_scalar = 1.0
+        img = transform = None
+        for stage, (scale, n_itr) in enumerate(zip(scales, self.n_itrs), start=1):
+            reg.drr.rescale_detector_(scale)
+            transform = XrayTransforms(reg.drr.detector.height, reg.drr.detector.width, equalize=self.equalize)
+            img = transform(gt)
+            step_size_scalar *= 2 ** (stage - 1)
+            optimizer = torch.optim.Adam(
+                [{"params": [reg.rotation], "lr": self.lr_rot / step_size_scalar},
+                 {"params": [reg.translation], "lr": self.lr_xyz / step_size_scalar}],
+                maximize=True,
+            )
+            scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(
+                optimizer, factor=0.1, patience=self.patience, threshold=self.threshold, mode="max")
+            n_plateaus, current_lr = 0, float("inf")
+            stage_losses, stage_params = [], []
+            for itr in range(n_itr):
+                t0 = time.perf_counter()
+                optimizer.zero_grad()
+                pred = transform(reg())
+                loss = self.imagesim(img, pred)
+                loss.sum().backward()
+                optimizer.step()
+                stage_losses.append(loss.detach())
+                stage_params.append(torch.cat([reg.rotation.detach(), reg.translation.detach()], dim=-1).clone())
+                scheduler.step(loss.detach().sum().item())   # the one host sync the plateau logic needs
+                times.append(time.perf_counter() - t0)
+                lr = scheduler.get_last_lr()
+                lrs.append(lr)
+                if lr[0] < current_lr:
+                    current_lr = lr[0]
+                    n_plateaus += 1
+                if n_plateaus == self.max_n_plateaus:
+                    break
+            if stage_losses:
+                nccs += torch.stack(stage_losses).reshape(-1).tolist()
+                traj += torch.stack(stage_params).reshape(len(stage_params), -1).tolist()
+            if self.verbose:
+                print(f"stage {stage}: {len(stage_losses)} iterations, ncc = {nccs[-1]:.4f}")
+        with torch.no_grad():
+            final_ncc = self.imagesim(img, transform(reg())).sum().item()
+        nccs.append(final_ncc)
+        return dict(final_pose=RigidTransform(reg.pose.matrix.detach()), init_pose=init_pose, nccs=nccs, times=times,
+                    lrs=lrs, trajectory=traj, runtime=sum(times), drr=reg.drr)
