@@ -44,7 +44,7 @@ def parse_scales(scales, crop: int, height: int):
 class Registrar:
     def __init__(self, drr: DRR, scales="8", n_itrs="500", parameterization="euler_angles", convention="ZXY",
                  lr_rot=1e-2, lr_xyz=1e0, patience=10, threshold=1e-4, max_n_plateaus=3, crop=0, equalize=False,
-                 mncc_patch_size=9, gncc_patch_size=11, sigma=0.0, beta=0.5, verbose=0):
+                 mncc_patch_size=9, gncc_patch_size=11, sigma=0.0, beta=0.5, verbose=0, use_graph=None):
         self.drr = drr
         self.scales = scales.split(",") if isinstance(scales, str) else [str(s) for s in scales]
         self.n_itrs = [int(n) for n in (n_itrs.split(",") if isinstance(n_itrs, str) else n_itrs)]
@@ -54,6 +54,10 @@ class Registrar:
         self.patience, self.threshold, self.max_n_plateaus = patience, threshold, max_n_plateaus
         self.crop, self.equalize, self.verbose = crop, equalize, verbose
         self.beta = beta
+        # Capture one whole iteration (render -> transforms -> similarity -> backward -> Adam) in a HIP
+        # graph per pyramid stage and replay it: the reference's iteration is ~150 tiny launches and is
+        # launch-bound (4.4 ms at 256^2 and at 512^2 alike on MI355X); replaying costs a fraction.
+        self.use_graph = torch.cuda.is_available() if use_graph is None else use_graph
         self.sim1 = MultiscaleNormalizedCrossCorrelation2d([None, mncc_patch_size], [0.5, 0.5])
         self.sim2 = GradientNormalizedCrossCorrelation2d(gncc_patch_size, sigma)
 
@@ -84,33 +88,62 @@ class Registrar:
             transform = XrayTransforms(reg.drr.detector.height, reg.drr.detector.width, equalize=self.equalize)
             img = transform(gt)
             step_size_scalar *= 2 ** (stage - 1)
+            graphed = self.use_graph and device.type == "cuda"
+            lr_rot = self.lr_rot / step_size_scalar
+            lr_xyz = self.lr_xyz / step_size_scalar
+            if graphed:  # capturable Adam reads its learning rates from device tensors
+                lr_rot, lr_xyz = torch.tensor(lr_rot, device=device), torch.tensor(lr_xyz, device=device)
             optimizer = torch.optim.Adam(
-                [{"params": [reg.rotation], "lr": self.lr_rot / step_size_scalar},
-                 {"params": [reg.translation], "lr": self.lr_xyz / step_size_scalar}],
-                maximize=True,
+                [{"params": [reg.rotation], "lr": lr_rot}, {"params": [reg.translation], "lr": lr_xyz}],
+                maximize=True, capturable=graphed,
             )
             scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(
                 optimizer, factor=0.1, patience=self.patience, threshold=self.threshold, mode="max")
             n_plateaus, current_lr = 0, float("inf")
             stage_losses, stage_params = [], []
-            for itr in range(n_itr):
-                t0 = time.perf_counter()
-                optimizer.zero_grad()
+
+            def iteration():
                 pred = transform(reg())
                 loss = self.imagesim(img, pred)
                 loss.sum().backward()
                 optimizer.step()
-                stage_losses.append(loss.detach())
+                return loss.detach()
+
+            graph = static_loss = None
+            n_warm = 3  # eager iterations before capture (they are real iterations of the optimisation)
+            for itr in range(n_itr):
+                t0 = time.perf_counter()
+                if graphed and itr == n_warm and graph is None:
+                    try:
+                        optimizer.zero_grad(set_to_none=True)
+                        graph = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(graph):
+                            static_loss = iteration()
+                        loss = static_loss
+                    except Exception as e:  # capture is an optimisation, never a requirement
+                        if self.verbose:
+                            print(f"graph capture failed ({e}); continuing eagerly")
+                        graph, graphed = None, False
+                        optimizer.zero_grad()
+                        loss = iteration()
+                elif graph is not None:
+                    graph.replay()
+                    loss = static_loss
+                else:
+                    optimizer.zero_grad()
+                    loss = iteration()
+                stage_losses.append(loss.clone())
                 stage_params.append(torch.cat([reg.rotation.detach(), reg.translation.detach()], dim=-1).clone())
-                scheduler.step(loss.detach().sum().item())   # the one host sync the plateau logic needs
+                scheduler.step(loss.sum().item())   # the one host sync the plateau logic needs
                 times.append(time.perf_counter() - t0)
-                lr = scheduler.get_last_lr()
+                lr = [float(x) for x in scheduler.get_last_lr()]
                 lrs.append(lr)
                 if lr[0] < current_lr:
                     current_lr = lr[0]
                     n_plateaus += 1
                 if n_plateaus == self.max_n_plateaus:
                     break
+            del graph
             if stage_losses:
                 nccs += torch.stack(stage_losses).reshape(-1).tolist()
                 traj += torch.stack(stage_params).reshape(len(stage_params), -1).tolist()
