@@ -42,6 +42,7 @@ struct RenderArgs {
     int B, n;
     xvr_drr_spec sp;
     int grid_w, grid_h, tiles_x, blocks_per_pose;
+    int tile_shape;  // -1: choose per workgroup; 0: 8x8 per wave; 1: 16 wide x 4 tall; 2: 4 wide x 16 tall
     float* __restrict__ out;
     float* __restrict__ jac;
     unsigned long long* work;
@@ -101,9 +102,30 @@ __device__ __forceinline__ bool map_ray(const RenderArgs& A, int& b, int& r) {
     int tid = threadIdx.x;
     if (A.grid_w > 0) {
         int ty = t / A.tiles_x, tx = t - ty * A.tiles_x;
-        int w = tid >> 6, l = tid & 63;
-        int px = tx * 16 + (w & 1) * 8 + (l & 7);
-        int py = ty * 16 + (w >> 1) * 8 + (l >> 3);
+        const int px0 = tx * 16, py0 = ty * 16;
+        // Shape of the 64-pixel patch each wavefront takes out of the workgroup's 16x16 tile.  Voxel rows
+        // are contiguous along z (volume axis 2): lanes that differ along the detector axis which runs
+        // along z share cache lines, lanes that differ along the other axis cost a line each.  So make the
+        // wave long along the z-aligned detector axis (decided per workgroup from two neighbouring rays).
+        int shape = A.tile_shape;
+        if (shape < 0) {
+            shape = 0;
+            if (A.grid_w > 1 && A.grid_h > 1) {
+                const int pc = px0 + 1 < A.grid_w ? px0 + 1 : px0 - 1;
+                const int pr = py0 + 1 < A.grid_h ? py0 + 1 : py0 - 1;
+                const float* T = A.target + (size_t)b * A.n * 3;
+                const float z00 = T[((size_t)py0 * A.grid_w + px0) * 3 + 2];
+                const float zc = fabsf(T[((size_t)py0 * A.grid_w + pc) * 3 + 2] - z00);
+                const float zr = fabsf(T[((size_t)pr * A.grid_w + px0) * 3 + 2] - z00);
+                shape = zc > 2.f * zr ? 1 : (zr > 2.f * zc ? 2 : 0);
+            }
+        }
+        const int w = tid >> 6, l = tid & 63;
+        int dx, dy;
+        if (shape == 1) { dx = l & 15; dy = w * 4 + (l >> 4); }
+        else if (shape == 2) { dx = w * 4 + (l & 3); dy = l >> 2; }
+        else { dx = (w & 1) * 8 + (l & 7); dy = (w >> 1) * 8 + (l >> 3); }
+        const int px = px0 + dx, py = py0 + dy;
         r = py * A.grid_w + px;
         return px < A.grid_w && py < A.grid_h;
     }
@@ -268,42 +290,59 @@ __global__ __launch_bounds__(WG) void k_trilinear_fwd(RenderArgs A) {
     unsigned cnt = 0;
     const float adx = A.sp.a[0] * R.d[0], ady = A.sp.a[1] * R.d[1], adz = A.sp.a[2] * R.d[2];
 
-    for (int k = kbeg; k <= kend; ++k) {
-        if (k < K.lo || k > K.hi) continue;
-        const float u = linspace_at(k, N, A.sp.near_, A.sp.far_, step);
-        const float al = CLIP ? fmaf(u, R.amax - R.amin, R.amin) : u;
-        const float px = fmaf(A.sp.a[0], fmaf(al, R.d[0], R.s[0]), A.sp.b[0]);
-        const float py = fmaf(A.sp.a[1], fmaf(al, R.d[1], R.s[1]), A.sp.b[1]);
-        const float pz = fmaf(A.sp.a[2], fmaf(al, R.d[2], R.s[2]), A.sp.b[2]);
-        Taps T;
-        make_taps(px, py, pz, D0, D1, D2, T);
-        const fpair P0 = load_pair(vol + T.base[0]);
-        const fpair P1 = load_pair(vol + T.base[1]);
-        const fpair P2 = load_pair(vol + T.base[2]);
-        const fpair P3 = load_pair(vol + T.base[3]);
-        const float v0 = fmaf(T.pz1, P0.y, T.pz0 * P0.x), v1 = fmaf(T.pz1, P1.y, T.pz0 * P1.x);
-        const float v2 = fmaf(T.pz1, P2.y, T.pz0 * P2.x), v3 = fmaf(T.pz1, P3.y, T.pz0 * P3.x);
-        const float r0 = fmaf(T.wy1, v1, T.wy0 * v0), r1 = fmaf(T.wy1, v3, T.wy0 * v2);
-        const float v = fmaf(T.wx1, r1, T.wx0 * r0);
-        ++cnt;
-        if (MASK) {
-            const int lab = nearest_label(A.mask, px, py, pz, D0, D1, D2, A.C);
-            lds[lab * WG + tid] += v;
-        } else {
-            S += v;
+    // Two steps per trip: the 8 independent 8-byte gathers of both samples are issued before either
+    // is consumed (the march is latency-bound, not bandwidth-bound: L2 at ~20 %, HBM at ~25 %).
+    for (int kk = kbeg; kk <= kend; kk += 2) {
+        bool act[2];
+        float u[2], al[2], pxs[2], pys[2], pzs[2];
+        Taps T[2];
+        fpair P[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = kk + h;
+            act[h] = k >= K.lo && k <= K.hi;
+            u[h] = linspace_at(k, N, A.sp.near_, A.sp.far_, step);
+            al[h] = CLIP ? fmaf(u[h], R.amax - R.amin, R.amin) : u[h];
+            pxs[h] = fmaf(A.sp.a[0], fmaf(al[h], R.d[0], R.s[0]), A.sp.b[0]);
+            pys[h] = fmaf(A.sp.a[1], fmaf(al[h], R.d[1], R.s[1]), A.sp.b[1]);
+            pzs[h] = fmaf(A.sp.a[2], fmaf(al[h], R.d[2], R.s[2]), A.sp.b[2]);
+            make_taps(pxs[h], pys[h], pzs[h], D0, D1, D2, T[h]);  // offsets are clamped: always loadable
         }
-        if (JAC) {
-            const float d0 = fmaf(T.qz1, P0.y, T.qz0 * P0.x), d1 = fmaf(T.qz1, P1.y, T.qz0 * P1.x);
-            const float d2 = fmaf(T.qz1, P2.y, T.qz0 * P2.x), d3 = fmaf(T.qz1, P3.y, T.qz0 * P3.x);
-            const float gz = fmaf(T.wx1, fmaf(T.wy1, d3, T.wy0 * d2), T.wx0 * fmaf(T.wy1, d1, T.wy0 * d0));
-            const float gx = fmaf(T.sx1, r1, T.sx0 * r0);
-            const float gy = fmaf(T.wx1, fmaf(T.sy1, v3, T.sy0 * v2), T.wx0 * fmaf(T.sy1, v1, T.sy0 * v0));
-            G[0] += gx; G[1] += gy; G[2] += gz;
-            H[0] = fmaf(al, gx, H[0]); H[1] = fmaf(al, gy, H[1]); H[2] = fmaf(al, gz, H[2]);
-            if (CLIP) {
-                const float gd = fmaf(gx, adx, fmaf(gy, ady, gz * adz));
-                E0 = fmaf(gd, 1.f - u, E0);
-                E1 = fmaf(gd, u, E1);
+        // unconditional (offsets are clamped into the volume): a branch here would split the loads into
+        // two exec-masked blocks with a full vmcnt(0) drain between them
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) P[h][q] = load_pair(vol + T[h].base[q]);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (!act[h]) continue;
+            const Taps& t = T[h];
+            const float v0 = fmaf(t.pz1, P[h][0].y, t.pz0 * P[h][0].x), v1 = fmaf(t.pz1, P[h][1].y, t.pz0 * P[h][1].x);
+            const float v2 = fmaf(t.pz1, P[h][2].y, t.pz0 * P[h][2].x), v3 = fmaf(t.pz1, P[h][3].y, t.pz0 * P[h][3].x);
+            const float r0 = fmaf(t.wy1, v1, t.wy0 * v0), r1 = fmaf(t.wy1, v3, t.wy0 * v2);
+            const float v = fmaf(t.wx1, r1, t.wx0 * r0);
+            ++cnt;
+            if (MASK) {
+                const int lab = nearest_label(A.mask, pxs[h], pys[h], pzs[h], D0, D1, D2, A.C);
+                lds[lab * WG + tid] += v;
+            } else {
+                S += v;
+            }
+            if (JAC) {
+                const float d0 = fmaf(t.qz1, P[h][0].y, t.qz0 * P[h][0].x), d1 = fmaf(t.qz1, P[h][1].y, t.qz0 * P[h][1].x);
+                const float d2 = fmaf(t.qz1, P[h][2].y, t.qz0 * P[h][2].x), d3 = fmaf(t.qz1, P[h][3].y, t.qz0 * P[h][3].x);
+                const float gz = fmaf(t.wx1, fmaf(t.wy1, d3, t.wy0 * d2), t.wx0 * fmaf(t.wy1, d1, t.wy0 * d0));
+                const float gx = fmaf(t.sx1, r1, t.sx0 * r0);
+                const float gy = fmaf(t.wx1, fmaf(t.sy1, v3, t.sy0 * v2), t.wx0 * fmaf(t.sy1, v1, t.sy0 * v0));
+                G[0] += gx; G[1] += gy; G[2] += gz;
+                H[0] = fmaf(al[h], gx, H[0]); H[1] = fmaf(al[h], gy, H[1]); H[2] = fmaf(al[h], gz, H[2]);
+                if (CLIP) {
+                    const float gd = fmaf(gx, adx, fmaf(gy, ady, gz * adz));
+                    E0 = fmaf(gd, 1.f - u[h], E0);
+                    E1 = fmaf(gd, u[h], E1);
+                }
             }
         }
     }
@@ -340,6 +379,194 @@ __global__ __launch_bounds__(WG) void k_trilinear_fwd(RenderArgs A) {
             float4* jp = reinterpret_cast<float4*>(A.jac + ((size_t)b * A.n + r) * XVR_DRR_JAC_STRIDE);
             jp[0] = make_float4(S * (CLIP ? A.sp.inv_denom * span : A.sp.inv_denom), js[0], js[1], js[2]);
             jp[1] = make_float4(jt[0], jt[1], jt[2], 0.f);
+        }
+    }
+    if (A.work) {
+        unsigned tot = wave_sum_u(cnt);
+        if ((tid & 63) == 0 && tot) atomicAdd(A.work, (unsigned long long)tot);
+    }
+}
+
+
+// =============================================================================================
+// trilinear forward with LDS-staged voxel bricks
+//
+// The direct kernel above is limited by how many distinct cache lines the texture-address unit must
+// visit per gather instruction (64 lanes x 8 B spread over 10-40 lines).  Here the workgroup (a 16x16
+// pixel tile = 256 rays) walks its rays in chunks of KC steps; per chunk it computes a conservative
+// bounding brick of every tap its rays will make, loads that brick once with row-contiguous loads
+// (16 consecutive lanes per voxel row), zero-fills the part outside the volume (= grid_sample's
+// padding, so the taps need no bounds logic), and then takes all 8 taps of every sample from LDS.
+// Sample positions are linear in k (p = P0 + k D), so ONE block reduction of min/max(P0), min/max(D)
+// gives every chunk's brick with a dozen fmas -- valid for any set of rays; for scattered rays the
+// brick simply does not fit and the chunk falls back to direct global loads (wave-uniform branch).
+// =============================================================================================
+constexpr int LDS_KC = 8;             // steps per chunk
+constexpr int LDS_BRICK_CAP = 12160;  // floats: 47.5 KiB brick + 0.5 KiB header -> 3 workgroups per CU
+constexpr int LDS_HDR = 128;          // floats reserved in front of the brick (reduction scratch)
+
+template <bool JAC>
+__global__ __launch_bounds__(WG) void k_trilinear_fwd_lds(RenderArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* const hdr = lds;
+    float* const brick = lds + LDS_HDR;
+    int b, r;
+    const bool valid = map_ray(A, b, r);
+    const int tid = threadIdx.x;
+    Ray R;
+    ray_setup(A, b, r, valid, R);
+    const int N = A.sp.n_points;
+    const float step = N > 1 ? (A.sp.far_ - A.sp.near_) / (float)(N - 1) : 0.f;
+    const KRange K = tri_krange(A, R, false, step);
+    const bool live = K.lo <= K.hi;
+    const float* __restrict__ vol = A.volume;
+    const int D0 = A.D0, D1 = A.D1, D2 = A.D2;
+
+    // linear model of this ray's sample positions in index space: p(k) ~ P0 + k * Dl
+    float P0[3], Dl[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        P0[i] = fmaf(A.sp.a[i], fmaf(A.sp.near_, R.d[i], R.s[i]), A.sp.b[i]);
+        Dl[i] = step * A.sp.a[i] * R.d[i];
+    }
+    // block reduction: min/max of P0 and Dl over the live rays, min/max of the k ranges
+    float red[14];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        red[i] = live ? P0[i] : INFINITY;
+        red[3 + i] = live ? -P0[i] : INFINITY;   // max as min of the negation
+        red[6 + i] = live ? Dl[i] : INFINITY;
+        red[9 + i] = live ? -Dl[i] : INFINITY;
+    }
+    red[12] = live ? (float)K.lo : INFINITY;
+    red[13] = live ? -(float)K.hi : INFINITY;
+#pragma unroll
+    for (int v = 0; v < 14; ++v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) red[v] = fminf(red[v], __shfl_xor(red[v], o));
+    }
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int v = 0; v < 14; ++v) hdr[(tid >> 6) * 16 + v] = red[v];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < 14; ++v) red[v] = fminf(fminf(hdr[v], hdr[16 + v]), fminf(hdr[32 + v], hdr[48 + v]));
+    __syncthreads();
+    const bool any_live = red[12] < INFINITY;
+    const int kbeg = any_live ? (int)red[12] : 1, kend = any_live ? (int)(-red[13]) : 0;
+
+    float S = 0.f;
+    float G[3] = {0.f, 0.f, 0.f}, H[3] = {0.f, 0.f, 0.f};
+    unsigned cnt = 0;
+
+    for (int k0 = kbeg; k0 <= kend; k0 += LDS_KC) {
+        const int k1 = min(k0 + LDS_KC - 1, kend);
+        // conservative brick of every tap in steps [k0, k1] (uniform across the workgroup)
+        int lo3[3], ex3[3];
+        bool fits = true;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float mn = fminf(fmaf((float)k0, red[6 + i], red[i]), fmaf((float)k1, red[6 + i], red[i]));
+            const float mx = fmaxf(fmaf((float)k0, -red[9 + i], -red[3 + i]), fmaf((float)k1, -red[9 + i], -red[3 + i]));
+            const float flo = floorf(mn - 0.02f), fhi = floorf(mx + 0.02f) + 1.f;
+            fits = fits && (fhi - flo) < 4096.f && fabsf(flo) < 1e6f;
+            lo3[i] = (int)flo;
+            ex3[i] = (int)(fhi - flo) + 1;
+        }
+        const int ex = ex3[0], ey = ex3[1], ez = ex3[2];
+        fits = fits && (long long)ex * ey * ez <= LDS_BRICK_CAP && ez <= 64;
+        if (fits) {
+            // cooperative load: 16 consecutive lanes per voxel row (contiguous along z), 16 rows per pass
+            const int sub = tid & 15;
+            const int nrows = ex * ey;
+            int row = tid >> 4;
+            int rx = row / ey, ry = row - rx * ey;
+            for (; row < nrows; row += 16) {
+                const int gx = lo3[0] + rx, gy = lo3[1] + ry;
+                const bool rin = (unsigned)gx < (unsigned)D0 && (unsigned)gy < (unsigned)D1;
+                const float* __restrict__ src = vol + ((size_t)(rin ? gx : 0) * D1 + (rin ? gy : 0)) * D2;
+                float* dst = brick + row * ez;
+                for (int zi = sub; zi < ez; zi += 16) {
+                    const int gz = lo3[2] + zi;
+                    dst[zi] = (rin && (unsigned)gz < (unsigned)D2) ? src[gz] : 0.f;
+                }
+                ry += 16;
+                while (ry >= ey) { ry -= ey; ++rx; }
+            }
+            __syncthreads();
+            const int sy = ez, sx = ey * ez;
+            for (int k = k0; k <= k1; ++k) {
+                if (k < K.lo || k > K.hi) continue;
+                const float al = linspace_at(k, N, A.sp.near_, A.sp.far_, step);
+                const float px = fmaf(A.sp.a[0], fmaf(al, R.d[0], R.s[0]), A.sp.b[0]);
+                const float py = fmaf(A.sp.a[1], fmaf(al, R.d[1], R.s[1]), A.sp.b[1]);
+                const float pz = fmaf(A.sp.a[2], fmaf(al, R.d[2], R.s[2]), A.sp.b[2]);
+                const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+                const float tx = px - fx, ty = py - fy, tz = pz - fz;
+                // local coordinates inside the brick (clamped: the brick is conservative by construction)
+                const int lx = min(max((int)fx - lo3[0], 0), ex - 2);
+                const int ly = min(max((int)fy - lo3[1], 0), ey - 2);
+                const int lz = min(max((int)fz - lo3[2], 0), ez - 2);
+                const float* t = brick + lx * sx + ly * sy + lz;
+                const float c000 = t[0], c001 = t[1], c010 = t[sy], c011 = t[sy + 1];
+                const float c100 = t[sx], c101 = t[sx + 1], c110 = t[sx + sy], c111 = t[sx + sy + 1];
+                const float v0 = fmaf(tz, c001 - c000, c000), v1 = fmaf(tz, c011 - c010, c010);
+                const float v2 = fmaf(tz, c101 - c100, c100), v3 = fmaf(tz, c111 - c110, c110);
+                const float r0 = fmaf(ty, v1 - v0, v0), r1 = fmaf(ty, v3 - v2, v2);
+                S += fmaf(tx, r1 - r0, r0);
+                ++cnt;
+                if (JAC) {
+                    const float gx = r1 - r0;
+                    const float gy = fmaf(tx, (v3 - v2) - (v1 - v0), v1 - v0);
+                    const float d0 = c001 - c000, d1 = c011 - c010, d2 = c101 - c100, d3 = c111 - c110;
+                    const float e0 = fmaf(ty, d1 - d0, d0), e1 = fmaf(ty, d3 - d2, d2);
+                    const float gz = fmaf(tx, e1 - e0, e0);
+                    G[0] += gx; G[1] += gy; G[2] += gz;
+                    H[0] = fmaf(al, gx, H[0]); H[1] = fmaf(al, gy, H[1]); H[2] = fmaf(al, gz, H[2]);
+                }
+            }
+            __syncthreads();
+        } else {
+            // brick too large for LDS (scattered rays / extreme obliquity): direct global taps for this chunk
+            for (int k = k0; k <= k1; ++k) {
+                if (k < K.lo || k > K.hi) continue;
+                const float al = linspace_at(k, N, A.sp.near_, A.sp.far_, step);
+                const float px = fmaf(A.sp.a[0], fmaf(al, R.d[0], R.s[0]), A.sp.b[0]);
+                const float py = fmaf(A.sp.a[1], fmaf(al, R.d[1], R.s[1]), A.sp.b[1]);
+                const float pz = fmaf(A.sp.a[2], fmaf(al, R.d[2], R.s[2]), A.sp.b[2]);
+                Taps T;
+                make_taps(px, py, pz, D0, D1, D2, T);
+                const fpair Q0 = load_pair(vol + T.base[0]);
+                const fpair Q1 = load_pair(vol + T.base[1]);
+                const fpair Q2 = load_pair(vol + T.base[2]);
+                const fpair Q3 = load_pair(vol + T.base[3]);
+                const float v0 = fmaf(T.pz1, Q0.y, T.pz0 * Q0.x), v1 = fmaf(T.pz1, Q1.y, T.pz0 * Q1.x);
+                const float v2 = fmaf(T.pz1, Q2.y, T.pz0 * Q2.x), v3 = fmaf(T.pz1, Q3.y, T.pz0 * Q3.x);
+                const float r0 = fmaf(T.wy1, v1, T.wy0 * v0), r1 = fmaf(T.wy1, v3, T.wy0 * v2);
+                S += fmaf(T.wx1, r1, T.wx0 * r0);
+                ++cnt;
+                if (JAC) {
+                    const float d0 = fmaf(T.qz1, Q0.y, T.qz0 * Q0.x), d1 = fmaf(T.qz1, Q1.y, T.qz0 * Q1.x);
+                    const float d2 = fmaf(T.qz1, Q2.y, T.qz0 * Q2.x), d3 = fmaf(T.qz1, Q3.y, T.qz0 * Q3.x);
+                    const float gz = fmaf(T.wx1, fmaf(T.wy1, d3, T.wy0 * d2), T.wx0 * fmaf(T.wy1, d1, T.wy0 * d0));
+                    const float gx = fmaf(T.sx1, r1, T.sx0 * r0);
+                    const float gy = fmaf(T.wx1, fmaf(T.sy1, v3, T.sy0 * v2), T.wx0 * fmaf(T.sy1, v1, T.sy0 * v0));
+                    G[0] += gx; G[1] += gy; G[2] += gz;
+                    H[0] = fmaf(al, gx, H[0]); H[1] = fmaf(al, gy, H[1]); H[2] = fmaf(al, gz, H[2]);
+                }
+            }
+        }
+    }
+
+    const float scale = R.L * A.sp.inv_denom;
+    if (valid) {
+        A.out[(size_t)b * A.n + r] = S * scale;
+        if (JAC) {
+            float4* jp = reinterpret_cast<float4*>(A.jac + ((size_t)b * A.n + r) * XVR_DRR_JAC_STRIDE);
+            jp[0] = make_float4(S * A.sp.inv_denom, scale * A.sp.a[0] * (G[0] - H[0]), scale * A.sp.a[1] * (G[1] - H[1]),
+                                scale * A.sp.a[2] * (G[2] - H[2]));
+            jp[1] = make_float4(scale * A.sp.a[0] * H[0], scale * A.sp.a[1] * H[1], scale * A.sp.a[2] * H[2], 0.f);
         }
     }
     if (A.work) {
@@ -572,7 +799,9 @@ __global__ __launch_bounds__(WG) void k_gather_prep(GatherArgs G) {
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) dev = fmaxf(dev, __shfl_xor(dev, o));
-    if ((threadIdx.x & 63) == 0 && dev > 0.f) atomicMax(G.flag, __float_as_uint(dev));
+    // only a wave that SEES a violation touches the flag (one word: 10^5 same-address atomics would
+    // serialise into more than a millisecond)
+    if ((threadIdx.x & 63) == 0 && dev > GATHER_DEV_TOL) atomicMax(G.flag, __float_as_uint(dev));
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         PoseLattice P = {};
         float s[3], nrm[3], st[3], ts[3], tmp[3];
@@ -753,27 +982,35 @@ __global__ __launch_bounds__(WG) void k_trilinear_gather_vol(GatherArgs G) {
                         const int jlo = (int)ceilf(fmaxf(lo - jmargin, 0.f));
                         const int jhi = (int)floorf(fminf(hiJ + jmargin, (float)(G.W - 1)));
                         const float4* __restrict__ row = q + (size_t)i * G.W;
-                        for (int j = jlo; j <= jhi; ++j) {
-                            const float4 t = row[j];
-                            const float ix = fmaf(al, t.x, s0), iy = fmaf(al, t.y, s1), iz = fmaf(al, t.z, s2);
-                            const float ux0 = fmaxf(1.f - fabsf(fmaf(a0, ix, bv0)), 0.f);
-                            const float uy0 = fmaxf(1.f - fabsf(fmaf(a1, iy, bv1)), 0.f);
-                            const float uz0 = fmaxf(1.f - fabsf(fmaf(a2, iz, bv2)), 0.f) * t.w;
-                            if (V == 1) {
-                                acc[0] = fmaf(ux0 * uy0, uz0, acc[0]);
-                            } else {
-                                const float ux1 = fmaxf(1.f - fabsf(fmaf(a0, ix, bw0)), 0.f);
-                                const float uy1 = fmaxf(1.f - fabsf(fmaf(a1, iy, bw1)), 0.f);
-                                const float uz1 = fmaxf(1.f - fabsf(fmaf(a2, iz, bw2)), 0.f) * t.w;
-                                const float p00 = ux0 * uy0, p01 = ux0 * uy1, p10 = ux1 * uy0, p11 = ux1 * uy1;
-                                acc[0] = fmaf(p00, uz0, acc[0]);
-                                acc[1 % (V * V * V)] = fmaf(p00, uz1, acc[1 % (V * V * V)]);
-                                acc[2 % (V * V * V)] = fmaf(p01, uz0, acc[2 % (V * V * V)]);
-                                acc[3 % (V * V * V)] = fmaf(p01, uz1, acc[3 % (V * V * V)]);
-                                acc[4 % (V * V * V)] = fmaf(p10, uz0, acc[4 % (V * V * V)]);
-                                acc[5 % (V * V * V)] = fmaf(p10, uz1, acc[5 % (V * V * V)]);
-                                acc[6 % (V * V * V)] = fmaf(p11, uz0, acc[6 % (V * V * V)]);
-                                acc[7 % (V * V * V)] = fmaf(p11, uz1, acc[7 % (V * V * V)]);
+                        // two candidates per trip: both 16-byte loads are issued before either is used
+                        for (int j = jlo; j <= jhi; j += 2) {
+                            const bool two = j < jhi;
+                            const float4 ta = row[j];
+                            float4 tb = row[two ? j + 1 : j];
+                            tb.w = two ? tb.w : 0.f;
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                const float4 t = h ? tb : ta;
+                                const float ix = fmaf(al, t.x, s0), iy = fmaf(al, t.y, s1), iz = fmaf(al, t.z, s2);
+                                const float ux0 = fmaxf(1.f - fabsf(fmaf(a0, ix, bv0)), 0.f);
+                                const float uy0 = fmaxf(1.f - fabsf(fmaf(a1, iy, bv1)), 0.f);
+                                const float uz0 = fmaxf(1.f - fabsf(fmaf(a2, iz, bv2)), 0.f) * t.w;
+                                if (V == 1) {
+                                    acc[0] = fmaf(ux0 * uy0, uz0, acc[0]);
+                                } else {
+                                    const float ux1 = fmaxf(1.f - fabsf(fmaf(a0, ix, bw0)), 0.f);
+                                    const float uy1 = fmaxf(1.f - fabsf(fmaf(a1, iy, bw1)), 0.f);
+                                    const float uz1 = fmaxf(1.f - fabsf(fmaf(a2, iz, bw2)), 0.f) * t.w;
+                                    const float p00 = ux0 * uy0, p01 = ux0 * uy1, p10 = ux1 * uy0, p11 = ux1 * uy1;
+                                    acc[0] = fmaf(p00, uz0, acc[0]);
+                                    acc[1 % (V * V * V)] = fmaf(p00, uz1, acc[1 % (V * V * V)]);
+                                    acc[2 % (V * V * V)] = fmaf(p01, uz0, acc[2 % (V * V * V)]);
+                                    acc[3 % (V * V * V)] = fmaf(p01, uz1, acc[3 % (V * V * V)]);
+                                    acc[4 % (V * V * V)] = fmaf(p10, uz0, acc[4 % (V * V * V)]);
+                                    acc[5 % (V * V * V)] = fmaf(p10, uz1, acc[5 % (V * V * V)]);
+                                    acc[6 % (V * V * V)] = fmaf(p11, uz0, acc[6 % (V * V * V)]);
+                                    acc[7 % (V * V * V)] = fmaf(p11, uz1, acc[7 % (V * V * V)]);
+                                }
                             }
                         }
                     }
@@ -884,6 +1121,7 @@ __global__ __launch_bounds__(WG) void k_siddon_gather_vol(GatherArgs G) {
 __global__ __launch_bounds__(WG) void k_backward_from_jac(const float* __restrict__ jac, const float* __restrict__ gout,
                                                          int n, float* gsrc, float* __restrict__ gtgt,
                                                          float* __restrict__ glen) {
+    __shared__ float part[3][WG / 64];
     const int b = blockIdx.y;
     const int r = blockIdx.x * WG + threadIdx.x;
     float js[3] = {0.f, 0.f, 0.f};
@@ -897,10 +1135,17 @@ __global__ __launch_bounds__(WG) void k_backward_from_jac(const float* __restric
         tp[0] = g * j1.x; tp[1] = g * j1.y; tp[2] = g * j1.z;
         if (glen) glen[ray] = g * j0.x;
     }
+    // grad_source is shared by all rays of the pose: wave butterfly (DPP/shfl), then the 4 waves of
+    // the block through LDS, then ONE atomic per component per block
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const float tot = wave_sum_f(js[i]);
-        if ((threadIdx.x & 63) == 0 && tot != 0.f) atomic_add_f32(gsrc + 3 * b + i, tot);
+        if ((threadIdx.x & 63) == 0) part[i][threadIdx.x >> 6] = tot;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const float tot = part[threadIdx.x][0] + part[threadIdx.x][1] + part[threadIdx.x][2] + part[threadIdx.x][3];
+        if (tot != 0.f) atomic_add_f32(gsrc + 3 * b + threadIdx.x, tot);
     }
 }
 
@@ -1099,6 +1344,11 @@ void fill_args(RenderArgs& A, const float* volume, const float* mask, int D0, in
     A.source = source; A.target = target; A.raylen = raylen;
     A.B = B; A.n = n; A.sp = *sp;
     A.grid_w = sp->ray_grid_w;
+    static const int forced_shape = [] {
+        const char* e = getenv("XVR_DRR_TILE_SHAPE");  // A/B switch: 0, 1, 2; default: per-workgroup choice
+        return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : -1;
+    }();
+    A.tile_shape = forced_shape;
     if (A.grid_w > 0) {
         A.grid_h = n / A.grid_w;
         A.tiles_x = (A.grid_w + 15) / 16;
@@ -1218,6 +1468,16 @@ int xvr_drr_trilinear_forward(const float* volume, const float* mask, int D0, in
     const size_t lds = mask ? (size_t)C * WG * sizeof(float) : 0;
     if (mask) return clip ? launch(k_trilinear_fwd<false, true, true>, A, lds, stream)
                           : launch(k_trilinear_fwd<false, true, false>, A, lds, stream);
+    // LDS-staged bricks are opt-in: measured 2.25x SLOWER than the direct kernel at C2 (19.8 vs 8.8 ms;
+    // with ~4 taps per voxel the L1/L2 already capture the reuse)
+    static const bool use_lds = [] {
+        const char* e = getenv("XVR_DRR_FWD_LDS");
+        return e && e[0] == '1';
+    }();
+    if (use_lds && !clip && A.grid_w > 0) {
+        const size_t bytes = (size_t)(LDS_HDR + LDS_BRICK_CAP) * sizeof(float);
+        return jac ? launch(k_trilinear_fwd_lds<true>, A, bytes, stream) : launch(k_trilinear_fwd_lds<false>, A, bytes, stream);
+    }
     if (jac) return clip ? launch(k_trilinear_fwd<true, false, true>, A, 0, stream)
                          : launch(k_trilinear_fwd<true, false, false>, A, 0, stream);
     return clip ? launch(k_trilinear_fwd<false, false, true>, A, 0, stream)
