@@ -33,6 +33,39 @@ HBM_COPY_GBS = 6290.0
 TAP_BYTES_PER_SAMPLE = 32   # 8 taps x 4 B; the voxel backward accumulates into the same 8
 
 
+# which profiled kernels make up each timed C-ABI call (one call may launch several kernels)
+TRAFFIC_KERNELS = {
+    "trilinear_forward": ["k_trilinear_fwd"],
+    "trilinear_backward": ["k_trilinear_gather_vol", "k_gather_prep", "k_gather_cull", "k_trilinear_bwd"],
+    "siddon_forward": ["k_siddon<"],
+    "siddon_backward": ["k_siddon_gather_vol", "k_gather_prep", "k_gather_cull", "k_siddon<"],
+    "backward_from_jac": ["k_backward_from_jac"],
+}
+
+
+def pmc_traffic(tag):
+    """HBM-side bytes per launch of the kernels behind one timed call, from the committed rocprofv3 PMC
+    passes (profiles/traffic.json, written by tools/summarize_profile.py: FETCH_SIZE + WRITE_SIZE, in
+    bytes, un-corrected -- see the gfx950 caveats in profiles/*_summary.md).  None when not profiled."""
+    path = ROOT / "profiles" / "traffic.json"
+    if not path.exists():
+        return None
+    try:
+        table = json.loads(path.read_text())
+    except ValueError:
+        return None
+    base = tag.split("[")[0].split("+")[0]
+    keys = TRAFFIC_KERNELS.get(base)
+    if not keys:
+        return None
+    tot, hit = 0.0, False
+    for name, v in table.items():
+        if any(k in name for k in keys) and (("fwd<true" in name) == ("+jac" in tag) or "fwd<" not in name):
+            tot += v.get("fetch_bytes", 0.0) + v.get("write_bytes", 0.0)
+            hit = True
+    return tot if hit else None
+
+
 def deepfluoro_poses(batch, seed):
     from xvr_amd.training import get_random_pose
 
@@ -151,7 +184,7 @@ def main():
         "achieved": dom["algorithmic_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": (dom["algorithmic_GBps"] or 0.0) / HBM_PEAK_GBS,
         "frac_of_measured_copy_peak": (dom["algorithmic_GBps"] or 0.0) / HBM_COPY_GBS,
-        "traffic": None,  # HBM bytes per launch from rocprofv3 PMC passes: see profiles/ and DESIGN.md
+        "traffic": pmc_traffic(dominant),
         "units_per_launch": units, "unit_name": "volume-touching samples" if args.renderer == "trilinear" else "voxel segments",
         "bytes_per_unit": bytes_per_unit, "avg_launch_ms": dom["avg_ms"],
         "nominal_units_per_launch": nominal_units or None,

@@ -42,3 +42,12 @@ if pm:
         if "WRITE_SIZE" in v:
             print(f"- derived: WRITE_SIZE per dispatch = {v['WRITE_SIZE']*1024/n/1e9:.3f} GB")
         print()
+import json  # noqa: E402
+traffic = {}
+for k, v in pm.items():
+    n = max(calls[(k, "FETCH_SIZE")], calls[(k, "WRITE_SIZE")], 1)
+    if "FETCH_SIZE" in v or "WRITE_SIZE" in v:
+        traffic[k] = {"fetch_bytes": v.get("FETCH_SIZE", 0.0) * 1024 / n, "write_bytes": v.get("WRITE_SIZE", 0.0) * 1024 / n,
+                      "dispatches": n}
+with open(f"{root}/traffic.json", "w") as f:
+    json.dump(traffic, f, indent=1)
