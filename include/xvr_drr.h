@@ -71,9 +71,11 @@ size_t xvr_drr_backward_workspace_bytes(int B, int n, int D0, int D1, int D2);
 /*
  * Trilinear ray-marching forward.  Replaces Trilinear.forward(volume, source, target, img, mask=...).
  *   mask     nullable; float labels, same shape as volume.
- *   jac      nullable [B][n][8]; only with C == 1.  Per ray: {out / raylen, d out/d source[3],
- *            d out/d target[3], 0}.  Filled in the same sweep (no second gather), consumed by
- *            xvr_drr_backward_from_jac.
+ *   jac      nullable [B][n][8].  Per ray: {out / raylen, d out/d source[3], d out/d target[3], 0},
+ *            where with a mask `out` means the SUM over channels.  Filled in the same sweep (no
+ *            second gather), consumed by xvr_drr_backward_from_jac -- which is the whole pose-side
+ *            backward whenever grad_out is the same for every channel (C == 1, or the channels were
+ *            only summed downstream, as xvr's trainer does: src/xvr/model/trainer.py:292-293).
  *   work     nullable device uint64: incremented by the number of samples that touched the volume
  *            (the kernel's own count of algorithmic work, for the roofline).
  */
@@ -117,8 +119,8 @@ int xvr_drr_siddon_backward(const float* volume, const float* mask, int D0, int 
                             float* grad_raylen, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
- * Pose-side backward from the jacobian saved by a forward call (C == 1): an elementwise product
- * with grad_out [B][1][n] plus a wave-level reduction of grad_source over each pose's rays.
+ * Pose-side backward from the jacobian saved by a forward call: an elementwise product with the
+ * (channel-uniform) grad_out [B][n] plus a wave-level reduction of grad_source over each pose's rays.
  *   grad_source [B][3] is ACCUMULATED into (caller zeroes it); grad_target [B][n][3] and
  *   grad_raylen [B][n] (nullable) are written.
  */

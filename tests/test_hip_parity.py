@@ -228,6 +228,42 @@ def test_voxel_gather_with_source_inside_the_volume():
 
 
 @pytest.mark.parametrize("renderer", ["trilinear", "siddon"])
+def test_masked_render_with_summed_channels_uses_the_sum_jacobian(renderer):
+    """xvr's trainer only sums the channels (trainer.py:292-293): grad_out is then an expanded,
+    channel-uniform tensor and the pose gradient must come out right through the channel-sum jacobian
+    (no re-march); a channel-dependent grad_out must still take the re-marching path.  Both vs the oracle."""
+    from xvr_amd import renderers
+    from xvr_amd.spec import RenderSpec
+
+    spec = RenderSpec(renderer=renderer, n_points=48)
+    case = make_case(seed=23)
+    n = case["height"] * case["width"]
+    w1 = torch.rand(2, 1, n, generator=torch.Generator().manual_seed(8))
+    wc = torch.rand(2, 3, n, generator=torch.Generator().manual_seed(9))
+    for mode in ("sum", "per-channel"):
+        launches = []
+        renderers.PROFILER = launches
+        try:
+            vol, src, tgt, img = (case[k].cuda().requires_grad_(k != "volume") for k in ("volume", "source", "target", "img"))
+            out = renderers.render(vol, src, tgt, img, spec, case["mask"].cuda(), ray_grid_w=case["width"])
+            loss = (out.sum(dim=1, keepdim=True) * w1.cuda()).sum() if mode == "sum" else (out * wc.cuda()).sum()
+            loss.backward()
+        finally:
+            renderers.PROFILER = None
+        names = [x[0] for x in launches]
+        assert ("backward_from_jac" in names) == (mode == "sum"), names
+        assert any(x.startswith(f"{renderer}_backward") for x in names) == (mode != "sum"), names
+        ovol, osrc, otgt, oimg = (case[k].clone().requires_grad_(k != "volume") for k in ("volume", "source", "target", "img"))
+        from oracle.diffdrr_restated import render as oracle_render
+        oout = oracle_render(ovol, osrc, otgt, oimg, to_oracle_spec(spec), case["mask"])
+        oloss = (oout.sum(dim=1, keepdim=True) * w1).sum() if mode == "sum" else (oout * wc).sum()
+        oloss.backward()
+        _close(out, oout, FWD_TOL, f"{mode}: out")
+        for a, b, name in ((src, osrc, "grad_source"), (tgt, otgt, "grad_target"), (img, oimg, "grad_img")):
+            _close(a.grad, b.grad, GRAD_TOL, f"{mode}: {name}")
+
+
+@pytest.mark.parametrize("renderer", ["trilinear", "siddon"])
 def test_recompute_backward_equals_jacobian_backward(renderer):
     """The two pose-gradient paths (saved jacobian vs re-march) must agree."""
     from xvr_amd.renderers import render
@@ -237,11 +273,17 @@ def test_recompute_backward_equals_jacobian_backward(renderer):
     case = make_case(seed=14, height=21, width=19)
     w = torch.rand(2, 1, 21 * 19).cuda()
     res = []
-    for use_mask in (False, True):  # an all-zero mask gives C = 1 and forces the re-march path
+    for remarch in (False, True):
         vol, src, tgt, img = (case[k].cuda().requires_grad_(k != "volume") for k in ("volume", "source", "target", "img"))
-        mask = torch.zeros_like(vol) if use_mask else None
-        out = render(vol, src, tgt, img, spec, mask, ray_grid_w=19)
-        (out * w).sum().backward()
+        if not remarch:
+            out = render(vol, src, tgt, img, spec, None, ray_grid_w=19)
+            (out * w).sum().backward()
+        else:
+            # two channels with identical weights: a non-expanded grad_out -> the re-marching backward
+            mask = (torch.rand_like(vol) > 0.5).float()
+            out2 = render(vol, src, tgt, img, spec, mask, ray_grid_w=19)
+            (out2 * w.expand(-1, 2, -1).clone()).sum().backward()
+            out = out2.sum(dim=1, keepdim=True)
         res.append((out, src.grad, tgt.grad, img.grad))
     for a, b, name in zip(res[0], res[1], ("out", "grad_source", "grad_target", "grad_img")):
         _close(a, b, 1e-5, name)

@@ -327,6 +327,7 @@ __global__ __launch_bounds__(WG) void k_trilinear_fwd(RenderArgs A) {
             if (MASK) {
                 const int lab = nearest_label(A.mask, pxs[h], pys[h], pzs[h], D0, D1, D2, A.C);
                 lds[lab * WG + tid] += v;
+                if (JAC) S += v;  // the jacobian saved with a mask is that of the channel SUM
             } else {
                 S += v;
             }
@@ -1240,6 +1241,7 @@ __global__ __launch_bounds__(WG) void k_siddon(RenderArgs A) {
             acc = fmaf(W, seg, acc);
         } else if (MASK) {
             lds[lab * WG + tid] = fmaf(v, seg, lds[lab * WG + tid]);
+            if (MODE == 1) acc = fmaf(v, seg, acc);  // jacobian of the channel sum
         } else {
             acc = fmaf(v, seg, acc);
         }
@@ -1460,12 +1462,13 @@ int xvr_drr_trilinear_forward(const float* volume, const float* mask, int D0, in
     if (sp->n_points < 1) return fail(XVR_DRR_E_ARG, "n_points must be >= 1");
     if (!(sp->far_ >= sp->near_)) return fail(XVR_DRR_E_ARG, "far must be >= near");
     if (!mask && C != 1) return fail(XVR_DRR_E_ARG, "C must be 1 without a mask");
-    if (jac && mask) return fail(XVR_DRR_E_UNSUPPORTED, "jacobian output is only available without a mask");
     RenderArgs A;
     fill_args(A, volume, mask, D0, D1, D2, C, source, target, raylen, B, n, sp);
     A.out = out; A.jac = jac; A.work = work;
     const bool clip = sp->clip_to_volume != 0;
     const size_t lds = mask ? (size_t)C * WG * sizeof(float) : 0;
+    if (mask && jac) return clip ? launch(k_trilinear_fwd<true, true, true>, A, lds, stream)
+                                 : launch(k_trilinear_fwd<true, true, false>, A, lds, stream);
     if (mask) return clip ? launch(k_trilinear_fwd<false, true, true>, A, lds, stream)
                           : launch(k_trilinear_fwd<false, true, false>, A, lds, stream);
     // LDS-staged bricks are opt-in: measured 2.25x SLOWER than the direct kernel at C2 (19.8 vs 8.8 ms;
@@ -1542,11 +1545,11 @@ int xvr_drr_siddon_forward(const float* volume, const float* mask, int D0, int D
     if (rc) return rc;
     if (!out) return fail(XVR_DRR_E_ARG, "out is null");
     if (!mask && C != 1) return fail(XVR_DRR_E_ARG, "C must be 1 without a mask");
-    if (jac && mask) return fail(XVR_DRR_E_UNSUPPORTED, "jacobian output is only available without a mask");
     RenderArgs A;
     fill_args(A, volume, mask, D0, D1, D2, C, source, target, raylen, B, n, sp);
     A.out = out; A.jac = jac; A.work = work;
     const size_t lds = mask ? (size_t)C * WG * sizeof(float) : 0;
+    if (mask && jac) return launch(k_siddon<1, true, false, false>, A, lds, stream);
     if (mask) return launch(k_siddon<0, true, false, false>, A, lds, stream);
     if (jac) return launch(k_siddon<1, false, false, false>, A, 0, stream);
     return launch(k_siddon<0, false, false, false>, A, 0, stream);

@@ -112,7 +112,7 @@ class _Render(torch.autograd.Function):
         msk_c = mask.contiguous() if mask is not None else None
         cs = make_cspec((D0, D1, D2), spec, ray_grid_w)
         need_pose = any(ctx.needs_input_grad[1:4])
-        use_jac = need_pose and mask is None
+        use_jac = need_pose  # with a mask: the jacobian of the channel sum (see backward)
         out = torch.empty(B, C, n, device=volume.device, dtype=torch.float32)
         jac = torch.empty(B, n, _lib.JAC_STRIDE, device=volume.device, dtype=torch.float32) if use_jac else None
         fn = lib.xvr_drr_trilinear_forward if spec.renderer == "trilinear" else lib.xvr_drr_siddon_forward
@@ -133,6 +133,12 @@ class _Render(torch.autograd.Function):
         D0, D1, D2 = vol_c.shape
         B, n, _ = tgt_c.shape
         dev = vol_c.device
+        # With several channels the saved jacobian is that of their sum: it is the whole pose gradient
+        # iff grad_out is the same for every channel.  Autograd tells us for free: the backward of
+        # `img.sum(dim=1)` (all xvr does with the channels, trainer.py:292-293) is an EXPANDED tensor
+        # (stride 0 along C).
+        uniform = C == 1 or gout.stride(1) == 0
+        g_uniform = gout[:, 0].contiguous() if uniform else None
         gout = gout.contiguous()
         need_vol = ctx.needs_input_grad[0]
         need_pose = any(ctx.needs_input_grad[1:4])
@@ -142,10 +148,10 @@ class _Render(torch.autograd.Function):
             gsrc = torch.zeros(B, 3, device=dev, dtype=torch.float32)
             gtgt = torch.empty(B, n, 3, device=dev, dtype=torch.float32)
             glen = torch.empty(B, n, device=dev, dtype=torch.float32)
-        from_jac = need_pose and jac is not None
+        from_jac = need_pose and jac is not None and uniform
         if from_jac:
             rc = _timed("backward_from_jac", lib.xvr_drr_backward_from_jac,
-                        _ptr(jac), _ptr(gout), B, n, _ptr(gsrc), _ptr(gtgt), _ptr(glen), _stream())
+                        _ptr(jac), _ptr(g_uniform), B, n, _ptr(gsrc), _ptr(gtgt), _ptr(glen), _stream())
             _lib.check(rc, "xvr_drr_backward_from_jac")
         if need_vol or (need_pose and not from_jac):
             cs = make_cspec((D0, D1, D2), spec, ctx.ray_grid_w)
