@@ -47,12 +47,101 @@ class Subject:
         return tuple((A[:3, :3] @ c + A[:3, 3]).tolist())
 
 
+def read_nifti(path):
+    """Minimal NIfTI-1 reader (.nii / .nii.gz, single-file, numpy only -- nibabel/torchio are not in
+    this image): returns (data [D0,D1,D2] float32 with scl_slope/inter applied, affine 4x4 float64),
+    re-oriented to RAS+ like torchio's ToCanonical (the reference loads CTs through torchio,
+    /root/reference/src/xvr/model/utils.py:52-56)."""
+    import gzip
+    import struct
+
+    import numpy as np
+
+    path = str(path)
+    opener = gzip.open if path.endswith(".gz") else open
+    with opener(path, "rb") as f:
+        raw = f.read()
+    for endian in ("<", ">"):
+        if struct.unpack(endian + "i", raw[:4])[0] == 348:
+            break
+    else:
+        raise ValueError(f"{path}: not a NIfTI-1 file")
+    if raw[344:348] not in (b"n+1\0", b"ni1\0"):
+        raise ValueError(f"{path}: bad NIfTI-1 magic {raw[344:348]!r}")
+    dim = struct.unpack(endian + "8h", raw[40:56])
+    datatype, bitpix = struct.unpack(endian + "hh", raw[70:74])
+    pixdim = struct.unpack(endian + "8f", raw[76:108])
+    vox_offset, slope, inter = struct.unpack(endian + "3f", raw[108:120])
+    qform_code, sform_code = struct.unpack(endian + "hh", raw[252:256])
+    dtypes = {2: "u1", 4: "i2", 8: "i4", 16: "f4", 64: "f8", 256: "i1", 512: "u2", 768: "u4"}
+    if datatype not in dtypes:
+        raise ValueError(f"{path}: unsupported NIfTI datatype {datatype}")
+    shape = tuple(int(d) for d in dim[1:1 + max(int(dim[0]), 3)]) + (1,) * (3 - min(int(dim[0]), 3))
+    shape3 = shape[:3]
+    if any(d != 1 for d in shape[3:]):
+        raise ValueError(f"{path}: only 3-D volumes are supported, got dims {shape}")
+    count = shape3[0] * shape3[1] * shape3[2]
+    data = np.frombuffer(raw, dtype=np.dtype(endian + dtypes[datatype]), count=count, offset=int(vox_offset))
+    data = data.reshape(shape3, order="F").astype(np.float32)
+    if slope not in (0.0, 1.0) or inter != 0.0:
+        if slope != 0.0:
+            data = data * np.float32(slope) + np.float32(inter)
+    if sform_code > 0:
+        affine = np.eye(4)
+        affine[0] = struct.unpack(endian + "4f", raw[280:296])
+        affine[1] = struct.unpack(endian + "4f", raw[296:312])
+        affine[2] = struct.unpack(endian + "4f", raw[312:328])
+    elif qform_code > 0:
+        b, c, d = struct.unpack(endian + "3f", raw[256:268])
+        off = struct.unpack(endian + "3f", raw[268:280])
+        a = np.sqrt(max(0.0, 1.0 - (b * b + c * c + d * d)))
+        R = np.array([[a * a + b * b - c * c - d * d, 2 * (b * c - a * d), 2 * (b * d + a * c)],
+                      [2 * (b * c + a * d), a * a + c * c - b * b - d * d, 2 * (c * d - a * b)],
+                      [2 * (b * d - a * c), 2 * (c * d + a * b), a * a + d * d - b * b - c * c]])
+        qfac = -1.0 if pixdim[0] < 0 else 1.0
+        affine = np.eye(4)
+        affine[:3, :3] = R @ np.diag([pixdim[1], pixdim[2], pixdim[3] * qfac])
+        affine[:3, 3] = off
+    else:
+        affine = np.diag([pixdim[1], pixdim[2], pixdim[3], 1.0])
+    # canonicalise to RAS+: permute / flip axes so that the affine's rotation part is closest to identity
+    lin = affine[:3, :3]
+    perm = [int(np.argmax(np.abs(lin[i]))) for i in range(3)]  # world axis i <- voxel axis perm[i]
+    if sorted(perm) != [0, 1, 2]:
+        perm = list(np.argsort(-np.abs(lin), axis=1)[:, 0])
+        if sorted(perm) != [0, 1, 2]:
+            raise ValueError(f"{path}: cannot canonicalise an affine this oblique")
+    data = np.transpose(data, perm)
+    P = np.zeros((4, 4))
+    for new, old in enumerate(perm):
+        P[old, new] = 1.0
+    P[3, 3] = 1.0
+    affine = affine @ P
+    for ax in range(3):
+        if affine[ax, ax] < 0:
+            data = np.flip(data, axis=ax)
+            F = np.eye(4)
+            F[ax, ax] = -1.0
+            F[ax, 3] = data.shape[ax] - 1
+            affine = affine @ F
+    return np.ascontiguousarray(data), affine
+
+
 def read(volume, labelmap=None, labels=None, orientation="AP", bone_attenuation_multiplier=1.0,
-         affine=None, spacing=(1.0, 1.0, 1.0), center_volume=True, hu=False) -> Subject:
-    """Build a Subject from tensors.  ``hu=True`` converts HU to density first; otherwise ``volume``
-    is taken to be a density already.  ``center_volume`` puts the isocentre at the world origin."""
+         affine=None, spacing=(1.0, 1.0, 1.0), center_volume=True, hu=None) -> Subject:
+    """Build a Subject from tensors or from NIfTI files (``volume`` / ``labelmap`` as paths, like the
+    reference's ``read(volume, mask, labels, orientation)``, /root/reference/src/xvr/renderer/load.py:29).
+    ``hu`` converts HU to density first (default: True for files, False for tensors, which are taken
+    to be densities already).  ``center_volume`` puts the isocentre at the world origin."""
     if not torch.is_tensor(volume):
-        raise NotImplementedError("file readers (NIfTI) are not part of this round; pass a tensor")
+        data, aff = read_nifti(volume)
+        volume = torch.from_numpy(data)
+        affine = torch.from_numpy(aff).to(torch.float32) if affine is None else affine
+        hu = True if hu is None else hu
+        if labelmap is not None and not torch.is_tensor(labelmap):
+            ldata, _ = read_nifti(labelmap)
+            labelmap = torch.from_numpy(ldata)
+    hu = bool(hu)
     volume = volume.to(torch.float32)
     if volume.dim() != 3:
         raise ValueError("volume must be [D0, D1, D2]")
