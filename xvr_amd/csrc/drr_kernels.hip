@@ -1154,20 +1154,10 @@ __global__ __launch_bounds__(WG) void k_backward_from_jac(const float* __restric
 // Siddon: exact traversal as an incremental merge of the three per-axis plane-crossing sequences
 // (no sort, no materialised alpha list).  MODE 0: forward; 1: forward + jacobian; 2: backward.
 // =============================================================================================
-struct SidState {
-    float inv_d[3];
-    int ip[3];      // index of the next plane to be crossed on each axis
-    int stp[3];     // +1 / -1
-    float an[3];    // alpha of that plane (INF when the axis has no further plane)
-};
-
-__device__ __forceinline__ float sid_alpha(const RenderArgs& A, const Ray& R, const SidState& st, int i, int S) {
-    const int p = st.ip[i];
-    if (p < 0 || p > S) return INFINITY;
-    return (((float)p + A.sp.plane0[i]) - R.s[i]) * st.inv_d[i];
-}
-
-template <int MODE, bool MASK, bool GPOSE, bool GVOL>
+// EXACT: the index map is the exact-geometry one (a = 1, b = shift - 1/2), so the voxel a segment
+// belongs to is the voxel between the planes just crossed: it is tracked incrementally (+-1 on the
+// crossed axis) instead of being re-derived from every segment's midpoint.
+template <int MODE, bool MASK, bool GPOSE, bool GVOL, bool EXACT>
 __global__ __launch_bounds__(WG) void k_siddon(RenderArgs A) {
     extern __shared__ float lds[];  // MASK: fwd -> channel accumulators, bwd -> upstream gradients
     if (MODE == 2 && A.skip_unless_flag_gt && !(*A.skip_unless_flag_gt > __float_as_uint(GATHER_DEV_TOL))) return;
@@ -1178,7 +1168,6 @@ __global__ __launch_bounds__(WG) void k_siddon(RenderArgs A) {
     ray_setup(A, b, r, valid, R);
     const float* __restrict__ vol = A.volume;
     const int D0 = A.D0, D1 = A.D1, D2 = A.D2;
-    const int Sz[3] = {D0, D1, D2};
     constexpr bool BWD = MODE == 2;
     constexpr bool DERIV = MODE == 1 || (BWD && GPOSE);
 
@@ -1192,20 +1181,27 @@ __global__ __launch_bounds__(WG) void k_siddon(RenderArgs A) {
 
     const float alo = R.amin, ahi = R.amax;
     bool live = valid && (ahi > alo);
-    SidState st;
+    // per axis: reciprocal direction, (plane0 - s) so that alpha(p) = ((float)p + ps) * inv_d -- the same
+    // value the sort formulation computes as ((p + plane0) - s) / d up to the reciprocal's rounding --,
+    // index of the next plane to cross, step, alpha of that plane.  No range check on p: a plane beyond
+    // the volume has alpha >= the axis' exit alpha >= ahi and is never selected before the loop ends.
+    float inv_d[3], an3[3];
+    int ip[3], stp[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        st.inv_d[i] = 1.f / R.d[i];
+        inv_d[i] = 1.f / R.d[i];
         const float f = fmaf(alo, R.d[i], R.s[i]) - A.sp.plane0[i];  // position in plane-index units
-        if (R.d[i] > 0.f) { st.stp[i] = 1; st.ip[i] = (int)floorf(f) + 1; }
-        else { st.stp[i] = -1; st.ip[i] = (int)ceilf(f) - 1; }
-        st.an[i] = live ? sid_alpha(A, R, st, i, Sz[i]) : INFINITY;
-        // a plane at or behind the entry point (fp noise) is skipped
-        if (live && st.an[i] <= alo) {
-            st.ip[i] += st.stp[i];
-            st.an[i] = sid_alpha(A, R, st, i, Sz[i]);
+        if (R.d[i] > 0.f) { stp[i] = 1; ip[i] = (int)floorf(f) + 1; }
+        else { stp[i] = -1; ip[i] = (int)ceilf(f) - 1; }
+        an3[i] = (((float)ip[i] + A.sp.plane0[i]) - R.s[i]) * inv_d[i];
+        if (an3[i] <= alo) {  // a plane at or behind the entry point (fp noise) is skipped
+            ip[i] += stp[i];
+            an3[i] = (((float)ip[i] + A.sp.plane0[i]) - R.s[i]) * inv_d[i];
         }
+        if (!live) an3[i] = INFINITY;
     }
+    // EXACT: the current voxel along an axis is the one just before the next plane in travel direction
+    const int vo0 = stp[0] > 0 ? 1 : 0, vo1 = stp[1] > 0 ? 1 : 0, vo2 = stp[2] > 0 ? 1 : 0;
 
     float acc = 0.f;                 // sum V * dalpha (C==1 fwd) / sum g V dalpha (bwd)
     float As[3] = {0.f, 0.f, 0.f};   // sum dW (alpha-1)/d  per axis
@@ -1216,68 +1212,86 @@ __global__ __launch_bounds__(WG) void k_siddon(RenderArgs A) {
     unsigned cnt = 0;
     const int max_iter = D0 + D1 + D2 + 8;
 
-    for (int it = 0; it < max_iter; ++it) {
-        if (!live) break;
-        float an = fminf(fminf(st.an[0], st.an[1]), fminf(st.an[2], ahi));
-        const float mid = 0.5f * (ac + an);
-        const float px = fmaf(A.sp.a[0], fmaf(mid, R.d[0], R.s[0]), A.sp.b[0]);
-        const float py = fmaf(A.sp.a[1], fmaf(mid, R.d[1], R.s[1]), A.sp.b[1]);
-        const float pz = fmaf(A.sp.a[2], fmaf(mid, R.d[2], R.s[2]), A.sp.b[2]);
-        const int ix = (int)rintf(px), iy = (int)rintf(py), iz = (int)rintf(pz);
-        const bool inb = (unsigned)ix < (unsigned)D0 && (unsigned)iy < (unsigned)D1 && (unsigned)iz < (unsigned)D2;
-        const int off = inb ? (ix * D1 + iy) * D2 + iz : 0;
-        const float v = inb ? vol[off] : 0.f;
-        const float seg = an - ac;
+    // Software pipeline, depth 1: the voxel (and label) of segment i is requested, then segment i-1 --
+    // whose load has had a whole traversal step to arrive -- is consumed.  The traversal itself never
+    // depends on loaded values, only the accumulation does.
+    bool have = false, exited = false;
+    float p_v = 0.f, p_seg = 0.f, p_ac = 0.f, p_lab = 0.f;
+    int p_ax = -1, p_off = 0;
+    bool p_inb = false;
+    float W = 0.f;
+
+    auto consume = [&]() {
+        const float v = p_v;
         int lab = 0;
-        if (MASK) lab = inb ? min(max((int)A.mask[off], 0), A.C - 1) : 0;
-        float W = v;
+        if (MASK) lab = p_inb ? min(max((int)p_lab, 0), A.C - 1) : 0;
+        W = v;
         if (BWD) {
             const float gk = MASK ? lds[lab * WG + tid] : g0;
             W = gk * v;
-            if (GVOL && inb) {
-                const float c = gk * R.L * seg;
-                if (c != 0.f) atomic_add_f32(A.gvol + off, c);
+            if (GVOL && p_inb) {
+                const float c = gk * R.L * p_seg;
+                if (c != 0.f) atomic_add_f32(A.gvol + p_off, c);
             }
-            acc = fmaf(W, seg, acc);
+            acc = fmaf(W, p_seg, acc);
         } else if (MASK) {
-            lds[lab * WG + tid] = fmaf(v, seg, lds[lab * WG + tid]);
-            if (MODE == 1) acc = fmaf(v, seg, acc);  // jacobian of the channel sum
+            lds[lab * WG + tid] = fmaf(v, p_seg, lds[lab * WG + tid]);
+            if (MODE == 1) acc = fmaf(v, p_seg, acc);  // jacobian of the channel sum
         } else {
-            acc = fmaf(v, seg, acc);
+            acc = fmaf(v, p_seg, acc);
         }
-        if (inb) ++cnt;
         if (DERIV) {
             const float dW = Wprev - W;  // d out / d alpha at the crossing that opened this segment
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const float m = (ax_prev == i) ? dW * st.inv_d[i] : 0.f;
-                As[i] = fmaf(m, ac - 1.f, As[i]);
-                At[i] = fmaf(m, -ac, At[i]);
+                const float m = (p_ax == i) ? dW * inv_d[i] : 0.f;
+                As[i] = fmaf(m, p_ac - 1.f, As[i]);
+                At[i] = fmaf(m, -p_ac, At[i]);
             }
             Wprev = W;
         }
+    };
+
+    for (int it = 0; it < max_iter; ++it) {
+        if (!live) break;
+        const float an = fminf(fminf(an3[0], an3[1]), fminf(an3[2], ahi));
+        int ix, iy, iz;
+        if (EXACT) {
+            ix = ip[0] - vo0; iy = ip[1] - vo1; iz = ip[2] - vo2;
+        } else {
+            const float mid = 0.5f * (ac + an);
+            ix = (int)rintf(fmaf(A.sp.a[0], fmaf(mid, R.d[0], R.s[0]), A.sp.b[0]));
+            iy = (int)rintf(fmaf(A.sp.a[1], fmaf(mid, R.d[1], R.s[1]), A.sp.b[1]));
+            iz = (int)rintf(fmaf(A.sp.a[2], fmaf(mid, R.d[2], R.s[2]), A.sp.b[2]));
+        }
+        const bool inb = (unsigned)ix < (unsigned)D0 && (unsigned)iy < (unsigned)D1 && (unsigned)iz < (unsigned)D2;
+        const int off = inb ? (ix * D1 + iy) * D2 + iz : 0;
+        const float v_new = vol[off];                       // always loadable (offset 0 when outside)
+        const float lab_new = MASK ? A.mask[off] : 0.f;
+        if (inb) ++cnt;
+        if (have) consume();
+        p_v = inb ? v_new : 0.f; p_seg = an - ac; p_ac = ac; p_ax = ax_prev; p_off = off; p_inb = inb; p_lab = lab_new;
+        have = true;
         if (an >= ahi) {
-            if (DERIV) {  // exit crossing: the next segment has W = 0
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const float m = (R.ax_out == i) ? W * st.inv_d[i] : 0.f;
-                    As[i] = fmaf(m, ahi - 1.f, As[i]);
-                    At[i] = fmaf(m, -ahi, At[i]);
-                }
-            }
+            exited = true;
             live = false;
         } else {
-            int ax = -1;
+            // advance every axis whose next plane has been reached (ties advance together), branch-free
+            const bool c0 = an3[0] <= an, c1 = an3[1] <= an, c2 = an3[2] <= an;
+            ip[0] += c0 ? stp[0] : 0; ip[1] += c1 ? stp[1] : 0; ip[2] += c2 ? stp[2] : 0;
 #pragma unroll
-            for (int i = 2; i >= 0; --i) {
-                if (st.an[i] <= an) {
-                    st.ip[i] += st.stp[i];
-                    st.an[i] = sid_alpha(A, R, st, i, Sz[i]);
-                    ax = i;
-                }
-            }
-            ax_prev = ax;
+            for (int i = 0; i < 3; ++i) an3[i] = (((float)ip[i] + A.sp.plane0[i]) - R.s[i]) * inv_d[i];
+            ax_prev = c0 ? 0 : (c1 ? 1 : 2);
             ac = an;
+        }
+    }
+    if (have) consume();
+    if (DERIV && exited) {  // exit crossing: beyond it W = 0
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float m = (R.ax_out == i) ? W * inv_d[i] : 0.f;
+            As[i] = fmaf(m, ahi - 1.f, As[i]);
+            At[i] = fmaf(m, -ahi, At[i]);
         }
     }
 
@@ -1433,6 +1447,15 @@ int launch_gather(bool siddon, const float* source, const float* target, const f
     return XVR_DRR_OK;
 }
 
+// a = 1 and b = shift - 1/2: the sampling index is x + shift - 1/2, i.e. the nearest voxel of a segment's
+// midpoint is the voxel between the planes that bound the segment
+bool siddon_exact_geometry(const xvr_drr_spec* sp) {
+    bool ok = true;
+    for (int i = 0; i < 3; ++i)
+        ok = ok && fabsf(sp->a[i] - 1.f) < 1e-6f && fabsf(sp->b[i] + sp->plane0[i] + 0.5f) < 1e-6f;
+    return ok;
+}
+
 bool gather_usable(const xvr_drr_spec* sp, int n, void* workspace, size_t workspace_bytes, int B, int D0, int D1,
                    int D2) {
     const int gw = sp->ray_grid_w, gh = gw > 0 ? n / gw : 0;
@@ -1549,10 +1572,11 @@ int xvr_drr_siddon_forward(const float* volume, const float* mask, int D0, int D
     fill_args(A, volume, mask, D0, D1, D2, C, source, target, raylen, B, n, sp);
     A.out = out; A.jac = jac; A.work = work;
     const size_t lds = mask ? (size_t)C * WG * sizeof(float) : 0;
-    if (mask && jac) return launch(k_siddon<1, true, false, false>, A, lds, stream);
-    if (mask) return launch(k_siddon<0, true, false, false>, A, lds, stream);
-    if (jac) return launch(k_siddon<1, false, false, false>, A, 0, stream);
-    return launch(k_siddon<0, false, false, false>, A, 0, stream);
+    const bool ex = siddon_exact_geometry(sp);
+    if (mask && jac) return (ex ? launch(k_siddon<1, true, false, false, true>, A, lds, stream) : launch(k_siddon<1, true, false, false, false>, A, lds, stream));
+    if (mask) return (ex ? launch(k_siddon<0, true, false, false, true>, A, lds, stream) : launch(k_siddon<0, true, false, false, false>, A, lds, stream));
+    if (jac) return (ex ? launch(k_siddon<1, false, false, false, true>, A, 0, stream) : launch(k_siddon<1, false, false, false, false>, A, 0, stream));
+    return (ex ? launch(k_siddon<0, false, false, false, true>, A, 0, stream) : launch(k_siddon<0, false, false, false, false>, A, 0, stream));
 }
 
 int xvr_drr_siddon_backward(const float* volume, const float* mask, int D0, int D1, int D2, int C,
@@ -1575,9 +1599,7 @@ int xvr_drr_siddon_backward(const float* volume, const float* mask, int D0, int 
     A.gout = grad_out; A.gvol = grad_volume; A.gsrc = grad_source; A.gtgt = grad_target; A.glen = grad_raylen;
     const size_t lds = mask ? (size_t)C * WG * sizeof(float) : 0;
     // the gather needs the exact-geometry index map (voxel credited = voxel whose box holds the segment)
-    bool exact_geom = true;
-    for (int i = 0; i < 3; ++i)
-        exact_geom = exact_geom && fabsf(sp->a[i] - 1.f) < 1e-6f && fabsf(sp->b[i] + sp->plane0[i] + 0.5f) < 1e-6f;
+    const bool exact_geom = siddon_exact_geometry(sp);
     if (gvol && !mask && exact_geom && gather_usable(sp, n, workspace, workspace_bytes, B, D0, D1, D2)) {
         unsigned* flag = nullptr;
         rc = launch_gather(true, source, target, raylen, grad_out, B, n, sp->ray_grid_w, D0, D1, D2, sp, grad_volume,
@@ -1586,20 +1608,22 @@ int xvr_drr_siddon_backward(const float* volume, const float* mask, int D0, int 
         if (gpose) {
             RenderArgs Ap = A;
             Ap.gvol = nullptr;
-            rc = launch(k_siddon<2, false, true, false>, Ap, 0, stream);
+            rc = launch(k_siddon<2, false, true, false, true>, Ap, 0, stream);
             if (rc) return rc;
         }
         RenderArgs Av = A;
         Av.gsrc = nullptr; Av.gtgt = nullptr; Av.glen = nullptr;
         Av.skip_unless_flag_gt = flag;
-        return launch(k_siddon<2, false, false, true>, Av, 0, stream);
+        return launch(k_siddon<2, false, false, true, true>, Av, 0, stream);
     }
-#define SID_BWD(M)                                                                      \
-    (gpose ? (gvol ? launch(k_siddon<2, M, true, true>, A, lds, stream)                 \
-                   : launch(k_siddon<2, M, true, false>, A, lds, stream))               \
-           : launch(k_siddon<2, M, false, true>, A, lds, stream))
+#define SID_BWD2(M, E)                                                                  \
+    (gpose ? (gvol ? launch(k_siddon<2, M, true, true, E>, A, lds, stream)              \
+                   : launch(k_siddon<2, M, true, false, E>, A, lds, stream))            \
+           : launch(k_siddon<2, M, false, true, E>, A, lds, stream))
+#define SID_BWD(M) (exact_geom ? SID_BWD2(M, true) : SID_BWD2(M, false))
     return mask ? SID_BWD(true) : SID_BWD(false);
 #undef SID_BWD
+#undef SID_BWD2
 }
 
 int xvr_drr_backward_from_jac(const float* jac, const float* grad_out, int B, int n, float* grad_source,
