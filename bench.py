@@ -132,9 +132,7 @@ def main():
         rot.grad = None
         xyz.grad = None
         pose = convert(rot, xyz, parameterization="euler_angles", convention="ZXY")
-        source, target = drr.detector(pose, None)
-        img = drr.render(density, source, target, **kw)
-        img = drr.reshape_transform(img, batch_size=B)
+        img = drr(pose, density=density, **kw)   # DRR.forward: rays -> render, [B,1,H,H]
         handle = None
         if world > 1:  # the exchange step of the path: every rank gets every rendered DRR (RCCL over xGMI)
             handle = dist.all_gather_into_tensor(gathered, img.detach(), async_op=True)

@@ -128,6 +128,22 @@ int xvr_drr_backward_from_jac(const float* jac, const float* grad_out, int B, in
                               float* grad_source, float* grad_target, float* grad_raylen,
                               void* stream);
 
+/*
+ * Ray generation in one pass.  Replaces the three torch calls xvr makes before every render --
+ * `source, target = drr.detector(pose, None)`, `img = (target - source).norm(dim=-1)`,
+ * `source, target = affinv(source), affinv(target)` (/root/reference/src/xvr/model/trainer.py:283-285;
+ * the same sequence inside DRR.forward, /root/reference/src/xvr/registrar/base.py:249).
+ *   cam  [B][24] = { Mv[3][3], s_v[3], Mw[3][3], s_w[3] }: target_vox(i,j) = Mv (i,j,1)^T, source_vox = s_v,
+ *        raylen(i,j) = | Mw (i,j,1)^T - s_w |   (i = detector row, j = column; the host folds calibration,
+ *        reorientation, pose and the CT's inverse affine into the two 3x3 maps)
+ *   out: source [B][3], target [B][H*W][3], raylen [B][H*W]
+ * backward: grad_cam [B][24] is ACCUMULATED into (caller zeroes it); grad_source / grad_raylen nullable.
+ */
+int xvr_drr_rays_forward(const float* cam, int B, int H, int W, float* source, float* target, float* raylen,
+                         void* stream);
+int xvr_drr_rays_backward(const float* cam, int B, int H, int W, const float* grad_source,
+                          const float* grad_target, const float* grad_raylen, float* grad_cam, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

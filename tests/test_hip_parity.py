@@ -564,6 +564,43 @@ def test_drr_module_matches_oracle_end_to_end(renderer):
     _close(drr(pose_gpu), ref2, FWD_TOL, "after set_intrinsics_")
 
 
+def test_fused_ray_generation_matches_the_detector_path():
+    """xvr_drr_rays_forward/backward == drr.detector -> norm -> affine_inverse (trainer.py:283-285),
+    values and gradients w.r.t. the pose parameters."""
+    from xvr_amd.data import make_phantom, read
+    from xvr_amd.drr import DRR, rays_from_camera
+    from xvr_amd.pose import convert
+
+    vol, _ = make_phantom(24, seed=4)
+    sub = read(vol, spacing=(1.5, 2.0, 2.5), orientation="PA")
+    for rev, (H, W) in ((True, (13, 10)), (False, (16, 21))):
+        drr = DRR(sub, 800.0, H, 3.0, width=W, dely=2.5, x0=4.0, y0=-3.0, renderer="trilinear", reverse_x_axis=rev).cuda()
+        rot = torch.tensor([[0.3, -0.2, 0.1], [2.9, 0.4, -0.3]], device="cuda")
+        xyz = torch.tensor([[10.0, 500.0, -20.0], [-5.0, 650.0, 8.0]], device="cuda")
+        ws = torch.rand(2, 1, 3, device="cuda")
+        wt = torch.rand(2, H * W, 3, device="cuda")
+        wl = torch.rand(2, 1, H * W, device="cuda")
+        grads = []
+        for fused in (True, False):
+            r, x = rot.clone().requires_grad_(True), xyz.clone().requires_grad_(True)
+            pose = convert(r, x, parameterization="euler_angles", convention="ZXY")
+            if fused:
+                s, t, L = rays_from_camera(drr.camera(pose), H, W)
+            else:
+                s, t = drr.detector(pose, None)
+                L = (t - s).norm(dim=-1).unsqueeze(1)
+                s, t = drr.affine_inverse(s), drr.affine_inverse(t)
+            ((s * ws).sum() + (t * wt).sum() + (L * wl).sum()).backward()
+            grads.append((s.detach(), t.detach(), L.detach(), r.grad, x.grad))
+        for a, b, name in zip(grads[0], grads[1], ("source", "target", "raylen", "d/d rot", "d/d xyz")):
+            _close(a, b, 2e-5 if name[0] != "d" else 2e-4, name)
+        # and the whole DRR.forward agrees between the two ray paths
+        pose = convert(rot, xyz, parameterization="euler_angles", convention="ZXY")
+        a = drr(pose)
+        drr.fused_rays = False
+        _close(a, drr(pose), 2e-5, "DRR.forward fused vs explicit rays")
+
+
 def test_render_samples_contract():
     """The exploded 4-call sequence of xvr's Trainer.render_samples (trainer.py:279-304)."""
     from xvr_amd.data import make_phantom, read

@@ -43,6 +43,8 @@ EXPORTS = {
     "xvr_drr_siddon_forward": (_FWD, ctypes.c_int),
     "xvr_drr_siddon_backward": (_BWD, ctypes.c_int),
     "xvr_drr_backward_from_jac": ([_P, _P, _I, _I, _P, _P, _P, _P], ctypes.c_int),
+    "xvr_drr_rays_forward": ([_P, _I, _I, _I, _P, _P, _P, _P], ctypes.c_int),
+    "xvr_drr_rays_backward": ([_P, _I, _I, _I, _P, _P, _P, _P, _P], ctypes.c_int),
 }
 
 _lib = None

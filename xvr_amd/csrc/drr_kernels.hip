@@ -1329,6 +1329,83 @@ __global__ __launch_bounds__(WG) void k_siddon(RenderArgs A) {
     }
 }
 
+
+// =============================================================================================
+// Ray generation fused into one pass (rows a2-a4 of SURVEY.md 8a): what xvr does with three torch
+// calls and ~40 launches -- drr.detector(pose, None), (target - source).norm(), affinv(source/target)
+// (src/xvr/model/trainer.py:283-285) -- is an affine map of the pixel index per pose:
+//     target_vox(i, j) = Mv (i, j, 1)^T,   raylen(i, j) = | Mw (i, j, 1)^T - s_w |
+// cam[b] = { Mv[3][3], s_v[3], Mw[3][3], s_w[3] } (24 floats, built by the host from the 4x4 pose).
+// =============================================================================================
+__global__ __launch_bounds__(WG) void k_rays_fwd(const float* __restrict__ cam, int H, int W, float* __restrict__ source,
+                                                 float* __restrict__ target, float* __restrict__ raylen) {
+    const int b = blockIdx.y, n = H * W;
+    const int r = blockIdx.x * WG + threadIdx.x;
+    const float* c = cam + 24 * b;
+    if (r == 0) { source[3 * b] = c[9]; source[3 * b + 1] = c[10]; source[3 * b + 2] = c[11]; }
+    if (r >= n) return;
+    const int i = r / W, j = r - i * W;
+    const float fi = (float)i, fj = (float)j;
+    float* t = target + ((size_t)b * n + r) * 3;
+    float l2 = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        t[a] = fmaf(c[3 * a], fi, fmaf(c[3 * a + 1], fj, c[3 * a + 2]));
+        const float w = fmaf(c[12 + 3 * a], fi, fmaf(c[12 + 3 * a + 1], fj, c[12 + 3 * a + 2])) - c[21 + a];
+        l2 = fmaf(w, w, l2);
+    }
+    raylen[(size_t)b * n + r] = sqrtf(l2);
+}
+
+// backward: 21 sums over a pose's rays (wave butterfly -> LDS across the 4 waves -> one atomic each per block)
+__global__ __launch_bounds__(WG) void k_rays_bwd(const float* __restrict__ cam, int H, int W, const float* __restrict__ g_source,
+                                                 const float* __restrict__ g_target, const float* __restrict__ g_raylen,
+                                                 float* g_cam) {
+    __shared__ float part[21][WG / 64];
+    const int b = blockIdx.y, n = H * W;
+    const int r = blockIdx.x * WG + threadIdx.x;
+    const float* c = cam + 24 * b;
+    float acc[21];
+#pragma unroll
+    for (int q = 0; q < 21; ++q) acc[q] = 0.f;
+    if (r < n) {
+        const int i = r / W, j = r - i * W;
+        const float pix[3] = {(float)i, (float)j, 1.f};
+        const float* gt = g_target + ((size_t)b * n + r) * 3;
+        float w[3], l2 = 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            w[a] = fmaf(c[12 + 3 * a], pix[0], fmaf(c[12 + 3 * a + 1], pix[1], c[12 + 3 * a + 2])) - c[21 + a];
+            l2 = fmaf(w[a], w[a], l2);
+        }
+        const float gl = g_raylen ? g_raylen[(size_t)b * n + r] : 0.f;
+        const float s = l2 > 0.f ? gl / sqrtf(l2) : 0.f;  // g_L * (unit direction) = s * w
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                acc[3 * a + m] = gt[a] * pix[m];           // d/d Mv[a][m]
+                acc[9 + 3 * a + m] = s * w[a] * pix[m];    // d/d Mw[a][m]
+            }
+            acc[18 + a] = -s * w[a];                        // d/d s_w[a]
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 21; ++q) {
+        const float tot = wave_sum_f(acc[q]);
+        if ((threadIdx.x & 63) == 0) part[q][threadIdx.x >> 6] = tot;
+    }
+    __syncthreads();
+    if (threadIdx.x < 21) {
+        const int q = threadIdx.x;
+        const float tot = part[q][0] + part[q][1] + part[q][2] + part[q][3];
+        // layout of g_cam mirrors cam: Mv 0..8, s_v 9..11, Mw 12..20, s_w 21..23
+        const int dst = q < 9 ? q : (q < 18 ? q + 3 : q + 3);
+        if (tot != 0.f) atomic_add_f32(g_cam + 24 * b + dst, tot);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 3 && g_source) atomic_add_f32(g_cam + 24 * b + 9 + threadIdx.x, g_source[3 * b + threadIdx.x]);
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -1624,6 +1701,29 @@ int xvr_drr_siddon_backward(const float* volume, const float* mask, int D0, int 
     return mask ? SID_BWD(true) : SID_BWD(false);
 #undef SID_BWD
 #undef SID_BWD2
+}
+
+int xvr_drr_rays_forward(const float* cam, int B, int H, int W, float* source, float* target, float* raylen,
+                         void* stream) {
+    if (!cam || !source || !target || !raylen) return fail(XVR_DRR_E_ARG, "null pointer argument");
+    if (B <= 0 || H <= 0 || W <= 0) return fail(XVR_DRR_E_ARG, "B, H, W must be positive");
+    dim3 grid((unsigned)(((long long)H * W + WG - 1) / WG), (unsigned)B);
+    hipLaunchKernelGGL(k_rays_fwd, grid, dim3(WG), 0, (hipStream_t)stream, cam, H, W, source, target, raylen);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
+    return XVR_DRR_OK;
+}
+
+int xvr_drr_rays_backward(const float* cam, int B, int H, int W, const float* grad_source, const float* grad_target,
+                          const float* grad_raylen, float* grad_cam, void* stream) {
+    if (!cam || !grad_target || !grad_cam) return fail(XVR_DRR_E_ARG, "null pointer argument");
+    if (B <= 0 || H <= 0 || W <= 0) return fail(XVR_DRR_E_ARG, "B, H, W must be positive");
+    dim3 grid((unsigned)(((long long)H * W + WG - 1) / WG), (unsigned)B);
+    hipLaunchKernelGGL(k_rays_bwd, grid, dim3(WG), 0, (hipStream_t)stream, cam, H, W, grad_source, grad_target,
+                       grad_raylen, grad_cam);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
+    return XVR_DRR_OK;
 }
 
 int xvr_drr_backward_from_jac(const float* jac, const float* grad_out, int B, int n, float* grad_source,

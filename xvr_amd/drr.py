@@ -15,12 +15,57 @@ from __future__ import annotations
 
 import torch
 
+import ctypes
+
+from . import _lib
 from .data import Subject
 from .detector import Detector, make_reorient
 from .pose import RigidTransform, convert
-from .renderers import Siddon, Trilinear
+from .renderers import Siddon, Trilinear, _ptr, _stream, _timed
 
-__all__ = ["DRR"]
+__all__ = ["DRR", "rays_from_camera"]
+
+
+class _RaysFromCamera(torch.autograd.Function):
+    """cam [B,24] -> (source [B,1,3], target [B,H*W,3], raylen [B,1,H*W]) in one HIP launch; the
+    backward reduces the three gradients to d/d cam [B,24] in one launch (xvr_drr_rays_*)."""
+
+    @staticmethod
+    def forward(ctx, cam, H, W):
+        lib = _lib.load()
+        cam_c = cam.contiguous()
+        B, n = cam_c.shape[0], H * W
+        source = torch.empty(B, 1, 3, device=cam.device, dtype=torch.float32)
+        target = torch.empty(B, n, 3, device=cam.device, dtype=torch.float32)
+        raylen = torch.empty(B, 1, n, device=cam.device, dtype=torch.float32)
+        rc = _timed("rays_forward", lib.xvr_drr_rays_forward, _ptr(cam_c), B, H, W, _ptr(source), _ptr(target),
+                    _ptr(raylen), _stream())
+        _lib.check(rc, "xvr_drr_rays_forward")
+        ctx.save_for_backward(cam_c)
+        ctx.hw = (H, W)
+        return source, target, raylen
+
+    @staticmethod
+    def backward(ctx, g_source, g_target, g_raylen):
+        lib = _lib.load()
+        (cam_c,) = ctx.saved_tensors
+        H, W = ctx.hw
+        B = cam_c.shape[0]
+        g_cam = torch.zeros_like(cam_c)
+        if g_target is None:
+            g_target = torch.zeros(B, H * W, 3, device=cam_c.device, dtype=torch.float32)
+        gs = g_source.contiguous() if g_source is not None else None
+        gl = g_raylen.contiguous() if g_raylen is not None else None
+        rc = _timed("rays_backward", lib.xvr_drr_rays_backward, _ptr(cam_c), B, H, W, _ptr(gs), _ptr(g_target.contiguous()),
+                    _ptr(gl), _ptr(g_cam), _stream())
+        _lib.check(rc, "xvr_drr_rays_backward")
+        return g_cam, None, None
+
+
+def rays_from_camera(cam: torch.Tensor, height: int, width: int):
+    if not cam.is_cuda or cam.dtype != torch.float32:
+        raise RuntimeError("rays_from_camera needs a float32 CUDA tensor (HIP kernel, no CPU path)")
+    return _RaysFromCamera.apply(cam, int(height), int(width))
 
 
 class DRR(torch.nn.Module):
@@ -48,6 +93,10 @@ class DRR(torch.nn.Module):
         else:
             raise ValueError(f"renderer must be 'siddon' or 'trilinear', got {renderer!r}")
         self.reshape = reshape
+        # one fused HIP launch for detector -> ray length -> inverse affine instead of ~40 torch launches
+        # (the explicit ``detector`` / ``affine_inverse`` calls of xvr's trainer keep working unchanged)
+        self.fused_rays = True
+        self.register_buffer("_e3", torch.tensor([0.0, 0.0, 1.0]), persistent=False)
         self._sync_ray_grid()
 
     def _sync_ray_grid(self):
@@ -68,13 +117,45 @@ class DRR(torch.nn.Module):
 
     # ------------------------------------------------------------------ rendering
     def forward(self, *args, parameterization=None, convention=None, calibration=None,
-                mask_to_channels=False, **kwargs):
-        """``drr(pose)`` with a RigidTransform, or ``drr(rot, xyz, parameterization=, convention=)``."""
+                mask_to_channels=False, density=None, **kwargs):
+        """``drr(pose)`` with a RigidTransform, or ``drr(rot, xyz, parameterization=, convention=)``.
+        ``density`` overrides the module's buffer (e.g. a leaf tensor whose gradient is wanted)."""
         pose = args[0] if parameterization is None else convert(
             *args, parameterization=parameterization, convention=convention)
-        source, target = self.detector(pose, calibration)
-        img = self.render(self.density, source, target, mask_to_channels, **kwargs)
+        density = self.density if density is None else density
+        if self.fused_rays and calibration is None and density.is_cuda:
+            source, target, img = rays_from_camera(self.camera(pose), self.detector.height, self.detector.width)
+            kwargs["mask"] = self.mask if mask_to_channels else None
+            img = self.renderer(density, source, target, img, **kwargs)
+        else:
+            source, target = self.detector(pose, calibration)
+            img = self.render(density, source, target, mask_to_channels, **kwargs)
         return self.reshape_transform(img, batch_size=len(pose))
+
+    def camera(self, pose: RigidTransform) -> torch.Tensor:
+        """[B,24] = {Mv, s_v, Mw, s_w}: target_vox(i,j) = Mv (i,j,1)^T, raylen(i,j) = |Mw (i,j,1)^T - s_w|.
+        Folds the calibration, the reorientation, the pose and the CT's inverse affine (tiny torch ops,
+        differentiable w.r.t. the pose)."""
+        d = self.detector
+        C = d._calibration
+        t0 = float((-d.height) // 2) + (1.0 if d.height % 2 else 0.5)
+        s0 = float((-d.width) // 2) + (1.0 if d.width % 2 else 0.5)
+        sg = -1.0 if d.reverse_x_axis else 1.0
+        z = self._e3[0]   # a 0 that lives on the device already (no host->device copy: graph-capture safe)
+        Kc = torch.stack([
+            torch.stack([C[0, 0], z, C[0, 0] * t0 + C[0, 3]]),
+            torch.stack([z, sg * C[1, 1], sg * C[1, 1] * s0 + C[1, 3]]),
+            torch.stack([z, z, C[2, 2]]),
+        ])
+        P = pose.matrix @ d._reorient            # reorient first, then the camera pose
+        e3 = self._e3
+        t_P = P[:, :3, 3]
+        Mw = P[:, :3, :3] @ Kc + t_P[:, :, None] * e3
+        A = self._affine_inverse[0]
+        Mv = A[:3, :3] @ Mw + A[:3, 3][None, :, None] * e3
+        s_v = t_P @ A[:3, :3].T + A[:3, 3]
+        B = len(pose)
+        return torch.cat([Mv.reshape(B, 9), s_v, Mw.reshape(B, 9), t_P], dim=1)
 
     def render(self, density, source, target, mask_to_channels=False, **kwargs):
         img = (target - source).norm(dim=-1).unsqueeze(1)        # world-mm length of every ray
