@@ -684,6 +684,59 @@ def RigidTransform_cpu(pose):
     return RigidTransform(pose.matrix.detach().cpu())
 
 
+def test_training_step_c5_render_twice_and_backprop_into_a_regressor():
+    """configs[4] in miniature (src/xvr/model/trainer.py:185-230): sample poses -> render #1 (no grad,
+    masked) -> keep -> regress poses with a (stand-in) network -> render #2 with grad -> PoseRegressionLoss
+    -> backward into the network.  The timm ResNet is out of scope; a small conv net stands in for it."""
+    from xvr_amd.data import make_phantom, read, transform_hu_to_density
+    from xvr_amd.drr import DRR
+    from xvr_amd.loss import PoseRegressionLoss
+    from xvr_amd.metrics import XrayTransforms
+    from xvr_amd.pose import N_ANGULAR_COMPONENTS, convert
+    from xvr_amd.training import get_random_pose, render_samples
+
+    torch.manual_seed(0)
+    vol, lab = make_phantom(48, n_ellipsoids=10, n_labels=4, seed=11)
+    hu = vol * 1400 - 1000  # a fake HU volume: the step converts it to density with a random bone multiplier
+    sub = read(hu, lab, spacing=(2.5, 2.5, 2.5), orientation="AP", hu=True)
+    H = 32
+    drr = DRR(sub, 1020.0, H, 8.0, renderer="trilinear", reverse_x_axis=False).cuda()
+    drr.register_buffer("volume", hu.cuda())
+    B = 6
+    pose = get_random_pose(170, 190, -10, 10, -5, 5, -20, 20, 600, 800, -20, 20, B, generator=torch.Generator().manual_seed(1)).cuda()
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.f = torch.nn.Sequential(torch.nn.Conv2d(1, 4, 3, 2, 1), torch.nn.ReLU(), torch.nn.AdaptiveAvgPool2d(4), torch.nn.Flatten())
+            self.xyz = torch.nn.Linear(64, 3)
+            self.rot = torch.nn.Linear(64, N_ANGULAR_COMPONENTS["quaternion_adjugate"])
+
+        def forward(self, x):
+            h = self.f(x)
+            rot = self.rot(h) + torch.tensor([1.0, 0, 0, 0, 1.0, 0, 0, 1.0, 0, 1.0], device=x.device) * 0.1 \
+                + torch.tensor([0, 0, 0, 1.0, 0, 0, 0, 0, 0, 0], device=x.device)  # bias towards yaw ~ 180 deg
+            return convert(rot, 1000.0 * 0.7 * torch.tensor([0.0, 1.0, 0.0], device=x.device) + 10.0 * self.xyz(h),
+                           parameterization="quaternion_adjugate")
+
+    net = Net().cuda()
+    transforms = XrayTransforms(H)
+    lossfn = PoseRegressionLoss(1020.0, weight_mvc=1e-3).cuda()
+    tmp = transform_hu_to_density(drr.volume, 4.2)
+    with torch.no_grad():
+        img, mask, keep = render_samples(drr, tmp, drr.mask, drr.affine_inverse, pose)
+    assert img.shape == (B, 1, H, H) and mask.shape == (B, 4, H, H) and keep.any()
+    img, mask, pose_k = img[keep], mask[keep], pose[keep]
+    pred_pose = net(transforms(img))
+    pred_img, pred_mask, _ = render_samples(drr, tmp, drr.mask, drr.affine_inverse, pred_pose)
+    loss, mncc, dgeo, rgeo, tgeo, dice, mvc = lossfn(transforms(img), mask, pose_k, transforms(pred_img), pred_mask, pred_pose)
+    loss.mean().backward()
+    grads = [p.grad for p in net.parameters()]
+    assert all(g is not None and torch.isfinite(g).all() for g in grads)
+    assert sum(g.abs().sum().item() for g in grads) > 0
+    assert mncc.shape == (int(keep.sum()),) and torch.isfinite(loss).all() and (dice >= 0).all() and (dice <= 1).all()
+
+
 def test_errors_are_python_exceptions():
     from xvr_amd.renderers import render
     from xvr_amd.spec import RenderSpec
