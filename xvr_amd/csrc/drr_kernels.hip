@@ -740,6 +740,7 @@ struct GatherArgs {
     float2* q2;              // siddon: [B][n] = (alpha_lo, alpha_hi) of the ray, as the forward clamps them
     int siddon;
     int V;                   // voxels per lane and axis in the gather (1 or 2)
+    int bd[3];               // voxels per gather workgroup (brick) along x, y, z
     unsigned* cull;          // [bricks][words] bit p set = pose p can touch the brick
     int words;               // ceil(B / 32)
     float* gvol;
@@ -844,10 +845,10 @@ __global__ __launch_bounds__(WG) void k_gather_prep(GatherArgs G) {
     }
 }
 
-// A gather workgroup covers a brick of (4V) x (8V) x (8V) voxels (x, y, z); each of its 256 lanes
-// owns a V x V x V block (V = 1 or 2).
-__device__ __forceinline__ void brick_coords(int blk, int D1, int D2, int V, int& bx, int& by, int& bz) {
-    const int nz = (D2 + 8 * V - 1) / (8 * V), ny = (D1 + 8 * V - 1) / (8 * V);
+// A gather workgroup covers a brick of bd[0] x bd[1] x bd[2] voxels (trilinear: one wavefront per
+// compact (4V)^3 brick, each lane a V^3 block; siddon: 256 lanes on 4 x 8 x 8 voxels).
+__device__ __forceinline__ void brick_coords(int blk, int D1, int D2, const int* bd, int& bx, int& by, int& bz) {
+    const int nz = (D2 + bd[2] - 1) / bd[2], ny = (D1 + bd[1] - 1) / bd[1];
     bz = blk % nz; blk /= nz;
     by = blk % ny; bx = blk / ny;
 }
@@ -859,11 +860,12 @@ __global__ __launch_bounds__(WG) void k_gather_cull(GatherArgs G, int nbricks) {
     const int lane = threadIdx.x & 31;
     if (brick >= nbricks) return;
     int bx, by, bz;
-    brick_coords(brick, G.D1, G.D2, G.V, bx, by, bz);
-    const float fV = (float)G.V;
-    const float c[3] = {bx * 4 * fV + 2.f * fV - 0.5f, by * 8 * fV + 4.f * fV - 0.5f, bz * 8 * fV + 4.f * fV - 0.5f};
-    // half extents (2,4,4) V - 0.5 (centres of the outer voxels) + 1 (interpolation support) + 0.5 (slack)
-    const float hx = (2.f * fV + 1.f) / G.sp.a[0], hy = (4.f * fV + 1.f) / G.sp.a[1], hz = (4.f * fV + 1.f) / G.sp.a[2];
+    brick_coords(brick, G.D1, G.D2, G.bd, bx, by, bz);
+    const float c[3] = {bx * G.bd[0] + 0.5f * (G.bd[0] - 1), by * G.bd[1] + 0.5f * (G.bd[1] - 1),
+                        bz * G.bd[2] + 0.5f * (G.bd[2] - 1)};
+    // half extent to the outermost voxel centre + 1 (interpolation support) + 0.5 (slack), in x units
+    const float hx = (0.5f * (G.bd[0] - 1) + 1.5f) / G.sp.a[0], hy = (0.5f * (G.bd[1] - 1) + 1.5f) / G.sp.a[1],
+                hz = (0.5f * (G.bd[2] - 1) + 1.5f) / G.sp.a[2];
     const float R = sqrtf(hx * hx + hy * hy + hz * hz);
     for (int wd = 0; wd < G.words; ++wd) {
         const int p = wd * 32 + lane;
@@ -899,15 +901,15 @@ __global__ __launch_bounds__(WG) void k_gather_cull(GatherArgs G, int nbricks) {
 // One lane owns a V x V x V block of voxels (V = 2: per-pose / per-step / per-row setup is paid once
 // for 8 voxels and the sample position is computed once per candidate); a workgroup covers a
 // (4V) x (8V) x (8V) brick so that its lanes' candidates share pixels.
-template <int V>
-__global__ __launch_bounds__(WG) void k_trilinear_gather_vol(GatherArgs G) {
+template <int V, bool NOLOAD = false>
+__global__ __launch_bounds__(64) void k_trilinear_gather_vol(GatherArgs G) {
     if (*G.flag > __float_as_uint(GATHER_DEV_TOL)) return;  // not a lattice: the scatter kernel runs instead
     constexpr float HS = V == 2 ? 1.5f : 1.0f;  // half-size of the block's interpolation support
     constexpr float CO = V == 2 ? 0.5f : 0.0f;  // block centre relative to its first voxel
     int bx, by, bz;
-    brick_coords(blockIdx.x, G.D1, G.D2, V, bx, by, bz);
-    const int tid = threadIdx.x;
-    const int vx = (bx * 4 + (tid >> 6)) * V, vy = (by * 8 + ((tid >> 3) & 7)) * V, vz = (bz * 8 + (tid & 7)) * V;
+    brick_coords(blockIdx.x, G.D1, G.D2, G.bd, bx, by, bz);
+    const int tid = threadIdx.x;  // one wavefront: 4 x 4 x 4 blocks
+    const int vx = (bx * 4 + (tid >> 4)) * V, vy = (by * 4 + ((tid >> 2) & 3)) * V, vz = (bz * 4 + (tid & 3)) * V;
     const bool inb = vx < G.D0 && vy < G.D1 && vz < G.D2;
     const float fv[3] = {(float)vx, (float)vy, (float)vz};
     float xv[3];  // block centre in x coordinates
@@ -986,8 +988,14 @@ __global__ __launch_bounds__(WG) void k_trilinear_gather_vol(GatherArgs G) {
                         // two candidates per trip: both 16-byte loads are issued before either is used
                         for (int j = jlo; j <= jhi; j += 2) {
                             const bool two = j < jhi;
-                            const float4 ta = row[j];
-                            float4 tb = row[two ? j + 1 : j];
+                            float4 ta, tb;
+                            if (NOLOAD) {  // ablation only (XVR_DRR_GATHER_ABLATE=1): same arithmetic, no memory
+                                ta = make_float4(q0x + (float)j, q0y, q0z, 1.f);
+                                tb = make_float4(q0x, q0y + (float)j, q0z, 1.f);
+                            } else {
+                                ta = row[j];
+                                tb = row[two ? j + 1 : j];
+                            }
                             tb.w = two ? tb.w : 0.f;
 #pragma unroll
                             for (int h = 0; h < 2; ++h) {
@@ -1052,7 +1060,7 @@ __global__ __launch_bounds__(WG) void k_trilinear_gather_vol(GatherArgs G) {
 __global__ __launch_bounds__(WG) void k_siddon_gather_vol(GatherArgs G) {
     if (*G.flag > __float_as_uint(GATHER_DEV_TOL)) return;
     int bx, by, bz;
-    brick_coords(blockIdx.x, G.D1, G.D2, 1, bx, by, bz);
+    brick_coords(blockIdx.x, G.D1, G.D2, G.bd, bx, by, bz);
     const int tid = threadIdx.x;
     const int vx = bx * 4 + (tid >> 6), vy = by * 8 + ((tid >> 3) & 7), vz = bz * 8 + (tid & 7);
     const bool inb = vx < G.D0 && vy < G.D1 && vz < G.D2;
@@ -1470,8 +1478,12 @@ int launch(Kern kern, const RenderArgs& A, size_t lds_bytes, void* stream) {
 // workspace layout of the gather path:
 //   [flag, 256 B][PoseLattice x B, 256-aligned][float4 x B*n][cull words: bricks x ceil(B/32)]
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
-long long n_bricks(int D0, int D1, int D2, int V = 1) {
-    return (long long)((D0 + 4 * V - 1) / (4 * V)) * ((D1 + 8 * V - 1) / (8 * V)) * ((D2 + 8 * V - 1) / (8 * V));
+long long n_bricks(int D0, int D1, int D2, const int* bd) {
+    return (long long)((D0 + bd[0] - 1) / bd[0]) * ((D1 + bd[1] - 1) / bd[1]) * ((D2 + bd[2] - 1) / bd[2]);
+}
+long long n_bricks_max(int D0, int D1, int D2) {  // the finest brick any variant uses: 4 x 4 x 4
+    const int bd[3] = {4, 4, 4};
+    return n_bricks(D0, D1, D2, bd);
 }
 // voxels per lane and axis in the trilinear gather: 2 unless XVR_DRR_GATHER_BLOCK=1 (A/B switch)
 int gather_block() {
@@ -1486,7 +1498,7 @@ size_t ws_q_off(int B) { return 256 + align256((size_t)B * sizeof(PoseLattice));
 size_t ws_q2_off(int B, int n) { return ws_q_off(B) + align256((size_t)B * (size_t)n * sizeof(float4)); }
 size_t ws_cull_off(int B, int n) { return ws_q2_off(B, n) + align256((size_t)B * (size_t)n * sizeof(float2)); }
 size_t ws_bytes(int B, int n, int D0, int D1, int D2) {
-    return ws_cull_off(B, n) + (size_t)n_bricks(D0, D1, D2) * (size_t)((B + 31) / 32) * sizeof(unsigned);
+    return ws_cull_off(B, n) + (size_t)n_bricks_max(D0, D1, D2) * (size_t)((B + 31) / 32) * sizeof(unsigned);
 }
 
 // Set up the workspace and launch prep -> cull -> gather.  The caller launches the scatter fallback
@@ -1504,6 +1516,8 @@ int launch_gather(bool siddon, const float* source, const float* target, const f
     G.q2 = reinterpret_cast<float2*>(ws + ws_q2_off(B, n));
     G.siddon = siddon ? 1 : 0;
     G.V = siddon ? 1 : gather_block();
+    if (siddon) { G.bd[0] = 4; G.bd[1] = 8; G.bd[2] = 8; }
+    else { G.bd[0] = G.bd[1] = G.bd[2] = 4 * G.V; }
     G.cull = reinterpret_cast<unsigned*>(ws + ws_cull_off(B, n));
     G.words = (B + 31) / 32;
     G.gvol = grad_volume;
@@ -1512,13 +1526,14 @@ int launch_gather(bool siddon, const float* source, const float* target, const f
     if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
     hipLaunchKernelGGL(k_gather_prep, dim3((unsigned)((n + WG - 1) / WG), (unsigned)B), dim3(WG), 0,
                        (hipStream_t)stream, G);
-    const long long bricks = n_bricks(D0, D1, D2, G.V);
+    const long long bricks = n_bricks(D0, D1, D2, G.bd);
     if (bricks >= (1LL << 31)) return fail(XVR_DRR_E_UNSUPPORTED, "grid too large");
     hipLaunchKernelGGL(k_gather_cull, dim3((unsigned)((bricks + WG / 32 - 1) / (WG / 32))), dim3(WG), 0,
                        (hipStream_t)stream, G, (int)bricks);
     if (siddon) hipLaunchKernelGGL(k_siddon_gather_vol, dim3((unsigned)bricks), dim3(WG), 0, (hipStream_t)stream, G);
-    else if (G.V == 2) hipLaunchKernelGGL(k_trilinear_gather_vol<2>, dim3((unsigned)bricks), dim3(WG), 0, (hipStream_t)stream, G);
-    else hipLaunchKernelGGL(k_trilinear_gather_vol<1>, dim3((unsigned)bricks), dim3(WG), 0, (hipStream_t)stream, G);
+    else if (G.V == 2 && getenv("XVR_DRR_GATHER_ABLATE")) hipLaunchKernelGGL((k_trilinear_gather_vol<2, true>), dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
+    else if (G.V == 2) hipLaunchKernelGGL(k_trilinear_gather_vol<2>, dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
+    else hipLaunchKernelGGL(k_trilinear_gather_vol<1>, dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
     return XVR_DRR_OK;
