@@ -1061,6 +1061,8 @@ __global__ __launch_bounds__(WG) void k_siddon_gather_vol(GatherArgs G) {
     if (*G.flag > __float_as_uint(GATHER_DEV_TOL)) return;
     int bx, by, bz;
     brick_coords(blockIdx.x, G.D1, G.D2, G.bd, bx, by, bz);
+    // 256 lanes on 4 x 8 x 8 voxels (one voxel per lane: the per-pose setup dominates, so a larger
+    // workgroup that amortises the cull words and pose constants wins here -- 4^3 bricks measured 10 % slower)
     const int tid = threadIdx.x;
     const int vx = bx * 4 + (tid >> 6), vy = by * 8 + ((tid >> 3) & 7), vz = bz * 8 + (tid & 7);
     const bool inb = vx < G.D0 && vy < G.D1 && vz < G.D2;
