@@ -196,6 +196,15 @@ def main():
         "nominal_units_per_launch": nominal_units or None,
     }
 
+    # the forward+backward PAIR priced as one unit (64 B per sample with the voxel gradient,
+    # 32 B without), over the summed HIP-event time of every kernel of a step
+    kernel_ms = sum(v["avg_ms"] * v["launches"] for v in kernels.values()) / args.steps
+    pair_bytes = units * bytes_per_unit * (1 if args.no_voxel_grad else 2)
+    roofline["forward_backward_pair"] = {
+        "achieved": pair_bytes / (kernel_ms * 1e-3) / 1e9, "unit": "GB/s", "frac": pair_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "kernel_ms_per_step": kernel_ms, "bytes_per_unit": bytes_per_unit * (1 if args.no_voxel_grad else 2),
+    }
+
     result = {
         "metric": "DRRs/sec (fwd+bwd) 512³ CT→256² detector; achieved HBM GB/s vs peak",
         "value": world * B * args.steps / elapsed, "unit": "DRRs/s",
