@@ -1,0 +1,55 @@
+/*
+ * xvr_sim.h -- C ABI of the fused image-similarity step of xvr's registration loop (part of
+ * libxvr_drr.so).  SURVEY.md section 8f rank 1: the step right after the renderer in every iteration,
+ *
+ *     pred_img = transform(pred_img)              /root/reference/src/xvr/registrar/base.py:250
+ *     loss = imagesim(img, pred_img)              /root/reference/src/xvr/registrar/base.py:251
+ *     loss.backward()                             /root/reference/src/xvr/registrar/base.py:252
+ *
+ * with transform = XrayTransforms (Standardize by the GLOBAL min/max -> Normalize(mean, std);
+ * /root/reference/src/xvr/utils/preprocess.py:5-31, the Resize is the identity for a DRR rendered at the
+ * stage's resolution) and imagesim = beta * MultiscaleNCC([None, p1], [.5, .5]) + (1 - beta) *
+ * GradientNCC(p2, sigma = 0)  (/root/reference/src/xvr/registrar/base.py:115-123).
+ *
+ * One call computes the similarity of every image of the batch AND its exact gradient w.r.t. the raw
+ * (un-transformed) moving image, including the terms through the global min / max of Standardize.
+ * All pointers are device pointers; kernels are enqueued on `stream`; returns 0 or a negative
+ * XVR_DRR_E_* code (message via xvr_drr_last_error()).
+ */
+#ifndef XVR_SIM_H
+#define XVR_SIM_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct xvr_sim_spec {
+    float mean, std;      /* Normalize(mean, std) after Standardize            (0.15, 0.1)          */
+    float std_eps;        /* Standardize: (x - min) / (max - min + std_eps)     (1e-6)               */
+    float ncc_eps;        /* added to every variance                            (1e-5)               */
+    float beta;           /* weight of the multiscale NCC vs the gradient NCC   (0.5)                */
+    int   mncc_patch;     /* patch size of the local term of the multiscale NCC (9)                  */
+    int   gncc_patch;     /* patch size of the gradient NCC                     (11)                 */
+} xvr_sim_spec;
+
+/* bytes of device scratch for a batch of B images of H x W */
+size_t xvr_sim_workspace_bytes(int B, int H, int W);
+
+/*
+ * fixed        [B][H][W]     the target image, ALREADY transformed (constant over the iterations)
+ * fixed_sobel  [B][2][H][W]  its Sobel pair (conv2d with the 3x3 Sobel kernels, zero padding 1)
+ * moving       [B][H][W]     the raw rendered DRRs
+ * loss         [B]           similarity of every image (written)
+ * grad_moving  [B][H][W]     d loss[b] / d moving (written; nullable)
+ */
+int xvr_sim_ncc_forward_backward(const float* fixed, const float* fixed_sobel, const float* moving,
+                                 int B, int H, int W, const xvr_sim_spec* spec,
+                                 float* loss, float* grad_moving,
+                                 void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XVR_SIM_H */

@@ -620,6 +620,41 @@ def test_render_samples_contract():
     _close(img1, img, FWD_TOL)
 
 
+@pytest.mark.parametrize("shape", [(1, 40, 36), (1, 64, 64), (3, 33, 47)])
+@pytest.mark.parametrize("beta", [0.5, 0.2])
+def test_fused_similarity_matches_torch_metrics_and_the_unfold_oracle(shape, beta):
+    """xvr_sim_ncc_forward_backward == XrayTransforms -> beta * mNCC + (1 - beta) * gradNCC, value and
+    gradient w.r.t. the RAW moving image (incl. the terms through Standardize's global min/max, whose
+    minimum is attained by many pixels of a DRR: torch spreads that gradient evenly)."""
+    from oracle import metrics_restated as mref
+    from xvr_amd.metrics import GradientNormalizedCrossCorrelation2d, MultiscaleNormalizedCrossCorrelation2d, XrayTransforms
+    from xvr_amd.similarity import FusedSimilarity
+
+    B, H, W = shape
+    g = torch.Generator().manual_seed(31)
+    fixed_raw = torch.rand(B, 1, H, W, generator=g) * 40
+    moving = (0.7 * fixed_raw + 12 * torch.rand(B, 1, H, W, generator=g)).clamp_min(6.0) - 6.0  # many exact zeros
+    moving[:, :, :6, :6] = 0.0
+    tf = XrayTransforms(H, W)
+    fixed = tf(fixed_raw)
+    sim = FusedSimilarity(fixed.cuda(), 9, 11, beta)
+    mv = moving.cuda().requires_grad_(True)
+    loss = sim(mv)
+    loss.sum().backward()
+    # torch path
+    m2 = moving.clone().requires_grad_(True)
+    s1, s2 = MultiscaleNormalizedCrossCorrelation2d([None, 9], [0.5, 0.5]), GradientNormalizedCrossCorrelation2d(11, 0.0)
+    y2 = tf(m2)
+    ref = beta * s1(fixed, y2) + (1 - beta) * s2(fixed, y2)
+    ref.sum().backward()
+    assert torch.allclose(loss.cpu(), ref, atol=2e-5), (loss.cpu(), ref)
+    _close(mv.grad, m2.grad, 2e-3, "d sim / d moving")
+    # the literal unfold formulation (oracle), value only
+    yo = mref.xray_transforms(moving.double(), H, W)
+    oref = beta * mref.multiscale_ncc(fixed.double(), yo) + (1 - beta) * mref.gradient_ncc(fixed.double(), yo, 11, 0.0)
+    assert torch.allclose(loss.cpu().double(), oref, atol=5e-5)
+
+
 def test_registration_c4_multiscale_refinement_and_first_step_parity():
     """configs[3] in miniature: multiscale (mNCC + gradient-NCC) pose refinement.  (1) the first
     iteration's similarity and its pose gradient match the oracle pipeline (CPU render + unfold NCC);

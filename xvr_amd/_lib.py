@@ -29,6 +29,18 @@ class CSpec(ctypes.Structure):
     ]
 
 
+class CSimSpec(ctypes.Structure):
+    _fields_ = [
+        ("mean", ctypes.c_float),
+        ("std", ctypes.c_float),
+        ("std_eps", ctypes.c_float),
+        ("ncc_eps", ctypes.c_float),
+        ("beta", ctypes.c_float),
+        ("mncc_patch", ctypes.c_int),
+        ("gncc_patch", ctypes.c_int),
+    ]
+
+
 _P = ctypes.c_void_p
 _I = ctypes.c_int
 _FWD = [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, ctypes.POINTER(CSpec), _P, _P, _P, _P]
@@ -43,6 +55,8 @@ EXPORTS = {
     "xvr_drr_siddon_forward": (_FWD, ctypes.c_int),
     "xvr_drr_siddon_backward": (_BWD, ctypes.c_int),
     "xvr_drr_backward_from_jac": ([_P, _P, _I, _I, _P, _P, _P, _P], ctypes.c_int),
+    "xvr_sim_workspace_bytes": ([_I, _I, _I], ctypes.c_size_t),
+    "xvr_sim_ncc_forward_backward": ([_P, _P, _P, _I, _I, _I, ctypes.POINTER(CSimSpec), _P, _P, _P, ctypes.c_size_t, _P], ctypes.c_int),
     "xvr_drr_rays_forward": ([_P, _I, _I, _I, _P, _P, _P, _P], ctypes.c_int),
     "xvr_drr_rays_backward": ([_P, _I, _I, _I, _P, _P, _P, _P, _P], ctypes.c_int),
 }

@@ -1568,6 +1568,8 @@ size_t xvr_drr_backward_workspace_bytes(int B, int n, int D0, int D1, int D2) {
 
 int xvr_drr_abi_version(void) { return XVR_DRR_ABI_VERSION; }
 const char* xvr_drr_last_error(void) { return g_err; }
+// shared by the other translation units of the library (sim_kernels.hip); not part of the public header
+void xvr_drr_set_last_error(const char* msg) { snprintf(g_err, sizeof(g_err), "%s", msg ? msg : ""); }
 
 int xvr_drr_trilinear_forward(const float* volume, const float* mask, int D0, int D1, int D2, int C,
                               const float* source, const float* target, const float* raylen, int B, int n,

@@ -1,0 +1,400 @@
+// Fused image-similarity step of xvr's registration loop for MI355X (gfx950): XrayTransforms
+// (Standardize by the global min/max -> Normalize) + multiscale NCC + gradient NCC, value AND exact
+// gradient w.r.t. the raw rendered image, in nine small launches instead of ~100 torch kernels.
+// C ABI: include/xvr_sim.h.  Reference being replaced:
+//   /root/reference/src/xvr/registrar/base.py:115-123 (imagesim), :250-252 (transform, loss, backward)
+//   /root/reference/src/xvr/utils/preprocess.py:5-31  (XrayTransforms)
+//
+// The reference's patch NCC unfolds every p x p patch into a channel (81x / 121x the image); here
+// each thread evaluates one patch from an LDS tile with a two-pass (mean, then centred moments)
+// scheme -- robust on the flat patches where eps decides -- and stores four per-patch maps
+//   A = 1/s, Bm = mu_f/s, Cm = cov/(v_y s), Dm = cov mu_y/(v_y s),   s = sqrt(v_f v_y),
+// from which the gradient is   d ncc / d y_i = (1 / (N_p p^2)) * ( f_i SA - SB - y_i SC + SD ),
+// S* = sums of the maps over the patches that contain pixel i (the adjoint box filter).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "xvr_drr.h"
+#include "xvr_sim.h"
+
+extern "C" void xvr_drr_set_last_error(const char* msg);  // drr_kernels.hip
+
+namespace {
+
+constexpr int TB = 256;
+constexpr int TILE = 16;      // output tile edge of the patch kernels
+constexpr int MAXP = 15;      // largest supported patch edge
+constexpr int N_ACC = 16;     // doubles per image
+
+
+struct SimHeader {           // first 256 bytes of the workspace
+    unsigned enc_min, enc_max;
+    int cnt_min, cnt_max;
+    double smin, smax;       // sum G_i (1 - x_i), sum G_i x_i  over the whole batch
+};
+
+__device__ __forceinline__ unsigned enc(float f) {
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float dec(unsigned u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// block-wide sum of `nv` doubles per thread -> atomicAdd into dst[0..nv)
+template <int NV>
+__device__ __forceinline__ void block_add(double (&v)[NV], double* dst) {
+    __shared__ double part[NV][TB / 64];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const double t = wave_sum_d(v[i]);
+        if ((threadIdx.x & 63) == 0) part[i][threadIdx.x >> 6] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < TB / 64; ++w) t += part[threadIdx.x][w];
+        if (t != 0.0) atomicAdd(dst + threadIdx.x, t);
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(TB) void k_sim_minmax(const float* __restrict__ m, long long n, SimHeader* hd) {
+    float lo = INFINITY, hi = -INFINITY;
+    for (long long i = (long long)blockIdx.x * TB + threadIdx.x; i < n; i += (long long)gridDim.x * TB) {
+        const float v = m[i];
+        lo = fminf(lo, v);
+        hi = fmaxf(hi, v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, o));
+        hi = fmaxf(hi, __shfl_xor(hi, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&hd->enc_min, enc(lo));
+        atomicMax(&hd->enc_max, enc(hi));
+    }
+}
+
+__global__ __launch_bounds__(TB) void k_sim_count(const float* __restrict__ m, long long n, SimHeader* hd) {
+    const float mn = dec(hd->enc_min), mx = dec(hd->enc_max);
+    int cmin = 0, cmax = 0;
+    for (long long i = (long long)blockIdx.x * TB + threadIdx.x; i < n; i += (long long)gridDim.x * TB) {
+        const float v = m[i];
+        cmin += v == mn;
+        cmax += v == mx;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        cmin += __shfl_xor(cmin, o);
+        cmax += __shfl_xor(cmax, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (cmin) atomicAdd(&hd->cnt_min, cmin);
+        if (cmax) atomicAdd(&hd->cnt_max, cmax);
+    }
+}
+
+// y = ((m - min) / (max - min + std_eps) - mean) / std  + the five global moments of (f, y) per image
+__global__ __launch_bounds__(TB) void k_sim_prep(const float* __restrict__ m, const float* __restrict__ f, int hw,
+                                                 const SimHeader* hd, xvr_sim_spec sp, float* __restrict__ y,
+                                                 double* acc) {
+    const int b = blockIdx.y;
+    const float mn = dec(hd->enc_min), mx = dec(hd->enc_max);
+    const float r = (mx - mn) + sp.std_eps;
+    double s[5] = {0, 0, 0, 0, 0};
+    for (int i = blockIdx.x * TB + threadIdx.x; i < hw; i += gridDim.x * TB) {
+        const size_t k = (size_t)b * hw + i;
+        const float yy = (((m[k] - mn) / r) - sp.mean) / sp.std;
+        const float ff = f[k];
+        y[k] = yy;
+        s[0] += yy; s[1] += (double)yy * yy; s[2] += ff; s[3] += (double)ff * ff; s[4] += (double)ff * yy;
+    }
+    block_add<5>(s, acc + (size_t)b * N_ACC);
+}
+
+// 3x3 Sobel pair with zero padding 1 (torch conv2d = cross-correlation)
+__global__ __launch_bounds__(TB) void k_sim_sobel(const float* __restrict__ y, int H, int W, float* __restrict__ g) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * TB + threadIdx.x;
+    if (i >= H * W) return;
+    const int r = i / W, c = i - r * W;
+    const float* Y = y + (size_t)b * H * W;
+    auto at = [&](int rr, int cc) { return (rr >= 0 && rr < H && cc >= 0 && cc < W) ? Y[rr * W + cc] : 0.f; };
+    const float a00 = at(r - 1, c - 1), a01 = at(r - 1, c), a02 = at(r - 1, c + 1);
+    const float a10 = at(r, c - 1), a12 = at(r, c + 1);
+    const float a20 = at(r + 1, c - 1), a21 = at(r + 1, c), a22 = at(r + 1, c + 1);
+    g[((size_t)b * 2 + 0) * H * W + i] = (a00 - a02) + 2.f * (a10 - a12) + (a20 - a22);
+    g[((size_t)b * 2 + 1) * H * W + i] = (a00 + 2.f * a01 + a02) - (a20 + 2.f * a21 + a22);
+}
+
+// one thread = one patch.  fimg / yimg: [B][nch][H][W] with channel `ch` selected.  maps: [4][B][Hp][Wp].
+__global__ __launch_bounds__(TB) void k_sim_patch(const float* __restrict__ fimg, const float* __restrict__ yimg, int nch,
+                                                  int ch, int H, int W, int p, float eps, float* __restrict__ maps,
+                                                  double* acc, int acc_slot) {
+    __shared__ float sf[(TILE + MAXP - 1) * (TILE + MAXP - 1)];
+    __shared__ float sy[(TILE + MAXP - 1) * (TILE + MAXP - 1)];
+    const int b = blockIdx.z;
+    const int Hp = H - p + 1, Wp = W - p + 1;
+    const int oy0 = blockIdx.y * TILE, ox0 = blockIdx.x * TILE;
+    const int E = TILE + p - 1;
+    const float* F = fimg + ((size_t)b * nch + ch) * H * W;
+    const float* Y = yimg + ((size_t)b * nch + ch) * H * W;
+    for (int t = threadIdx.x; t < E * E; t += TB) {
+        const int rr = oy0 + t / E, cc = ox0 + t % E;
+        const bool in = rr < H && cc < W;
+        sf[t] = in ? F[rr * W + cc] : 0.f;
+        sy[t] = in ? Y[rr * W + cc] : 0.f;
+    }
+    __syncthreads();
+    const int ty = threadIdx.x / TILE, tx = threadIdx.x % TILE;
+    const int oy = oy0 + ty, ox = ox0 + tx;
+    double ncc_d = 0.0;
+    if (oy < Hp && ox < Wp) {
+        const float inv = 1.f / (float)(p * p);
+        float mf = 0.f, my = 0.f;
+        for (int u = 0; u < p; ++u)
+            for (int v = 0; v < p; ++v) {
+                mf += sf[(ty + u) * E + tx + v];
+                my += sy[(ty + u) * E + tx + v];
+            }
+        mf *= inv;
+        my *= inv;
+        float vf = 0.f, vy = 0.f, cv = 0.f;
+        for (int u = 0; u < p; ++u)
+            for (int v = 0; v < p; ++v) {
+                const float df = sf[(ty + u) * E + tx + v] - mf, dy = sy[(ty + u) * E + tx + v] - my;
+                vf = fmaf(df, df, vf);
+                vy = fmaf(dy, dy, vy);
+                cv = fmaf(df, dy, cv);
+            }
+        vf = vf * inv + eps;
+        vy = vy * inv + eps;
+        cv *= inv;
+        const float s = sqrtf(vf * vy);
+        const float ncc = cv / s;
+        const size_t np = (size_t)Hp * Wp, o = ((size_t)b * Hp + oy) * Wp + ox, st = (size_t)gridDim.z * np;
+        maps[o] = 1.f / s;
+        maps[st + o] = mf / s;
+        maps[2 * st + o] = cv / (vy * s);
+        maps[3 * st + o] = cv * my / (vy * s);
+        ncc_d = ncc;
+    }
+    double v1[1] = {ncc_d};
+    block_add<1>(v1, acc + (size_t)b * N_ACC + acc_slot);
+}
+
+// G[i] (+)= scale * ( f_i SA - SB - y_i SC + SD ),  S* = sums of the maps over the patches containing i
+__global__ __launch_bounds__(TB) void k_sim_patch_grad(const float* __restrict__ fimg, const float* __restrict__ yimg, int nch,
+                                                       int ch, int H, int W, int p, const float* __restrict__ maps,
+                                                       float scale, float* __restrict__ G, int g_nch, int g_ch) {
+    __shared__ float sm[4][(TILE + MAXP - 1) * (TILE + MAXP - 1)];
+    const int b = blockIdx.z;
+    const int Hp = H - p + 1, Wp = W - p + 1;
+    const int r0 = blockIdx.y * TILE, c0 = blockIdx.x * TILE;
+    const int E = TILE + p - 1;
+    const size_t np = (size_t)Hp * Wp, st = (size_t)gridDim.z * np;
+    // patches containing pixel (r, c) have origins in [r - p + 1, r] x [c - p + 1, c]: stage that window
+    for (int t = threadIdx.x; t < E * E; t += TB) {
+        const int oy = r0 - (p - 1) + t / E, ox = c0 - (p - 1) + t % E;
+        const bool in = oy >= 0 && oy < Hp && ox >= 0 && ox < Wp;
+        const size_t o = ((size_t)b * Hp + oy) * Wp + ox;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sm[k][t] = in ? maps[k * st + o] : 0.f;
+    }
+    __syncthreads();
+    const int ty = threadIdx.x / TILE, tx = threadIdx.x % TILE;
+    const int r = r0 + ty, c = c0 + tx;
+    if (r >= H || c >= W) return;
+    float sa = 0.f, sb = 0.f, sc = 0.f, sd = 0.f;
+    for (int u = 0; u < p; ++u)
+        for (int v = 0; v < p; ++v) {
+            const int t = (ty + u) * E + tx + v;
+            sa += sm[0][t]; sb += sm[1][t]; sc += sm[2][t]; sd += sm[3][t];
+        }
+    const size_t i = ((size_t)b * nch + ch) * H * W + (size_t)r * W + c;
+    const float g = scale * (fimg[i] * sa - sb - yimg[i] * sc + sd);
+    G[((size_t)b * g_nch + g_ch) * H * W + (size_t)r * W + c] = g;
+}
+
+// total gradient w.r.t. y: local term (already in Gy) + global NCC term + Sobel^T of the gradient-NCC
+// terms; direct part of d/d moving = a * G; accumulates the sums the min/max terms need.
+__global__ __launch_bounds__(TB) void k_sim_final(const float* __restrict__ m, const float* __restrict__ f,
+                                                  const float* __restrict__ y, const float* __restrict__ Gy,
+                                                  const float* __restrict__ Gg, int H, int W, SimHeader* hd,
+                                                  const double* __restrict__ acc, xvr_sim_spec sp,
+                                                  float* __restrict__ grad) {
+    const int b = blockIdx.y, hw = H * W;
+    const int i = blockIdx.x * TB + threadIdx.x;
+    const float mn = dec(hd->enc_min), mx = dec(hd->enc_max);
+    const float r = (mx - mn) + sp.std_eps;
+    const float a = 1.f / (r * sp.std);
+    const double* A = acc + (size_t)b * N_ACC;
+    const double n = (double)hw;
+    const double muy = A[0] / n, muf = A[2] / n;
+    const double vy = A[1] / n - muy * muy + sp.ncc_eps, vf = A[3] / n - muf * muf + sp.ncc_eps;
+    const double cov = A[4] / n - muf * muy;
+    const double sg = sqrt(vf * vy);
+    double s2[2] = {0.0, 0.0};
+    if (i < hw) {
+        const int rr = i / W, cc = i - rr * W;
+        const size_t k = (size_t)b * hw + i;
+        const float yy = y[k], ff = f[k];
+        float G = Gy[k];
+        G += (float)(0.5 * sp.beta / n * ((ff - muf) / sg - cov * (yy - muy) / (vy * sg)));
+        // Sobel^T: dL/dy[r,c] = sum_{u,v} K[u][v] * Gg[r - u + 1, c - v + 1]
+        const float* gx = Gg + ((size_t)b * 2 + 0) * hw;
+        const float* gy = Gg + ((size_t)b * 2 + 1) * hw;
+        auto at = [&](const float* P, int r2, int c2) { return (r2 >= 0 && r2 < H && c2 >= 0 && c2 < W) ? P[r2 * W + c2] : 0.f; };
+        // Kx = [[1,0,-1],[2,0,-2],[1,0,-1]]
+        G += at(gx, rr + 1, cc + 1) - at(gx, rr + 1, cc - 1) + 2.f * (at(gx, rr, cc + 1) - at(gx, rr, cc - 1)) +
+             at(gx, rr - 1, cc + 1) - at(gx, rr - 1, cc - 1);
+        // Ky = [[1,2,1],[0,0,0],[-1,-2,-1]]
+        G += at(gy, rr + 1, cc + 1) + 2.f * at(gy, rr + 1, cc) + at(gy, rr + 1, cc - 1) -
+             (at(gy, rr - 1, cc + 1) + 2.f * at(gy, rr - 1, cc) + at(gy, rr - 1, cc - 1));
+        const float x = (m[k] - mn) / r;
+        if (grad) grad[k] = a * G;
+        s2[0] = (double)G * (1.0 - x);
+        s2[1] = (double)G * x;
+    }
+    block_add<2>(s2, &hd->smin);
+}
+
+// Standardize's min and max are functions of the image too: their gradient goes, evenly, to every
+// pixel that attains them (torch's full-reduction min/max backward)
+__global__ __launch_bounds__(TB) void k_sim_minmax_grad(const float* __restrict__ m, long long n, const SimHeader* hd,
+                                                        xvr_sim_spec sp, float* __restrict__ grad) {
+    const float mn = dec(hd->enc_min), mx = dec(hd->enc_max);
+    const float r = (mx - mn) + sp.std_eps;
+    const double a = 1.0 / ((double)r * sp.std);
+    const float gmin = (float)(-a * hd->smin / (double)max(hd->cnt_min, 1));
+    const float gmax = (float)(-a * hd->smax / (double)max(hd->cnt_max, 1));
+    for (long long i = (long long)blockIdx.x * TB + threadIdx.x; i < n; i += (long long)gridDim.x * TB) {
+        const float v = m[i];
+        float add = 0.f;
+        if (v == mn) add += gmin;
+        if (v == mx) add += gmax;
+        if (add != 0.f) grad[i] += add;
+    }
+}
+
+__global__ void k_sim_loss(const double* __restrict__ acc, int B, int H, int W, xvr_sim_spec sp, float* __restrict__ loss) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double* A = acc + (size_t)b * N_ACC;
+    const double n = (double)H * W;
+    const double muy = A[0] / n, muf = A[2] / n;
+    const double vy = A[1] / n - muy * muy + sp.ncc_eps, vf = A[3] / n - muf * muf + sp.ncc_eps;
+    const double cov = A[4] / n - muf * muy;
+    const double ncc_g = cov / sqrt(vf * vy);
+    const double n1 = (double)(H - sp.mncc_patch + 1) * (W - sp.mncc_patch + 1);
+    const double n2 = (double)(H - sp.gncc_patch + 1) * (W - sp.gncc_patch + 1);
+    const double mncc = 0.5 * ncc_g + 0.5 * A[5] / n1;
+    const double gncc = 0.5 * (A[6] + A[7]) / n2;
+    loss[b] = (float)(sp.beta * mncc + (1.0 - sp.beta) * gncc);
+}
+
+int sim_fail(int code, const char* msg) {
+    xvr_drr_set_last_error(msg);  // one error buffer for the whole library (xvr_drr_last_error())
+    return code;
+}
+
+size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct Layout {
+    size_t acc, y, gy, m1, m2, Gy, Gg, total;
+};
+
+Layout layout(int B, int H, int W, int p1, int p2) {
+    Layout L;
+    const size_t hw = (size_t)H * W;
+    size_t o = 256;
+    L.acc = o; o += al((size_t)B * N_ACC * sizeof(double));
+    L.y = o; o += al((size_t)B * hw * 4);
+    L.gy = o; o += al((size_t)B * 2 * hw * 4);
+    L.m1 = o; o += al((size_t)4 * B * (size_t)(H - p1 + 1) * (W - p1 + 1) * 4);
+    L.m2 = o; o += al((size_t)2 * 4 * B * (size_t)(H - p2 + 1) * (W - p2 + 1) * 4);
+    L.Gy = o; o += al((size_t)B * hw * 4);
+    L.Gg = o; o += al((size_t)B * 2 * hw * 4);
+    L.total = o;
+    return L;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t xvr_sim_workspace_bytes(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    // sized for the smallest legal patches (largest maps)
+    return layout(B, H, W, 1, 1).total;
+}
+
+int xvr_sim_ncc_forward_backward(const float* fixed, const float* fixed_sobel, const float* moving, int B, int H, int W,
+                                 const xvr_sim_spec* sp, float* loss, float* grad_moving, void* workspace,
+                                 size_t workspace_bytes, void* stream_) {
+    if (!fixed || !fixed_sobel || !moving || !sp || !loss || !workspace) return sim_fail(XVR_DRR_E_ARG, "null pointer argument");
+    if (B <= 0 || H <= 0 || W <= 0) return sim_fail(XVR_DRR_E_ARG, "B, H, W must be positive");
+    const int p1 = sp->mncc_patch, p2 = sp->gncc_patch;
+    if (p1 < 1 || p2 < 1 || p1 > MAXP || p2 > MAXP) return sim_fail(XVR_DRR_E_UNSUPPORTED, "patch size must be in [1, 15]");
+    if (H < p1 || W < p1 || H < p2 || W < p2) return sim_fail(XVR_DRR_E_ARG, "image smaller than a patch");
+    const Layout L = layout(B, H, W, p1, p2);
+    if (workspace_bytes < L.total) return sim_fail(XVR_DRR_E_ARG, "workspace too small");
+    hipStream_t stream = (hipStream_t)stream_;
+    char* ws = static_cast<char*>(workspace);
+    SimHeader* hd = reinterpret_cast<SimHeader*>(ws);
+    double* acc = reinterpret_cast<double*>(ws + L.acc);
+    float* y = reinterpret_cast<float*>(ws + L.y);
+    float* gyb = reinterpret_cast<float*>(ws + L.gy);
+    float* m1 = reinterpret_cast<float*>(ws + L.m1);
+    float* m2 = reinterpret_cast<float*>(ws + L.m2);
+    float* Gy = reinterpret_cast<float*>(ws + L.Gy);
+    float* Gg = reinterpret_cast<float*>(ws + L.Gg);
+    const int hw = H * W;
+    const long long n = (long long)B * hw;
+
+    hipError_t e = hipMemsetAsync(ws, 0, L.y, stream);  // header + accumulators
+    if (e != hipSuccess) return sim_fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
+    e = hipMemsetAsync(ws, 0xff, 4, stream);            // enc_min = 0xffffffff (enc_max = 0 from the memset)
+    if (e != hipSuccess) return sim_fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
+
+    const unsigned rb = (unsigned)((n + TB - 1) / TB < 1024 ? (n + TB - 1) / TB : 1024);
+    hipLaunchKernelGGL(k_sim_minmax, dim3(rb), dim3(TB), 0, stream, moving, n, hd);
+    hipLaunchKernelGGL(k_sim_count, dim3(rb), dim3(TB), 0, stream, moving, n, hd);
+    const unsigned pb = (unsigned)((hw + TB - 1) / TB < 256 ? (hw + TB - 1) / TB : 256);
+    hipLaunchKernelGGL(k_sim_prep, dim3(pb, B), dim3(TB), 0, stream, moving, fixed, hw, hd, *sp, y, acc);
+    hipLaunchKernelGGL(k_sim_sobel, dim3((hw + TB - 1) / TB, B), dim3(TB), 0, stream, y, H, W, gyb);
+    auto tiles = [&](int hh, int ww) { return dim3((ww + TILE - 1) / TILE, (hh + TILE - 1) / TILE, B); };
+    const size_t np2 = (size_t)B * (H - p2 + 1) * (W - p2 + 1);
+    hipLaunchKernelGGL(k_sim_patch, tiles(H - p1 + 1, W - p1 + 1), dim3(TB), 0, stream, fixed, y, 1, 0, H, W, p1,
+                       sp->ncc_eps, m1, acc, 5);
+    hipLaunchKernelGGL(k_sim_patch, tiles(H - p2 + 1, W - p2 + 1), dim3(TB), 0, stream, fixed_sobel, gyb, 2, 0, H, W, p2,
+                       sp->ncc_eps, m2, acc, 6);
+    hipLaunchKernelGGL(k_sim_patch, tiles(H - p2 + 1, W - p2 + 1), dim3(TB), 0, stream, fixed_sobel, gyb, 2, 1, H, W, p2,
+                       sp->ncc_eps, m2 + 4 * np2, acc, 7);
+    const double n1 = (double)(H - p1 + 1) * (W - p1 + 1), n2 = (double)(H - p2 + 1) * (W - p2 + 1);
+    const float sc1 = (float)(0.5 * sp->beta / (n1 * p1 * p1));
+    const float sc2 = (float)(0.5 * (1.0 - sp->beta) / (n2 * p2 * p2));
+    hipLaunchKernelGGL(k_sim_patch_grad, tiles(H, W), dim3(TB), 0, stream, fixed, y, 1, 0, H, W, p1, m1, sc1, Gy, 1, 0);
+    hipLaunchKernelGGL(k_sim_patch_grad, tiles(H, W), dim3(TB), 0, stream, fixed_sobel, gyb, 2, 0, H, W, p2, m2, sc2, Gg, 2, 0);
+    hipLaunchKernelGGL(k_sim_patch_grad, tiles(H, W), dim3(TB), 0, stream, fixed_sobel, gyb, 2, 1, H, W, p2, m2 + 4 * np2, sc2,
+                       Gg, 2, 1);
+    hipLaunchKernelGGL(k_sim_final, dim3((hw + TB - 1) / TB, B), dim3(TB), 0, stream, moving, fixed, y, Gy, Gg, H, W, hd, acc,
+                       *sp, grad_moving);
+    if (grad_moving) hipLaunchKernelGGL(k_sim_minmax_grad, dim3(rb), dim3(TB), 0, stream, moving, n, hd, *sp, grad_moving);
+    hipLaunchKernelGGL(k_sim_loss, dim3((B + 63) / 64), dim3(64), 0, stream, acc, B, H, W, *sp, loss);
+    e = hipGetLastError();
+    if (e != hipSuccess) return sim_fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
+    return XVR_DRR_OK;
+}
+
+}  // extern "C"

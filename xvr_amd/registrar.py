@@ -31,6 +31,7 @@ from .metrics import (GradientNormalizedCrossCorrelation2d, MultiscaleNormalized
                       XrayTransforms)
 from .pose import RigidTransform
 from .registration import Registration
+from .similarity import FusedSimilarity
 
 
 def parse_scales(scales, crop: int, height: int):
@@ -44,7 +45,7 @@ def parse_scales(scales, crop: int, height: int):
 class Registrar:
     def __init__(self, drr: DRR, scales="8", n_itrs="500", parameterization="euler_angles", convention="ZXY",
                  lr_rot=1e-2, lr_xyz=1e0, patience=10, threshold=1e-4, max_n_plateaus=3, crop=0, equalize=False,
-                 mncc_patch_size=9, gncc_patch_size=11, sigma=0.0, beta=0.5, verbose=0, use_graph=None):
+                 mncc_patch_size=9, gncc_patch_size=11, sigma=0.0, beta=0.5, verbose=0, use_graph=None, fused=None):
         self.drr = drr
         self.scales = scales.split(",") if isinstance(scales, str) else [str(s) for s in scales]
         self.n_itrs = [int(n) for n in (n_itrs.split(",") if isinstance(n_itrs, str) else n_itrs)]
@@ -58,6 +59,10 @@ class Registrar:
         # graph per pyramid stage and replay it: the reference's iteration is ~150 tiny launches and is
         # launch-bound (4.4 ms at 256^2 and at 512^2 alike on MI355X); replaying costs a fraction.
         self.use_graph = torch.cuda.is_available() if use_graph is None else use_graph
+        self.mncc_patch_size, self.gncc_patch_size, self.sigma = mncc_patch_size, gncc_patch_size, sigma
+        # transforms + similarity + their backward as one fused HIP call (xvr_amd/similarity.py) when the
+        # configuration allows it; plain torch otherwise
+        self.fused = fused
         self.sim1 = MultiscaleNormalizedCrossCorrelation2d([None, mncc_patch_size], [0.5, 0.5])
         self.sim2 = GradientNormalizedCrossCorrelation2d(gncc_patch_size, sigma)
 
@@ -87,6 +92,10 @@ class Registrar:
             reg.drr.rescale_detector_(scale)
             transform = XrayTransforms(reg.drr.detector.height, reg.drr.detector.width, equalize=self.equalize)
             img = transform(gt)
+            h, w = reg.drr.detector.height, reg.drr.detector.width
+            use_fused = (self.fused if self.fused is not None else True) and device.type == "cuda" and \
+                FusedSimilarity.supported(h, w, self.mncc_patch_size, self.gncc_patch_size, self.sigma, self.equalize)
+            fused_sim = FusedSimilarity(img, self.mncc_patch_size, self.gncc_patch_size, self.beta) if use_fused else None
             step_size_scalar *= 2 ** (stage - 1)
             graphed = self.use_graph and device.type == "cuda"
             lr_rot = self.lr_rot / step_size_scalar
@@ -103,8 +112,10 @@ class Registrar:
             stage_losses, stage_params = [], []
 
             def iteration():
-                pred = transform(reg())
-                loss = self.imagesim(img, pred)
+                if fused_sim is not None:
+                    loss = fused_sim(reg())
+                else:
+                    loss = self.imagesim(img, transform(reg()))
                 loss.sum().backward()
                 optimizer.step()
                 return loss.detach()

@@ -1,0 +1,74 @@
+"""Fused image similarity of the registration loop: XrayTransforms + mNCC + gradient-NCC, value and
+gradient in one C-ABI call (include/xvr_sim.h, xvr_amd/csrc/sim_kernels.hip).
+
+Replaces, per iteration, ``pred = transform(pred); loss = imagesim(img, pred); loss.backward()``
+(/root/reference/src/xvr/registrar/base.py:250-252) for the default similarity
+``beta * MultiscaleNCC([None, p1]) + (1 - beta) * GradientNCC(p2, sigma=0)``
+(/root/reference/src/xvr/registrar/base.py:115-123).  The plain-torch implementation in
+``xvr_amd.metrics`` remains the general path (sigma > 0, Equalize, resizing, CPU) and the cross-check.
+"""
+
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+from .metrics import Sobel
+from .renderers import _ptr, _stream, _timed
+
+
+class _FusedNCC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, moving, fixed, fixed_sobel, spec, workspace):
+        lib = _lib.load()
+        B, _, H, W = moving.shape
+        mov = moving.contiguous()
+        loss = torch.empty(B, device=moving.device, dtype=torch.float32)
+        need = ctx.needs_input_grad[0]
+        grad = torch.empty_like(mov) if need else None
+        rc = _timed("ncc_forward_backward", lib.xvr_sim_ncc_forward_backward, _ptr(fixed), _ptr(fixed_sobel), _ptr(mov),
+                    B, H, W, ctypes.byref(spec), _ptr(loss), _ptr(grad), _ptr(workspace), workspace.numel() * 4, _stream())
+        _lib.check(rc, "xvr_sim_ncc_forward_backward")
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        (grad,) = ctx.saved_tensors
+        # The kernels return d(sum_b loss[b]) / d moving: Standardize's min/max couple the images of a
+        # batch, so per-image upstream weights are only exact for one image or a uniform weight.
+        if gout.numel() == 1 or gout.stride(0) == 0:
+            return grad * gout.reshape(-1)[0], None, None, None, None
+        if not bool((gout == gout[0]).all()):
+            raise NotImplementedError("FusedSimilarity: non-uniform per-image loss weights in a batch; "
+                                      "use xvr_amd.metrics (plain torch) for that")
+        return grad * gout[0], None, None, None, None
+
+
+class FusedSimilarity(torch.nn.Module):
+    """``sim(moving_raw) -> [B]`` against a fixed, already transformed target image."""
+
+    def __init__(self, fixed: torch.Tensor, mncc_patch_size=9, gncc_patch_size=11, beta=0.5, mean=0.15, std=0.1,
+                 eps=1e-5):
+        super().__init__()
+        if not fixed.is_cuda or fixed.dtype != torch.float32 or fixed.dim() != 4 or fixed.shape[1] != 1:
+            raise RuntimeError("FusedSimilarity needs a float32 CUDA target of shape [B,1,H,W] (HIP kernels, no CPU path)")
+        self.register_buffer("fixed", fixed.contiguous())
+        self.register_buffer("fixed_sobel", Sobel(0.0).to(fixed.device)(fixed).contiguous())
+        self.spec = _lib.CSimSpec(mean, std, 1e-6, eps, beta, int(mncc_patch_size), int(gncc_patch_size))
+        B, _, H, W = fixed.shape
+        nbytes = _lib.load().xvr_sim_workspace_bytes(B, H, W)
+        self.register_buffer("workspace", torch.empty((nbytes + 3) // 4, device=fixed.device, dtype=torch.float32), persistent=False)
+
+    @staticmethod
+    def supported(height, width, mncc_patch_size, gncc_patch_size, sigma, equalize) -> bool:
+        big = max(mncc_patch_size, gncc_patch_size)
+        return ((not equalize) and (not sigma) and 1 <= min(mncc_patch_size, gncc_patch_size) and big <= 15
+                and min(height, width) >= big and torch.cuda.is_available())
+
+    def forward(self, moving: torch.Tensor) -> torch.Tensor:
+        if moving.shape != self.fixed.shape:
+            raise ValueError(f"moving {tuple(moving.shape)} and fixed {tuple(self.fixed.shape)} differ")
+        return _FusedNCC.apply(moving, self.fixed, self.fixed_sobel, self.spec, self.workspace)
