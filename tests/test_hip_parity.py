@@ -711,6 +711,15 @@ def test_registration_c4_multiscale_refinement_and_first_step_parity():
     assert err1 < 0.35 * err0, (err0, err1)
     assert out["drr"].detector.height == 64 and len(out["trajectory"]) == len(out["nccs"]) - 1
     assert out["lrs"][0] == [1e-2, 1.0] and out["lrs"][-1][0] <= 1e-2 / 2
+    # the parameters.pt dictionary has the reference's keys (registrar/base.py:355-394)
+    params = reg.parameters_dict(out, volume="phantom", xray="synthetic")
+    assert set(params) >= {"drr", "xray", "optimization", "init_pose", "final_pose", "type", "runtime", "trajectory"}
+    assert params["final_pose"].shape == (1, 4, 4) and params["final_pose"].device.type == "cpu"
+    assert set(params["trajectory"][0]) == {"r1", "r2", "r3", "tx", "ty", "tz", "ncc", "times", "lr_rot", "lr_xyz"}
+    assert params["drr"]["renderer"] == "trilinear" and params["optimization"]["scales"] == ["4", "2"]
+    # fused similarity + graph replay and the plain-torch eager loop reach the same optimum
+    out_ref = Registrar(drr, scales="4,2", n_itrs="60,40", patience=6, max_n_plateaus=2, use_graph=False, fused=False).run(gt, init_pose)
+    assert abs(out_ref["nccs"][-1] - out["nccs"][-1]) < 0.02
 
 
 def RigidTransform_cpu(pose):

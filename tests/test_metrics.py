@@ -63,3 +63,27 @@ def test_double_geodesic():
     assert abs(ang.item() - 0.1 * 510.0) < 1e-2
     assert abs(tr.item() - 2 * 800.0 * torch.sin(torch.tensor(0.05)).item()) < 1e-2
     assert abs(dbl.item() - (ang.item() ** 2 + tr.item() ** 2) ** 0.5) < 1e-3
+
+
+def test_equalize_matches_reference_lines_and_flattens_the_histogram():
+    """Line-by-line restatement of src/xvr/utils/preprocess.py:34-66, checked against its own definition."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(2, 1, 24, 20, generator=g) ** 3  # skewed towards 0
+    eq = metrics.Equalize(n_bins=64, tau=0.02)
+    y = eq(x)
+    assert y.shape == x.shape and y.min() >= -1e-6 and y.max() <= 1 + 1e-6
+    # reference formula, vectorised over the batch
+    B = 2
+    bins = torch.linspace(0, 1, 64)[None, None]
+    diff = x.view(B, -1, 1) - bins
+    w = (-diff.square() / (2 * 0.02**2)).exp()
+    hist = w.sum(dim=1)
+    hist = hist / (hist.sum(dim=1, keepdim=True) + 1e-10)
+    cdf = torch.cumsum(hist, dim=1)
+    cdfn = (cdf - cdf[:, 0:1]) / (1 - cdf[:, 0:1] + 1e-10)
+    ref = ((w / (w.sum(dim=-1, keepdim=True) + 1e-10)) * cdfn[:, None]).sum(dim=-1).view(B, 1, 24, 20)
+    assert torch.allclose(y, ref, atol=1e-6)
+    # equalisation spreads the values: the median moves towards 0.5
+    assert abs(y.median().item() - 0.5) < abs(x.median().item() - 0.5)
+    t = metrics.XrayTransforms(24, 20, equalize=True)
+    assert torch.isfinite(t(x * 100)).all()

@@ -74,3 +74,25 @@ def test_quaternion_adjugate_head_is_differentiable():
     assert torch.allclose(R @ R.transpose(-1, -2), torch.eye(3).expand(4, 3, 3), atol=1e-5)
     R.sum().backward()
     assert torch.isfinite(rot.grad).all()
+
+
+def test_projection_helpers_invert_the_detector_geometry():
+    """perspective_projection / inverse_projection (metrics/evaluator.py:19-25) against Detector.forward:
+    the pixel a detector target projects to is its own (col, row), and back."""
+    from xvr_amd.data import make_phantom, read
+    from xvr_amd.drr import DRR
+
+    vol, _ = make_phantom(16, seed=1)
+    for rev, (H, W) in ((False, (6, 8)), (True, (7, 5))):
+        drr = DRR(read(vol, orientation="PA"), 900.0, H, 2.0, width=W, dely=3.0, x0=5.0, y0=-4.0, reverse_x_axis=rev)
+        pose = _random_pose(2, seed=4)
+        source, target = drr.detector(pose, None)
+        pix = drr.perspective_projection(pose, target)               # [B, n, 2] as (col, row)
+        cols = torch.arange(W, dtype=torch.float32).repeat(H)
+        rows = torch.arange(H, dtype=torch.float32).repeat_interleave(W)
+        assert torch.allclose(pix[..., 0], cols.expand(2, -1), atol=1e-3)
+        assert torch.allclose(pix[..., 1], rows.expand(2, -1), atol=1e-3)
+        # points half way along the rays project to the same pixels; inverse_projection returns the targets
+        mid = 0.5 * (source + target)
+        assert torch.allclose(drr.perspective_projection(pose, mid), pix, atol=1e-3)
+        assert torch.allclose(drr.inverse_projection(pose, pix), target, atol=1e-2)

@@ -119,21 +119,47 @@ class DoubleGeodesicSE3(torch.nn.Module):
         return angular, trans, (angular.square() + trans.square() + self.eps).sqrt()
 
 
+class Equalize(torch.nn.Module):
+    """Differentiable (soft-histogram) histogram equalisation of images in [0, 1]
+    (/root/reference/src/xvr/utils/preprocess.py:34-66): Gaussian-kernel histogram over n_bins, its
+    normalised CDF, and each pixel mapped to the CDF averaged with its own bin weights."""
+
+    def __init__(self, n_bins: int = 256, tau: float = 0.01, eps: float = 1e-10):
+        super().__init__()
+        self.n_bins, self.tau, self.eps = n_bins, tau, eps
+
+    def forward(self, x):
+        B, _, H, W = x.shape
+        bins = torch.linspace(0, 1, self.n_bins, device=x.device, dtype=x.dtype)[None, None]
+        out = []
+        for b in range(B):  # one image at a time: the [pixels, bins] weight matrix is H*W*n_bins floats
+            diff = x[b].reshape(1, -1, 1) - bins
+            weights = (-diff.square() / (2 * self.tau**2)).exp()
+            histogram = weights.sum(dim=1)
+            histogram = histogram / (histogram.sum(dim=1, keepdim=True) + self.eps)
+            cdf = torch.cumsum(histogram, dim=1)
+            cdf_min = cdf[:, 0:1]
+            cdf_normalized = (cdf - cdf_min) / (1 - cdf_min + self.eps)
+            weights_norm = weights / (weights.sum(dim=-1, keepdim=True) + self.eps)
+            out.append((weights_norm * cdf_normalized[:, None]).sum(dim=-1).view(1, 1, H, W))
+        return torch.cat(out)
+
+
 class XrayTransforms(torch.nn.Module):
-    """Standardize (global min-max) -> Resize((h, w)) -> Normalize(mean, std), applied to every rendered
-    DRR each iteration (/root/reference/src/xvr/utils/preprocess.py:5-31; call sites
-    /root/reference/src/xvr/registrar/base.py:213-218,250, /root/reference/src/xvr/model/trainer.py:207,216).
-    ``equalize`` (the soft-histogram Equalize) is not provided this round."""
+    """Standardize (global min-max) -> [Equalize] -> Resize((h, w)) -> Normalize(mean, std), applied to
+    every rendered DRR each iteration (/root/reference/src/xvr/utils/preprocess.py:5-31; call sites
+    /root/reference/src/xvr/registrar/base.py:213-218,250, /root/reference/src/xvr/model/trainer.py:207,216)."""
 
     def __init__(self, height: int, width: int | None = None, mean: float = 0.15, std: float = 0.1, equalize: bool = False):
         super().__init__()
-        if equalize:
-            raise NotImplementedError("Equalize is not provided in this round")
+        self.equalize = Equalize() if equalize else None
         self.height, self.width = height, height if width is None else width
         self.mean, self.std = mean, std
 
     def forward(self, x):
         x = (x - x.min()) / (x.max() - x.min() + 1e-6)
+        if self.equalize is not None:
+            x = self.equalize(x)
         if tuple(x.shape[-2:]) != (self.height, self.width):
             x = F.interpolate(x, size=(self.height, self.width), mode="bilinear", antialias=True, align_corners=False)
         return (x - self.mean) / self.std

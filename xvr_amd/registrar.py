@@ -165,3 +165,32 @@ class Registrar:
         nccs.append(final_ncc)
         return dict(final_pose=RigidTransform(reg.pose.matrix.detach()), init_pose=init_pose, nccs=nccs, times=times,
                     lrs=lrs, trajectory=traj, runtime=sum(times), drr=reg.drr)
+
+    def parameters_dict(self, result: dict, intrinsics: dict | None = None, volume=None, mask=None, xray=None,
+                        registrar_type: str = "fixed") -> dict:
+        """The ``parameters.pt`` dictionary of the reference (/root/reference/src/xvr/registrar/base.py:355-394):
+        same keys, 4x4 CPU poses, and the trajectory as the rows of the reference's DataFrame
+        (r1, r2, r3, tx, ty, tz, ncc, times, lr_rot, lr_xyz) -- a list of dicts here, pandas is optional."""
+        d = result["drr"].detector
+        cols = ["r1", "r2", "r3", "tx", "ty", "tz", "ncc", "times", "lr_rot", "lr_xyz"]
+        init = result["init_pose"].convert(self.parameterization, self.convention)
+        rows = [torch.cat(init, dim=-1).reshape(-1).tolist()] + result["trajectory"]
+        n = min(len(rows), len(result["nccs"]), len(result["times"]), len(result["lrs"]))
+        traj = [dict(zip(cols, [*rows[i], result["nccs"][i], result["times"][i], *result["lrs"][i]])) for i in range(n)]
+        intr = intrinsics or dict(sdd=d.sdd, height=d.height, width=d.width, delx=d.delx, dely=d.dely, x0=d.x0, y0=d.y0)
+        return {
+            "drr": {"volume": volume, "mask": mask, "labels": None, "orientation": self.drr.subject.orientation, **intr,
+                    "reverse_x_axis": d.reverse_x_axis, "renderer": self.drr.renderer.renderer_name,
+                    "read_kwargs": {}, "drr_kwargs": {"voxel_shift": self.drr.renderer.voxel_shift}},
+            "xray": {"filename": xray, "crop": self.crop, "subtract_background": False, "linearize": False, "reducefn": "max"},
+            "optimization": {"equalize": self.equalize, "init_only": False, "scales": self.scales, "n_itrs": self.n_itrs,
+                             "parameterization": self.parameterization, "convention": self.convention,
+                             "lr_rot": self.lr_rot, "lr_xyz": self.lr_xyz, "patience": self.patience,
+                             "max_n_plateaus": self.max_n_plateaus},
+            "init_pose": result["init_pose"].matrix.detach().cpu(),
+            "final_pose": result["final_pose"].matrix.detach().cpu(),
+            "type": registrar_type, "runtime": result["runtime"], "trajectory": traj,
+        }
+
+    def save(self, path, result: dict, **kw) -> None:
+        torch.save(self.parameters_dict(result, **kw), path)
