@@ -144,6 +144,20 @@ int xvr_drr_rays_forward(const float* cam, int B, int H, int W, float* source, f
 int xvr_drr_rays_backward(const float* cam, int B, int H, int W, const float* grad_source,
                           const float* grad_target, const float* grad_raylen, float* grad_cam, void* stream);
 
+/*
+ * HU -> density of a whole CT.  Replaces diffdrr.data.transform_hu_to_density(volume, multiplier), which
+ * xvr calls on the full volume before the renders of every training step
+ * (/root/reference/src/xvr/model/trainer.py:124,196-197).
+ *   xvr_drr_hu_stats      one reduction per CT: per-class (air / soft tissue / bone) min, max, presence
+ *                         into `stats` (48 bytes of device memory); independent of the multiplier
+ *   xvr_drr_hu_to_density one read + one write per step; the min-max normalisation constants are derived
+ *                         on the device from `stats` and the multiplier (no host sync)
+ * Volumes must be 16-byte aligned; `n` = number of voxels.
+ */
+int xvr_drr_hu_stats(const float* hu, long long n, void* stats, void* stream);
+int xvr_drr_hu_to_density(const float* hu, long long n, const void* stats, float bone_multiplier,
+                          float* density, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

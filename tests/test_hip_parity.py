@@ -781,6 +781,24 @@ def test_training_step_c5_render_twice_and_backprop_into_a_regressor():
     assert mncc.shape == (int(keep.sum()),) and torch.isfinite(loss).all() and (dice >= 0).all() and (dice <= 1).all()
 
 
+@pytest.mark.parametrize("case", ["ct-like", "no-soft", "only-soft", "odd-size"])
+def test_fused_hu_to_density_matches_the_torch_definition(case):
+    from xvr_amd.data import _transform_hu_to_density_torch, transform_hu_to_density
+
+    g = torch.Generator().manual_seed(12)
+    shape = (33, 21, 19) if case == "odd-size" else (48, 40, 32)
+    hu = torch.rand(*shape, generator=g) * 2800 - 1100
+    if case == "no-soft":
+        hu = torch.where((hu > -800) & (hu <= 350), torch.full_like(hu, 900.0), hu)
+    if case == "only-soft":
+        hu = hu.clamp(-700, 300)
+    for mult in (1.0, 3.7, 10.0):
+        got = transform_hu_to_density(hu.cuda(), mult)
+        want = _transform_hu_to_density_torch(hu, mult)
+        assert got.shape == want.shape and float(got.min()) == 0.0
+        _close(got, want, 2e-6, f"{case} x{mult}")
+
+
 def test_errors_are_python_exceptions():
     from xvr_amd.renderers import render
     from xvr_amd.spec import RenderSpec

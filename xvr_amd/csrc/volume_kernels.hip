@@ -1,0 +1,151 @@
+// HU -> density for a whole CT in one streaming pass.
+//
+// xvr re-maps the full volume with a fresh random bone multiplier before the two renders of EVERY
+// training step (/root/reference/src/xvr/model/trainer.py:124,196-197, diffdrr.data.transform_hu_to_density):
+//     air (<= -800 HU) -> the minimum soft-tissue value; bone (> 350 HU) -> HU * multiplier; soft tissue
+//     unchanged; then min-max normalised to [0, 1].
+// In torch that is ~8 full passes over 512 MiB (3.5 ms on MI355X).  The normalisation constants follow
+// analytically from per-class min / max / count, which do NOT depend on the multiplier: they are
+// reduced once per CT (k_hu_stats) and every step is then a single read + write (k_hu_map).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "xvr_drr.h"
+
+extern "C" void xvr_drr_set_last_error(const char* msg);
+
+namespace {
+
+constexpr int TB = 256;
+constexpr float HU_AIR = -800.f, HU_BONE = 350.f;
+
+// stats[0..2] = encoded min of air, soft, bone; stats[3..5] = encoded max; stats[6..8] = presence
+__device__ __forceinline__ unsigned enc(float f) {
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float dec(unsigned u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+__global__ __launch_bounds__(TB) void k_hu_stats(const float* __restrict__ hu, long long n, unsigned* st) {
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    unsigned cnt[3] = {0, 0, 0};
+    const long long n4 = n >> 2;
+    const long long stride = (long long)gridDim.x * TB;
+    for (long long i = (long long)blockIdx.x * TB + threadIdx.x; i < n4; i += stride) {
+        const float4 v4 = reinterpret_cast<const float4*>(hu)[i];
+        const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = v[k] <= HU_AIR ? 0 : (v[k] > HU_BONE ? 2 : 1);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                mn[q] = c == q ? fminf(mn[q], v[k]) : mn[q];
+                mx[q] = c == q ? fmaxf(mx[q], v[k]) : mx[q];
+                cnt[q] += c == q;
+            }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const float v = hu[(n4 << 2) + threadIdx.x];
+        const int c = v <= HU_AIR ? 0 : (v > HU_BONE ? 2 : 1);
+        for (int q = 0; q < 3; ++q)
+            if (c == q) { mn[q] = fminf(mn[q], v); mx[q] = fmaxf(mx[q], v); ++cnt[q]; }
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[q] = fminf(mn[q], __shfl_xor(mn[q], o));
+            mx[q] = fmaxf(mx[q], __shfl_xor(mx[q], o));
+            cnt[q] += __shfl_xor(cnt[q], o);
+        }
+        if ((threadIdx.x & 63) == 0 && cnt[q]) {
+            atomicMin(&st[q], enc(mn[q]));
+            atomicMax(&st[3 + q], enc(mx[q]));
+            atomicAdd(&st[6 + q], cnt[q] > 0 ? 1u : 0u);  // presence only (a count could overflow 32 bits)
+        }
+    }
+}
+
+struct HuMap {
+    float soft_min, dmin, inv_range;
+};
+
+__device__ __forceinline__ HuMap hu_constants(const unsigned* st, float mult) {
+    const bool has_air = st[6] > 0, has_soft = st[7] > 0, has_bone = st[8] > 0;
+    const float amin = dec(st[0]), smin = dec(st[1]), bmin = dec(st[2]), smax = dec(st[4]), bmax = dec(st[5]);
+    HuMap m;
+    // "soft.min() if soft.any() else volume.min()"
+    m.soft_min = has_soft ? smin : fminf(has_air ? amin : INFINITY, has_bone ? bmin : INFINITY);
+    float lo = INFINITY, hi = -INFINITY;
+    if (has_air) { lo = fminf(lo, m.soft_min); hi = fmaxf(hi, m.soft_min); }
+    if (has_soft) { lo = fminf(lo, smin); hi = fmaxf(hi, smax); }
+    if (has_bone) {
+        const float b0 = bmin * mult, b1 = bmax * mult;
+        lo = fminf(lo, fminf(b0, b1));
+        hi = fmaxf(hi, fmaxf(b0, b1));
+    }
+    m.dmin = lo;
+    m.inv_range = fmaxf(hi - lo, 1.17549435e-38f);  // .clamp_min(tiny)
+    return m;
+}
+
+__global__ __launch_bounds__(TB) void k_hu_map(const float* __restrict__ hu, long long n, const unsigned* __restrict__ st,
+                                               float mult, float* __restrict__ out) {
+    const HuMap m = hu_constants(st, mult);
+    auto f = [&](float v) {
+        const float d = v <= HU_AIR ? m.soft_min : (v > HU_BONE ? v * mult : v);
+        return (d - m.dmin) / m.inv_range;
+    };
+    const long long n4 = n >> 2;
+    const long long stride = (long long)gridDim.x * TB;
+    for (long long i = (long long)blockIdx.x * TB + threadIdx.x; i < n4; i += stride) {
+        const float4 v = reinterpret_cast<const float4*>(hu)[i];
+        reinterpret_cast<float4*>(out)[i] = make_float4(f(v.x), f(v.y), f(v.z), f(v.w));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const long long i = (n4 << 2) + threadIdx.x;
+        out[i] = f(hu[i]);
+    }
+}
+
+int vfail(int code, const char* msg) {
+    xvr_drr_set_last_error(msg);
+    return code;
+}
+
+}  // namespace
+
+extern "C" {
+
+int xvr_drr_hu_stats(const float* hu, long long n, void* stats, void* stream_) {
+    if (!hu || !stats || n <= 0) return vfail(XVR_DRR_E_ARG, "bad argument");
+    if (reinterpret_cast<uintptr_t>(hu) & 15u) return vfail(XVR_DRR_E_ARG, "volume must be 16-byte aligned");
+    hipStream_t stream = (hipStream_t)stream_;
+    // mins start at 0xffffffff (12 bytes), maxes and presence at 0 (device memsets: graph-capture safe)
+    hipError_t e = hipMemsetAsync(stats, 0xff, 12, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(static_cast<char*>(stats) + 12, 0, 36, stream);
+    if (e != hipSuccess) return vfail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
+    const long long blocks = ((n >> 2) + TB - 1) / TB;
+    hipLaunchKernelGGL(k_hu_stats, dim3((unsigned)(blocks < 4096 ? (blocks > 0 ? blocks : 1) : 4096)), dim3(TB), 0, stream, hu, n,
+                       static_cast<unsigned*>(stats));
+    e = hipGetLastError();
+    return e == hipSuccess ? XVR_DRR_OK : vfail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
+}
+
+int xvr_drr_hu_to_density(const float* hu, long long n, const void* stats, float bone_multiplier, float* density,
+                          void* stream_) {
+    if (!hu || !stats || !density || n <= 0) return vfail(XVR_DRR_E_ARG, "bad argument");
+    if ((reinterpret_cast<uintptr_t>(hu) | reinterpret_cast<uintptr_t>(density)) & 15u)
+        return vfail(XVR_DRR_E_ARG, "volumes must be 16-byte aligned");
+    const long long blocks = ((n >> 2) + TB - 1) / TB;
+    hipLaunchKernelGGL(k_hu_map, dim3((unsigned)(blocks < 8192 ? (blocks > 0 ? blocks : 1) : 8192)), dim3(TB), 0,
+                       (hipStream_t)stream_, hu, n, static_cast<const unsigned*>(stats), bone_multiplier, density);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? XVR_DRR_OK : vfail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
+}
+
+}  // extern "C"

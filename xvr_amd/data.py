@@ -16,10 +16,46 @@ from typing import Optional
 import torch
 
 
+def _hu_to_density_hip(volume: torch.Tensor, mult: float) -> torch.Tensor:
+    """One streaming HIP pass (xvr_drr_hu_to_density).  The per-class statistics do not depend on the
+    multiplier: they are reduced once and remembered ON the tensor object (keyed by its version counter --
+    never by address: the caching allocator hands the same address to unrelated tensors)."""
+    import ctypes
+
+    from . import _lib
+    from .renderers import _ptr, _stream, _timed
+
+    lib = _lib.load()
+    vol = volume if volume.is_contiguous() else volume.contiguous()
+    cached = getattr(volume, "_xvr_hu_stats", None)
+    if cached is not None and cached[0] == volume._version and vol is volume:
+        stats = cached[1]
+    else:
+        stats = torch.empty(16, dtype=torch.int32, device=vol.device)
+        _lib.check(lib.xvr_drr_hu_stats(_ptr(vol), ctypes.c_longlong(vol.numel()), _ptr(stats), _stream()), "xvr_drr_hu_stats")
+        if vol is volume:
+            try:
+                volume._xvr_hu_stats = (volume._version, stats)
+            except AttributeError:
+                pass
+    out = torch.empty_like(vol)
+    rc = _timed("hu_to_density", lib.xvr_drr_hu_to_density, _ptr(vol), ctypes.c_longlong(vol.numel()), _ptr(stats),
+                ctypes.c_float(mult), _ptr(out), _stream())
+    _lib.check(rc, "xvr_drr_hu_to_density")
+    return out
+
+
 def transform_hu_to_density(volume: torch.Tensor, bone_attenuation_multiplier: float) -> torch.Tensor:
     """Piecewise HU -> density map used before every training render
     (/root/reference/src/xvr/model/trainer.py:124,196-197): air (<= -800 HU) is set to the minimum
-    soft-tissue value, bone (> 350 HU) is scaled, then the result is min-max normalised to [0, 1]."""
+    soft-tissue value, bone (> 350 HU) is scaled, then the result is min-max normalised to [0, 1].
+    On the GPU this is one fused streaming pass; the torch formulation below is the CPU path / definition."""
+    if volume.is_cuda and volume.dtype == torch.float32 and not volume.requires_grad:
+        return _hu_to_density_hip(volume, float(bone_attenuation_multiplier))
+    return _transform_hu_to_density_torch(volume, bone_attenuation_multiplier)
+
+
+def _transform_hu_to_density_torch(volume: torch.Tensor, bone_attenuation_multiplier: float) -> torch.Tensor:
     volume = volume.to(torch.float32)
     air = volume <= -800
     bone = volume > 350
