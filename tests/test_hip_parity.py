@@ -799,6 +799,26 @@ def test_fused_hu_to_density_matches_the_torch_definition(case):
         _close(got, want, 2e-6, f"{case} x{mult}")
 
 
+def test_empty_batch_renders_to_an_empty_image():
+    """`img[keep]` with nothing kept (trainer.py:202-204) must not raise inside the renderer."""
+    from xvr_amd.data import make_phantom, read
+    from xvr_amd.drr import DRR
+    from xvr_amd.pose import RigidTransform
+    from xvr_amd.renderers import render
+    from xvr_amd.spec import RenderSpec
+
+    vol, lab = make_phantom(16, n_labels=3, seed=2)
+    drr = DRR(read(vol, lab), 600.0, 8, 4.0, renderer="trilinear").cuda()
+    empty = RigidTransform(torch.zeros(0, 4, 4, device="cuda"))
+    assert drr(empty).shape == (0, 1, 8, 8)
+    assert drr(empty, mask_to_channels=True).shape == (0, 3, 8, 8)
+    v = vol.cuda().requires_grad_(True)
+    out = render(v, torch.zeros(0, 1, 3, device="cuda"), torch.zeros(0, 5, 3, device="cuda"), torch.zeros(0, 1, 5, device="cuda"), RenderSpec())
+    assert out.shape == (0, 1, 5)
+    out.sum().backward()
+    assert v.grad is not None and v.grad.abs().max() == 0
+
+
 def test_errors_are_python_exceptions():
     from xvr_amd.renderers import render
     from xvr_amd.spec import RenderSpec

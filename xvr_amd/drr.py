@@ -65,6 +65,10 @@ class _RaysFromCamera(torch.autograd.Function):
 def rays_from_camera(cam: torch.Tensor, height: int, width: int):
     if not cam.is_cuda or cam.dtype != torch.float32:
         raise RuntimeError("rays_from_camera needs a float32 CUDA tensor (HIP kernel, no CPU path)")
+    if cam.shape[0] == 0:
+        z = cam.sum() * 0
+        n = int(height) * int(width)
+        return z.expand(0, 1, 3), z.expand(0, n, 3), z.expand(0, 1, n)
     return _RaysFromCamera.apply(cam, int(height), int(width))
 
 
@@ -112,7 +116,8 @@ class DRR(torch.nn.Module):
 
     def reshape_transform(self, img, batch_size):
         if self.reshape:
-            img = img.view(batch_size, -1, self.detector.height, self.detector.width)
+            # (channels spelled out: -1 is ambiguous for an empty batch)
+            img = img.reshape(batch_size, img.shape[1], self.detector.height, self.detector.width)
         return img
 
     # ------------------------------------------------------------------ rendering

@@ -194,6 +194,10 @@ def render(volume, source, target, img, spec: RenderSpec, mask=None, ray_grid_w:
         C = 1
     if ray_grid_w and n % ray_grid_w:
         ray_grid_w = 0
+    if B == 0 or n == 0:
+        # an empty batch (xvr's `img[keep]` can select nothing, trainer.py:202-204) renders to an empty
+        # image that still hangs off the inputs' autograd graph
+        return (source.sum() + target.sum() + img.sum() + 0 * volume.sum()).expand(B, C, n)
     return _Render.apply(volume, source, target, img, mask, spec, int(ray_grid_w), C, work)
 
 
