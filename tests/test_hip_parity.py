@@ -289,7 +289,7 @@ def test_recompute_backward_equals_jacobian_backward(renderer):
         _close(a, b, 1e-5, name)
 
 
-@pytest.mark.parametrize("name", sorted(p.stem for p in GOLDEN.glob("*.npz")))
+@pytest.mark.parametrize("name", sorted(p.stem for p in GOLDEN.glob("*.npz") if not p.stem.startswith("xvr_reference")))
 def test_golden_fixtures_on_gpu(name):
     from xvr_amd.renderers import render
     from xvr_amd.spec import RenderSpec
