@@ -57,3 +57,65 @@ def test_compat_shim_exposes_the_diffdrr_names_xvr_imports():
         for k in [k for k in sys.modules if k == "diffdrr" or k.startswith("diffdrr.")]:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+REF = Path("/root/reference/src/xvr")
+
+
+def _load_ref(relpath, name):
+    import importlib.util
+
+    import pytest
+
+    if not (REF / relpath).exists():
+        pytest.skip("the reference tree is not present on this machine")
+    spec = importlib.util.spec_from_file_location(name, REF / relpath)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_registrar_defaults_equal_the_reference_config():
+    """xvr_amd.registrar.Registrar's defaults are the reference's RegistrarArgs (src/xvr/config/registrar.py)."""
+    import inspect
+
+    from xvr_amd.registrar import Registrar
+
+    ref = _load_ref("config/registrar.py", "xvr_ref_config_registrar").RegistrarArgs()
+    mine = {k: v.default for k, v in inspect.signature(Registrar.__init__).parameters.items() if v.default is not inspect._empty}
+    for key in ("scales", "n_itrs", "parameterization", "convention", "lr_rot", "lr_xyz", "patience", "threshold",
+                "max_n_plateaus", "crop", "equalize"):
+        assert mine[key] == getattr(ref, key), key
+    tr = _load_ref("config/trainer.py", "xvr_ref_config_trainer").TrainerArgs()
+    assert tr.renderer == "trilinear" and tr.batch_size == 116 and tr.parameterization == "quaternion_adjugate"
+
+
+def test_reference_evaluator_runs_on_this_drr():
+    """The reference's own Evaluator (src/xvr/metrics/evaluator.py: mPE, mRPE, mTRE, double geodesic) imports only
+    diffdrr; over the compat shim it runs unmodified against this package's DRR (CPU-side geometry only)."""
+    saved = {k: v for k, v in sys.modules.items() if k == "diffdrr" or k.startswith("diffdrr.")}
+    try:
+        from xvr_amd.compat import install_as_diffdrr
+
+        install_as_diffdrr(force=True)
+        ev_mod = _load_ref("metrics/evaluator.py", "xvr_ref_evaluator")
+        from xvr_amd.data import make_phantom, read
+        from xvr_amd.drr import DRR
+        from xvr_amd.pose import convert
+
+        vol, _ = make_phantom(16, seed=1)
+        drr = DRR(read(vol, orientation="AP"), 1020.0, 32, 4.0, reverse_x_axis=False)
+        fiducials = torch.tensor([[[10.0, -5.0, 3.0], [-8.0, 6.0, -2.0], [0.0, 0.0, 12.0]]])
+        ev = ev_mod.Evaluator(drr, fiducials)
+        true = convert(torch.tensor([[0.1, 0.05, -0.02]]), torch.tensor([[2.0, 700.0, -3.0]]), parameterization="euler_angles", convention="ZXY")
+        same = ev(true, true)
+        assert all(abs(x) < 1e-3 for x in same), same
+        # a pure 5 mm shift along the detector's column direction: mTRE = 5 mm exactly, mPE ~ 5 mm x magnification
+        moved = convert(torch.tensor([[0.1, 0.05, -0.02]]), torch.tensor([[2.0, 700.0, 2.0]]), parameterization="euler_angles", convention="ZXY")
+        mpe, mrpe, mtre, dgeo = ev(true, moved)
+        assert abs(mtre - 5.0) < 1e-3 and abs(dgeo - 5.0) < 1e-2
+        assert 5.0 < mpe < 5.0 * 1020.0 / 600.0 and mrpe > 0
+    finally:
+        for k in [k for k in sys.modules if k == "diffdrr" or k.startswith("diffdrr.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)

@@ -113,8 +113,13 @@ class DoubleGeodesicSE3(torch.nn.Module):
 
     def forward(self, pose_1: RigidTransform, pose_2: RigidTransform):
         R = pose_1.matrix[..., :3, :3].transpose(-1, -2) @ pose_2.matrix[..., :3, :3]
-        cos = ((R.diagonal(dim1=-2, dim2=-1).sum(-1) - 1) / 2).clamp(-1 + 1e-7, 1 - 1e-7)
-        angular = 0.5 * self.sdd * torch.acos(cos)
+        # rotation angle as atan2(|axis part|, cos): exactly ~0 for identical rotations (the reference's
+        # Evaluator relies on that, metrics/evaluator.py:15,33) and with finite gradients everywhere,
+        # unlike acos of a clamped trace
+        cos = (R.diagonal(dim1=-2, dim2=-1).sum(-1) - 1) / 2
+        sin = 0.5 * torch.sqrt((R[..., 2, 1] - R[..., 1, 2]) ** 2 + (R[..., 0, 2] - R[..., 2, 0]) ** 2
+                               + (R[..., 1, 0] - R[..., 0, 1]) ** 2 + 1e-24)
+        angular = 0.5 * self.sdd * torch.atan2(sin, cos)
         trans = (pose_1.matrix[..., :3, 3] - pose_2.matrix[..., :3, 3]).norm(dim=-1)
         return angular, trans, (angular.square() + trans.square() + self.eps).sqrt()
 
