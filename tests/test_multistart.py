@@ -1,0 +1,25 @@
+"""configs[3] in miniature across 2 ranks (gloo, both on cuda:0): sharded multi-start registration."""
+import re
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+@pytest.mark.gpu
+def test_multistart_registration_two_ranks():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", str(ROOT / "tools" / "register_multistart.py"), "--backend", "gloo", "--single-device",
+           "--starts", "3"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("rank ")]
+    assert len(lines) == 2, out.stdout
+    found = [re.search(r"refined (\d+) starts; best ncc ([\d.]+) from rank (\d); pose error ([\d.]+) mm", l) for l in lines]
+    assert all(found)
+    assert sorted(int(m.group(1)) for m in found) == [1, 2]                      # 3 starts split 2 + 1
+    assert len({(m.group(2), m.group(3), m.group(4)) for m in found}) == 1          # every rank agrees on the winner
+    assert float(found[0].group(2)) > 0.9 and float(found[0].group(4)) < 6.0

@@ -194,3 +194,25 @@ class Registrar:
 
     def save(self, path, result: dict, **kw) -> None:
         torch.save(self.parameters_dict(result, **kw), path)
+
+
+def register_multistart(registrar: Registrar, gt: torch.Tensor, init_poses: RigidTransform, intrinsics: dict | None = None):
+    """Multi-start registration (configs[3]: several initial poses, one or more per GPU).  The initial
+    poses are split contiguously over the ranks (``shard_bounds``); every rank refines its own starts
+    independently -- no communication inside the optimisation -- and one 68-byte all-gather of
+    (final similarity, 4x4 pose) lets every rank take the arg-max.  Returns (best_ncc, best_pose[4,4],
+    rank_of_best, local_results)."""
+    from .distributed import multistart_best, shard_bounds
+
+    lo, hi = shard_bounds(len(init_poses))
+    results = [registrar.run(gt, init_poses[i], intrinsics) for i in range(lo, hi)]
+    device = registrar.drr.density.device
+    if results:
+        best = max(results, key=lambda r: r["nccs"][-1])
+        score = torch.tensor(best["nccs"][-1], device=device)
+        pose = best["final_pose"].matrix.detach().reshape(4, 4).to(device)
+    else:  # more ranks than starts: this rank abstains
+        score = torch.tensor(float("-inf"), device=device)
+        pose = torch.eye(4, device=device)
+    best_score, best_pose, best_rank = multistart_best(score, pose)
+    return best_score, best_pose, best_rank, results
