@@ -1,0 +1,93 @@
+/*
+ * xvr_pose.h -- C ABI of the pose side of xvr's registration loop (part of libxvr_drr.so).
+ *
+ * Every iteration of `_RegistrarBase.run_test_time_optimization`
+ * (/root/reference/src/xvr/registrar/base.py:245-280) wraps the render in three pieces of pose arithmetic
+ * that the reference runs as ~200 tiny framework launches:
+ *
+ *   reg()                 rot, xyz -> convert(...) -> detector / affine_inverse     base.py:249
+ *   loss.backward()       ... and the chain back to rot.grad / xyz.grad             base.py:252
+ *   optimizer.step()      Adam(maximize=True) on the two parameter groups           base.py:221-228,253
+ *   scheduler.step(loss)  ReduceLROnPlateau(factor, patience, threshold, mode=max)  base.py:229-235,262
+ *   n_plateaus / break    stop after max_n_plateaus learning-rate drops             base.py:270-278
+ *
+ * Here they are two launches per iteration:
+ *   xvr_pose_camera_forward  Euler angles + translation -> the camera vector cam[24] that
+ *                            xvr_drr_rays_forward consumes.  The map pose matrix -> cam is affine
+ *                            (calibration, reorientation and the CT's inverse affine are constants of a
+ *                            pyramid stage), so it is handed over as G[24][12], c[24]:
+ *                            cam = G * vec(M[:3,:4]) + c with M = [R | R t], R = R_a0 R_a1 R_a2.
+ *   xvr_pose_opt_step        the chain rule cam -> (rot, xyz), the Adam update, the plateau scheduler and
+ *                            the stopping rule, with ALL optimiser state on the device.  Once a pose has
+ *                            met the stopping rule the call is a no-op for it, so a host may enqueue (or
+ *                            graph-replay) several iterations without a device->host sync in between and
+ *                            still obtain exactly the trajectory of a loop that checks after every step.
+ *
+ * All pointers are device pointers (fp32 unless noted); kernels are enqueued on `stream`; return value 0
+ * or a negative XVR_DRR_E_* code (xvr_drr_last_error() has the text).
+ */
+#ifndef XVR_POSE_H
+#define XVR_POSE_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Per-pose optimiser state, resident in device memory (one element per pose of the batch). */
+typedef struct xvr_pose_opt_state {
+    float m[6], v[6];    /* Adam first / second moments of (r0, r1, r2, tx, ty, tz)                     */
+    float lr[2];         /* current learning rates (rotation, translation)                               */
+    float seen_lr;       /* smallest rotation lr counted so far (the reference's `current_lr`)           */
+    int   step;          /* Adam step count                                                              */
+    int   n_bad;         /* ReduceLROnPlateau.num_bad_epochs                                             */
+    int   n_plateaus;    /* learning-rate levels seen, the initial one included                          */
+    int   done;          /* 1 once n_plateaus == max_n_plateaus: later steps leave this pose untouched  */
+    int   iter;          /* iterations taken = rows of `history` written                                 */
+    double best;         /* ReduceLROnPlateau.best                                                       */
+} xvr_pose_opt_state;
+
+typedef struct xvr_pose_opt_spec {
+    int   axes[3];            /* Euler convention, 0 = X, 1 = Y, 2 = Z  ("ZXY" -> {2, 0, 1})             */
+    float beta1, beta2, eps;  /* Adam                                    (0.9, 0.999, 1e-8)              */
+    int   maximize;           /* 1: ascend (the reference maximises the similarity)                      */
+    float factor;             /* ReduceLROnPlateau.factor                (0.1)                           */
+    int   patience;           /* ReduceLROnPlateau.patience                                              */
+    double threshold;         /* relative improvement threshold, mode = max  (1e-4)                      */
+    double lr_eps;            /* minimal lr decrease that is applied      (1e-8)                         */
+    int   max_n_plateaus;     /* stopping rule                                                           */
+    int   max_iters;          /* rows per pose in `history`                                              */
+} xvr_pose_opt_spec;
+
+#define XVR_POSE_HISTORY_COLS 9   /* r0 r1 r2 tx ty tz (after the update), loss (before it), lr_rot, lr_xyz (after) */
+
+/* rot [B][3], xyz [B][3], G [24][12], c [24] -> cam [B][24] */
+int xvr_pose_camera_forward(const float* rot, const float* xyz, int B, const int axes[3], const float* G,
+                            const float* c, float* cam, void* stream);
+
+/* grad_cam [B][24] -> grad_rot [B][3], grad_xyz [B][3] (written) */
+int xvr_pose_camera_backward(const float* rot, const float* xyz, int B, const int axes[3], const float* G,
+                             const float* grad_cam, float* grad_rot, float* grad_xyz, void* stream);
+
+/* sizeof(xvr_pose_opt_state) as the library was compiled (88): lets a binding verify its own layout */
+size_t xvr_pose_opt_state_bytes(void);
+
+/* reset the state of B poses: zero moments, step 0, lr = (lr_rot, lr_xyz), best = -inf */
+int xvr_pose_opt_init(xvr_pose_opt_state* state, int B, float lr_rot, float lr_xyz, void* stream);
+
+/*
+ * One optimiser iteration for every pose that is not done:
+ *   grad_cam [B][24]  d (sum of losses) / d cam; CONSUMED: reset to zero for the next accumulation
+ *   loss     [B]      the similarity the gradient belongs to (fed to the plateau scheduler)
+ *   rot, xyz          updated in place
+ *   history  [B][max_iters][XVR_POSE_HISTORY_COLS]  row state.iter is written (nullable)
+ */
+int xvr_pose_opt_step(float* rot, float* xyz, int B, const xvr_pose_opt_spec* spec, const float* G,
+                      float* grad_cam, const float* loss, xvr_pose_opt_state* state, float* history,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XVR_POSE_H */

@@ -10,16 +10,19 @@ ROOT = Path(__file__).resolve().parents[1]
 
 
 def _declared():
-    text = (ROOT / "include" / "xvr_drr.h").read_text()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(xvr_drr_[a-z_0-9]+)\s*\(", text)))
+    names = set()
+    for header in sorted((ROOT / "include").glob("*.h")):      # xvr_drr.h, xvr_sim.h, xvr_pose.h
+        text = re.sub(r"/\*.*?\*/", "", header.read_text(), flags=re.S)
+        names |= set(re.findall(r"\b(xvr_(?:drr|sim|pose)_[a-z_0-9]+)\s*\(", text))
+    return sorted(names)
 
 
 def test_header_declares_the_expected_entry_points():
     names = _declared()
     for want in ("xvr_drr_abi_version", "xvr_drr_last_error", "xvr_drr_trilinear_forward",
                  "xvr_drr_trilinear_backward", "xvr_drr_siddon_forward", "xvr_drr_siddon_backward",
-                 "xvr_drr_backward_from_jac"):
+                 "xvr_drr_backward_from_jac", "xvr_sim_ncc_forward_backward", "xvr_pose_camera_forward",
+                 "xvr_pose_opt_step"):
         assert want in names
 
 
@@ -30,7 +33,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert lib.xvr_drr_abi_version() == _lib.ABI_VERSION
     raw = ctypes.CDLL(str(_lib.library_path()))
     for name in _declared():
-        assert hasattr(raw, name), f"{name} declared in include/xvr_drr.h but not exported"
+        assert hasattr(raw, name), f"{name} declared in include/*.h but not exported"
         assert name in _lib.EXPORTS, f"{name} has no ctypes prototype"
 
 

@@ -1,0 +1,157 @@
+"""Device-resident pose arithmetic of the registration loop (include/xvr_pose.h) against the torch chain it
+replaces: convert -> DRR.camera, autograd, torch.optim.Adam(maximize=True), ReduceLROnPlateau and the
+stopping rule of /root/reference/src/xvr/registrar/base.py:221-280."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from xvr_amd import _lib
+from xvr_amd.data import make_phantom, read
+from xvr_amd.drr import DRR
+from xvr_amd.pose import convert
+
+
+def _drr(device, size=24, det=32, **kw):
+    vol, _ = make_phantom(size, n_ellipsoids=4, seed=3, device=device)
+    return DRR(read(vol, spacing=(2.0, 2.5, 3.0), orientation=kw.pop("orientation", "AP")), 1020.0, det, 2.0, x0=3.0, y0=-2.0,
+               renderer="trilinear", **kw).to(device)
+
+
+def test_camera_is_affine_in_the_pose_matrix():
+    drr = _drr("cpu")
+    G, c = drr.camera_affine()
+    pose = convert(torch.tensor([[0.3, -0.2, 0.5], [3.0, 0.1, -0.4]]), torch.tensor([[10.0, 700.0, -20.0], [-5.0, 850.0, 12.0]]),
+                   parameterization="euler_angles", convention="ZXY")
+    cam = drr.camera(pose)
+    lin = pose.matrix[:, :3, :4].reshape(2, 12) @ G.T + c
+    assert torch.allclose(cam, lin, rtol=1e-6, atol=1e-4)
+
+
+def test_state_layout_matches_header():
+    from xvr_amd.pose_opt import STATE_DTYPE
+    assert ctypes.sizeof(_lib.CPoseOptState) == STATE_DTYPE.itemsize == 88
+    for name, _ in _lib.CPoseOptState._fields_:
+        assert getattr(_lib.CPoseOptState, name).offset == STATE_DTYPE.fields[name][1], name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("convention", ["ZXY", "ZYX", "XYZ", "ZXZ", "YXY"])
+@pytest.mark.parametrize("orientation", ["AP", "PA"])
+def test_pose_camera_matches_torch_chain(convention, orientation):
+    from xvr_amd.pose_opt import pose_camera
+    drr = _drr("cuda", orientation=orientation, reverse_x_axis=(orientation == "AP"))
+    g = torch.Generator().manual_seed(5)
+    rot = ((torch.rand(7, 3, generator=g) - 0.5) * 6.0).cuda().requires_grad_()
+    xyz = ((torch.rand(7, 3, generator=g) - 0.5) * 100 + torch.tensor([0.0, 800.0, 0.0])).cuda().requires_grad_()
+    w = torch.randn(7, 24, generator=g).cuda()
+    ref = drr.camera(convert(rot, xyz, parameterization="euler_angles", convention=convention))
+    g_ref = torch.autograd.grad((ref * w).sum(), [rot, xyz])
+    G, c = drr.camera_affine()
+    cam = pose_camera(rot, xyz, G, c, convention)
+    g_hip = torch.autograd.grad((cam * w).sum(), [rot, xyz])
+    # fp32 with entries up to ~1e3: a few ulp of the largest terms
+    assert torch.allclose(cam, ref, rtol=2e-6, atol=2e-4), (cam - ref).abs().max()
+    for a, b in zip(g_hip, g_ref):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-3 * b.abs().max().item()), (a - b).abs().max()
+
+
+@pytest.mark.gpu
+def test_opt_step_matches_adam_and_plateau_scheduler():
+    """Same synthetic camera gradients and losses through the kernel and through torch.optim.Adam(maximize) +
+    ReduceLROnPlateau + the reference's plateau counting."""
+    from xvr_amd.pose_opt import STATE_DTYPE, axes_of
+    lib = _lib.load()
+    drr = _drr("cuda")
+    G, c = drr.camera_affine()
+    B, T, patience, max_pl = 3, 60, 2, 3
+    g = torch.Generator().manual_seed(11)
+    rot0 = (torch.rand(B, 3, generator=g) - 0.5)
+    xyz0 = (torch.rand(B, 3, generator=g) - 0.5) * 50 + torch.tensor([0.0, 800.0, 0.0])
+    gcams = torch.randn(T, B, 24, generator=g) * torch.logspace(-3, 0, 24)
+    # losses: rise, then stall (plateaus), different per pose
+    losses = torch.stack([torch.minimum(torch.arange(T) * 0.01, torch.tensor(0.05 * (b + 1))) + 1e-6 * torch.randn(T, generator=g)
+                          for b in range(B)], dim=1).float()
+
+    # --- torch: one optimiser + scheduler per pose (the reference loop is B = 1)
+    ref_rows, ref_iters = [], []
+    for b in range(B):
+        rot = rot0[b:b + 1].clone().cuda().requires_grad_()
+        xyz = xyz0[b:b + 1].clone().cuda().requires_grad_()
+        opt = torch.optim.Adam([{"params": [rot], "lr": 1e-2}, {"params": [xyz], "lr": 1.0}], maximize=True)
+        sch = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, factor=0.1, patience=patience, threshold=1e-4, mode="max")
+        n_pl, cur, rows = 0, float("inf"), []
+        for t in range(T):
+            opt.zero_grad()
+            cam = drr.camera(convert(rot, xyz, parameterization="euler_angles", convention="ZXY"))
+            (cam * gcams[t, b:b + 1].cuda()).sum().backward()
+            opt.step()
+            sch.step(losses[t, b].item())
+            lr = sch.get_last_lr()
+            rows.append(torch.cat([rot.detach(), xyz.detach()], 1).reshape(-1).cpu().tolist() + [losses[t, b].item(), *lr])
+            if lr[0] < cur:
+                cur, n_pl = lr[0], n_pl + 1
+            if n_pl == max_pl:
+                break
+        ref_rows.append(np.array(rows))
+        ref_iters.append(len(rows))
+
+    # --- HIP
+    rot, xyz = rot0.clone().cuda(), xyz0.clone().cuda()
+    spec = _lib.CPoseOptSpec(axes_of("ZXY"), 0.9, 0.999, 1e-8, 1, 0.1, patience, 1e-4, 1e-8, max_pl, T)
+    state = torch.zeros(B * STATE_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    hist = torch.zeros(B, T, _lib.POSE_HISTORY_COLS, device="cuda")
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    assert lib.xvr_pose_opt_init(P(state), B, 1e-2, 1.0, None) == 0
+    for t in range(T):
+        gc = gcams[t].clone().cuda()
+        rc = lib.xvr_pose_opt_step(P(rot), P(xyz), B, ctypes.byref(spec), P(G), P(gc), P(losses[t].cuda().contiguous()), P(state),
+                                   P(hist), None)
+        assert rc == 0, lib.xvr_drr_last_error()
+        assert float(gc.abs().max()) == 0.0        # consumed
+    st = np.frombuffer(state.cpu().numpy().tobytes(), dtype=STATE_DTYPE)
+    assert st["iter"].tolist() == ref_iters
+    assert st["done"].tolist() == [int(n < T) for n in ref_iters]
+    assert len(set(ref_iters)) > 1                 # the poses really stopped at different times
+    h = hist.cpu().numpy()
+    for b in range(B):
+        got, want = h[b, : ref_iters[b]], ref_rows[b]
+        np.testing.assert_allclose(got[:, 6:], want[:, 6:], rtol=1e-6)                 # loss, lr_rot, lr_xyz: exact up to fp32 print
+        np.testing.assert_allclose(got[:, :3], want[:, :3], rtol=0, atol=2e-5)         # angles (steps of 1e-2)
+        np.testing.assert_allclose(got[:, 3:6], want[:, 3:6], rtol=0, atol=2e-3)       # mm (steps of 1)
+        assert np.abs(h[b, ref_iters[b]:]).max(initial=0.0) == 0.0                      # nothing written after `done`
+    # parameters frozen after done
+    np.testing.assert_array_equal(torch.cat([rot, xyz], 1).cpu().numpy(), np.stack([h[b, ref_iters[b] - 1, :6] for b in range(B)]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("renderer", ["trilinear", "siddon"])
+def test_device_loop_follows_autograd_loop(renderer):
+    """The whole stage on the device vs the autograd + torch.optim loop (same kernels for render and
+    similarity): same trajectory for the first iterations, same optimum."""
+    from xvr_amd.metrics import DoubleGeodesicSE3
+    from xvr_amd.registrar import Registrar
+    vol, _ = make_phantom(48, n_ellipsoids=8, seed=8, device="cuda")
+    drr = DRR(read(vol, spacing=(2.5,) * 3, orientation="AP"), 1020.0, 96, 1.8, renderer=renderer, reverse_x_axis=False,
+              voxel_shift=0.0 if renderer == "trilinear" else 0.5).cuda()
+    true = convert(torch.tensor([[3.10, 0.05, -0.03]]), torch.tensor([[4.0, 700.0, -6.0]]), parameterization="euler_angles", convention="ZXY")
+    init = convert(torch.tensor([[3.18, 0.0, 0.02]]), torch.tensor([[-6.0, 715.0, 5.0]]), parameterization="euler_angles", convention="ZXY")
+    with torch.no_grad():
+        gt = drr(convert(torch.tensor([[3.10, 0.05, -0.03]]).cuda(), torch.tensor([[4.0, 700.0, -6.0]]).cuda(),
+                         parameterization="euler_angles", convention="ZXY"))
+    kw = dict(scales="2,1", n_itrs="40,30", patience=5, max_n_plateaus=2)
+    a = Registrar(drr, device_loop=True, check_every=5, **kw).run(gt, init)
+    b = Registrar(drr, device_loop=False, use_graph=False, **kw).run(gt, init)
+    ta, tb = np.array(a["trajectory"]), np.array(b["trajectory"])
+    # Siddon's pose gradient is piecewise (nearest-voxel lookups): ulp differences grow quickly, so only the
+    # first steps are compared pointwise there
+    k = min(10 if renderer == "trilinear" else 3, len(ta), len(tb))
+    np.testing.assert_allclose(ta[:k, :3], tb[:k, :3], atol=2e-3)     # Adam steps are lr-sized: 1e-2 rad, 1 mm
+    np.testing.assert_allclose(ta[:k, 3:], tb[:k, 3:], atol=0.2)
+    np.testing.assert_allclose(a["nccs"][:k], b["nccs"][:k], atol=2e-3)
+    geo = DoubleGeodesicSE3(1020.0)
+    ea, eb = geo(true, a["final_pose"].cpu())[2].item(), geo(true, b["final_pose"].cpu())[2].item()
+    e0 = geo(true, init)[2].item()
+    assert ea < 0.25 * e0 and eb < 0.25 * e0 and abs(ea - eb) < 2.0, (e0, ea, eb)
+    assert len(a["trajectory"]) + 1 == len(a["nccs"]) and len(a["times"]) == len(a["nccs"]) == len(a["lrs"])

@@ -41,8 +41,42 @@ class CSimSpec(ctypes.Structure):
     ]
 
 
+class CPoseOptSpec(ctypes.Structure):   # include/xvr_pose.h: xvr_pose_opt_spec
+    _fields_ = [
+        ("axes", ctypes.c_int * 3),
+        ("beta1", ctypes.c_float),
+        ("beta2", ctypes.c_float),
+        ("eps", ctypes.c_float),
+        ("maximize", ctypes.c_int),
+        ("factor", ctypes.c_float),
+        ("patience", ctypes.c_int),
+        ("threshold", ctypes.c_double),
+        ("lr_eps", ctypes.c_double),
+        ("max_n_plateaus", ctypes.c_int),
+        ("max_iters", ctypes.c_int),
+    ]
+
+
+class CPoseOptState(ctypes.Structure):  # include/xvr_pose.h: xvr_pose_opt_state (device resident)
+    _fields_ = [
+        ("m", ctypes.c_float * 6),
+        ("v", ctypes.c_float * 6),
+        ("lr", ctypes.c_float * 2),
+        ("seen_lr", ctypes.c_float),
+        ("step", ctypes.c_int),
+        ("n_bad", ctypes.c_int),
+        ("n_plateaus", ctypes.c_int),
+        ("done", ctypes.c_int),
+        ("iter", ctypes.c_int),
+        ("best", ctypes.c_double),
+    ]
+
+
+POSE_HISTORY_COLS = 9
+
 _P = ctypes.c_void_p
 _I = ctypes.c_int
+_AX = ctypes.POINTER(ctypes.c_int)
 _FWD = [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, ctypes.POINTER(CSpec), _P, _P, _P, _P]
 _BWD = [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, ctypes.POINTER(CSpec), _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]
 
@@ -61,6 +95,11 @@ EXPORTS = {
     "xvr_drr_hu_to_density": ([_P, ctypes.c_longlong, _P, ctypes.c_float, _P, _P], ctypes.c_int),
     "xvr_drr_rays_forward": ([_P, _I, _I, _I, _P, _P, _P, _P], ctypes.c_int),
     "xvr_drr_rays_backward": ([_P, _I, _I, _I, _P, _P, _P, _P, _P], ctypes.c_int),
+    "xvr_pose_camera_forward": ([_P, _P, _I, _AX, _P, _P, _P, _P], ctypes.c_int),
+    "xvr_pose_camera_backward": ([_P, _P, _I, _AX, _P, _P, _P, _P, _P], ctypes.c_int),
+    "xvr_pose_opt_state_bytes": ([], ctypes.c_size_t),
+    "xvr_pose_opt_init": ([_P, _I, ctypes.c_float, ctypes.c_float, _P], ctypes.c_int),
+    "xvr_pose_opt_step": ([_P, _P, _I, ctypes.POINTER(CPoseOptSpec), _P, _P, _P, _P, _P, _P], ctypes.c_int),
 }
 
 _lib = None

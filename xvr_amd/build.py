@@ -12,8 +12,9 @@ from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
-SRC = [PKG / "csrc" / "drr_kernels.hip", PKG / "csrc" / "sim_kernels.hip", PKG / "csrc" / "volume_kernels.hip"]
-HDR = [ROOT / "include" / "xvr_drr.h", ROOT / "include" / "xvr_sim.h"]
+SRC = [PKG / "csrc" / "drr_kernels.hip", PKG / "csrc" / "sim_kernels.hip", PKG / "csrc" / "volume_kernels.hip",
+       PKG / "csrc" / "pose_kernels.hip"]
+HDR = [ROOT / "include" / "xvr_drr.h", ROOT / "include" / "xvr_sim.h", ROOT / "include" / "xvr_pose.h"]
 LIB = PKG / "lib" / "libxvr_drr.so"
 
 HIPCC_FLAGS = [

@@ -142,25 +142,42 @@ class DRR(torch.nn.Module):
         Folds the calibration, the reorientation, the pose and the CT's inverse affine (tiny torch ops,
         differentiable w.r.t. the pose)."""
         d = self.detector
-        C = d._calibration
+        return self._camera_from_matrix(pose.matrix, d._calibration, d._reorient, self._affine_inverse[0], self._e3)
+
+    def _camera_from_matrix(self, matrix, C, reorient, A, e3):
+        d = self.detector
         t0 = float((-d.height) // 2) + (1.0 if d.height % 2 else 0.5)
         s0 = float((-d.width) // 2) + (1.0 if d.width % 2 else 0.5)
         sg = -1.0 if d.reverse_x_axis else 1.0
-        z = self._e3[0]   # a 0 that lives on the device already (no host->device copy: graph-capture safe)
+        z = e3[0]   # a 0 that lives on the device already (no host->device copy: graph-capture safe)
         Kc = torch.stack([
             torch.stack([C[0, 0], z, C[0, 0] * t0 + C[0, 3]]),
             torch.stack([z, sg * C[1, 1], sg * C[1, 1] * s0 + C[1, 3]]),
             torch.stack([z, z, C[2, 2]]),
         ])
-        P = pose.matrix @ d._reorient            # reorient first, then the camera pose
-        e3 = self._e3
+        P = matrix @ reorient                    # reorient first, then the camera pose
         t_P = P[:, :3, 3]
         Mw = P[:, :3, :3] @ Kc + t_P[:, :, None] * e3
-        A = self._affine_inverse[0]
         Mv = A[:3, :3] @ Mw + A[:3, 3][None, :, None] * e3
         s_v = t_P @ A[:3, :3].T + A[:3, 3]
-        B = len(pose)
+        B = matrix.shape[0]
         return torch.cat([Mv.reshape(B, 9), s_v, Mw.reshape(B, 9), t_P], dim=1)
+
+    def camera_affine(self):
+        """The camera vector is AFFINE in the top three rows of the pose matrix: cam = G vec(M[:3,:4]) + c.
+        Returns (G [24,12], c [24]) as float32 on the module's device, evaluated in float64 on the 12 basis
+        matrices -- the constants of one pyramid stage that xvr_pose_camera_forward consumes."""
+        d = self.detector
+        f64 = dict(dtype=torch.float64, device="cpu")
+        basis = torch.zeros(13, 4, 4, **f64)
+        for k in range(12):
+            basis[k + 1, k // 4, k % 4] = 1.0
+        cams = self._camera_from_matrix(basis, d._calibration.to(**f64), d._reorient.to(**f64),
+                                        self._affine_inverse[0].to(**f64), self._e3.to(**f64))
+        c = cams[0]
+        G = (cams[1:] - c).T.contiguous()
+        dev = self._affine.device
+        return G.to(device=dev, dtype=torch.float32), c.to(device=dev, dtype=torch.float32)
 
     def render(self, density, source, target, mask_to_channels=False, **kwargs):
         img = (target - source).norm(dim=-1).unsqueeze(1)        # world-mm length of every ray

@@ -1,0 +1,192 @@
+"""Device-resident pose optimisation for the registration loop (include/xvr_pose.h).
+
+``RegistrationStage`` runs one pyramid stage of ``_RegistrarBase.run_test_time_optimization``
+(/root/reference/src/xvr/registrar/base.py:245-280) as EIGHT C-ABI launches per iteration and no
+autograd tape:
+
+    pose -> camera            xvr_pose_camera_forward          (reg(): convert + detector + affine_inverse)
+    camera -> rays            xvr_drr_rays_forward
+    rays -> DRR + jacobian    xvr_drr_{trilinear,siddon}_forward
+    DRR -> similarity + grad  xvr_sim_ncc_forward_backward     (transform, imagesim, backward of both)
+    grad -> rays              xvr_drr_backward_from_jac        (loss.backward() through the renderer)
+    rays -> camera            xvr_drr_rays_backward
+    camera -> pose, Adam, ReduceLROnPlateau, stopping rule     xvr_pose_opt_step
+
+The optimiser, the scheduler and the stopping rule keep their state on the device, so the host replays a
+captured HIP graph ``check_every`` times between looks at the ``done`` flag; iterations enqueued after a
+pose has met the stopping rule are no-ops, i.e. the trajectory is exactly that of a loop which checks
+after every step.  ``PoseCamera`` exposes the first step to autograd for callers with their own loop.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import time
+
+import numpy as np
+import torch
+
+from . import _lib
+from .renderers import _ptr, _stream, _timed, make_cspec
+
+__all__ = ["PoseCamera", "pose_camera", "RegistrationStage", "axes_of"]
+
+STATE_DTYPE = np.dtype([("m", "f4", 6), ("v", "f4", 6), ("lr", "f4", 2), ("seen_lr", "f4"), ("step", "i4"),
+                        ("n_bad", "i4"), ("n_plateaus", "i4"), ("done", "i4"), ("iter", "i4"), ("best", "f8")], align=True)
+
+
+def axes_of(convention: str):
+    if not isinstance(convention, str) or len(convention) != 3 or any(ch not in "XYZ" for ch in convention):
+        raise ValueError(f"invalid Euler convention {convention!r}")
+    return (ctypes.c_int * 3)(*["XYZ".index(ch) for ch in convention])
+
+
+class PoseCamera(torch.autograd.Function):
+    """(rot [B,3] Euler angles, xyz [B,3]) -> cam [B,24] for the constants (G, c) of ``DRR.camera_affine``."""
+
+    @staticmethod
+    def forward(ctx, rot, xyz, G, c, convention):
+        lib = _lib.load()
+        rot_c, xyz_c = rot.contiguous(), xyz.contiguous()
+        B = rot_c.shape[0]
+        cam = torch.empty(B, 24, device=rot.device, dtype=torch.float32)
+        rc = _timed("pose_camera_forward", lib.xvr_pose_camera_forward, _ptr(rot_c), _ptr(xyz_c), B, axes_of(convention),
+                    _ptr(G), _ptr(c), _ptr(cam), _stream())
+        _lib.check(rc, "xvr_pose_camera_forward")
+        ctx.save_for_backward(rot_c, xyz_c, G)
+        ctx.convention = convention
+        return cam
+
+    @staticmethod
+    def backward(ctx, g_cam):
+        lib = _lib.load()
+        rot_c, xyz_c, G = ctx.saved_tensors
+        B = rot_c.shape[0]
+        g_rot, g_xyz = torch.empty_like(rot_c), torch.empty_like(xyz_c)
+        rc = _timed("pose_camera_backward", lib.xvr_pose_camera_backward, _ptr(rot_c), _ptr(xyz_c), B,
+                    axes_of(ctx.convention), _ptr(G), _ptr(g_cam.contiguous()), _ptr(g_rot), _ptr(g_xyz), _stream())
+        _lib.check(rc, "xvr_pose_camera_backward")
+        return g_rot, g_xyz, None, None, None
+
+
+def pose_camera(rot, xyz, G, c, convention="ZXY"):
+    for name, t in (("rot", rot), ("xyz", xyz), ("G", G), ("c", c)):
+        if not t.is_cuda or t.dtype != torch.float32:
+            raise RuntimeError(f"{name} must be a float32 CUDA tensor (HIP kernel, no CPU path)")
+    if rot.shape != xyz.shape or rot.dim() != 2 or rot.shape[1] != 3:
+        raise ValueError("rot and xyz must both be [B, 3]")
+    return PoseCamera.apply(rot, xyz, G.contiguous(), c.contiguous(), convention)
+
+
+class RegistrationStage:
+    """One pyramid stage on the device.  ``drr``: the (already rescaled) DRR module; ``sim``: a
+    ``FusedSimilarity`` built on the transformed target of this stage; ``rot``/``xyz``: [B,3] float32 CUDA
+    tensors, updated IN PLACE."""
+
+    def __init__(self, drr, sim, rot, xyz, convention="ZXY", lr_rot=1e-2, lr_xyz=1.0, patience=10, threshold=1e-4,
+                 max_n_plateaus=3, max_iters=500, factor=0.1, betas=(0.9, 0.999), eps=1e-8, maximize=True):
+        self.lib = _lib.load()
+        if self.lib.xvr_pose_opt_state_bytes() != STATE_DTYPE.itemsize or ctypes.sizeof(_lib.CPoseOptState) != STATE_DTYPE.itemsize:
+            raise _lib.HipLibraryError("xvr_pose_opt_state layout mismatch between the library and the binding")
+        dev = drr.density.device
+        for name, t in (("rot", rot), ("xyz", xyz)):
+            if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous() or t.dim() != 2 or t.shape[1] != 3:
+                raise RuntimeError(f"{name} must be a contiguous float32 CUDA tensor [B, 3] (HIP kernels, no CPU path)")
+        self.drr, self.sim, self.rot, self.xyz = drr, sim, rot, xyz
+        self.B = B = rot.shape[0]
+        self.H, self.W = drr.detector.height, drr.detector.width
+        if tuple(sim.fixed.shape) != (B, 1, self.H, self.W):
+            raise ValueError(f"similarity target {tuple(sim.fixed.shape)} does not match {B} poses at {self.H}x{self.W}")
+        n = self.n = self.H * self.W
+        self.G, self.c = drr.camera_affine()
+        self.axes = axes_of(convention)
+        self.spec = _lib.CPoseOptSpec(self.axes, betas[0], betas[1], eps, int(bool(maximize)), factor, int(patience),
+                                      float(threshold), 1e-8, int(max_n_plateaus), int(max_iters))
+        self.max_iters = int(max_iters)
+        self.rspec = drr.renderer.make_spec()
+        self.cspec = make_cspec(tuple(drr.density.shape), self.rspec, self.W)
+        self.render_fn = (self.lib.xvr_drr_trilinear_forward if self.rspec.renderer == "trilinear"
+                          else self.lib.xvr_drr_siddon_forward)
+        f = dict(device=dev, dtype=torch.float32)
+        self.cam, self.g_cam = torch.empty(B, 24, **f), torch.zeros(B, 24, **f)
+        self.source, self.g_source = torch.empty(B, 3, **f), torch.empty(B, 3, **f)
+        self.target, self.g_target = torch.empty(B, n, 3, **f), torch.empty(B, n, 3, **f)
+        self.raylen, self.g_raylen = torch.empty(B, n, **f), torch.empty(B, n, **f)
+        self.img, self.g_img = torch.empty(B, 1, self.H, self.W, **f), torch.empty(B, 1, self.H, self.W, **f)
+        self.jac = torch.empty(B, n, _lib.JAC_STRIDE, **f)
+        self.loss = torch.empty(B, **f)
+        self.history = torch.zeros(B, self.max_iters, _lib.POSE_HISTORY_COLS, **f)
+        self.state = torch.zeros(B * STATE_DTYPE.itemsize, device=dev, dtype=torch.uint8)
+        _lib.check(self.lib.xvr_pose_opt_init(_ptr(self.state), B, float(lr_rot), float(lr_xyz), _stream()),
+                   "xvr_pose_opt_init")
+        self.graph = None
+
+    # -- the eight launches --------------------------------------------------------------------------
+    def render(self):
+        lib, B, H, W, n, s = self.lib, self.B, self.H, self.W, self.n, _stream()
+        vol = self.drr.density
+        _lib.check(_timed("pose_camera_forward", lib.xvr_pose_camera_forward, _ptr(self.rot), _ptr(self.xyz), B, self.axes,
+                          _ptr(self.G), _ptr(self.c), _ptr(self.cam), s), "xvr_pose_camera_forward")
+        _lib.check(_timed("rays_forward", lib.xvr_drr_rays_forward, _ptr(self.cam), B, H, W, _ptr(self.source),
+                          _ptr(self.target), _ptr(self.raylen), s), "xvr_drr_rays_forward")
+        _lib.check(_timed(f"{self.rspec.renderer}_forward+jac", self.render_fn, _ptr(vol), None, *vol.shape, 1,
+                          _ptr(self.source), _ptr(self.target), _ptr(self.raylen), B, n, ctypes.byref(self.cspec),
+                          _ptr(self.img), _ptr(self.jac), None, s), f"xvr_drr_{self.rspec.renderer}_forward")
+
+    def iteration(self):
+        lib, B, H, W, n = self.lib, self.B, self.H, self.W, self.n
+        self.render()
+        s, sim = _stream(), self.sim
+        _lib.check(_timed("ncc_forward_backward", lib.xvr_sim_ncc_forward_backward, _ptr(sim.fixed), _ptr(sim.fixed_sobel),
+                          _ptr(self.img), B, H, W, ctypes.byref(sim.spec), _ptr(self.loss), _ptr(self.g_img),
+                          _ptr(sim.workspace), sim.workspace.numel() * 4, s), "xvr_sim_ncc_forward_backward")
+        self.g_source.zero_()
+        _lib.check(_timed("backward_from_jac", lib.xvr_drr_backward_from_jac, _ptr(self.jac), _ptr(self.g_img), B, n,
+                          _ptr(self.g_source), _ptr(self.g_target), _ptr(self.g_raylen), s), "xvr_drr_backward_from_jac")
+        _lib.check(_timed("rays_backward", lib.xvr_drr_rays_backward, _ptr(self.cam), B, H, W, _ptr(self.g_source),
+                          _ptr(self.g_target), _ptr(self.g_raylen), _ptr(self.g_cam), s), "xvr_drr_rays_backward")
+        _lib.check(_timed("pose_opt_step", lib.xvr_pose_opt_step, _ptr(self.rot), _ptr(self.xyz), B,
+                          ctypes.byref(self.spec), _ptr(self.G), _ptr(self.g_cam), _ptr(self.loss), _ptr(self.state),
+                          _ptr(self.history), s), "xvr_pose_opt_step")
+
+    # -- host control --------------------------------------------------------------------------------
+    def read_state(self) -> np.ndarray:
+        """Device -> host copy of the optimiser state (the one sync of a chunk of iterations)."""
+        return np.frombuffer(self.state.cpu().numpy().tobytes(), dtype=STATE_DTYPE)
+
+    def capture(self):
+        """Two eager iterations (real ones) to warm allocations and module loading, then capture one."""
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.iteration()
+        self.graph = g
+
+    def run(self, n_itr: int, check_every: int = 8, use_graph: bool = True):
+        """Up to ``n_itr`` iterations (never more than ``max_iters`` in total); stops at the first check
+        after every pose is done.  Returns (state, seconds per iteration of each chunk as a list)."""
+        n_itr = min(int(n_itr), self.max_iters - int(self.read_state()["iter"].max()))
+        times, taken = [], 0
+        st = self.read_state()
+        while taken < n_itr and not st["done"].all():
+            k = min(check_every, n_itr - taken)
+            t0 = time.perf_counter()
+            if use_graph and self.graph is None and taken >= 2:
+                self.capture()   # capture enqueues nothing: the k replays below are the iterations
+            for _ in range(k if (self.graph is not None or not use_graph) else min(k, 2 - taken)):
+                if self.graph is not None:
+                    self.graph.replay()
+                else:
+                    self.iteration()
+                taken += 1
+            before = st["iter"].copy()
+            st = self.read_state()
+            done_now = int((st["iter"] - before).max())
+            dt = time.perf_counter() - t0
+            times += [dt / max(done_now, 1)] * done_now
+        return st, times
+
+    def results(self):
+        """history rows of every pose that were actually written: list over poses of arrays [iters, 9]."""
+        st = self.read_state()
+        h = self.history.cpu().numpy()
+        return [h[b, : int(st["iter"][b])] for b in range(self.B)]

@@ -30,6 +30,7 @@ from .drr import DRR
 from .metrics import (GradientNormalizedCrossCorrelation2d, MultiscaleNormalizedCrossCorrelation2d,
                       XrayTransforms)
 from .pose import RigidTransform
+from .pose_opt import RegistrationStage
 from .registration import Registration
 from .similarity import FusedSimilarity
 
@@ -45,7 +46,8 @@ def parse_scales(scales, crop: int, height: int):
 class Registrar:
     def __init__(self, drr: DRR, scales="8", n_itrs="500", parameterization="euler_angles", convention="ZXY",
                  lr_rot=1e-2, lr_xyz=1e0, patience=10, threshold=1e-4, max_n_plateaus=3, crop=0, equalize=False,
-                 mncc_patch_size=9, gncc_patch_size=11, sigma=0.0, beta=0.5, verbose=0, use_graph=None, fused=None):
+                 mncc_patch_size=9, gncc_patch_size=11, sigma=0.0, beta=0.5, verbose=0, use_graph=None, fused=None,
+                 device_loop=None, check_every=8):
         self.drr = drr
         self.scales = scales.split(",") if isinstance(scales, str) else [str(s) for s in scales]
         self.n_itrs = [int(n) for n in (n_itrs.split(",") if isinstance(n_itrs, str) else n_itrs)]
@@ -63,6 +65,10 @@ class Registrar:
         # transforms + similarity + their backward as one fused HIP call (xvr_amd/similarity.py) when the
         # configuration allows it; plain torch otherwise
         self.fused = fused
+        # pose -> camera, its chain rule, Adam, the plateau scheduler and the stopping rule on the device too
+        # (xvr_amd/pose_opt.py): eight launches per iteration, one host sync every `check_every` iterations.
+        # Needs the fused similarity and Euler angles; None = use it whenever possible.
+        self.device_loop, self.check_every = device_loop, check_every
         self.sim1 = MultiscaleNormalizedCrossCorrelation2d([None, mncc_patch_size], [0.5, 0.5])
         self.sim2 = GradientNormalizedCrossCorrelation2d(gncc_patch_size, sigma)
 
@@ -100,6 +106,20 @@ class Registrar:
             graphed = self.use_graph and device.type == "cuda"
             lr_rot = self.lr_rot / step_size_scalar
             lr_xyz = self.lr_xyz / step_size_scalar
+            if (self.device_loop if self.device_loop is not None else True) and use_fused and n_itr > 0 \
+                    and self.parameterization == "euler_angles":
+                stage_run = RegistrationStage(reg.drr, fused_sim, reg.rotation.data, reg.translation.data, self.convention,
+                                              lr_rot, lr_xyz, self.patience, self.threshold, self.max_n_plateaus,
+                                              max_iters=n_itr)
+                _, stage_times = stage_run.run(n_itr, self.check_every, use_graph=graphed)
+                rows = stage_run.results()[0]
+                nccs += rows[:, 6].tolist()
+                traj += rows[:, :6].tolist()
+                lrs += rows[:, 7:9].tolist()
+                times += stage_times
+                if self.verbose:
+                    print(f"stage {stage}: {len(rows)} iterations on the device, ncc = {nccs[-1]:.4f}")
+                continue
             if graphed:  # capturable Adam reads its learning rates from device tensors
                 lr_rot, lr_xyz = torch.tensor(lr_rot, device=device), torch.tensor(lr_xyz, device=device)
             optimizer = torch.optim.Adam(

@@ -250,8 +250,11 @@ class Trilinear(_RendererBase):
         super().__init__(voxel_shift, eps, filter_intersections_outside_volume, **spec_overrides)
         self.near, self.far, self.mode = near, far, mode
 
+    def make_spec(self, n_points: int = 500, align_corners: bool = False) -> RenderSpec:
+        return self._spec(near=self.near, far=self.far, n_points=n_points, align_corners=align_corners)
+
     def forward(self, volume, source, target, img, n_points: int = 500, align_corners: bool = False, mask=None):
-        spec = self._spec(near=self.near, far=self.far, n_points=n_points, align_corners=align_corners)
+        spec = self.make_spec(n_points, align_corners)
         return render(volume, source, target, img, spec, mask, self._grid_w(target.shape[1]), self._n_channels(mask))
 
 
@@ -269,8 +272,11 @@ class Siddon(_RendererBase):
         self.mode = mode
         self.stop_gradients_through_grid_sample = stop_gradients_through_grid_sample
 
+    def make_spec(self, align_corners: bool = False) -> RenderSpec:
+        return self._spec(align_corners=align_corners)
+
     def forward(self, volume, source, target, img, align_corners: bool = False, mask=None):
-        spec = self._spec(align_corners=align_corners)
+        spec = self.make_spec(align_corners)
         if self.stop_gradients_through_grid_sample:
             volume = volume.detach()
         return render(volume, source, target, img, spec, mask, self._grid_w(target.shape[1]), self._n_channels(mask))
