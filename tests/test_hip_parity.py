@@ -88,6 +88,32 @@ def test_forward_matches_oracle(kw, grid):
     _close(_hip_render(case, spec, grid_w=gw), _oracle_render(case, spec), FWD_TOL, "forward")
 
 
+@pytest.mark.parametrize("ns", [1, 2, 4, 16, 102, 104])
+@pytest.mark.parametrize("kw", [s for s in SPECS if s["renderer"] == "trilinear"], ids=_id)
+@pytest.mark.parametrize("grid", ["tiled", "linear"])
+def test_sample_split_forward_and_jacobian(ns, kw, grid, monkeypatch):
+    """The forward march splits every ray's samples over `ns` wavefronts when the launch is small (auto:
+    these test sizes get 8, bench sizes get 1; 1xx = the 16x16-tile variant).  Every split factor, forced, against the oracle: the
+    image and the pose-side gradients that come from the jacobian written in the same sweep."""
+    from xvr_amd.spec import RenderSpec
+
+    monkeypatch.setenv("XVR_DRR_FWD_SPLIT", str(ns))
+    spec = RenderSpec(**kw)
+    case = make_case(seed=21, height=19, width=27)
+    w = torch.rand(2, 1, 19 * 27, generator=torch.Generator().manual_seed(4))
+    gw = 27 if grid == "tiled" else 0
+    vol, src, tgt, img = (case[k].cuda() for k in ("volume", "source", "target", "img"))
+    for t in (src, tgt, img):
+        t.requires_grad_(True)
+    from xvr_amd.renderers import render
+    out = render(vol, src, tgt, img, spec, None, ray_grid_w=gw)
+    (out * w.cuda()).sum().backward()
+    ref = _oracle_render(case, spec, grads=True, w=w)
+    _close(out, ref[0], FWD_TOL, f"forward ns={ns}")
+    for h, r, name in zip((src.grad, tgt.grad, img.grad), ref[2:], ("grad_source", "grad_target", "grad_img")):
+        _close(h, r, GRAD_TOL, f"{name} ns={ns}")
+
+
 @pytest.mark.parametrize("kw", [s for s in SPECS if not s.get("clip_to_volume")], ids=_id)
 def test_forward_with_mask_matches_oracle(kw):
     from xvr_amd.spec import RenderSpec

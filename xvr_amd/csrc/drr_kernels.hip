@@ -95,11 +95,10 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned i, unsigned nb) {
     return x * q + (x < rem ? x : rem) + j;
 }
 
-__device__ __forceinline__ bool map_ray(const RenderArgs& A, int& b, int& r) {
+__device__ __forceinline__ bool map_ray(const RenderArgs& A, int& b, int& r, int tid) {
     unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
     b = (int)(lb / (unsigned)A.blocks_per_pose);
     int t = (int)(lb - (unsigned)b * (unsigned)A.blocks_per_pose);
-    int tid = threadIdx.x;
     if (A.grid_w > 0) {
         int ty = t / A.tiles_x, tx = t - ty * A.tiles_x;
         const int px0 = tx * 16, py0 = ty * 16;
@@ -264,26 +263,18 @@ __device__ __forceinline__ KRange tri_krange(const RenderArgs& A, const Ray& R, 
 // =============================================================================================
 // trilinear forward (+ optional per-ray jacobian in the same sweep)
 // =============================================================================================
+struct TriAcc {  // per-lane sums of one ray (or of one slice of its samples)
+    float S, G[3], H[3], E0, E1;
+    unsigned cnt;
+};
+
+// Samples kbeg..kend (wave-uniform bounds; lanes mask themselves with their own K) of the lane's ray.
 template <bool JAC, bool MASK, bool CLIP>
-__global__ __launch_bounds__(WG) void k_trilinear_fwd(RenderArgs A) {
-    extern __shared__ float lds[];  // MASK: per-lane channel accumulators [C][WG]
-    int b, r;
-    const bool valid = map_ray(A, b, r);
-    const int tid = threadIdx.x;
-    Ray R;
-    ray_setup(A, b, r, valid, R);
+__device__ __forceinline__ void tri_march(const RenderArgs& A, const Ray& R, const KRange K, const int kbeg, const int kend,
+                                          const float step, float* lds, const int tid, TriAcc& acc) {
     const int N = A.sp.n_points;
-    const float step = N > 1 ? (A.sp.far_ - A.sp.near_) / (float)(N - 1) : 0.f;
-    const KRange K = tri_krange(A, R, CLIP, step);
-    const int kbeg = __builtin_amdgcn_readfirstlane(wave_min_i(K.lo));
-    const int kend = __builtin_amdgcn_readfirstlane(wave_max_i(K.hi));
-    const float span = fmaxf(R.amax - R.amin, 0.f);
     const float* __restrict__ vol = A.volume;
     const int D0 = A.D0, D1 = A.D1, D2 = A.D2;
-
-    if (MASK) {
-        for (int c = 0; c < A.C; ++c) lds[c * WG + tid] = 0.f;
-    }
     float S = 0.f;
     float G[3] = {0.f, 0.f, 0.f}, H[3] = {0.f, 0.f, 0.f};
     float E0 = 0.f, E1 = 0.f;
@@ -300,7 +291,7 @@ __global__ __launch_bounds__(WG) void k_trilinear_fwd(RenderArgs A) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int k = kk + h;
-            act[h] = k >= K.lo && k <= K.hi;
+            act[h] = k >= K.lo && k <= K.hi && k <= kend;
             u[h] = linspace_at(k, N, A.sp.near_, A.sp.far_, step);
             al[h] = CLIP ? fmaf(u[h], R.amax - R.amin, R.amin) : u[h];
             pxs[h] = fmaf(A.sp.a[0], fmaf(al[h], R.d[0], R.s[0]), A.sp.b[0]);
@@ -347,43 +338,156 @@ __global__ __launch_bounds__(WG) void k_trilinear_fwd(RenderArgs A) {
             }
         }
     }
+    acc.S = S;
+    acc.cnt = cnt;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { acc.G[i] = G[i]; acc.H[i] = H[i]; }
+    acc.E0 = E0;
+    acc.E1 = E1;
+}
 
+// Scale the sums and write the pixel (and its jacobian row).
+template <bool JAC, bool MASK, bool CLIP>
+__device__ __forceinline__ void tri_finish(const RenderArgs& A, const Ray& R, const int b, const int r, const float* lds,
+                                           const int tid, const TriAcc& acc) {
+    const float S = acc.S;
+    const float span = fmaxf(R.amax - R.amin, 0.f);
     const float base_scale = R.L * A.sp.inv_denom;
     const float scale = CLIP ? base_scale * span : base_scale;
-    if (valid) {
-        if (MASK) {
-            for (int c = 0; c < A.C; ++c) A.out[((size_t)b * A.C + c) * A.n + r] = lds[c * WG + tid] * scale;
-        } else {
-            A.out[(size_t)b * A.n + r] = S * scale;
+    if (MASK) {
+        for (int c = 0; c < A.C; ++c) A.out[((size_t)b * A.C + c) * A.n + r] = lds[c * WG + tid] * scale;
+    } else {
+        A.out[(size_t)b * A.n + r] = S * scale;
+    }
+    if (JAC) {
+        float js[3], jt[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            jt[i] = scale * A.sp.a[i] * acc.H[i];
+            js[i] = scale * A.sp.a[i] * (acc.G[i] - acc.H[i]);
         }
-        if (JAC) {
-            float js[3], jt[3];
+        if (CLIP) {
+            const float dmin = base_scale * (-S + span * acc.E0), dmax = base_scale * (S + span * acc.E1);
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                jt[i] = scale * A.sp.a[i] * H[i];
-                js[i] = scale * A.sp.a[i] * (G[i] - H[i]);
-            }
-            if (CLIP) {
-                const float dmin = base_scale * (-S + span * E0), dmax = base_scale * (S + span * E1);
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    if (R.ax_in == i && span > 0.f) {
-                        js[i] += dmin * (R.amin - 1.f) / R.d[i];
-                        jt[i] += dmin * (-R.amin) / R.d[i];
-                    }
-                    if (R.ax_out == i && span > 0.f) {
-                        js[i] += dmax * (R.amax - 1.f) / R.d[i];
-                        jt[i] += dmax * (-R.amax) / R.d[i];
-                    }
+                if (R.ax_in == i && span > 0.f) {
+                    js[i] += dmin * (R.amin - 1.f) / R.d[i];
+                    jt[i] += dmin * (-R.amin) / R.d[i];
+                }
+                if (R.ax_out == i && span > 0.f) {
+                    js[i] += dmax * (R.amax - 1.f) / R.d[i];
+                    jt[i] += dmax * (-R.amax) / R.d[i];
                 }
             }
-            float4* jp = reinterpret_cast<float4*>(A.jac + ((size_t)b * A.n + r) * XVR_DRR_JAC_STRIDE);
-            jp[0] = make_float4(S * (CLIP ? A.sp.inv_denom * span : A.sp.inv_denom), js[0], js[1], js[2]);
-            jp[1] = make_float4(jt[0], jt[1], jt[2], 0.f);
+        }
+        float4* jp = reinterpret_cast<float4*>(A.jac + ((size_t)b * A.n + r) * XVR_DRR_JAC_STRIDE);
+        jp[0] = make_float4(S * (CLIP ? A.sp.inv_denom * span : A.sp.inv_denom), js[0], js[1], js[2]);
+        jp[1] = make_float4(jt[0], jt[1], jt[2], 0.f);
+    }
+}
+
+template <bool JAC, bool MASK, bool CLIP>
+__global__ __launch_bounds__(WG) void k_trilinear_fwd(RenderArgs A) {
+    extern __shared__ float lds[];  // MASK: per-lane channel accumulators [C][WG]
+    int b, r;
+    const bool valid = map_ray(A, b, r, threadIdx.x);
+    const int tid = threadIdx.x;
+    Ray R;
+    ray_setup(A, b, r, valid, R);
+    const int N = A.sp.n_points;
+    const float step = N > 1 ? (A.sp.far_ - A.sp.near_) / (float)(N - 1) : 0.f;
+    const KRange K = tri_krange(A, R, CLIP, step);
+    const int kbeg = __builtin_amdgcn_readfirstlane(wave_min_i(K.lo));
+    const int kend = __builtin_amdgcn_readfirstlane(wave_max_i(K.hi));
+    if (MASK) {
+        for (int c = 0; c < A.C; ++c) lds[c * WG + tid] = 0.f;
+    }
+    TriAcc acc;
+    tri_march<JAC, MASK, CLIP>(A, R, K, kbeg, kend, step, lds, tid, acc);
+    if (valid) tri_finish<JAC, MASK, CLIP>(A, R, b, r, lds, tid, acc);
+    if (A.work) {
+        unsigned tot = wave_sum_u(acc.cnt);
+        if ((tid & 63) == 0 && tot) atomicAdd(A.work, (unsigned long long)tot);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sample-split forward for SMALL batches (registration renders one pose: 256^2 rays are 1024
+// wavefronts, one per SIMD, and every wavefront walks its ~250 in-volume samples with nothing to hide
+// the gather latency behind).  Here the 64 x NS lanes of a workgroup share ONE 8x8 pixel tile:
+// wavefront w marches the w-th slice of the samples, the partial sums meet in LDS and wavefront 0
+// writes the pixel.  Sums are combined in a fixed order (slice 0, 1, 2, ...): deterministic, but the
+// rounding differs from the unsplit kernel's single running sum (same tolerance against the oracle).
+// ---------------------------------------------------------------------------------------------
+constexpr int SPLIT_MAX = 16;
+constexpr int SPLIT_VALS = 9;  // S, G[3], H[3], E0, E1
+
+// TILE16 = false: the workgroup is ONE 8x8 tile x NS slices (NS <= 16): spreads tiny launches over many CUs.
+// TILE16 = true:  the workgroup is the unsplit kernel's 16x16 tile (4 wavefronts, shape-adaptive) x NS
+//                 slices (NS <= 4): wavefronts of one slice march neighbouring tiles in step and share
+//                 cache lines, as in the unsplit kernel.
+template <bool JAC, bool CLIP, bool TILE16>
+__global__ __launch_bounds__(64 * SPLIT_MAX) void k_trilinear_fwd_split(RenderArgs A) {
+    extern __shared__ float lds[];  // [NS - 1][SPLIT_VALS][TILE16 ? 256 : 64]
+    constexpr int TL = TILE16 ? 256 : 64;   // rays per workgroup
+    const int tid = threadIdx.x, l = tid & (TL - 1), w = tid / TL, NS = blockDim.x / TL;
+    int b, r;
+    bool valid;
+    if (TILE16) {
+        valid = map_ray(A, b, r, l);
+    } else {
+        const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+        b = (int)(lb / (unsigned)A.blocks_per_pose);
+        const int t = (int)(lb - (unsigned)b * (unsigned)A.blocks_per_pose);
+        if (A.grid_w > 0) {
+            const int ty = t / A.tiles_x, tx = t - ty * A.tiles_x;
+            const int px = tx * 8 + (l & 7), py = ty * 8 + (l >> 3);
+            r = py * A.grid_w + px;
+            valid = px < A.grid_w && py < A.grid_h;
+        } else {
+            r = t * 64 + l;
+            valid = r < A.n;
         }
     }
+    Ray R;
+    ray_setup(A, b, r, valid, R);
+    const int N = A.sp.n_points;
+    const float step = N > 1 ? (A.sp.far_ - A.sp.near_) / (float)(N - 1) : 0.f;
+    const KRange K = tri_krange(A, R, CLIP, step);
+    const int kbeg = __builtin_amdgcn_readfirstlane(wave_min_i(K.lo));
+    const int kend = __builtin_amdgcn_readfirstlane(wave_max_i(K.hi));
+    TriAcc acc;
+    {
+        const int len = kend >= kbeg ? kend - kbeg + 1 : 0;
+        const int chunk = (((len + NS - 1) / NS) + 1) & ~1;   // even: the march takes two samples per trip
+        const int my_beg = kbeg + w * chunk;
+        const int my_end = min(kend, my_beg + chunk - 1);
+        tri_march<JAC, false, CLIP>(A, R, K, my_beg, my_end, step, nullptr, tid, acc);
+    }
+    if (w > 0) {
+        float* p = lds + (size_t)(w - 1) * SPLIT_VALS * TL + l;
+        p[0] = acc.S;
+        if (JAC) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { p[(1 + i) * TL] = acc.G[i]; p[(4 + i) * TL] = acc.H[i]; }
+            if (CLIP) { p[7 * TL] = acc.E0; p[8 * TL] = acc.E1; }
+        }
+    }
+    __syncthreads();
+    if (w == 0) {
+        for (int v = 1; v < NS; ++v) {
+            const float* p = lds + (size_t)(v - 1) * SPLIT_VALS * TL + l;
+            acc.S += p[0];
+            if (JAC) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { acc.G[i] += p[(1 + i) * TL]; acc.H[i] += p[(4 + i) * TL]; }
+                if (CLIP) { acc.E0 += p[7 * TL]; acc.E1 += p[8 * TL]; }
+            }
+        }
+        if (valid) tri_finish<JAC, false, CLIP>(A, R, b, r, nullptr, tid, acc);
+    }
     if (A.work) {
-        unsigned tot = wave_sum_u(cnt);
+        unsigned tot = wave_sum_u(acc.cnt);
         if ((tid & 63) == 0 && tot) atomicAdd(A.work, (unsigned long long)tot);
     }
 }
@@ -412,7 +516,7 @@ __global__ __launch_bounds__(WG) void k_trilinear_fwd_lds(RenderArgs A) {
     float* const hdr = lds;
     float* const brick = lds + LDS_HDR;
     int b, r;
-    const bool valid = map_ray(A, b, r);
+    const bool valid = map_ray(A, b, r, threadIdx.x);
     const int tid = threadIdx.x;
     Ray R;
     ray_setup(A, b, r, valid, R);
@@ -585,7 +689,7 @@ __global__ __launch_bounds__(WG) void k_trilinear_bwd(RenderArgs A) {
     // fallback role: when a gather launch precedes this one, run only if it declined (rays not a lattice)
     if (A.skip_unless_flag_gt && !(*A.skip_unless_flag_gt > __float_as_uint(GATHER_DEV_TOL))) return;
     int b, r;
-    const bool valid = map_ray(A, b, r);
+    const bool valid = map_ray(A, b, r, threadIdx.x);
     const int tid = threadIdx.x;
     Ray R;
     ray_setup(A, b, r, valid, R);
@@ -1172,7 +1276,7 @@ __global__ __launch_bounds__(WG) void k_siddon(RenderArgs A) {
     extern __shared__ float lds[];  // MASK: fwd -> channel accumulators, bwd -> upstream gradients
     if (MODE == 2 && A.skip_unless_flag_gt && !(*A.skip_unless_flag_gt > __float_as_uint(GATHER_DEV_TOL))) return;
     int b, r;
-    const bool valid = map_ray(A, b, r);
+    const bool valid = map_ray(A, b, r, threadIdx.x);
     const int tid = threadIdx.x;
     Ray R;
     ray_setup(A, b, r, valid, R);
@@ -1477,6 +1581,53 @@ int launch(Kern kern, const RenderArgs& A, size_t lds_bytes, void* stream) {
     return XVR_DRR_OK;
 }
 
+// Sample slices per ray for the forward march, measured on MI355X (tools/bench_small_batch.py,
+// profiles/r01_small_batch_split.txt).  Splitting pays while the launch is LATENCY-bound: few
+// wavefronts, each walking ~250 dependent gathers.  It stops paying once the launch is bound by the
+// compulsory read of the volume (one pose of 256^2 rays through 512^3 reads ~0.5 GB: 94 us = 5.4 TB/s
+// without any split), or by throughput (>= ~2048 wavefronts).  Returns 1 for the unsplit kernel.
+// XVR_DRR_FWD_SPLIT forces a choice: <n> = 8x8 tiles x n slices, 1<nn> (102, 104) = 16x16 tiles x n.
+int split_factor(int B, int n, long long voxels, bool* tile16) {
+    const char* env = getenv("XVR_DRR_FWD_SPLIT");   // read per call: tests switch it within one process
+    const int forced = env ? atoi(env) : 0;
+    int ns = 1;
+    *tile16 = false;
+    if (forced > 0) {
+        *tile16 = forced >= 100;
+        const int want = forced % 100, cap = *tile16 ? 4 : SPLIT_MAX;
+        while (ns * 2 <= want && ns * 2 <= cap) ns *= 2;
+        return ns;
+    }
+    const long long waves = (long long)B * ((n + 63) / 64);
+    const bool tiny_vol = voxels * 4 <= (32LL << 20);    // at home in the L2s
+    const bool small_vol = voxels * 4 <= (128LL << 20);  // at home in the 256 MB infinity cache
+    if (waves <= 128) return tiny_vol ? 8 : 4;
+    if (waves <= 256) return 4;
+    if (waves <= 512) return tiny_vol ? 4 : 2;
+    if (waves <= 1024 && small_vol) { *tile16 = true; return 2; }
+    return 1;
+}
+
+template <typename Kern>
+int launch_split(Kern kern, RenderArgs A, int ns, bool tile16, void* stream) {
+    const int tl = tile16 ? 256 : 64;
+    if (!tile16) {
+        if (A.grid_w > 0) {   // 8x8 tiles, one per workgroup
+            A.tiles_x = (A.grid_w + 7) / 8;
+            A.blocks_per_pose = A.tiles_x * ((A.grid_h + 7) / 8);
+        } else {
+            A.blocks_per_pose = (A.n + 63) / 64;
+        }
+    }
+    const long long nblocks = (long long)A.B * A.blocks_per_pose;
+    if (nblocks >= (1LL << 31)) return fail(XVR_DRR_E_UNSUPPORTED, "grid too large");
+    const size_t lds_bytes = (size_t)(ns - 1) * SPLIT_VALS * tl * sizeof(float);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(tl * ns), lds_bytes, (hipStream_t)stream, A);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
+    return XVR_DRR_OK;
+}
+
 // workspace layout of the gather path:
 //   [flag, 256 B][PoseLattice x B, 256-aligned][float4 x B*n][cull words: bricks x ceil(B/32)]
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -1599,6 +1750,15 @@ int xvr_drr_trilinear_forward(const float* volume, const float* mask, int D0, in
     if (use_lds && !clip && A.grid_w > 0) {
         const size_t bytes = (size_t)(LDS_HDR + LDS_BRICK_CAP) * sizeof(float);
         return jac ? launch(k_trilinear_fwd_lds<true>, A, bytes, stream) : launch(k_trilinear_fwd_lds<false>, A, bytes, stream);
+    }
+    bool tile16 = false;
+    const int ns = split_factor(B, n, (long long)D0 * D1 * D2, &tile16);
+    if (ns > 1) {
+#define XVR_SPLIT(J, Cl) (tile16 ? launch_split(k_trilinear_fwd_split<J, Cl, true>, A, ns, true, stream) \
+                                 : launch_split(k_trilinear_fwd_split<J, Cl, false>, A, ns, false, stream))
+        if (jac) return clip ? XVR_SPLIT(true, true) : XVR_SPLIT(true, false);
+        return clip ? XVR_SPLIT(false, true) : XVR_SPLIT(false, false);
+#undef XVR_SPLIT
     }
     if (jac) return clip ? launch(k_trilinear_fwd<true, false, true>, A, 0, stream)
                          : launch(k_trilinear_fwd<true, false, false>, A, 0, stream);
