@@ -57,15 +57,25 @@ __device__ inline void pose_matrix(const Axes ax, const float* th, const float* 
     }
 }
 
-// d loss / d (th, t) from d loss / d cam: g_m = G^T g_cam, then through M = [R | R t].
-__device__ inline void pose_chain(const Axes ax, const float* th, const float* t, const float* __restrict__ G,
-                                  const float* g_cam, float* g_th, float* g_t) {
-    float gm[12];
-    for (int k = 0; k < 12; ++k) gm[k] = 0.f;
-    for (int r = 0; r < 24; ++r) {
-        const float g = g_cam[r];
-        for (int k = 0; k < 12; ++k) gm[k] = fmaf(G[r * 12 + k], g, gm[k]);
+// g_m = G^T g_cam for pose b, computed by one wavefront: lane k < 12 owns column k of G (24 coalesced
+// loads), lane r < 24 holds g_cam[r]; every lane ends up with all 12 entries.  `consume` zeroes g_cam.
+__device__ inline void wave_gt_g(const float* __restrict__ G, float* g_cam_b, bool consume, float* gm) {
+    const int lane = threadIdx.x & 63;
+    float mine = 0.f;
+    if (lane < 24) {
+        mine = g_cam_b[lane];
+        if (consume) g_cam_b[lane] = 0.f;
     }
+    float col = 0.f;
+    for (int r = 0; r < 24; ++r) {
+        const float g = __shfl(mine, r);
+        if (lane < 12) col = fmaf(G[r * 12 + lane], g, col);
+    }
+    for (int k = 0; k < 12; ++k) gm[k] = __shfl(col, k);
+}
+
+// d loss / d (th, t) from g_m = d loss / d vec(M[:3,:4]), through M = [R | R t].
+__device__ inline void pose_chain(const Axes ax, const float* th, const float* t, const float* gm, float* g_th, float* g_t) {
     float R0[9], R1[9], R2[9], d0[9], d1[9], d2[9], T[9], R[9];
     axis_rotation(ax.a[0], th[0], R0, d0);
     axis_rotation(ax.a[1], th[1], R1, d1);
@@ -104,19 +114,18 @@ __global__ void k_pose_camera_fwd(const float* __restrict__ rot, const float* __
     }
 }
 
-__global__ void k_pose_camera_bwd(const float* __restrict__ rot, const float* __restrict__ xyz, int B, Axes ax,
-                                  const float* __restrict__ G, const float* __restrict__ g_cam,
-                                  float* __restrict__ g_rot, float* __restrict__ g_xyz) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
+__global__ __launch_bounds__(64) void k_pose_camera_bwd(const float* __restrict__ rot, const float* __restrict__ xyz, int B,
+                                                        Axes ax, const float* __restrict__ G, const float* __restrict__ g_cam,
+                                                        float* __restrict__ g_rot, float* __restrict__ g_xyz) {
+    const int b = blockIdx.x;   // one wavefront per pose
+    float gm[12], gth[3], gt[3];
+    wave_gt_g(G, const_cast<float*>(g_cam) + (size_t)b * 24, false, gm);
     float th[3] = {rot[b * 3], rot[b * 3 + 1], rot[b * 3 + 2]};
     float t[3] = {xyz[b * 3], xyz[b * 3 + 1], xyz[b * 3 + 2]};
-    float gc[24], gth[3], gt[3];
-    for (int r = 0; r < 24; ++r) gc[r] = g_cam[b * 24 + r];
-    pose_chain(ax, th, t, G, gc, gth, gt);
-    for (int i = 0; i < 3; ++i) {
-        g_rot[b * 3 + i] = gth[i];
-        g_xyz[b * 3 + i] = gt[i];
+    pose_chain(ax, th, t, gm, gth, gt);
+    if (threadIdx.x < 3) {
+        g_rot[b * 3 + threadIdx.x] = gth[threadIdx.x];
+        g_xyz[b * 3 + threadIdx.x] = gt[threadIdx.x];
     }
 }
 
@@ -133,22 +142,19 @@ __global__ void k_pose_opt_init(xvr_pose_opt_state* st, int B, float lr_rot, flo
     st[b] = s;
 }
 
-__global__ void k_pose_opt_step(float* __restrict__ rot, float* __restrict__ xyz, int B, xvr_pose_opt_spec sp,
+__global__ __launch_bounds__(64) void k_pose_opt_step(float* __restrict__ rot, float* __restrict__ xyz, int B, xvr_pose_opt_spec sp,
                                 const float* __restrict__ G, float* __restrict__ g_cam, const float* __restrict__ loss,
                                 xvr_pose_opt_state* __restrict__ state, float* __restrict__ history) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    float gc[24];
-    for (int r = 0; r < 24; ++r) {
-        gc[r] = g_cam[b * 24 + r];
-        g_cam[b * 24 + r] = 0.f;   // consumed: the next rays-backward accumulates from zero
-    }
+    const int b = blockIdx.x;   // one wavefront per pose; every lane carries the scalars, lane 0 writes
+    float gm[12];
+    wave_gt_g(G, g_cam + (size_t)b * 24, true, gm);   // consumed: the next rays-backward accumulates from zero
     xvr_pose_opt_state s = state[b];
     if (s.done) return;
     Axes ax = {{sp.axes[0], sp.axes[1], sp.axes[2]}};
     float p[6] = {rot[b * 3], rot[b * 3 + 1], rot[b * 3 + 2], xyz[b * 3], xyz[b * 3 + 1], xyz[b * 3 + 2]};
     float g[6];
-    pose_chain(ax, p, p + 3, G, gc, g, g + 3);
+    pose_chain(ax, p, p + 3, gm, g, g + 3);
+    if (threadIdx.x != 0) return;   // (after the loads above: every lane read the same, unmodified state)
 
     // Adam, in the operation order of torch.optim.Adam(capturable=True)
     s.step += 1;
@@ -231,7 +237,7 @@ extern "C" int xvr_pose_camera_backward(const float* rot, const float* xyz, int 
     if (!rot || !xyz || !G || !grad_cam || !grad_rot || !grad_xyz || B <= 0) return pfail(XVR_DRR_E_ARG, "bad argument");
     if (!axes_ok(axes)) return pfail(XVR_DRR_E_ARG, "axes must be in {0,1,2} with the middle one distinct from its neighbours");
     Axes ax = {{axes[0], axes[1], axes[2]}};
-    hipLaunchKernelGGL(k_pose_camera_bwd, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, rot, xyz, B, ax, G,
+    hipLaunchKernelGGL(k_pose_camera_bwd, dim3(B), dim3(64), 0, (hipStream_t)stream, rot, xyz, B, ax, G,
                        grad_cam, grad_rot, grad_xyz);
     return launched("pose_camera_backward");
 }
@@ -251,7 +257,7 @@ extern "C" int xvr_pose_opt_step(float* rot, float* xyz, int B, const xvr_pose_o
     if (!axes_ok(spec->axes)) return pfail(XVR_DRR_E_ARG, "axes must be in {0,1,2} with the middle one distinct from its neighbours");
     if (spec->max_n_plateaus < 1 || spec->patience < 0 || (history && spec->max_iters < 1))
         return pfail(XVR_DRR_E_ARG, "bad optimiser spec");
-    hipLaunchKernelGGL(k_pose_opt_step, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, rot, xyz, B, *spec, G,
+    hipLaunchKernelGGL(k_pose_opt_step, dim3(B), dim3(64), 0, (hipStream_t)stream, rot, xyz, B, *spec, G,
                        grad_cam, loss, state, history);
     return launched("pose_opt_step");
 }

@@ -1,6 +1,6 @@
 // Fused image-similarity step of xvr's registration loop for MI355X (gfx950): XrayTransforms
 // (Standardize by the global min/max -> Normalize) + multiscale NCC + gradient NCC, value AND exact
-// gradient w.r.t. the raw rendered image, in nine small launches instead of ~100 torch kernels.
+// gradient w.r.t. the raw rendered image, in seven small launches instead of ~100 torch kernels.
 // C ABI: include/xvr_sim.h.  Reference being replaced:
 //   /root/reference/src/xvr/registrar/base.py:115-123 (imagesim), :250-252 (transform, loss, backward)
 //   /root/reference/src/xvr/utils/preprocess.py:5-31  (XrayTransforms)
@@ -67,7 +67,16 @@ __device__ __forceinline__ void block_add(double (&v)[NV], double* dst) {
     __syncthreads();
 }
 
+// header + accumulators: everything zero except enc_min = 0xffffffff (one launch instead of two memsets)
+__global__ __launch_bounds__(TB) void k_sim_init(unsigned* __restrict__ w, int nwords) {
+    const int i = blockIdx.x * TB + threadIdx.x;
+    if (i < nwords) w[i] = i == 0 ? 0xffffffffu : 0u;
+}
+
+// global min / max of the batch (Standardize takes them over the whole tensor): few blocks, one atomic
+// pair per block (1024 same-address atomics cost 25 us; 64 cost nothing)
 __global__ __launch_bounds__(TB) void k_sim_minmax(const float* __restrict__ m, long long n, SimHeader* hd) {
+    __shared__ float plo[TB / 64], phi[TB / 64];
     float lo = INFINITY, hi = -INFINITY;
     for (long long i = (long long)blockIdx.x * TB + threadIdx.x; i < n; i += (long long)gridDim.x * TB) {
         const float v = m[i];
@@ -80,19 +89,53 @@ __global__ __launch_bounds__(TB) void k_sim_minmax(const float* __restrict__ m, 
         hi = fmaxf(hi, __shfl_xor(hi, o));
     }
     if ((threadIdx.x & 63) == 0) {
+        plo[threadIdx.x >> 6] = lo;
+        phi[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < TB / 64; ++w) {
+            lo = fminf(lo, plo[w]);
+            hi = fmaxf(hi, phi[w]);
+        }
         atomicMin(&hd->enc_min, enc(lo));
         atomicMax(&hd->enc_max, enc(hi));
     }
 }
 
-__global__ __launch_bounds__(TB) void k_sim_count(const float* __restrict__ m, long long n, SimHeader* hd) {
+// y = ((m - min) / (max - min + std_eps) - mean) / std, the five global moments of (f, y) per image, how
+// many pixels attain the min / the max (their gradient is shared evenly), and the 3x3 Sobel pair of y
+// with zero padding 1 (torch conv2d = cross-correlation) -- y at the 8 neighbours is recomputed from m
+// with the same expression, so the Sobel input is bit-identical to the stored y.
+__global__ __launch_bounds__(TB) void k_sim_prep(const float* __restrict__ m, const float* __restrict__ f, int H, int W,
+                                                 SimHeader* hd, xvr_sim_spec sp, float* __restrict__ y,
+                                                 float* __restrict__ g, double* acc) {
+    const int b = blockIdx.y, hw = H * W;
     const float mn = dec(hd->enc_min), mx = dec(hd->enc_max);
+    const float r = (mx - mn) + sp.std_eps;
+    const float* M = m + (size_t)b * hw;
+    auto yof = [&](float v) { return (((v - mn) / r) - sp.mean) / sp.std; };
+    auto at = [&](int rr, int cc) { return (rr >= 0 && rr < H && cc >= 0 && cc < W) ? yof(M[rr * W + cc]) : 0.f; };
+    double s[5] = {0, 0, 0, 0, 0};
     int cmin = 0, cmax = 0;
-    for (long long i = (long long)blockIdx.x * TB + threadIdx.x; i < n; i += (long long)gridDim.x * TB) {
-        const float v = m[i];
+    for (int i = blockIdx.x * TB + threadIdx.x; i < hw; i += gridDim.x * TB) {
+        const size_t k = (size_t)b * hw + i;
+        const float v = M[i];
+        const float yy = yof(v);
+        const float ff = f[k];
+        y[k] = yy;
+        s[0] += yy; s[1] += (double)yy * yy; s[2] += ff; s[3] += (double)ff * ff; s[4] += (double)ff * yy;
         cmin += v == mn;
         cmax += v == mx;
+        const int rr = i / W, c = i - rr * W;
+        const float a00 = at(rr - 1, c - 1), a01 = at(rr - 1, c), a02 = at(rr - 1, c + 1);
+        const float a10 = at(rr, c - 1), a12 = at(rr, c + 1);
+        const float a20 = at(rr + 1, c - 1), a21 = at(rr + 1, c), a22 = at(rr + 1, c + 1);
+        g[((size_t)b * 2 + 0) * hw + i] = (a00 - a02) + 2.f * (a10 - a12) + (a20 - a22);
+        g[((size_t)b * 2 + 1) * hw + i] = (a00 + 2.f * a01 + a02) - (a20 + 2.f * a21 + a22);
     }
+    block_add<5>(s, acc + (size_t)b * N_ACC);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         cmin += __shfl_xor(cmin, o);
@@ -104,48 +147,35 @@ __global__ __launch_bounds__(TB) void k_sim_count(const float* __restrict__ m, l
     }
 }
 
-// y = ((m - min) / (max - min + std_eps) - mean) / std  + the five global moments of (f, y) per image
-__global__ __launch_bounds__(TB) void k_sim_prep(const float* __restrict__ m, const float* __restrict__ f, int hw,
-                                                 const SimHeader* hd, xvr_sim_spec sp, float* __restrict__ y,
-                                                 double* acc) {
-    const int b = blockIdx.y;
-    const float mn = dec(hd->enc_min), mx = dec(hd->enc_max);
-    const float r = (mx - mn) + sp.std_eps;
-    double s[5] = {0, 0, 0, 0, 0};
-    for (int i = blockIdx.x * TB + threadIdx.x; i < hw; i += gridDim.x * TB) {
-        const size_t k = (size_t)b * hw + i;
-        const float yy = (((m[k] - mn) / r) - sp.mean) / sp.std;
-        const float ff = f[k];
-        y[k] = yy;
-        s[0] += yy; s[1] += (double)yy * yy; s[2] += ff; s[3] += (double)ff * ff; s[4] += (double)ff * yy;
-    }
-    block_add<5>(s, acc + (size_t)b * N_ACC);
-}
-
-// 3x3 Sobel pair with zero padding 1 (torch conv2d = cross-correlation)
-__global__ __launch_bounds__(TB) void k_sim_sobel(const float* __restrict__ y, int H, int W, float* __restrict__ g) {
-    const int b = blockIdx.y;
-    const int i = blockIdx.x * TB + threadIdx.x;
-    if (i >= H * W) return;
-    const int r = i / W, c = i - r * W;
-    const float* Y = y + (size_t)b * H * W;
-    auto at = [&](int rr, int cc) { return (rr >= 0 && rr < H && cc >= 0 && cc < W) ? Y[rr * W + cc] : 0.f; };
-    const float a00 = at(r - 1, c - 1), a01 = at(r - 1, c), a02 = at(r - 1, c + 1);
-    const float a10 = at(r, c - 1), a12 = at(r, c + 1);
-    const float a20 = at(r + 1, c - 1), a21 = at(r + 1, c), a22 = at(r + 1, c + 1);
-    g[((size_t)b * 2 + 0) * H * W + i] = (a00 - a02) + 2.f * (a10 - a12) + (a20 - a22);
-    g[((size_t)b * 2 + 1) * H * W + i] = (a00 + 2.f * a01 + a02) - (a20 + 2.f * a21 + a22);
-}
+// The three patch NCCs of the similarity (local mNCC term on the image, gradient NCC on the two Sobel
+// channels) run as ONE launch: blockIdx.z = job * B + image.  Each is only a few hundred workgroups.
+struct PatchJob {
+    const float* f;      // [B][nch][H][W], channel ch
+    const float* y;
+    int nch, ch, p;
+    float* maps;         // [4][B][Hp][Wp]
+    int acc_slot;
+    float scale;         // backward: weight of this term
+    float* G;            // backward: [B][g_nch][H][W], channel g_ch
+    int g_nch, g_ch;
+};
+struct PatchJobs {
+    PatchJob j[3];
+};
 
 // one thread = one patch.  fimg / yimg: [B][nch][H][W] with channel `ch` selected.  maps: [4][B][Hp][Wp].
-__global__ __launch_bounds__(TB) void k_sim_patch(const float* __restrict__ fimg, const float* __restrict__ yimg, int nch,
-                                                  int ch, int H, int W, int p, float eps, float* __restrict__ maps,
-                                                  double* acc, int acc_slot) {
+__global__ __launch_bounds__(TB) void k_sim_patch(PatchJobs jobs, int B, int H, int W, float eps, double* acc) {
     __shared__ float sf[(TILE + MAXP - 1) * (TILE + MAXP - 1)];
     __shared__ float sy[(TILE + MAXP - 1) * (TILE + MAXP - 1)];
-    const int b = blockIdx.z;
+    const int job = blockIdx.z / B, b = blockIdx.z - job * B;
+    const PatchJob J = jobs.j[job];
+    const float* __restrict__ fimg = J.f;
+    const float* __restrict__ yimg = J.y;
+    float* __restrict__ maps = J.maps;
+    const int nch = J.nch, ch = J.ch, p = J.p, acc_slot = J.acc_slot;
     const int Hp = H - p + 1, Wp = W - p + 1;
     const int oy0 = blockIdx.y * TILE, ox0 = blockIdx.x * TILE;
+    if (oy0 >= Hp || ox0 >= Wp) return;   // the grid is sized for the job with the smallest patch
     const int E = TILE + p - 1;
     const float* F = fimg + ((size_t)b * nch + ch) * H * W;
     const float* Y = yimg + ((size_t)b * nch + ch) * H * W;
@@ -182,7 +212,7 @@ __global__ __launch_bounds__(TB) void k_sim_patch(const float* __restrict__ fimg
         cv *= inv;
         const float s = sqrtf(vf * vy);
         const float ncc = cv / s;
-        const size_t np = (size_t)Hp * Wp, o = ((size_t)b * Hp + oy) * Wp + ox, st = (size_t)gridDim.z * np;
+        const size_t np = (size_t)Hp * Wp, o = ((size_t)b * Hp + oy) * Wp + ox, st = (size_t)B * np;
         maps[o] = 1.f / s;
         maps[st + o] = mf / s;
         maps[2 * st + o] = cv / (vy * s);
@@ -194,15 +224,20 @@ __global__ __launch_bounds__(TB) void k_sim_patch(const float* __restrict__ fimg
 }
 
 // G[i] (+)= scale * ( f_i SA - SB - y_i SC + SD ),  S* = sums of the maps over the patches containing i
-__global__ __launch_bounds__(TB) void k_sim_patch_grad(const float* __restrict__ fimg, const float* __restrict__ yimg, int nch,
-                                                       int ch, int H, int W, int p, const float* __restrict__ maps,
-                                                       float scale, float* __restrict__ G, int g_nch, int g_ch) {
+__global__ __launch_bounds__(TB) void k_sim_patch_grad(PatchJobs jobs, int B, int H, int W) {
     __shared__ float sm[4][(TILE + MAXP - 1) * (TILE + MAXP - 1)];
-    const int b = blockIdx.z;
+    const int job = blockIdx.z / B, b = blockIdx.z - job * B;
+    const PatchJob J = jobs.j[job];
+    const float* __restrict__ fimg = J.f;
+    const float* __restrict__ yimg = J.y;
+    const float* __restrict__ maps = J.maps;
+    float* __restrict__ G = J.G;
+    const int nch = J.nch, ch = J.ch, p = J.p, g_nch = J.g_nch, g_ch = J.g_ch;
+    const float scale = J.scale;
     const int Hp = H - p + 1, Wp = W - p + 1;
     const int r0 = blockIdx.y * TILE, c0 = blockIdx.x * TILE;
     const int E = TILE + p - 1;
-    const size_t np = (size_t)Hp * Wp, st = (size_t)gridDim.z * np;
+    const size_t np = (size_t)Hp * Wp, st = (size_t)B * np;
     // patches containing pixel (r, c) have origins in [r - p + 1, r] x [c - p + 1, c]: stage that window
     for (int t = threadIdx.x; t < E * E; t += TB) {
         const int oy = r0 - (p - 1) + t / E, ox = c0 - (p - 1) + t % E;
@@ -271,8 +306,25 @@ __global__ __launch_bounds__(TB) void k_sim_final(const float* __restrict__ m, c
 
 // Standardize's min and max are functions of the image too: their gradient goes, evenly, to every
 // pixel that attains them (torch's full-reduction min/max backward)
+__device__ __forceinline__ float sim_loss_of(const double* __restrict__ A, int H, int W, const xvr_sim_spec& sp) {
+    const double n = (double)H * W;
+    const double muy = A[0] / n, muf = A[2] / n;
+    const double vy = A[1] / n - muy * muy + sp.ncc_eps, vf = A[3] / n - muf * muf + sp.ncc_eps;
+    const double cov = A[4] / n - muf * muy;
+    const double ncc_g = cov / sqrt(vf * vy);
+    const double n1 = (double)(H - sp.mncc_patch + 1) * (W - sp.mncc_patch + 1);
+    const double n2 = (double)(H - sp.gncc_patch + 1) * (W - sp.gncc_patch + 1);
+    const double mncc = 0.5 * ncc_g + 0.5 * A[5] / n1;
+    const double gncc = 0.5 * (A[6] + A[7]) / n2;
+    return (float)(sp.beta * mncc + (1.0 - sp.beta) * gncc);
+}
+
 __global__ __launch_bounds__(TB) void k_sim_minmax_grad(const float* __restrict__ m, long long n, const SimHeader* hd,
-                                                        xvr_sim_spec sp, float* __restrict__ grad) {
+                                                        xvr_sim_spec sp, float* __restrict__ grad,
+                                                        const double* __restrict__ acc, int B, int H, int W,
+                                                        float* __restrict__ loss) {
+    if (blockIdx.x == 0)   // the similarity values ride along (saves the launch of k_sim_loss)
+        for (int b = threadIdx.x; b < B; b += TB) loss[b] = sim_loss_of(acc + (size_t)b * N_ACC, H, W, sp);
     const float mn = dec(hd->enc_min), mx = dec(hd->enc_max);
     const float r = (mx - mn) + sp.std_eps;
     const double a = 1.0 / ((double)r * sp.std);
@@ -289,18 +341,7 @@ __global__ __launch_bounds__(TB) void k_sim_minmax_grad(const float* __restrict_
 
 __global__ void k_sim_loss(const double* __restrict__ acc, int B, int H, int W, xvr_sim_spec sp, float* __restrict__ loss) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    const double* A = acc + (size_t)b * N_ACC;
-    const double n = (double)H * W;
-    const double muy = A[0] / n, muf = A[2] / n;
-    const double vy = A[1] / n - muy * muy + sp.ncc_eps, vf = A[3] / n - muf * muf + sp.ncc_eps;
-    const double cov = A[4] / n - muf * muy;
-    const double ncc_g = cov / sqrt(vf * vy);
-    const double n1 = (double)(H - sp.mncc_patch + 1) * (W - sp.mncc_patch + 1);
-    const double n2 = (double)(H - sp.gncc_patch + 1) * (W - sp.gncc_patch + 1);
-    const double mncc = 0.5 * ncc_g + 0.5 * A[5] / n1;
-    const double gncc = 0.5 * (A[6] + A[7]) / n2;
-    loss[b] = (float)(sp.beta * mncc + (1.0 - sp.beta) * gncc);
+    if (b < B) loss[b] = sim_loss_of(acc + (size_t)b * N_ACC, H, W, sp);
 }
 
 int sim_fail(int code, const char* msg) {
@@ -362,37 +403,32 @@ int xvr_sim_ncc_forward_backward(const float* fixed, const float* fixed_sobel, c
     const int hw = H * W;
     const long long n = (long long)B * hw;
 
-    hipError_t e = hipMemsetAsync(ws, 0, L.y, stream);  // header + accumulators
-    if (e != hipSuccess) return sim_fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
-    e = hipMemsetAsync(ws, 0xff, 4, stream);            // enc_min = 0xffffffff (enc_max = 0 from the memset)
-    if (e != hipSuccess) return sim_fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
-
-    const unsigned rb = (unsigned)((n + TB - 1) / TB < 1024 ? (n + TB - 1) / TB : 1024);
+    const int nwords = (int)(L.y / 4);   // header + accumulators
+    hipLaunchKernelGGL(k_sim_init, dim3((nwords + TB - 1) / TB), dim3(TB), 0, stream, reinterpret_cast<unsigned*>(ws), nwords);
+    const long long want = (n + (long long)TB * 16 - 1) / ((long long)TB * 16);
+    const unsigned rb = (unsigned)(want < 1 ? 1 : (want > 256 ? 256 : want));
     hipLaunchKernelGGL(k_sim_minmax, dim3(rb), dim3(TB), 0, stream, moving, n, hd);
-    hipLaunchKernelGGL(k_sim_count, dim3(rb), dim3(TB), 0, stream, moving, n, hd);
     const unsigned pb = (unsigned)((hw + TB - 1) / TB < 256 ? (hw + TB - 1) / TB : 256);
-    hipLaunchKernelGGL(k_sim_prep, dim3(pb, B), dim3(TB), 0, stream, moving, fixed, hw, hd, *sp, y, acc);
-    hipLaunchKernelGGL(k_sim_sobel, dim3((hw + TB - 1) / TB, B), dim3(TB), 0, stream, y, H, W, gyb);
-    auto tiles = [&](int hh, int ww) { return dim3((ww + TILE - 1) / TILE, (hh + TILE - 1) / TILE, B); };
+    hipLaunchKernelGGL(k_sim_prep, dim3(pb, B), dim3(TB), 0, stream, moving, fixed, H, W, hd, *sp, y, gyb, acc);
     const size_t np2 = (size_t)B * (H - p2 + 1) * (W - p2 + 1);
-    hipLaunchKernelGGL(k_sim_patch, tiles(H - p1 + 1, W - p1 + 1), dim3(TB), 0, stream, fixed, y, 1, 0, H, W, p1,
-                       sp->ncc_eps, m1, acc, 5);
-    hipLaunchKernelGGL(k_sim_patch, tiles(H - p2 + 1, W - p2 + 1), dim3(TB), 0, stream, fixed_sobel, gyb, 2, 0, H, W, p2,
-                       sp->ncc_eps, m2, acc, 6);
-    hipLaunchKernelGGL(k_sim_patch, tiles(H - p2 + 1, W - p2 + 1), dim3(TB), 0, stream, fixed_sobel, gyb, 2, 1, H, W, p2,
-                       sp->ncc_eps, m2 + 4 * np2, acc, 7);
     const double n1 = (double)(H - p1 + 1) * (W - p1 + 1), n2 = (double)(H - p2 + 1) * (W - p2 + 1);
     const float sc1 = (float)(0.5 * sp->beta / (n1 * p1 * p1));
     const float sc2 = (float)(0.5 * (1.0 - sp->beta) / (n2 * p2 * p2));
-    hipLaunchKernelGGL(k_sim_patch_grad, tiles(H, W), dim3(TB), 0, stream, fixed, y, 1, 0, H, W, p1, m1, sc1, Gy, 1, 0);
-    hipLaunchKernelGGL(k_sim_patch_grad, tiles(H, W), dim3(TB), 0, stream, fixed_sobel, gyb, 2, 0, H, W, p2, m2, sc2, Gg, 2, 0);
-    hipLaunchKernelGGL(k_sim_patch_grad, tiles(H, W), dim3(TB), 0, stream, fixed_sobel, gyb, 2, 1, H, W, p2, m2 + 4 * np2, sc2,
-                       Gg, 2, 1);
+    PatchJobs jobs;
+    jobs.j[0] = {fixed, y, 1, 0, p1, m1, 5, sc1, Gy, 1, 0};
+    jobs.j[1] = {fixed_sobel, gyb, 2, 0, p2, m2, 6, sc2, Gg, 2, 0};
+    jobs.j[2] = {fixed_sobel, gyb, 2, 1, p2, m2 + 4 * np2, 7, sc2, Gg, 2, 1};
+    const int pmin = p1 < p2 ? p1 : p2;
+    auto tiles = [&](int hh, int ww) { return dim3((ww + TILE - 1) / TILE, (hh + TILE - 1) / TILE, 3 * B); };
+    hipLaunchKernelGGL(k_sim_patch, tiles(H - pmin + 1, W - pmin + 1), dim3(TB), 0, stream, jobs, B, H, W, sp->ncc_eps, acc);
+    hipLaunchKernelGGL(k_sim_patch_grad, tiles(H, W), dim3(TB), 0, stream, jobs, B, H, W);
     hipLaunchKernelGGL(k_sim_final, dim3((hw + TB - 1) / TB, B), dim3(TB), 0, stream, moving, fixed, y, Gy, Gg, H, W, hd, acc,
                        *sp, grad_moving);
-    if (grad_moving) hipLaunchKernelGGL(k_sim_minmax_grad, dim3(rb), dim3(TB), 0, stream, moving, n, hd, *sp, grad_moving);
-    hipLaunchKernelGGL(k_sim_loss, dim3((B + 63) / 64), dim3(64), 0, stream, acc, B, H, W, *sp, loss);
-    e = hipGetLastError();
+    const long long want2 = (n + (long long)TB * 4 - 1) / ((long long)TB * 4);
+    const unsigned gb = (unsigned)(want2 < 1 ? 1 : (want2 > 1024 ? 1024 : want2));
+    if (grad_moving) hipLaunchKernelGGL(k_sim_minmax_grad, dim3(gb), dim3(TB), 0, stream, moving, n, hd, *sp, grad_moving, acc, B, H, W, loss);
+    else hipLaunchKernelGGL(k_sim_loss, dim3((B + 63) / 64), dim3(64), 0, stream, acc, B, H, W, *sp, loss);
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return sim_fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
     return XVR_DRR_OK;
 }
