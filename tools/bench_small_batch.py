@@ -34,7 +34,7 @@ def timed(fn, n=30):
     return sum(t) / len(t) * 1e3
 
 
-for renderer in ("trilinear",):
+for renderer in (sys.argv[2:] or ["trilinear", "siddon"]):
     for B in (1, 2, 4, 8):
         for det in (64, 128, 256, 512):
             drr = DRR(sub, 1020.0, det, 1.4 * 256 / det, renderer=renderer, reverse_x_axis=False,

@@ -422,33 +422,38 @@ __global__ __launch_bounds__(WG) void k_trilinear_fwd(RenderArgs A) {
 constexpr int SPLIT_MAX = 16;
 constexpr int SPLIT_VALS = 9;  // S, G[3], H[3], E0, E1
 
-// TILE16 = false: the workgroup is ONE 8x8 tile x NS slices (NS <= 16): spreads tiny launches over many CUs.
-// TILE16 = true:  the workgroup is the unsplit kernel's 16x16 tile (4 wavefronts, shape-adaptive) x NS
-//                 slices (NS <= 4): wavefronts of one slice march neighbouring tiles in step and share
-//                 cache lines, as in the unsplit kernel.
+// Lane -> (pose, ray, slice) in the split kernels.  TILE16 = false: the workgroup is ONE 8x8 tile x NS
+// slices; true: the unsplit kernels' 16x16 tile (4 wavefronts, shape-adaptive) x NS slices.
+template <bool TILE16>
+__device__ __forceinline__ bool map_ray_split(const RenderArgs& A, int& b, int& r, int& l, int& w, int& NS) {
+    constexpr int TL = TILE16 ? 256 : 64;
+    const int tid = threadIdx.x;
+    l = tid & (TL - 1);
+    w = tid / TL;
+    NS = blockDim.x / TL;
+    if (TILE16) return map_ray(A, b, r, l);
+    const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+    b = (int)(lb / (unsigned)A.blocks_per_pose);
+    const int t = (int)(lb - (unsigned)b * (unsigned)A.blocks_per_pose);
+    if (A.grid_w > 0) {
+        const int ty = t / A.tiles_x, tx = t - ty * A.tiles_x;
+        const int px = tx * 8 + (l & 7), py = ty * 8 + (l >> 3);
+        r = py * A.grid_w + px;
+        return px < A.grid_w && py < A.grid_h;
+    }
+    r = t * 64 + l;
+    return r < A.n;
+}
+
+// TILE16 = false (NS <= 16) spreads tiny launches over many CUs; TILE16 = true (NS <= 4) keeps the
+// wavefronts of one slice marching neighbouring tiles in step, sharing cache lines as in the unsplit kernel.
 template <bool JAC, bool CLIP, bool TILE16>
 __global__ __launch_bounds__(64 * SPLIT_MAX) void k_trilinear_fwd_split(RenderArgs A) {
     extern __shared__ float lds[];  // [NS - 1][SPLIT_VALS][TILE16 ? 256 : 64]
     constexpr int TL = TILE16 ? 256 : 64;   // rays per workgroup
-    const int tid = threadIdx.x, l = tid & (TL - 1), w = tid / TL, NS = blockDim.x / TL;
-    int b, r;
-    bool valid;
-    if (TILE16) {
-        valid = map_ray(A, b, r, l);
-    } else {
-        const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
-        b = (int)(lb / (unsigned)A.blocks_per_pose);
-        const int t = (int)(lb - (unsigned)b * (unsigned)A.blocks_per_pose);
-        if (A.grid_w > 0) {
-            const int ty = t / A.tiles_x, tx = t - ty * A.tiles_x;
-            const int px = tx * 8 + (l & 7), py = ty * 8 + (l >> 3);
-            r = py * A.grid_w + px;
-            valid = px < A.grid_w && py < A.grid_h;
-        } else {
-            r = t * 64 + l;
-            valid = r < A.n;
-        }
-    }
+    const int tid = threadIdx.x;
+    int b, r, l, w, NS;
+    const bool valid = map_ray_split<TILE16>(A, b, r, l, w, NS);
     Ray R;
     ray_setup(A, b, r, valid, R);
     const int N = A.sp.n_points;
@@ -1271,12 +1276,18 @@ __global__ __launch_bounds__(WG) void k_backward_from_jac(const float* __restric
 // EXACT: the index map is the exact-geometry one (a = 1, b = shift - 1/2), so the voxel a segment
 // belongs to is the voxel between the planes just crossed: it is tracked incrementally (+-1 on the
 // crossed axis) instead of being re-derived from every segment's midpoint.
-template <int MODE, bool MASK, bool GPOSE, bool GVOL, bool EXACT>
-__global__ __launch_bounds__(WG) void k_siddon(RenderArgs A) {
-    extern __shared__ float lds[];  // MASK: fwd -> channel accumulators, bwd -> upstream gradients
+// SPLIT (forward, no mask, exact geometry only): 0 = one lane walks the whole ray; 1 / 2 = the ray's
+// alpha range is cut into NS equal slices walked by NS wavefronts of the workgroup (8x8 / 16x16 tiles, see
+// k_trilinear_fwd_split) and the partial sums meet in LDS.  A voxel segment that straddles a cut is
+// credited to the same voxel from both sides (exact geometry: the voxel is the one between the planes),
+// so only the rounding of that one product differs from the unsplit walk.
+template <int MODE, bool MASK, bool GPOSE, bool GVOL, bool EXACT, int SPLIT = 0>
+__global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAX : WG) void k_siddon(RenderArgs A) {
+    extern __shared__ float lds[];  // MASK: fwd -> channel accumulators, bwd -> upstream gradients; SPLIT: partial sums
+    static_assert(!SPLIT || (MODE != 2 && !MASK && EXACT), "split walk: forward, unmasked, exact geometry");
     if (MODE == 2 && A.skip_unless_flag_gt && !(*A.skip_unless_flag_gt > __float_as_uint(GATHER_DEV_TOL))) return;
-    int b, r;
-    const bool valid = map_ray(A, b, r, threadIdx.x);
+    int b, r, sl_l = 0, sl_w = 0, sl_n = 1;
+    const bool valid = SPLIT ? map_ray_split<SPLIT == 2>(A, b, r, sl_l, sl_w, sl_n) : map_ray(A, b, r, threadIdx.x);
     const int tid = threadIdx.x;
     Ray R;
     ray_setup(A, b, r, valid, R);
@@ -1293,14 +1304,20 @@ __global__ __launch_bounds__(WG) void k_siddon(RenderArgs A) {
         g0 = valid ? A.gout[(size_t)b * A.n + r] : 0.f;
     }
 
-    const float alo = R.amin, ahi = R.amax;
-    bool live = valid && (ahi > alo);
+    float alo = R.amin, ahi = R.amax;
+    if (SPLIT) {   // cut k sits at fmaf(k / NS, amax - amin, amin): both neighbours compute it identically
+        const float a0 = R.amin, a1 = R.amax, inv = 1.f / (float)sl_n;
+        if (sl_w > 0) alo = fmaf((float)sl_w * inv, a1 - a0, a0);
+        if (sl_w < sl_n - 1) ahi = fmaf((float)(sl_w + 1) * inv, a1 - a0, a0);
+    }
+    bool live = valid && (ahi > alo) && (R.amax > R.amin);
     // per axis: reciprocal direction, (plane0 - s) so that alpha(p) = ((float)p + ps) * inv_d -- the same
     // value the sort formulation computes as ((p + plane0) - s) / d up to the reciprocal's rounding --,
     // index of the next plane to cross, step, alpha of that plane.  No range check on p: a plane beyond
     // the volume has alpha >= the axis' exit alpha >= ahi and is never selected before the loop ends.
     float inv_d[3], an3[3];
     int ip[3], stp[3];
+    bool on_plane = false;   // the walk starts on a plane (always at the entry face; at a cut: see plane_at_cut)
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         inv_d[i] = 1.f / R.d[i];
@@ -1309,8 +1326,16 @@ __global__ __launch_bounds__(WG) void k_siddon(RenderArgs A) {
         else { stp[i] = -1; ip[i] = (int)ceilf(f) - 1; }
         an3[i] = (((float)ip[i] + A.sp.plane0[i]) - R.s[i]) * inv_d[i];
         if (an3[i] <= alo) {  // a plane at or behind the entry point (fp noise) is skipped
+            on_plane = true;
             ip[i] += stp[i];
             an3[i] = (((float)ip[i] + A.sp.plane0[i]) - R.s[i]) * inv_d[i];
+        } else if (SPLIT && sl_w > 0) {
+            // a slice must start at the FIRST plane beyond its cut by the same alpha arithmetic the previous
+            // slice ends with; the position-based guess above can be one plane late when the cut sits
+            // within an ulp of a plane
+            const float ap = (((float)(ip[i] - stp[i]) + A.sp.plane0[i]) - R.s[i]) * inv_d[i];
+            if (ap > alo) { ip[i] -= stp[i]; an3[i] = ap; }
+            else if (ap == alo) on_plane = true;
         }
         if (!live) an3[i] = INFINITY;
     }
@@ -1321,9 +1346,12 @@ __global__ __launch_bounds__(WG) void k_siddon(RenderArgs A) {
     float As[3] = {0.f, 0.f, 0.f};   // sum dW (alpha-1)/d  per axis
     float At[3] = {0.f, 0.f, 0.f};   // sum dW (-alpha)/d   per axis
     float Wprev = 0.f;
-    int ax_prev = R.ax_in;           // axis of the crossing that opened the current segment (-1: none)
+    int ax_prev = (SPLIT && sl_w > 0) ? -1 : R.ax_in;  // axis of the crossing that opened the current segment (-1: none)
     float ac = alo;
     unsigned cnt = 0;
+    // the work counter counts voxel segments: a slice that starts inside a voxel continues the previous
+    // slice's last segment
+    bool first_of_slice = SPLIT && sl_w > 0 && !on_plane;
     const int max_iter = D0 + D1 + D2 + 8;
 
     // Software pipeline, depth 1: the voxel (and label) of segment i is requested, then segment i-1 --
@@ -1382,16 +1410,21 @@ __global__ __launch_bounds__(WG) void k_siddon(RenderArgs A) {
         const int off = inb ? (ix * D1 + iy) * D2 + iz : 0;
         const float v_new = vol[off];                       // always loadable (offset 0 when outside)
         const float lab_new = MASK ? A.mask[off] : 0.f;
-        if (inb) ++cnt;
+        if (inb && !first_of_slice && (!SPLIT || an > ac)) ++cnt;
+        first_of_slice = false;
         if (have) consume();
         p_v = inb ? v_new : 0.f; p_seg = an - ac; p_ac = ac; p_ax = ax_prev; p_off = off; p_inb = inb; p_lab = lab_new;
         have = true;
-        if (an >= ahi) {
+        // advance every axis whose next plane has been reached (ties advance together), branch-free
+        const bool c0 = an3[0] <= an, c1 = an3[1] <= an, c2 = an3[2] <= an;
+        // A plane exactly AT a cut (routine: the cuts of opposite-face rays fall on the centre planes) is
+        // crossed by the slice that ends there: one more, zero-length, segment carries its jacobian term;
+        // the next slice starts behind the plane.
+        const bool plane_at_cut = SPLIT && sl_w < sl_n - 1 && (c0 || c1 || c2);
+        if (an >= ahi && !plane_at_cut) {
             exited = true;
             live = false;
         } else {
-            // advance every axis whose next plane has been reached (ties advance together), branch-free
-            const bool c0 = an3[0] <= an, c1 = an3[1] <= an, c2 = an3[2] <= an;
             ip[0] += c0 ? stp[0] : 0; ip[1] += c1 ? stp[1] : 0; ip[2] += c2 ? stp[2] : 0;
 #pragma unroll
             for (int i = 0; i < 3; ++i) an3[i] = (((float)ip[i] + A.sp.plane0[i]) - R.s[i]) * inv_d[i];
@@ -1400,7 +1433,7 @@ __global__ __launch_bounds__(WG) void k_siddon(RenderArgs A) {
         }
     }
     if (have) consume();
-    if (DERIV && exited) {  // exit crossing: beyond it W = 0
+    if (DERIV && exited && (!SPLIT || sl_w == sl_n - 1)) {  // exit crossing: beyond it W = 0
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const float m = (R.ax_out == i) ? W * inv_d[i] : 0.f;
@@ -1409,8 +1442,30 @@ __global__ __launch_bounds__(WG) void k_siddon(RenderArgs A) {
         }
     }
 
+    if (SPLIT) {
+        constexpr int TL = SPLIT == 2 ? 256 : 64;
+        if (sl_w > 0) {
+            float* p = lds + (size_t)(sl_w - 1) * 7 * TL + sl_l;
+            p[0] = acc;
+            if (MODE == 1) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { p[(1 + i) * TL] = As[i]; p[(4 + i) * TL] = At[i]; }
+            }
+        }
+        __syncthreads();
+        if (sl_w == 0) {
+            for (int v = 1; v < sl_n; ++v) {
+                const float* p = lds + (size_t)(v - 1) * 7 * TL + sl_l;
+                acc += p[0];
+                if (MODE == 1) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) { As[i] += p[(1 + i) * TL]; At[i] += p[(4 + i) * TL]; }
+                }
+            }
+        }
+    }
     if (!BWD) {
-        if (valid) {
+        if (valid && (!SPLIT || sl_w == 0)) {
             if (MASK) {
                 for (int c = 0; c < A.C; ++c) A.out[((size_t)b * A.C + c) * A.n + r] = lds[c * WG + tid] * R.L;
             } else {
@@ -1587,7 +1642,7 @@ int launch(Kern kern, const RenderArgs& A, size_t lds_bytes, void* stream) {
 // compulsory read of the volume (one pose of 256^2 rays through 512^3 reads ~0.5 GB: 94 us = 5.4 TB/s
 // without any split), or by throughput (>= ~2048 wavefronts).  Returns 1 for the unsplit kernel.
 // XVR_DRR_FWD_SPLIT forces a choice: <n> = 8x8 tiles x n slices, 1<nn> (102, 104) = 16x16 tiles x n.
-int split_factor(int B, int n, long long voxels, bool* tile16) {
+int split_factor(int B, int n, long long voxels, bool siddon, bool* tile16) {
     const char* env = getenv("XVR_DRR_FWD_SPLIT");   // read per call: tests switch it within one process
     const int forced = env ? atoi(env) : 0;
     int ns = 1;
@@ -1599,6 +1654,12 @@ int split_factor(int B, int n, long long voxels, bool* tile16) {
         return ns;
     }
     const long long waves = (long long)B * ((n + 63) / 64);
+    if (siddon) {   // one dependent load per step: latency-bound for longer than the trilinear march
+        if (waves <= 256) return 8;
+        if (waves <= 512) return 4;
+        if (waves <= 2048) { *tile16 = true; return 2; }
+        return 1;
+    }
     const bool tiny_vol = voxels * 4 <= (32LL << 20);    // at home in the L2s
     const bool small_vol = voxels * 4 <= (128LL << 20);  // at home in the 256 MB infinity cache
     if (waves <= 128) return tiny_vol ? 8 : 4;
@@ -1609,7 +1670,7 @@ int split_factor(int B, int n, long long voxels, bool* tile16) {
 }
 
 template <typename Kern>
-int launch_split(Kern kern, RenderArgs A, int ns, bool tile16, void* stream) {
+int launch_split(Kern kern, RenderArgs A, int ns, bool tile16, int vals, void* stream) {
     const int tl = tile16 ? 256 : 64;
     if (!tile16) {
         if (A.grid_w > 0) {   // 8x8 tiles, one per workgroup
@@ -1621,7 +1682,7 @@ int launch_split(Kern kern, RenderArgs A, int ns, bool tile16, void* stream) {
     }
     const long long nblocks = (long long)A.B * A.blocks_per_pose;
     if (nblocks >= (1LL << 31)) return fail(XVR_DRR_E_UNSUPPORTED, "grid too large");
-    const size_t lds_bytes = (size_t)(ns - 1) * SPLIT_VALS * tl * sizeof(float);
+    const size_t lds_bytes = (size_t)(ns - 1) * vals * tl * sizeof(float);
     hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(tl * ns), lds_bytes, (hipStream_t)stream, A);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
@@ -1752,10 +1813,10 @@ int xvr_drr_trilinear_forward(const float* volume, const float* mask, int D0, in
         return jac ? launch(k_trilinear_fwd_lds<true>, A, bytes, stream) : launch(k_trilinear_fwd_lds<false>, A, bytes, stream);
     }
     bool tile16 = false;
-    const int ns = split_factor(B, n, (long long)D0 * D1 * D2, &tile16);
+    const int ns = split_factor(B, n, (long long)D0 * D1 * D2, false, &tile16);
     if (ns > 1) {
-#define XVR_SPLIT(J, Cl) (tile16 ? launch_split(k_trilinear_fwd_split<J, Cl, true>, A, ns, true, stream) \
-                                 : launch_split(k_trilinear_fwd_split<J, Cl, false>, A, ns, false, stream))
+#define XVR_SPLIT(J, Cl) (tile16 ? launch_split(k_trilinear_fwd_split<J, Cl, true>, A, ns, true, SPLIT_VALS, stream) \
+                                 : launch_split(k_trilinear_fwd_split<J, Cl, false>, A, ns, false, SPLIT_VALS, stream))
         if (jac) return clip ? XVR_SPLIT(true, true) : XVR_SPLIT(true, false);
         return clip ? XVR_SPLIT(false, true) : XVR_SPLIT(false, false);
 #undef XVR_SPLIT
@@ -1831,6 +1892,14 @@ int xvr_drr_siddon_forward(const float* volume, const float* mask, int D0, int D
     const bool ex = siddon_exact_geometry(sp);
     if (mask && jac) return (ex ? launch(k_siddon<1, true, false, false, true>, A, lds, stream) : launch(k_siddon<1, true, false, false, false>, A, lds, stream));
     if (mask) return (ex ? launch(k_siddon<0, true, false, false, true>, A, lds, stream) : launch(k_siddon<0, true, false, false, false>, A, lds, stream));
+    bool tile16 = false;
+    const int ns = ex ? split_factor(B, n, (long long)D0 * D1 * D2, true, &tile16) : 1;
+    if (ns > 1) {
+        if (jac) return tile16 ? launch_split(k_siddon<1, false, false, false, true, 2>, A, ns, true, 7, stream)
+                               : launch_split(k_siddon<1, false, false, false, true, 1>, A, ns, false, 7, stream);
+        return tile16 ? launch_split(k_siddon<0, false, false, false, true, 2>, A, ns, true, 7, stream)
+                      : launch_split(k_siddon<0, false, false, false, true, 1>, A, ns, false, 7, stream);
+    }
     if (jac) return (ex ? launch(k_siddon<1, false, false, false, true>, A, 0, stream) : launch(k_siddon<1, false, false, false, false>, A, 0, stream));
     return (ex ? launch(k_siddon<0, false, false, false, true>, A, 0, stream) : launch(k_siddon<0, false, false, false, false>, A, 0, stream));
 }

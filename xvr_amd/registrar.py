@@ -150,6 +150,7 @@ class Registrar:
                         graph = torch.cuda.CUDAGraph()
                         with torch.cuda.graph(graph):
                             static_loss = iteration()
+                        graph.replay()   # capturing enqueues nothing: this replay IS iteration `itr`
                         loss = static_loss
                     except Exception as e:  # capture is an optimisation, never a requirement
                         if self.verbose:
