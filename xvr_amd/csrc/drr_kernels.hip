@@ -1010,6 +1010,11 @@ __global__ __launch_bounds__(WG) void k_gather_cull(GatherArgs G, int nbricks) {
 // One lane owns a V x V x V block of voxels (V = 2: per-pose / per-step / per-row setup is paid once
 // for 8 voxels and the sample position is computed once per candidate); a workgroup covers a
 // (4V) x (8V) x (8V) brick so that its lanes' candidates share pixels.
+// max(1 - |d|, 0), the trilinear weight of a voxel at signed distance d, in ONE instruction: 1 - |d| never
+// exceeds 1, so the [0, 1] clamp equals the max and folds into the subtraction's clamp bit
+// (v_sub_f32 dst, 1.0, |d| clamp) -- the gather's inner loop is VALU-bound and has six of these per candidate.
+__device__ __forceinline__ float hat01(float d) { return __builtin_amdgcn_fmed3f(1.f - fabsf(d), 0.f, 1.f); }
+
 template <int V, bool NOLOAD = false>
 __global__ __launch_bounds__(64) void k_trilinear_gather_vol(GatherArgs G) {
     if (*G.flag > __float_as_uint(GATHER_DEV_TOL)) return;  // not a lattice: the scatter kernel runs instead
@@ -1062,6 +1067,7 @@ __global__ __launch_bounds__(64) void k_trilinear_gather_vol(GatherArgs G) {
             if (!inb || !(av == av)) khi = -1;
             const float grw = P.gr[0] * w0 + P.gr[1] * w1 + P.gr[2] * w2;
             const float4* __restrict__ q = G.q + (size_t)p * G.n;
+            const float Bx = fmaf(a0, s0, bv0), By = fmaf(a1, s1, bv1), Bz = fmaf(a2, s2, bv2);
             for (int k = klo; k <= khi; ++k) {
                 const float al = linspace_at(k, N, near_, far_, step);
                 if (al > 1e-12f) {
@@ -1084,6 +1090,7 @@ __global__ __launch_bounds__(64) void k_trilinear_gather_vol(GatherArgs G) {
                     const float ry = fabsf(ucy) < 1e-9f ? 1e9f : 1.f / ucy;
                     const float rz = fabsf(ucz) < 1e-9f ? 1e9f : 1.f / ucz;
                     const float ax_ = HS * fabsf(rx), ay_ = HS * fabsf(ry), az_ = HS * fabsf(rz);
+                    const float Ax = al * a0, Ay = al * a1, Az = al * a2;
                     for (int i = ilo; i <= ihi; ++i) {
                         const float fi = (float)i;
                         const float qx = fmaf(fi, urx, q0x), qy = fmaf(fi, ury, q0y), qz = fmaf(fi, urz, q0z);
@@ -1109,16 +1116,21 @@ __global__ __launch_bounds__(64) void k_trilinear_gather_vol(GatherArgs G) {
 #pragma unroll
                             for (int h = 0; h < 2; ++h) {
                                 const float4 t = h ? tb : ta;
-                                const float ix = fmaf(al, t.x, s0), iy = fmaf(al, t.y, s1), iz = fmaf(al, t.z, s2);
-                                const float ux0 = fmaxf(1.f - fabsf(fmaf(a0, ix, bv0)), 0.f);
-                                const float uy0 = fmaxf(1.f - fabsf(fmaf(a1, iy, bv1)), 0.f);
-                                const float uz0 = fmaxf(1.f - fabsf(fmaf(a2, iz, bv2)), 0.f) * t.w;
+                                // signed distance of the sample from the block's first voxel, per axis:
+                                // a (s + alpha d) + b - v folded into one fma (within an ulp of the
+                                // forward's two-fma chain); the second voxel sits exactly 1 further
+                                const float dx = fmaf(Ax, t.x, Bx), dy = fmaf(Ay, t.y, By), dz = fmaf(Az, t.z, Bz);
+                                const float ux0 = hat01(dx);
+                                const float uy0 = hat01(dy);
+                                const float uz0 = hat01(dz) * t.w;
                                 if (V == 1) {
                                     acc[0] = fmaf(ux0 * uy0, uz0, acc[0]);
                                 } else {
-                                    const float ux1 = fmaxf(1.f - fabsf(fmaf(a0, ix, bw0)), 0.f);
-                                    const float uy1 = fmaxf(1.f - fabsf(fmaf(a1, iy, bw1)), 0.f);
-                                    const float uz1 = fmaxf(1.f - fabsf(fmaf(a2, iz, bw2)), 0.f) * t.w;
+                                    const float ux1 = hat01(dx - 1.f);
+                                    const float uy1 = hat01(dy - 1.f);
+                                    const float uz1 = hat01(dz - 1.f) * t.w;
+                                    // (packed v_pk_mul/fma_f32 on (z, z+1) pairs measured SLOWER, 15.9 vs 14.7 ms:
+                                    //  the pair building / broadcast moves cost more than the halved fma count)
                                     const float p00 = ux0 * uy0, p01 = ux0 * uy1, p10 = ux1 * uy0, p11 = ux1 * uy1;
                                     acc[0] = fmaf(p00, uz0, acc[0]);
                                     acc[1 % (V * V * V)] = fmaf(p00, uz1, acc[1 % (V * V * V)]);
@@ -1144,9 +1156,9 @@ __global__ __launch_bounds__(64) void k_trilinear_gather_vol(GatherArgs G) {
 #pragma unroll
                         for (int e = 0; e < V * V * V; ++e) {
                             const float ox = (float)(e >> 2 & 1), oy = (float)(e >> 1 & 1), oz = (float)(e & 1);
-                            const float ux = fmaxf(1.f - fabsf(fmaf(a0, ix, bv0 - ox)), 0.f);
-                            const float uy = fmaxf(1.f - fabsf(fmaf(a1, iy, bv1 - oy)), 0.f);
-                            const float uz = fmaxf(1.f - fabsf(fmaf(a2, iz, bv2 - oz)), 0.f);
+                            const float ux = hat01(fmaf(a0, ix, bv0 - ox));
+                            const float uy = hat01(fmaf(a1, iy, bv1 - oy));
+                            const float uz = hat01(fmaf(a2, iz, bv2 - oz));
                             acc[e] = fmaf(ux * uy * uz, t.w, acc[e]);
                         }
                     }
