@@ -145,6 +145,19 @@ int xvr_drr_rays_backward(const float* cam, int B, int H, int W, const float* gr
                           const float* grad_target, const float* grad_raylen, float* grad_cam, void* stream);
 
 /*
+ * Jacobian -> camera in one pass (= xvr_drr_backward_from_jac followed by xvr_drr_rays_backward, without
+ * materialising grad_target / grad_raylen), for callers that optimise the pose and never look at per-ray
+ * gradients: the registration loop (/root/reference/src/xvr/registrar/base.py:252, loss.backward()).
+ *   jac [B][H*W][8] from a forward call, grad_out [B][H*W] (C == 1), cam [B][24]  ->  grad_cam [B][24] WRITTEN
+ * The sums are order-deterministic (fixed-order two-level reduction, no float atomics): identical bits on
+ * every run.  `workspace`: xvr_drr_jac_to_camera_workspace_bytes() bytes, ZERO-FILLED ONCE by the caller
+ * before the first use; every call leaves it ready for the next one.
+ */
+size_t xvr_drr_jac_to_camera_workspace_bytes(int B, int H, int W);
+int xvr_drr_jac_to_camera_backward(const float* jac, const float* grad_out, const float* cam, int B, int H, int W,
+                                   float* grad_cam, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * HU -> density of a whole CT.  Replaces diffdrr.data.transform_hu_to_density(volume, multiplier), which
  * xvr calls on the full volume before the renders of every training step
  * (/root/reference/src/xvr/model/trainer.py:124,196-197).

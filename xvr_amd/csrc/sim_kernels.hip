@@ -48,23 +48,51 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
-// block-wide sum of `nv` doubles per thread -> atomicAdd into dst[0..nv)
+// Order-deterministic grid reduction of NV doubles per thread: block `blk` of `nblk` stores its partial
+// sums, the block that draws the last ticket adds all partials in a fixed order and WRITES dst[0..NV).
+// No floating-point atomics: the similarity and its gradient are the same bits on every run.
+// (call at most once per kernel: static shared memory)
 template <int NV>
-__device__ __forceinline__ void block_add(double (&v)[NV], double* dst) {
+__device__ __forceinline__ void grid_add_det(double (&v)[NV], double* partial, int blk, int nblk, unsigned* counter,
+                                             double* dst) {
+    constexpr int NG = TB / NV;   // groups of NV threads that add the partials
     __shared__ double part[NV][TB / 64];
+    __shared__ double fin[NG][NV];
+    __shared__ bool last;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const double t = wave_sum_d(v[i]);
         if ((threadIdx.x & 63) == 0) part[i][threadIdx.x >> 6] = t;
     }
     __syncthreads();
+    // Publishing without a device-wide fence (a release fence writes the XCD's whole L2 back, ~70 ns per
+    // block, serialised): partials are stored and loaded with agent-scope atomics, which go to the level
+    // where the 8 XCDs are coherent; the barrier's wait for outstanding stores orders them before the ticket.
     if (threadIdx.x < NV) {
         double t = 0.0;
 #pragma unroll
         for (int w = 0; w < TB / 64; ++w) t += part[threadIdx.x][w];
-        if (t != 0.0) atomicAdd(dst + threadIdx.x, t);
+        __hip_atomic_store(partial + (size_t)blk * NV + threadIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();   // includes s_waitcnt vmcnt(0): the stores above have completed
+    if (threadIdx.x == 0)
+        last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nblk - 1);
+    __syncthreads();
+    if (!last) return;
+    const int q = threadIdx.x % NV, grp = threadIdx.x / NV;
+    if (grp < NG) {
+        double t = 0.0;
+#pragma unroll 4
+        for (int k = grp; k < nblk; k += NG)
+            t += __hip_atomic_load(partial + (size_t)k * NV + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fin[grp][q] = t;
     }
     __syncthreads();
+    if (threadIdx.x < NV) {
+        double t = 0.0;
+        for (int k = 0; k < NG; ++k) t += fin[k][threadIdx.x];
+        dst[threadIdx.x] = t;
+    }
 }
 
 // header + accumulators: everything zero except enc_min = 0xffffffff (one launch instead of two memsets)
@@ -110,7 +138,7 @@ __global__ __launch_bounds__(TB) void k_sim_minmax(const float* __restrict__ m, 
 // with the same expression, so the Sobel input is bit-identical to the stored y.
 __global__ __launch_bounds__(TB) void k_sim_prep(const float* __restrict__ m, const float* __restrict__ f, int H, int W,
                                                  SimHeader* hd, xvr_sim_spec sp, float* __restrict__ y,
-                                                 float* __restrict__ g, double* acc) {
+                                                 float* __restrict__ g, double* acc, double* partial, unsigned* tickets) {
     const int b = blockIdx.y, hw = H * W;
     const float mn = dec(hd->enc_min), mx = dec(hd->enc_max);
     const float r = (mx - mn) + sp.std_eps;
@@ -135,16 +163,16 @@ __global__ __launch_bounds__(TB) void k_sim_prep(const float* __restrict__ m, co
         g[((size_t)b * 2 + 0) * hw + i] = (a00 - a02) + 2.f * (a10 - a12) + (a20 - a22);
         g[((size_t)b * 2 + 1) * hw + i] = (a00 + 2.f * a01 + a02) - (a20 + 2.f * a21 + a22);
     }
-    block_add<5>(s, acc + (size_t)b * N_ACC);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         cmin += __shfl_xor(cmin, o);
         cmax += __shfl_xor(cmax, o);
     }
-    if ((threadIdx.x & 63) == 0) {
+    if ((threadIdx.x & 63) == 0) {   // integer atomics: exact in any order
         if (cmin) atomicAdd(&hd->cnt_min, cmin);
         if (cmax) atomicAdd(&hd->cnt_max, cmax);
     }
+    grid_add_det<5>(s, partial + (size_t)b * gridDim.x * 5, blockIdx.x, gridDim.x, tickets + b, acc + (size_t)b * N_ACC);
 }
 
 // The three patch NCCs of the similarity (local mNCC term on the image, gradient NCC on the two Sobel
@@ -164,7 +192,8 @@ struct PatchJobs {
 };
 
 // one thread = one patch.  fimg / yimg: [B][nch][H][W] with channel `ch` selected.  maps: [4][B][Hp][Wp].
-__global__ __launch_bounds__(TB) void k_sim_patch(PatchJobs jobs, int B, int H, int W, float eps, double* acc) {
+__global__ __launch_bounds__(TB) void k_sim_patch(PatchJobs jobs, int B, int H, int W, float eps, double* acc,
+                                                  double* partial, unsigned* tickets) {
     __shared__ float sf[(TILE + MAXP - 1) * (TILE + MAXP - 1)];
     __shared__ float sy[(TILE + MAXP - 1) * (TILE + MAXP - 1)];
     const int job = blockIdx.z / B, b = blockIdx.z - job * B;
@@ -220,7 +249,9 @@ __global__ __launch_bounds__(TB) void k_sim_patch(PatchJobs jobs, int B, int H, 
         ncc_d = ncc;
     }
     double v1[1] = {ncc_d};
-    block_add<1>(v1, acc + (size_t)b * N_ACC + acc_slot);
+    const int ntx = (Wp + TILE - 1) / TILE, nty = (Hp + TILE - 1) / TILE;   // the tiles of THIS job
+    grid_add_det<1>(v1, partial + (size_t)blockIdx.z * gridDim.x * gridDim.y, blockIdx.y * ntx + blockIdx.x, ntx * nty,
+                    tickets + blockIdx.z, acc + (size_t)b * N_ACC + acc_slot);
 }
 
 // G[i] (+)= scale * ( f_i SA - SB - y_i SC + SD ),  S* = sums of the maps over the patches containing i
@@ -267,7 +298,7 @@ __global__ __launch_bounds__(TB) void k_sim_final(const float* __restrict__ m, c
                                                   const float* __restrict__ y, const float* __restrict__ Gy,
                                                   const float* __restrict__ Gg, int H, int W, SimHeader* hd,
                                                   const double* __restrict__ acc, xvr_sim_spec sp,
-                                                  float* __restrict__ grad) {
+                                                  float* __restrict__ grad, double* partial, unsigned* tickets) {
     const int b = blockIdx.y, hw = H * W;
     const int i = blockIdx.x * TB + threadIdx.x;
     const float mn = dec(hd->enc_min), mx = dec(hd->enc_max);
@@ -301,7 +332,7 @@ __global__ __launch_bounds__(TB) void k_sim_final(const float* __restrict__ m, c
         s2[0] = (double)G * (1.0 - x);
         s2[1] = (double)G * x;
     }
-    block_add<2>(s2, &hd->smin);
+    grid_add_det<2>(s2, partial, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, tickets, &hd->smin);
 }
 
 // Standardize's min and max are functions of the image too: their gradient goes, evenly, to every
@@ -352,20 +383,26 @@ int sim_fail(int code, const char* msg) {
 size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Layout {
-    size_t acc, y, gy, m1, m2, Gy, Gg, total;
+    size_t acc, tickets, y, gy, m1, m2, Gy, Gg, part_prep, part_patch, part_final, total;
 };
+constexpr unsigned PREP_BLOCKS_MAX = 256;
 
 Layout layout(int B, int H, int W, int p1, int p2) {
     Layout L;
     const size_t hw = (size_t)H * W;
     size_t o = 256;
     L.acc = o; o += al((size_t)B * N_ACC * sizeof(double));
-    L.y = o; o += al((size_t)B * hw * 4);
+    L.tickets = o; o += al((size_t)(4 * B + 1) * sizeof(unsigned));   // prep [B], patch [3B], final [1]
+    L.y = o; o += al((size_t)B * hw * 4);   // everything before y is reset by k_sim_init
     L.gy = o; o += al((size_t)B * 2 * hw * 4);
     L.m1 = o; o += al((size_t)4 * B * (size_t)(H - p1 + 1) * (W - p1 + 1) * 4);
     L.m2 = o; o += al((size_t)2 * 4 * B * (size_t)(H - p2 + 1) * (W - p2 + 1) * 4);
     L.Gy = o; o += al((size_t)B * hw * 4);
     L.Gg = o; o += al((size_t)B * 2 * hw * 4);
+    const size_t tiles = (size_t)((W - (p1 < p2 ? p1 : p2) + 1 + TILE - 1) / TILE) * ((H - (p1 < p2 ? p1 : p2) + 1 + TILE - 1) / TILE);
+    L.part_prep = o; o += al((size_t)B * PREP_BLOCKS_MAX * 5 * sizeof(double));
+    L.part_patch = o; o += al((size_t)3 * B * tiles * sizeof(double));
+    L.part_final = o; o += al((size_t)B * ((hw + TB - 1) / TB) * 2 * sizeof(double));
     L.total = o;
     return L;
 }
@@ -408,8 +445,10 @@ int xvr_sim_ncc_forward_backward(const float* fixed, const float* fixed_sobel, c
     const long long want = (n + (long long)TB * 16 - 1) / ((long long)TB * 16);
     const unsigned rb = (unsigned)(want < 1 ? 1 : (want > 256 ? 256 : want));
     hipLaunchKernelGGL(k_sim_minmax, dim3(rb), dim3(TB), 0, stream, moving, n, hd);
-    const unsigned pb = (unsigned)((hw + TB - 1) / TB < 256 ? (hw + TB - 1) / TB : 256);
-    hipLaunchKernelGGL(k_sim_prep, dim3(pb, B), dim3(TB), 0, stream, moving, fixed, H, W, hd, *sp, y, gyb, acc);
+    unsigned* tickets = reinterpret_cast<unsigned*>(ws + L.tickets);
+    const unsigned pb = (unsigned)((hw + TB - 1) / TB < (int)PREP_BLOCKS_MAX ? (hw + TB - 1) / TB : PREP_BLOCKS_MAX);
+    hipLaunchKernelGGL(k_sim_prep, dim3(pb, B), dim3(TB), 0, stream, moving, fixed, H, W, hd, *sp, y, gyb, acc,
+                       reinterpret_cast<double*>(ws + L.part_prep), tickets);
     const size_t np2 = (size_t)B * (H - p2 + 1) * (W - p2 + 1);
     const double n1 = (double)(H - p1 + 1) * (W - p1 + 1), n2 = (double)(H - p2 + 1) * (W - p2 + 1);
     const float sc1 = (float)(0.5 * sp->beta / (n1 * p1 * p1));
@@ -420,10 +459,11 @@ int xvr_sim_ncc_forward_backward(const float* fixed, const float* fixed_sobel, c
     jobs.j[2] = {fixed_sobel, gyb, 2, 1, p2, m2 + 4 * np2, 7, sc2, Gg, 2, 1};
     const int pmin = p1 < p2 ? p1 : p2;
     auto tiles = [&](int hh, int ww) { return dim3((ww + TILE - 1) / TILE, (hh + TILE - 1) / TILE, 3 * B); };
-    hipLaunchKernelGGL(k_sim_patch, tiles(H - pmin + 1, W - pmin + 1), dim3(TB), 0, stream, jobs, B, H, W, sp->ncc_eps, acc);
+    hipLaunchKernelGGL(k_sim_patch, tiles(H - pmin + 1, W - pmin + 1), dim3(TB), 0, stream, jobs, B, H, W, sp->ncc_eps, acc,
+                       reinterpret_cast<double*>(ws + L.part_patch), tickets + B);
     hipLaunchKernelGGL(k_sim_patch_grad, tiles(H, W), dim3(TB), 0, stream, jobs, B, H, W);
     hipLaunchKernelGGL(k_sim_final, dim3((hw + TB - 1) / TB, B), dim3(TB), 0, stream, moving, fixed, y, Gy, Gg, H, W, hd, acc,
-                       *sp, grad_moving);
+                       *sp, grad_moving, reinterpret_cast<double*>(ws + L.part_final), tickets + 4 * B);
     const long long want2 = (n + (long long)TB * 4 - 1) / ((long long)TB * 4);
     const unsigned gb = (unsigned)(want2 < 1 ? 1 : (want2 > 1024 ? 1024 : want2));
     if (grad_moving) hipLaunchKernelGGL(k_sim_minmax_grad, dim3(gb), dim3(TB), 0, stream, moving, n, hd, *sp, grad_moving, acc, B, H, W, loss);

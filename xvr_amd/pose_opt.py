@@ -1,21 +1,21 @@
 """Device-resident pose optimisation for the registration loop (include/xvr_pose.h).
 
 ``RegistrationStage`` runs one pyramid stage of ``_RegistrarBase.run_test_time_optimization``
-(/root/reference/src/xvr/registrar/base.py:245-280) as EIGHT C-ABI launches per iteration and no
+(/root/reference/src/xvr/registrar/base.py:245-280) as SIX C-ABI calls per iteration and no
 autograd tape:
 
     pose -> camera            xvr_pose_camera_forward          (reg(): convert + detector + affine_inverse)
     camera -> rays            xvr_drr_rays_forward
     rays -> DRR + jacobian    xvr_drr_{trilinear,siddon}_forward
     DRR -> similarity + grad  xvr_sim_ncc_forward_backward     (transform, imagesim, backward of both)
-    grad -> rays              xvr_drr_backward_from_jac        (loss.backward() through the renderer)
-    rays -> camera            xvr_drr_rays_backward
+    grad -> camera            xvr_drr_jac_to_camera_backward   (loss.backward() through renderer and rays)
     camera -> pose, Adam, ReduceLROnPlateau, stopping rule     xvr_pose_opt_step
 
 The optimiser, the scheduler and the stopping rule keep their state on the device, so the host replays a
 captured HIP graph ``check_every`` times between looks at the ``done`` flag; iterations enqueued after a
 pose has met the stopping rule are no-ops, i.e. the trajectory is exactly that of a loop which checks
-after every step.  ``PoseCamera`` exposes the first step to autograd for callers with their own loop.
+after every step.  Every reduction on this path adds in a fixed order (no floating-point atomics), so a
+registration is reproducible bit for bit from run to run.  ``PoseCamera`` exposes the first step to autograd for callers with their own loop.
 """
 
 from __future__ import annotations
@@ -109,9 +109,9 @@ class RegistrationStage:
                           else self.lib.xvr_drr_siddon_forward)
         f = dict(device=dev, dtype=torch.float32)
         self.cam, self.g_cam = torch.empty(B, 24, **f), torch.zeros(B, 24, **f)
-        self.source, self.g_source = torch.empty(B, 3, **f), torch.empty(B, 3, **f)
-        self.target, self.g_target = torch.empty(B, n, 3, **f), torch.empty(B, n, 3, **f)
-        self.raylen, self.g_raylen = torch.empty(B, n, **f), torch.empty(B, n, **f)
+        self.source, self.target, self.raylen = torch.empty(B, 3, **f), torch.empty(B, n, 3, **f), torch.empty(B, n, **f)
+        nbytes = self.lib.xvr_drr_jac_to_camera_workspace_bytes(B, self.H, self.W)
+        self.j2c_ws = torch.zeros((nbytes + 3) // 4, **f)   # zero-filled once; every call leaves it ready for the next
         self.img, self.g_img = torch.empty(B, 1, self.H, self.W, **f), torch.empty(B, 1, self.H, self.W, **f)
         self.jac = torch.empty(B, n, _lib.JAC_STRIDE, **f)
         self.loss = torch.empty(B, **f)
@@ -121,7 +121,7 @@ class RegistrationStage:
                    "xvr_pose_opt_init")
         self.graph = None
 
-    # -- the eight launches --------------------------------------------------------------------------
+    # -- the six calls --------------------------------------------------------------------------
     def render(self):
         lib, B, H, W, n, s = self.lib, self.B, self.H, self.W, self.n, _stream()
         vol = self.drr.density
@@ -140,11 +140,9 @@ class RegistrationStage:
         _lib.check(_timed("ncc_forward_backward", lib.xvr_sim_ncc_forward_backward, _ptr(sim.fixed), _ptr(sim.fixed_sobel),
                           _ptr(self.img), B, H, W, ctypes.byref(sim.spec), _ptr(self.loss), _ptr(self.g_img),
                           _ptr(sim.workspace), sim.workspace.numel() * 4, s), "xvr_sim_ncc_forward_backward")
-        self.g_source.zero_()
-        _lib.check(_timed("backward_from_jac", lib.xvr_drr_backward_from_jac, _ptr(self.jac), _ptr(self.g_img), B, n,
-                          _ptr(self.g_source), _ptr(self.g_target), _ptr(self.g_raylen), s), "xvr_drr_backward_from_jac")
-        _lib.check(_timed("rays_backward", lib.xvr_drr_rays_backward, _ptr(self.cam), B, H, W, _ptr(self.g_source),
-                          _ptr(self.g_target), _ptr(self.g_raylen), _ptr(self.g_cam), s), "xvr_drr_rays_backward")
+        _lib.check(_timed("jac_to_camera_backward", lib.xvr_drr_jac_to_camera_backward, _ptr(self.jac), _ptr(self.g_img),
+                          _ptr(self.cam), B, H, W, _ptr(self.g_cam), _ptr(self.j2c_ws), self.j2c_ws.numel() * 4, s),
+                   "xvr_drr_jac_to_camera_backward")
         _lib.check(_timed("pose_opt_step", lib.xvr_pose_opt_step, _ptr(self.rot), _ptr(self.xyz), B,
                           ctypes.byref(self.spec), _ptr(self.G), _ptr(self.g_cam), _ptr(self.loss), _ptr(self.state),
                           _ptr(self.history), s), "xvr_pose_opt_step")
