@@ -32,6 +32,9 @@ typedef struct xvr_sim_spec {
     float beta;           /* weight of the multiscale NCC vs the gradient NCC   (0.5)                */
     int   mncc_patch;     /* patch size of the local term of the multiscale NCC (9)                  */
     int   gncc_patch;     /* patch size of the gradient NCC                     (11)                 */
+    int   per_image;      /* 0: Standardize by the min/max of the WHOLE batch tensor, as the reference's
+                             transform does (identical for B = 1); 1: by each image's own min/max, so that
+                             the images of a batch are independent problems (batched multi-start)        */
 } xvr_sim_spec;
 
 /* bytes of device scratch for a batch of B images of H x W */

@@ -216,3 +216,56 @@ def test_device_registration_is_bitwise_reproducible():
         assert r["trajectory"] == runs[0]["trajectory"]
         assert r["nccs"][:-1] == runs[0]["nccs"][:-1]      # (the last entry is the torch-metrics re-evaluation)
         assert torch.equal(r["final_pose"].matrix, runs[0]["final_pose"].matrix)
+
+
+@pytest.mark.gpu
+def test_batched_multistart_matches_one_by_one():
+    """Registrar.run_batch: B starts as independent problems in one batch (own optimiser state, own
+    standardisation) follow the same trajectories as B separate runs."""
+    from xvr_amd.registrar import Registrar
+    vol, _ = make_phantom(64, n_ellipsoids=8, seed=8, device="cuda")
+    drr = DRR(read(vol, spacing=(2.0,) * 3, orientation="AP"), 1020.0, 128, 1.4, renderer="trilinear", reverse_x_axis=False,
+              voxel_shift=0.0).cuda()
+    rot0, xyz0 = torch.tensor([[3.10, 0.05, -0.03]]), torch.tensor([[4.0, 700.0, -6.0]])
+    with torch.no_grad():
+        gt = drr(convert(rot0.cuda(), xyz0.cuda(), parameterization="euler_angles", convention="ZXY"))
+    g = torch.Generator().manual_seed(1)
+    drot, dxyz = (torch.rand(3, 3, generator=g) - 0.5) * 0.2, (torch.rand(3, 3, generator=g) - 0.5) * 30.0
+    inits = convert(rot0 + drot, xyz0 + dxyz, parameterization="euler_angles", convention="ZXY")
+    reg = Registrar(drr, scales="2,1", n_itrs="30,20", patience=4, max_n_plateaus=2, device_loop=True)
+    batch = reg.run_batch(gt, inits)
+    assert len(batch) == 3
+    lengths = set()
+    for b in range(3):
+        single = reg.run(gt, inits[b])
+        tb, ts = np.array(batch[b]["trajectory"]), np.array(single["trajectory"])
+        k = min(8, len(tb), len(ts))
+        np.testing.assert_allclose(tb[:k, :3], ts[:k, :3], atol=2e-3)
+        np.testing.assert_allclose(tb[:k, 3:], ts[:k, 3:], atol=0.2)
+        np.testing.assert_allclose(batch[b]["nccs"][:k], single["nccs"][:k], atol=2e-3)
+        assert batch[b]["nccs"][-1] > 0.9 * single["nccs"][-1]
+        assert len(batch[b]["times"]) == len(batch[b]["nccs"]) == len(batch[b]["lrs"]) == len(batch[b]["trajectory"]) + 1
+        lengths.add(len(tb))
+    # determinism carries over to the batch
+    again = reg.run_batch(gt, inits)
+    assert all(a["trajectory"] == b["trajectory"] for a, b in zip(again, batch))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(3, 40, 36), (2, 64, 64)])
+def test_fused_similarity_per_image_equals_one_image_at_a_time(shape):
+    from xvr_amd.similarity import FusedSimilarity
+    B, H, W = shape
+    g = torch.Generator().manual_seed(7)
+    fixed = torch.rand(B, 1, H, W, generator=g).cuda()
+    moving = (torch.rand(B, 1, H, W, generator=g) * torch.tensor([1.0, 3.0, 0.5][:B]).reshape(B, 1, 1, 1)).cuda().requires_grad_()
+    w = torch.tensor([1.0, -2.0, 0.5][:B]).cuda()
+    sim = FusedSimilarity(fixed, per_image=True)
+    loss = sim(moving)
+    (loss * w).sum().backward()
+    for b in range(B):
+        mb = moving[b:b + 1].detach().clone().requires_grad_()
+        lb = FusedSimilarity(fixed[b:b + 1])(mb)
+        (lb * w[b]).sum().backward()
+        assert torch.allclose(loss[b], lb[0], rtol=1e-6, atol=1e-7)
+        assert torch.allclose(moving.grad[b], mb.grad[0], rtol=1e-5, atol=1e-9)

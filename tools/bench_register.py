@@ -61,3 +61,14 @@ for H, delx in ((256, 0.1360 * 8), (512, 0.1360 * 4)):
         n_it = len(out["nccs"]) - 1
         steady = sum(out["times"][-50:]) / 50 * 1e3
         print(f"  Registrar.run use_graph={use_graph}: {n_it} iterations, {steady:.2f} ms / iteration (last 50), ncc {out['nccs'][0]:.4f} -> {out['nccs'][-1]:.4f}")
+    g = torch.Generator().manual_seed(0)
+    B = 8
+    inits = convert(rot.cpu() + (torch.rand(B, 3, generator=g) - 0.5) * 0.06, xyz.cpu() + (torch.rand(B, 3, generator=g) - 0.5) * 10.0,
+                    parameterization="euler_angles", convention="ZXY")
+    Rb = Registrar(drr, scales="1", n_itrs="120", max_n_plateaus=100)
+    torch.cuda.synchronize()
+    outs = Rb.run_batch(gt, inits)
+    torch.cuda.synchronize()
+    steady = sum(outs[0]["times"][-50:]) / 50 * 1e3
+    print(f"  Registrar.run_batch, {B} starts in one batch: {steady:.2f} ms / iteration of all {B} (= {steady / B:.3f} ms per pose-iteration), "
+          f"final ncc {min(o['nccs'][-1] for o in outs):.4f} .. {max(o['nccs'][-1] for o in outs):.4f}")

@@ -21,6 +21,9 @@ ap.add_argument("--det", type=int, default=128)
 ap.add_argument("--starts", type=int, default=4)
 ap.add_argument("--backend", default="nccl")
 ap.add_argument("--single-device", action="store_true")
+ap.add_argument("--batched", action="store_true", help="refine this rank's starts as one batch")
+ap.add_argument("--scales", default="4,2")
+ap.add_argument("--itrs", default="60,40")
 args = ap.parse_args()
 world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
 local = 0 if args.single_device else int(os.environ.get("LOCAL_RANK", "0"))
@@ -40,12 +43,18 @@ g = torch.Generator().manual_seed(0)   # the same starts on every rank; each ran
 drot = (torch.rand(args.starts, 3, generator=g) - 0.5) * 2 * 0.17      # +-10 degrees
 dxyz = (torch.rand(args.starts, 3, generator=g) - 0.5) * 2 * 20.0      # +-20 mm
 inits = convert(true_rot + drot, true_xyz + dxyz, parameterization="euler_angles", convention="ZXY")
-reg = Registrar(drr, scales="4,2", n_itrs="60,40", patience=6, max_n_plateaus=2)
-score, pose, best_rank, local = register_multistart(reg, gt, inits)
+reg = Registrar(drr, scales=args.scales, n_itrs=args.itrs, patience=6, max_n_plateaus=2)
+import time  # noqa: E402
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+score, pose, best_rank, local = register_multistart(reg, gt, inits, batched=args.batched)
+torch.cuda.synchronize()
+wall = time.perf_counter() - t0
 geo = DoubleGeodesicSE3(1020.0)
 err = geo(true_pose, RigidTransform(pose.cpu()[None]))[2].item()
 errs0 = [geo(true_pose, inits[i])[2].item() for i in range(args.starts)]
 print(f"rank {rank}/{world}: refined {len(local)} starts; best ncc {score.item():.4f} from rank {best_rank}; "
-      f"pose error {err:.2f} mm (starts were {min(errs0):.1f}-{max(errs0):.1f} mm off)", flush=True)
+      f"pose error {err:.2f} mm (starts were {min(errs0):.1f}-{max(errs0):.1f} mm off); "
+      f"{sum(len(r['trajectory']) for r in local)} iterations in {wall:.2f} s{' (batched)' if args.batched else ''}", flush=True)
 if world > 1:
     dist.destroy_process_group()

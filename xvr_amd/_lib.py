@@ -38,6 +38,7 @@ class CSimSpec(ctypes.Structure):
         ("beta", ctypes.c_float),
         ("mncc_patch", ctypes.c_int),
         ("gncc_patch", ctypes.c_int),
+        ("per_image", ctypes.c_int),
     ]
 
 

@@ -96,16 +96,20 @@ __device__ __forceinline__ void grid_add_det(double (&v)[NV], double* partial, i
 }
 
 // header + accumulators: everything zero except enc_min = 0xffffffff (one launch instead of two memsets)
-__global__ __launch_bounds__(TB) void k_sim_init(unsigned* __restrict__ w, int nwords) {
+__global__ __launch_bounds__(TB) void k_sim_init(unsigned* __restrict__ w, int nwords, int header_words) {
     const int i = blockIdx.x * TB + threadIdx.x;
-    if (i < nwords) w[i] = i == 0 ? 0xffffffffu : 0u;
+    constexpr int HW_ = (int)(sizeof(SimHeader) / 4);   // enc_min is the first word of every header
+    if (i < nwords) w[i] = (i < header_words && i % HW_ == 0) ? 0xffffffffu : 0u;
 }
 
 // global min / max of the batch (Standardize takes them over the whole tensor): few blocks, one atomic
 // pair per block (1024 same-address atomics cost 25 us; 64 cost nothing)
+// (gridDim.y = 1: over the whole batch tensor, the reference's Standardize; = B: per image, spec.per_image)
 __global__ __launch_bounds__(TB) void k_sim_minmax(const float* __restrict__ m, long long n, SimHeader* hd) {
     __shared__ float plo[TB / 64], phi[TB / 64];
     float lo = INFINITY, hi = -INFINITY;
+    m += (size_t)blockIdx.y * n;
+    hd += blockIdx.y;
     for (long long i = (long long)blockIdx.x * TB + threadIdx.x; i < n; i += (long long)gridDim.x * TB) {
         const float v = m[i];
         lo = fminf(lo, v);
@@ -140,6 +144,7 @@ __global__ __launch_bounds__(TB) void k_sim_prep(const float* __restrict__ m, co
                                                  SimHeader* hd, xvr_sim_spec sp, float* __restrict__ y,
                                                  float* __restrict__ g, double* acc, double* partial, unsigned* tickets) {
     const int b = blockIdx.y, hw = H * W;
+    hd += sp.per_image ? b : 0;
     const float mn = dec(hd->enc_min), mx = dec(hd->enc_max);
     const float r = (mx - mn) + sp.std_eps;
     const float* M = m + (size_t)b * hw;
@@ -301,6 +306,7 @@ __global__ __launch_bounds__(TB) void k_sim_final(const float* __restrict__ m, c
                                                   float* __restrict__ grad, double* partial, unsigned* tickets) {
     const int b = blockIdx.y, hw = H * W;
     const int i = blockIdx.x * TB + threadIdx.x;
+    hd += sp.per_image ? b : 0;
     const float mn = dec(hd->enc_min), mx = dec(hd->enc_max);
     const float r = (mx - mn) + sp.std_eps;
     const float a = 1.f / (r * sp.std);
@@ -332,7 +338,9 @@ __global__ __launch_bounds__(TB) void k_sim_final(const float* __restrict__ m, c
         s2[0] = (double)G * (1.0 - x);
         s2[1] = (double)G * x;
     }
-    grid_add_det<2>(s2, partial, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, tickets, &hd->smin);
+    const bool pi = sp.per_image != 0;   // per image: one reduction group per image; else one over the batch
+    grid_add_det<2>(s2, partial + (pi ? (size_t)b * gridDim.x * 2 : 0), pi ? (int)blockIdx.x : (int)(blockIdx.y * gridDim.x + blockIdx.x),
+                    pi ? (int)gridDim.x : (int)(gridDim.x * gridDim.y), tickets + (pi ? b : 0), &hd->smin);
 }
 
 // Standardize's min and max are functions of the image too: their gradient goes, evenly, to every
@@ -354,8 +362,12 @@ __global__ __launch_bounds__(TB) void k_sim_minmax_grad(const float* __restrict_
                                                         xvr_sim_spec sp, float* __restrict__ grad,
                                                         const double* __restrict__ acc, int B, int H, int W,
                                                         float* __restrict__ loss) {
-    if (blockIdx.x == 0)   // the similarity values ride along (saves the launch of k_sim_loss)
+    if (blockIdx.x == 0 && blockIdx.y == 0)   // the similarity values ride along (saves the launch of k_sim_loss)
         for (int b = threadIdx.x; b < B; b += TB) loss[b] = sim_loss_of(acc + (size_t)b * N_ACC, H, W, sp);
+    // gridDim.y = 1: n = the whole batch, one header; = B (spec.per_image): n = one image, header blockIdx.y
+    m += (size_t)blockIdx.y * n;
+    grad += (size_t)blockIdx.y * n;
+    hd += blockIdx.y;
     const float mn = dec(hd->enc_min), mx = dec(hd->enc_max);
     const float r = (mx - mn) + sp.std_eps;
     const double a = 1.0 / ((double)r * sp.std);
@@ -390,9 +402,9 @@ constexpr unsigned PREP_BLOCKS_MAX = 256;
 Layout layout(int B, int H, int W, int p1, int p2) {
     Layout L;
     const size_t hw = (size_t)H * W;
-    size_t o = 256;
+    size_t o = al((size_t)B * sizeof(SimHeader));   // one header per image (only the first is used unless per_image)
     L.acc = o; o += al((size_t)B * N_ACC * sizeof(double));
-    L.tickets = o; o += al((size_t)(4 * B + 1) * sizeof(unsigned));   // prep [B], patch [3B], final [1]
+    L.tickets = o; o += al((size_t)(5 * B) * sizeof(unsigned));   // prep [B], patch [3B], final [B]
     L.y = o; o += al((size_t)B * hw * 4);   // everything before y is reset by k_sim_init
     L.gy = o; o += al((size_t)B * 2 * hw * 4);
     L.m1 = o; o += al((size_t)4 * B * (size_t)(H - p1 + 1) * (W - p1 + 1) * 4);
@@ -441,10 +453,14 @@ int xvr_sim_ncc_forward_backward(const float* fixed, const float* fixed_sobel, c
     const long long n = (long long)B * hw;
 
     const int nwords = (int)(L.y / 4);   // header + accumulators
-    hipLaunchKernelGGL(k_sim_init, dim3((nwords + TB - 1) / TB), dim3(TB), 0, stream, reinterpret_cast<unsigned*>(ws), nwords);
-    const long long want = (n + (long long)TB * 16 - 1) / ((long long)TB * 16);
+    hipLaunchKernelGGL(k_sim_init, dim3((nwords + TB - 1) / TB), dim3(TB), 0, stream, reinterpret_cast<unsigned*>(ws), nwords,
+                       (int)(B * sizeof(SimHeader) / 4));
+    const bool per_image = sp->per_image != 0;
+    const long long n_mm = per_image ? (long long)hw : n;   // elements one min/max group spans
+    const unsigned groups = per_image ? (unsigned)B : 1u;
+    const long long want = (n_mm + (long long)TB * 16 - 1) / ((long long)TB * 16);
     const unsigned rb = (unsigned)(want < 1 ? 1 : (want > 256 ? 256 : want));
-    hipLaunchKernelGGL(k_sim_minmax, dim3(rb), dim3(TB), 0, stream, moving, n, hd);
+    hipLaunchKernelGGL(k_sim_minmax, dim3(rb, groups), dim3(TB), 0, stream, moving, n_mm, hd);
     unsigned* tickets = reinterpret_cast<unsigned*>(ws + L.tickets);
     const unsigned pb = (unsigned)((hw + TB - 1) / TB < (int)PREP_BLOCKS_MAX ? (hw + TB - 1) / TB : PREP_BLOCKS_MAX);
     hipLaunchKernelGGL(k_sim_prep, dim3(pb, B), dim3(TB), 0, stream, moving, fixed, H, W, hd, *sp, y, gyb, acc,
@@ -464,9 +480,9 @@ int xvr_sim_ncc_forward_backward(const float* fixed, const float* fixed_sobel, c
     hipLaunchKernelGGL(k_sim_patch_grad, tiles(H, W), dim3(TB), 0, stream, jobs, B, H, W);
     hipLaunchKernelGGL(k_sim_final, dim3((hw + TB - 1) / TB, B), dim3(TB), 0, stream, moving, fixed, y, Gy, Gg, H, W, hd, acc,
                        *sp, grad_moving, reinterpret_cast<double*>(ws + L.part_final), tickets + 4 * B);
-    const long long want2 = (n + (long long)TB * 4 - 1) / ((long long)TB * 4);
+    const long long want2 = (n_mm + (long long)TB * 4 - 1) / ((long long)TB * 4);
     const unsigned gb = (unsigned)(want2 < 1 ? 1 : (want2 > 1024 ? 1024 : want2));
-    if (grad_moving) hipLaunchKernelGGL(k_sim_minmax_grad, dim3(gb), dim3(TB), 0, stream, moving, n, hd, *sp, grad_moving, acc, B, H, W, loss);
+    if (grad_moving) hipLaunchKernelGGL(k_sim_minmax_grad, dim3(gb, groups), dim3(TB), 0, stream, moving, n_mm, hd, *sp, grad_moving, acc, B, H, W, loss);
     else hipLaunchKernelGGL(k_sim_loss, dim3((B + 63) / 64), dim3(64), 0, stream, acc, B, H, W, *sp, loss);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return sim_fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));

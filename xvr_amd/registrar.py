@@ -29,7 +29,7 @@ import torch
 from .drr import DRR
 from .metrics import (GradientNormalizedCrossCorrelation2d, MultiscaleNormalizedCrossCorrelation2d,
                       XrayTransforms)
-from .pose import RigidTransform
+from .pose import RigidTransform, convert
 from .pose_opt import RegistrationStage
 from .registration import Registration
 from .similarity import FusedSimilarity
@@ -187,6 +187,66 @@ class Registrar:
         return dict(final_pose=RigidTransform(reg.pose.matrix.detach()), init_pose=init_pose, nccs=nccs, times=times,
                     lrs=lrs, trajectory=traj, runtime=sum(times), drr=reg.drr)
 
+    def run_batch(self, gt: torch.Tensor, init_poses: RigidTransform, intrinsics: dict | None = None) -> list:
+        """Multi-start in ONE batch: the B initial poses are B independent registrations of the same target,
+        advanced together by the device-resident stage (xvr_amd/pose_opt.py) -- every pose has its own Adam
+        moments, plateau scheduler, learning rates and stopping flag on the device, the similarity
+        standardises every rendered image by its own min/max (``per_image``), and a stage ends when all poses
+        have met the stopping rule (finished poses are left untouched).  One launch then renders B poses, which
+        fills the GPU where a single 256^2 pose is one wavefront per SIMD.  Same schedule per pose as ``run``;
+        needs Euler angles and the fused similarity.  Returns one result dict per pose."""
+        device = self.drr.density.device
+        *_, height, width = gt.shape
+        B = len(init_poses)
+        if self.parameterization != "euler_angles" or device.type != "cuda":
+            raise RuntimeError("run_batch needs the device-resident loop: Euler angles on a GPU")
+        drr = deepcopy(self.drr)
+        if intrinsics is not None:
+            drr.set_intrinsics_(**{**intrinsics, "height": height, "width": width})
+        elif (drr.detector.height, drr.detector.width) != (height, width):
+            raise ValueError("gt and the DRR detector differ in size; pass intrinsics")
+        scales = parse_scales(self.scales, self.crop, height)
+        rot, xyz = init_poses.convert(self.parameterization, self.convention)
+        rot, xyz = rot.to(device).contiguous().clone(), xyz.to(device).contiguous().clone()
+        gt = gt.to(device)
+        per = [dict(traj=[], nccs=[], lrs=[[self.lr_rot, self.lr_xyz]], times=[0.0]) for _ in range(B)]
+        step_size_scalar = 1.0
+        transform = img = None
+        for stage, (scale, n_itr) in enumerate(zip(scales, self.n_itrs), start=1):
+            drr.rescale_detector_(scale)
+            h, w = drr.detector.height, drr.detector.width
+            if not FusedSimilarity.supported(h, w, self.mncc_patch_size, self.gncc_patch_size, self.sigma, self.equalize):
+                raise RuntimeError("run_batch needs the fused similarity (sigma = 0, no equalisation, patches <= 15)")
+            transform = XrayTransforms(h, w, equalize=self.equalize)
+            img = transform(gt)
+            sim = FusedSimilarity(img.expand(B, -1, -1, -1).contiguous(), self.mncc_patch_size, self.gncc_patch_size, self.beta,
+                                  per_image=True)
+            step_size_scalar *= 2 ** (stage - 1)
+            if n_itr <= 0:
+                continue
+            stage_run = RegistrationStage(drr, sim, rot, xyz, self.convention, self.lr_rot / step_size_scalar,
+                                          self.lr_xyz / step_size_scalar, self.patience, self.threshold, self.max_n_plateaus,
+                                          max_iters=n_itr)
+            _, stage_times = stage_run.run(n_itr, self.check_every, use_graph=self.use_graph)
+            for b, rows in enumerate(stage_run.results()):
+                per[b]["nccs"] += rows[:, 6].tolist()
+                per[b]["traj"] += rows[:, :6].tolist()
+                per[b]["lrs"] += rows[:, 7:9].tolist()
+                per[b]["times"] += stage_times[: len(rows)]
+            if self.verbose:
+                print(f"stage {stage}: iterations per pose {[len(r) for r in stage_run.results()]}")
+        final = convert(rot, xyz, parameterization=self.parameterization, convention=self.convention)
+        with torch.no_grad():
+            moving = transform(drr(final))
+            final_ncc = [self.imagesim(img, moving[b:b + 1]).sum().item() for b in range(B)]
+        out = []
+        for b in range(B):
+            per[b]["nccs"].append(final_ncc[b])
+            out.append(dict(final_pose=RigidTransform(final.matrix[b:b + 1].detach()), init_pose=init_poses[b], nccs=per[b]["nccs"],
+                            times=per[b]["times"], lrs=per[b]["lrs"], trajectory=per[b]["traj"], runtime=sum(per[b]["times"]),
+                            drr=drr))
+        return out
+
     def parameters_dict(self, result: dict, intrinsics: dict | None = None, volume=None, mask=None, xray=None,
                         registrar_type: str = "fixed") -> dict:
         """The ``parameters.pt`` dictionary of the reference (/root/reference/src/xvr/registrar/base.py:355-394):
@@ -217,16 +277,21 @@ class Registrar:
         torch.save(self.parameters_dict(result, **kw), path)
 
 
-def register_multistart(registrar: Registrar, gt: torch.Tensor, init_poses: RigidTransform, intrinsics: dict | None = None):
+def register_multistart(registrar: Registrar, gt: torch.Tensor, init_poses: RigidTransform, intrinsics: dict | None = None,
+                        batched: bool = False):
     """Multi-start registration (configs[3]: several initial poses, one or more per GPU).  The initial
     poses are split contiguously over the ranks (``shard_bounds``); every rank refines its own starts
     independently -- no communication inside the optimisation -- and one 68-byte all-gather of
-    (final similarity, 4x4 pose) lets every rank take the arg-max.  Returns (best_ncc, best_pose[4,4],
+    (final similarity, 4x4 pose) lets every rank take the arg-max.  ``batched``: a rank refines its starts
+    together in one batch (``Registrar.run_batch``) instead of one after the other.  Returns (best_ncc, best_pose[4,4],
     rank_of_best, local_results)."""
     from .distributed import multistart_best, shard_bounds
 
     lo, hi = shard_bounds(len(init_poses))
-    results = [registrar.run(gt, init_poses[i], intrinsics) for i in range(lo, hi)]
+    if batched and hi > lo:   # this rank's starts as one batch (Registrar.run_batch)
+        results = registrar.run_batch(gt, init_poses[lo:hi], intrinsics)
+    else:
+        results = [registrar.run(gt, init_poses[i], intrinsics) for i in range(lo, hi)]
     device = registrar.drr.density.device
     if results:
         best = max(results, key=lambda r: r["nccs"][-1])

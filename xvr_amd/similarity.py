@@ -32,13 +32,17 @@ class _FusedNCC(torch.autograd.Function):
                     B, H, W, ctypes.byref(spec), _ptr(loss), _ptr(grad), _ptr(workspace), workspace.numel() * 4, _stream())
         _lib.check(rc, "xvr_sim_ncc_forward_backward")
         ctx.save_for_backward(grad)
+        ctx.per_image = bool(spec.per_image)
         return loss
 
     @staticmethod
     def backward(ctx, gout):
         (grad,) = ctx.saved_tensors
         # The kernels return d(sum_b loss[b]) / d moving: Standardize's min/max couple the images of a
-        # batch, so per-image upstream weights are only exact for one image or a uniform weight.
+        # batch, so per-image upstream weights are only exact for one image or a uniform weight --
+        # unless every image is standardised on its own (per_image), where they are independent.
+        if ctx.per_image:
+            return grad * gout.reshape(-1, 1, 1, 1), None, None, None, None
         if gout.numel() == 1 or gout.stride(0) == 0:
             return grad * gout.reshape(-1)[0], None, None, None, None
         if not bool((gout == gout[0]).all()):
@@ -51,13 +55,13 @@ class FusedSimilarity(torch.nn.Module):
     """``sim(moving_raw) -> [B]`` against a fixed, already transformed target image."""
 
     def __init__(self, fixed: torch.Tensor, mncc_patch_size=9, gncc_patch_size=11, beta=0.5, mean=0.15, std=0.1,
-                 eps=1e-5):
+                 eps=1e-5, per_image=False):
         super().__init__()
         if not fixed.is_cuda or fixed.dtype != torch.float32 or fixed.dim() != 4 or fixed.shape[1] != 1:
             raise RuntimeError("FusedSimilarity needs a float32 CUDA target of shape [B,1,H,W] (HIP kernels, no CPU path)")
         self.register_buffer("fixed", fixed.contiguous())
         self.register_buffer("fixed_sobel", Sobel(0.0).to(fixed.device)(fixed).contiguous())
-        self.spec = _lib.CSimSpec(mean, std, 1e-6, eps, beta, int(mncc_patch_size), int(gncc_patch_size))
+        self.spec = _lib.CSimSpec(mean, std, 1e-6, eps, beta, int(mncc_patch_size), int(gncc_patch_size), int(bool(per_image)))
         B, _, H, W = fixed.shape
         nbytes = _lib.load().xvr_sim_workspace_bytes(B, H, W)
         self.register_buffer("workspace", torch.empty((nbytes + 3) // 4, device=fixed.device, dtype=torch.float32), persistent=False)
