@@ -70,7 +70,8 @@ size_t xvr_drr_backward_workspace_bytes(int B, int n, int D0, int D1, int D2);
 
 /*
  * Trilinear ray-marching forward.  Replaces Trilinear.forward(volume, source, target, img, mask=...).
- *   mask     nullable; float labels, same shape as volume.
+ *   mask     nullable; float labels, same shape as volume.  NULL with C in [2, 16]: the labels are packed
+ *            into `volume` (xvr_drr_pack_labels below).
  *   jac      nullable [B][n][8].  Per ray: {out / raylen, d out/d source[3], d out/d target[3], 0},
  *            where with a mask `out` means the SUM over channels.  Filled in the same sweep (no
  *            second gather), consumed by xvr_drr_backward_from_jac -- which is the whole pose-side
@@ -143,6 +144,19 @@ int xvr_drr_rays_forward(const float* cam, int B, int H, int W, float* source, f
                          void* stream);
 int xvr_drr_rays_backward(const float* cam, int B, int H, int W, const float* grad_source,
                           const float* grad_target, const float* grad_raylen, float* grad_cam, void* stream);
+
+/*
+ * Labels packed into the volume, for the mask -> channels renders of the training loop
+ * (/root/reference/src/xvr/model/trainer.py:288, `renderer(..., mask=seg)`).  The label of a sample is the
+ * label of its NEAREST voxel, which is always one of the 8 voxels the interpolation loads anyway; with the
+ * label stored in the low 4 mantissa bits of every voxel the separate lookup (a fifth gather per sample,
+ * +50 % render time) disappears.
+ *   xvr_drr_pack_labels   packed[i] = volume[i] with mantissa bits 0..3 := min(max((int)mask[i], 0), 15)
+ *   forward calls         pass `packed` as the volume, mask = NULL and C in [2, 16]
+ * The density the render sees differs from `volume` by at most 15 ulp (1.8e-6 relative).  Backward calls
+ * take the original volume and mask.
+ */
+int xvr_drr_pack_labels(const float* volume, const float* mask, long long n, float* packed, void* stream);
 
 /*
  * Jacobian -> camera in one pass (= xvr_drr_backward_from_jac followed by xvr_drr_rays_backward, without

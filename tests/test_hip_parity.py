@@ -117,10 +117,15 @@ def test_sample_split_forward_and_jacobian(ns, kw, grid, monkeypatch):
         _close(h, r, GRAD_TOL, f"{name} ns={ns}")
 
 
+@pytest.mark.parametrize("packed", [True, False], ids=["packed-labels", "mask-lookup"])
 @pytest.mark.parametrize("kw", [s for s in SPECS if not s.get("clip_to_volume")], ids=_id)
-def test_forward_with_mask_matches_oracle(kw):
+def test_forward_with_mask_matches_oracle(kw, packed, monkeypatch):
+    """mask -> channels, with the labels packed into the volume's low mantissa bits (default for <= 16
+    channels) and with the separate lookup in the mask volume."""
+    from xvr_amd import renderers
     from xvr_amd.spec import RenderSpec
 
+    monkeypatch.setattr(renderers, "PACK_LABELS", packed)
     spec = RenderSpec(**kw)
     case = make_case(seed=12)
     hip = _hip_render(case, spec, mask=case["mask"], grid_w=case["width"])
@@ -865,3 +870,36 @@ def test_errors_are_python_exceptions():
         render(vol[:1], src, tgt, img, RenderSpec())  # a dimension < 2 -> XVR_DRR_E_ARG -> RuntimeError
     # the stream is still usable afterwards
     assert torch.isfinite(render(vol, src, tgt, img, RenderSpec())).all()
+
+
+@pytest.mark.parametrize("renderer", ["trilinear", "siddon"])
+def test_packed_labels_are_the_mask_lookup_up_to_15_ulp_of_density(renderer, monkeypatch):
+    """Same channels from both label paths (the label of a sample is bit-identical; only the density moves,
+    by <= 15 ulp), 16 labels, values past 15 clamp like the C - 1 clamp of the lookup; the packed copy is
+    rebuilt when either tensor changes in place."""
+    from xvr_amd import renderers
+    from xvr_amd.renderers import render
+    from xvr_amd.spec import RenderSpec
+
+    spec = RenderSpec(renderer=renderer, n_points=80) if renderer == "trilinear" else RenderSpec(renderer="siddon")
+    case = make_case(seed=31, shape=(22, 26, 30), height=20, width=24, n_labels=16)
+    vol, mask = case["volume"].cuda(), case["mask"].cuda()
+    src, tgt, img = (case[k].cuda() for k in ("source", "target", "img"))
+    outs = {}
+    for packed in (True, False):
+        monkeypatch.setattr(renderers, "PACK_LABELS", packed)
+        outs[packed] = render(vol, src, tgt, img, spec, mask, ray_grid_w=24)
+    assert outs[True].shape[1] == 16
+    _close(outs[True], outs[False], 1e-5, "packed vs lookup")
+    assert getattr(vol, "_xvr_packed", None) is not None
+    # in-place edits invalidate the packed copy
+    monkeypatch.setattr(renderers, "PACK_LABELS", True)
+    mask.fmod_(4.0)
+    a = render(vol, src, tgt, img, spec, mask, ray_grid_w=24, n_channels=16)
+    monkeypatch.setattr(renderers, "PACK_LABELS", False)
+    b = render(vol, src, tgt, img, spec, mask, ray_grid_w=24, n_channels=16)
+    _close(a, b, 1e-5, "after an in-place label edit")
+    assert float(a[:, 4:].abs().max()) == 0.0
+    monkeypatch.setattr(renderers, "PACK_LABELS", True)
+    vol.mul_(0.5)
+    _close(render(vol, src, tgt, img, spec, mask, ray_grid_w=24, n_channels=16), 0.5 * b, 1e-5, "after an in-place density edit")

@@ -96,6 +96,7 @@ EXPORTS = {
     "xvr_drr_hu_to_density": ([_P, ctypes.c_longlong, _P, ctypes.c_float, _P, _P], ctypes.c_int),
     "xvr_drr_rays_forward": ([_P, _I, _I, _I, _P, _P, _P, _P], ctypes.c_int),
     "xvr_drr_rays_backward": ([_P, _I, _I, _I, _P, _P, _P, _P, _P], ctypes.c_int),
+    "xvr_drr_pack_labels": ([_P, _P, ctypes.c_longlong, _P, _P], ctypes.c_int),
     "xvr_drr_jac_to_camera_workspace_bytes": ([_I, _I, _I], ctypes.c_size_t),
     "xvr_drr_jac_to_camera_backward": ([_P, _P, _P, _I, _I, _I, _P, _P, ctypes.c_size_t, _P], ctypes.c_int),
     "xvr_pose_camera_forward": ([_P, _P, _I, _AX, _P, _P, _P, _P], ctypes.c_int),

@@ -119,7 +119,37 @@ int vfail(int code, const char* msg) {
 
 }  // namespace
 
+// packed[i] = volume[i] with its low 4 mantissa bits replaced by the label min(max((int)mask[i], 0), 15)
+__global__ __launch_bounds__(TB) void k_pack_labels(const float* __restrict__ vol, const float* __restrict__ mask, long long n,
+                                                    float* __restrict__ packed) {
+    const long long n4 = n >> 2;
+    for (long long i = (long long)blockIdx.x * TB + threadIdx.x; i < n4; i += (long long)gridDim.x * TB) {
+        const float4 v = reinterpret_cast<const float4*>(vol)[i], m = reinterpret_cast<const float4*>(mask)[i];
+        auto pk = [](float d, float l) {
+            const unsigned lab = (unsigned)min(max((int)l, 0), 15);
+            return __uint_as_float((__float_as_uint(d) & ~15u) | lab);
+        };
+        reinterpret_cast<float4*>(packed)[i] = make_float4(pk(v.x, m.x), pk(v.y, m.y), pk(v.z, m.z), pk(v.w, m.w));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) {
+        const long long i = (n4 << 2) + threadIdx.x;
+        const unsigned lab = (unsigned)min(max((int)mask[i], 0), 15);
+        packed[i] = __uint_as_float((__float_as_uint(vol[i]) & ~15u) | lab);
+    }
+}
+
 extern "C" {
+
+int xvr_drr_pack_labels(const float* volume, const float* mask, long long n, float* packed, void* stream_) {
+    if (!volume || !mask || !packed || n <= 0) return vfail(XVR_DRR_E_ARG, "bad argument");
+    if ((reinterpret_cast<uintptr_t>(volume) | reinterpret_cast<uintptr_t>(mask) | reinterpret_cast<uintptr_t>(packed)) & 15u)
+        return vfail(XVR_DRR_E_ARG, "volumes must be 16-byte aligned");
+    const long long blocks = ((n >> 2) + TB - 1) / TB;
+    hipLaunchKernelGGL(k_pack_labels, dim3((unsigned)(blocks < 8192 ? (blocks > 0 ? blocks : 1) : 8192)), dim3(TB), 0,
+                       (hipStream_t)stream_, volume, mask, n, packed);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? XVR_DRR_OK : vfail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
+}
 
 int xvr_drr_hu_stats(const float* hu, long long n, void* stats, void* stream_) {
     if (!hu || !stats || n <= 0) return vfail(XVR_DRR_E_ARG, "bad argument");

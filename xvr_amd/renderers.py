@@ -96,6 +96,32 @@ def _workspace(lib, B, n, shape, device):
     return ws, ws.numel() * 4
 
 
+# Mask -> channels renders with at most 16 labels use a copy of the volume that carries every voxel's label
+# in its low 4 mantissa bits (xvr_drr_pack_labels; include/xvr_drr.h): the label lookup then costs no gather.
+# The density seen by the render moves by <= 15 ulp (1.8e-6 relative).  False (or XVR_DRR_PACK_LABELS=0)
+# keeps the separate lookup in the mask volume.
+import os as _os
+
+PACK_LABELS = _os.environ.get("XVR_DRR_PACK_LABELS", "1") != "0"
+
+
+def _packed_volume(lib, volume, mask):
+    """The label-carrying copy of ``volume``; cached ON the volume tensor object (an address-keyed cache goes
+    stale when the allocator hands the same address to the next step's density)."""
+    key = (id(mask), mask.data_ptr(), mask._version, volume._version)
+    hit = getattr(volume, "_xvr_packed", None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    packed = torch.empty_like(volume)
+    rc = _timed("pack_labels", lib.xvr_drr_pack_labels, _ptr(volume), _ptr(mask), volume.numel(), _ptr(packed), _stream())
+    _lib.check(rc, "xvr_drr_pack_labels")
+    try:
+        volume._xvr_packed = (key, packed)
+    except AttributeError:   # pragma: no cover  (exotic tensor subclasses without a __dict__)
+        pass
+    return packed
+
+
 class _Render(torch.autograd.Function):
     """forward: one fused sweep (with the per-ray jacobian when a pose gradient may be needed);
     backward: elementwise-from-jacobian for the pose, a re-march with scatter for the voxels."""
@@ -116,8 +142,11 @@ class _Render(torch.autograd.Function):
         out = torch.empty(B, C, n, device=volume.device, dtype=torch.float32)
         jac = torch.empty(B, n, _lib.JAC_STRIDE, device=volume.device, dtype=torch.float32) if use_jac else None
         fn = lib.xvr_drr_trilinear_forward if spec.renderer == "trilinear" else lib.xvr_drr_siddon_forward
+        vol_f, msk_f = vol_c, msk_c
+        if msk_c is not None and PACK_LABELS and 2 <= C <= 16 and vol_c.data_ptr() % 16 == 0 and msk_c.data_ptr() % 16 == 0:
+            vol_f, msk_f = _packed_volume(lib, vol_c, msk_c), None     # labels ride in the taps
         rc = _timed(f"{spec.renderer}_forward" + ("+jac" if use_jac else ""), fn,
-                    _ptr(vol_c), _ptr(msk_c), D0, D1, D2, C, _ptr(src_c), _ptr(tgt_c), _ptr(len_c), B, n,
+                    _ptr(vol_f), _ptr(msk_f), D0, D1, D2, C, _ptr(src_c), _ptr(tgt_c), _ptr(len_c), B, n,
                     ctypes.byref(cs), _ptr(out), _ptr(jac), _ptr(work), _stream())
         _lib.check(rc, f"xvr_drr_{spec.renderer}_forward")
         ctx.spec, ctx.ray_grid_w, ctx.C = spec, ray_grid_w, C
