@@ -105,6 +105,7 @@ class DRR(torch.nn.Module):
 
     def _sync_ray_grid(self):
         self.renderer.ray_grid = (self.detector.height, self.detector.width)
+        self._cam_affine = None   # the pose -> camera constants belong to the detector just replaced
 
     @property
     def affine(self) -> RigidTransform:
@@ -125,17 +126,39 @@ class DRR(torch.nn.Module):
                 mask_to_channels=False, density=None, **kwargs):
         """``drr(pose)`` with a RigidTransform, or ``drr(rot, xyz, parameterization=, convention=)``.
         ``density`` overrides the module's buffer (e.g. a leaf tensor whose gradient is wanted)."""
-        pose = args[0] if parameterization is None else convert(
-            *args, parameterization=parameterization, convention=convention)
         density = self.density if density is None else density
         if self.fused_rays and calibration is None and density.is_cuda:
-            source, target, img = rays_from_camera(self.camera(pose), self.detector.height, self.detector.width)
+            # pose -> camera through the affine map of camera_affine(): ONE HIP launch from Euler angles
+            # (xvr_pose_camera_forward), one addmm from a 4x4 pose -- instead of the ~60 tiny torch launches of
+            # convert() + camera(), which cost 0.5 ms per call and dominate a one-pose render
+            G, c = self._camera_affine_cached()
+            if (parameterization == "euler_angles" and len(args) == 2 and args[0].is_cuda and args[1].is_cuda
+                    and args[0].dtype == args[1].dtype == torch.float32 and args[0].dim() == 2 and len(args[0]) > 0):
+                from .pose_opt import pose_camera
+                batch_size = len(args[0])
+                cam = pose_camera(args[0], args[1], G, c, convention)
+            else:
+                pose = args[0] if parameterization is None else convert(
+                    *args, parameterization=parameterization, convention=convention)
+                batch_size = len(pose)
+                cam = torch.addmm(c, pose.matrix[:, :3, :].reshape(batch_size, 12), G.T)
+            source, target, img = rays_from_camera(cam, self.detector.height, self.detector.width)
             kwargs["mask"] = self.mask if mask_to_channels else None
             img = self.renderer(density, source, target, img, **kwargs)
         else:
+            pose = args[0] if parameterization is None else convert(
+                *args, parameterization=parameterization, convention=convention)
+            batch_size = len(pose)
             source, target = self.detector(pose, calibration)
             img = self.render(density, source, target, mask_to_channels, **kwargs)
-        return self.reshape_transform(img, batch_size=len(pose))
+        return self.reshape_transform(img, batch_size=batch_size)
+
+    def _camera_affine_cached(self):
+        key = (id(self.detector), self._affine_inverse.device, self._affine_inverse._version)
+        hit = getattr(self, "_cam_affine", None)
+        if hit is None or hit[0] != key:
+            hit = self._cam_affine = (key, *self.camera_affine())
+        return hit[1], hit[2]
 
     def camera(self, pose: RigidTransform) -> torch.Tensor:
         """[B,24] = {Mv, s_v, Mw, s_w}: target_vox(i,j) = Mv (i,j,1)^T, raylen(i,j) = |Mw (i,j,1)^T - s_w|.

@@ -29,4 +29,7 @@ class Registration(torch.nn.Module):
                        parameterization=self.parameterization, convention=self.convention)
 
     def forward(self, **kwargs):
-        return self.drr(self.pose, **kwargs)
+        # (the DRR turns Euler parameters into its camera with one HIP launch; other parameterisations go
+        #  through convert() as before)
+        return self.drr(self.rotation, self.translation, parameterization=self.parameterization,
+                        convention=self.convention, **kwargs)
