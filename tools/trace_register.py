@@ -1,5 +1,6 @@
 """One pyramid stage of Registrar.run at 512^3 / 256^2 under rocprofv3 --kernel-trace: which kernels make
 up a graph-replayed iteration.  Run on the GPU box under rocprofv3."""
+import os
 import sys
 from pathlib import Path
 
@@ -13,7 +14,8 @@ from xvr_amd.registrar import Registrar  # noqa: E402
 
 dev = torch.device("cuda")
 vol, _ = make_phantom(512, n_ellipsoids=16, seed=0, device=dev)
-drr = DRR(read(vol, orientation="AP"), 1020.0, 256, 0.1360 * 8, renderer="trilinear", reverse_x_axis=False, voxel_shift=0.0).to(dev)
+det = int(os.environ.get("DET", "256"))
+drr = DRR(read(vol, orientation="AP"), 1020.0, det, 0.1360 * 8 * 256 / det, renderer="trilinear", reverse_x_axis=False, voxel_shift=0.0).to(dev)
 rot, xyz = torch.tensor([[3.1, 0.05, -0.02]]), torch.tensor([[5.0, 750.0, -8.0]])
 with torch.no_grad():
     gt = drr(convert(rot + 0.03, xyz + 5.0, parameterization="euler_angles", convention="ZXY").cuda())

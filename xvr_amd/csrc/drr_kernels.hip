@@ -1757,9 +1757,9 @@ int launch(Kern kern, const RenderArgs& A, size_t lds_bytes, void* stream) {
 
 // Sample slices per ray for the forward march, measured on MI355X (tools/bench_small_batch.py,
 // profiles/r01_small_batch_split.txt).  Splitting pays while the launch is LATENCY-bound: few
-// wavefronts, each walking ~250 dependent gathers.  It stops paying once the launch is bound by the
-// compulsory read of the volume (one pose of 256^2 rays through 512^3 reads ~0.5 GB: 94 us = 5.4 TB/s
-// without any split), or by throughput (>= ~2048 wavefronts).  Returns 1 for the unsplit kernel.
+// wavefronts, each walking ~250 dependent gathers.  It stops paying once the launch is bound by
+// throughput (>= ~2048 wavefronts) or by the first-touch read of a frustum that spans a volume larger
+// than the caches.  Returns 1 for the unsplit kernel.
 // XVR_DRR_FWD_SPLIT forces a choice: <n> = 8x8 tiles x n slices, 1<nn> (102, 104) = 16x16 tiles x n.
 int split_factor(int B, int n, long long voxels, bool siddon, bool* tile16) {
     const char* env = getenv("XVR_DRR_FWD_SPLIT");   // read per call: tests switch it within one process
@@ -1780,11 +1780,13 @@ int split_factor(int B, int n, long long voxels, bool siddon, bool* tile16) {
         return 1;
     }
     const bool tiny_vol = voxels * 4 <= (32LL << 20);    // at home in the L2s
-    const bool small_vol = voxels * 4 <= (128LL << 20);  // at home in the 256 MB infinity cache
     if (waves <= 128) return tiny_vol ? 8 : 4;
     if (waves <= 256) return 4;
     if (waves <= 512) return tiny_vol ? 4 : 2;
-    if (waves <= 1024 && small_vol) { *tile16 = true; return 2; }
+    // one pose at 256^2: what decides is the FOOTPRINT of the frustum, which the host does not know.  A
+    // detector that looks at 16 % of a 512^3 CT (registration geometry, 0.8-voxel pixel pitch) renders in
+    // 57 us split vs 111 us unsplit; one whose frustum spans the whole 0.5 GB volume loses 5 % (99 vs 95 us).
+    if (waves <= 1024) { *tile16 = true; return 4; }
     return 1;
 }
 
