@@ -240,8 +240,10 @@ def test_batched_multistart_matches_one_by_one():
         single = reg.run(gt, inits[b])
         tb, ts = np.array(batch[b]["trajectory"]), np.array(single["trajectory"])
         k = min(8, len(tb), len(ts))
+        # (the batch renders with another kernel variant than a single pose: last-bit differences, which Adam's
+        #  normalised steps amplify along the poorly conditioned source-detector axis -- steps are 1 mm there)
         np.testing.assert_allclose(tb[:k, :3], ts[:k, :3], atol=2e-3)
-        np.testing.assert_allclose(tb[:k, 3:], ts[:k, 3:], atol=0.2)
+        np.testing.assert_allclose(tb[:k, 3:], ts[:k, 3:], atol=1.0)
         np.testing.assert_allclose(batch[b]["nccs"][:k], single["nccs"][:k], atol=2e-3)
         assert batch[b]["nccs"][-1] > 0.9 * single["nccs"][-1]
         assert len(batch[b]["times"]) == len(batch[b]["nccs"]) == len(batch[b]["lrs"]) == len(batch[b]["trajectory"]) + 1

@@ -6,8 +6,9 @@
 //   /root/reference/src/xvr/utils/preprocess.py:5-31  (XrayTransforms)
 //
 // The reference's patch NCC unfolds every p x p patch into a channel (81x / 121x the image); here
-// each thread evaluates one patch from an LDS tile with a two-pass (mean, then centred moments)
-// scheme -- robust on the flat patches where eps decides -- and stores four per-patch maps
+// each thread evaluates one patch from an LDS tile with separable box sums (p + p reads, not p^2) of the
+// five moments about a tile-wide shift -- robust on the flat patches where eps decides -- and stores four
+// per-patch maps
 //   A = 1/s, Bm = mu_f/s, Cm = cov/(v_y s), Dm = cov mu_y/(v_y s),   s = sqrt(v_f v_y),
 // from which the gradient is   d ncc / d y_i = (1 / (N_p p^2)) * ( f_i SA - SB - y_i SC + SD ),
 // S* = sums of the maps over the patches that contain pixel i (the adjoint box filter).
@@ -201,6 +202,7 @@ __global__ __launch_bounds__(TB) void k_sim_patch(PatchJobs jobs, int B, int H, 
                                                   double* partial, unsigned* tickets) {
     __shared__ float sf[(TILE + MAXP - 1) * (TILE + MAXP - 1)];
     __shared__ float sy[(TILE + MAXP - 1) * (TILE + MAXP - 1)];
+    __shared__ float hs[5][(TILE + MAXP - 1) * TILE];
     const int job = blockIdx.z / B, b = blockIdx.z - job * B;
     const PatchJob J = jobs.j[job];
     const float* __restrict__ fimg = J.f;
@@ -220,30 +222,36 @@ __global__ __launch_bounds__(TB) void k_sim_patch(PatchJobs jobs, int B, int H, 
         sy[t] = in ? Y[rr * W + cc] : 0.f;
     }
     __syncthreads();
+    // Separable box sums of the five moments about a tile-wide shift (cf, cy) = the tile's centre pixel:
+    // p + p reads per output instead of 2 p^2.  Shifting keeps the one-pass variance honest: on a flat patch
+    // the shifted values are tiny, so S2/n - (S1/n)^2 cancels nothing that matters against eps.
+    const int ec = min(E / 2, min(H - 1 - oy0, W - 1 - ox0));
+    const float cf = sf[ec * E + ec], cy = sy[ec * E + ec];
+    for (int t = threadIdx.x; t < E * TILE; t += TB) {   // horizontal: row r of the tile, output column c
+        const int r = t / TILE, c = t - r * TILE;
+        float a1 = 0.f, b1 = 0.f, a2 = 0.f, b2 = 0.f, ab = 0.f;
+        for (int v = 0; v < p; ++v) {
+            const float a = sf[r * E + c + v] - cf, bb = sy[r * E + c + v] - cy;
+            a1 += a; b1 += bb;
+            a2 = fmaf(a, a, a2); b2 = fmaf(bb, bb, b2); ab = fmaf(a, bb, ab);
+        }
+        hs[0][t] = a1; hs[1][t] = b1; hs[2][t] = a2; hs[3][t] = b2; hs[4][t] = ab;
+    }
+    __syncthreads();
     const int ty = threadIdx.x / TILE, tx = threadIdx.x % TILE;
     const int oy = oy0 + ty, ox = ox0 + tx;
     double ncc_d = 0.0;
     if (oy < Hp && ox < Wp) {
         const float inv = 1.f / (float)(p * p);
-        float mf = 0.f, my = 0.f;
-        for (int u = 0; u < p; ++u)
-            for (int v = 0; v < p; ++v) {
-                mf += sf[(ty + u) * E + tx + v];
-                my += sy[(ty + u) * E + tx + v];
-            }
-        mf *= inv;
-        my *= inv;
-        float vf = 0.f, vy = 0.f, cv = 0.f;
-        for (int u = 0; u < p; ++u)
-            for (int v = 0; v < p; ++v) {
-                const float df = sf[(ty + u) * E + tx + v] - mf, dy = sy[(ty + u) * E + tx + v] - my;
-                vf = fmaf(df, df, vf);
-                vy = fmaf(dy, dy, vy);
-                cv = fmaf(df, dy, cv);
-            }
-        vf = vf * inv + eps;
-        vy = vy * inv + eps;
-        cv *= inv;
+        float s1f = 0.f, s1y = 0.f, s2f = 0.f, s2y = 0.f, sfy = 0.f;
+        for (int u = 0; u < p; ++u) {                     // vertical
+            const int t = (ty + u) * TILE + tx;
+            s1f += hs[0][t]; s1y += hs[1][t]; s2f += hs[2][t]; s2y += hs[3][t]; sfy += hs[4][t];
+        }
+        const float mfs = s1f * inv, mys = s1y * inv;      // means relative to the shift
+        const float mf = mfs + cf, my = mys + cy;
+        const float vf = fmaxf(fmaf(-mfs, mfs, s2f * inv), 0.f) + eps, vy = fmaxf(fmaf(-mys, mys, s2y * inv), 0.f) + eps;
+        const float cv = fmaf(-mfs, mys, sfy * inv);
         const float s = sqrtf(vf * vy);
         const float ncc = cv / s;
         const size_t np = (size_t)Hp * Wp, o = ((size_t)b * Hp + oy) * Wp + ox, st = (size_t)B * np;
@@ -262,6 +270,7 @@ __global__ __launch_bounds__(TB) void k_sim_patch(PatchJobs jobs, int B, int H, 
 // G[i] (+)= scale * ( f_i SA - SB - y_i SC + SD ),  S* = sums of the maps over the patches containing i
 __global__ __launch_bounds__(TB) void k_sim_patch_grad(PatchJobs jobs, int B, int H, int W) {
     __shared__ float sm[4][(TILE + MAXP - 1) * (TILE + MAXP - 1)];
+    __shared__ float hs[4][(TILE + MAXP - 1) * TILE];
     const int job = blockIdx.z / B, b = blockIdx.z - job * B;
     const PatchJob J = jobs.j[job];
     const float* __restrict__ fimg = J.f;
@@ -283,15 +292,25 @@ __global__ __launch_bounds__(TB) void k_sim_patch_grad(PatchJobs jobs, int B, in
         for (int k = 0; k < 4; ++k) sm[k][t] = in ? maps[k * st + o] : 0.f;
     }
     __syncthreads();
+    // separable box sum of the four maps: horizontal into hs, then vertical (p + p reads instead of p^2)
+    for (int t = threadIdx.x; t < E * TILE; t += TB) {
+        const int rr = t / TILE, cc = t - rr * TILE;
+        float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f;
+        for (int v = 0; v < p; ++v) {
+            const int q = rr * E + cc + v;
+            h0 += sm[0][q]; h1 += sm[1][q]; h2 += sm[2][q]; h3 += sm[3][q];
+        }
+        hs[0][t] = h0; hs[1][t] = h1; hs[2][t] = h2; hs[3][t] = h3;
+    }
+    __syncthreads();
     const int ty = threadIdx.x / TILE, tx = threadIdx.x % TILE;
     const int r = r0 + ty, c = c0 + tx;
     if (r >= H || c >= W) return;
     float sa = 0.f, sb = 0.f, sc = 0.f, sd = 0.f;
-    for (int u = 0; u < p; ++u)
-        for (int v = 0; v < p; ++v) {
-            const int t = (ty + u) * E + tx + v;
-            sa += sm[0][t]; sb += sm[1][t]; sc += sm[2][t]; sd += sm[3][t];
-        }
+    for (int u = 0; u < p; ++u) {
+        const int t = (ty + u) * TILE + tx;
+        sa += hs[0][t]; sb += hs[1][t]; sc += hs[2][t]; sd += hs[3][t];
+    }
     const size_t i = ((size_t)b * nch + ch) * H * W + (size_t)r * W + c;
     const float g = scale * (fimg[i] * sa - sb - yimg[i] * sc + sd);
     G[((size_t)b * g_nch + g_ch) * H * W + (size_t)r * W + c] = g;
