@@ -119,3 +119,61 @@ def test_reference_evaluator_runs_on_this_drr():
         for k in [k for k in sys.modules if k == "diffdrr" or k.startswith("diffdrr.")]:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+def test_reference_initialize_drr_runs_over_the_shim(tmp_path):
+    """The reference's own DRR factory (src/xvr/renderer/load.py: read(volume, mask, labels, orientation) ->
+    DRR(subject, sdd, height, delx, width, dely, x0, y0, reverse_x_axis=, renderer=, **drr_kwargs).to(device))
+    runs unmodified over the compat shim on NIfTI files, and hands back this package's DRR with the surface xvr
+    touches afterwards (trainer.py:251-256, registrar/base.py:155-212)."""
+    import struct
+
+    saved = {k: v for k, v in sys.modules.items() if k == "diffdrr" or k.startswith("diffdrr.")}
+    try:
+        from xvr_amd.compat import install_as_diffdrr
+
+        install_as_diffdrr(force=True)
+        load = _load_ref("renderer/load.py", "xvr_ref_renderer_load")
+
+        def write_nifti(path, data, affine, dtype):
+            hdr = bytearray(348)
+            struct.pack_into("<i", hdr, 0, 348)
+            struct.pack_into("<8h", hdr, 40, 3, *data.shape, 1, 1, 1, 1)
+            struct.pack_into("<h", hdr, 70, {"<i2": 4, "<f4": 16}[dtype])
+            struct.pack_into("<h", hdr, 72, {"<i2": 16, "<f4": 32}[dtype])
+            struct.pack_into("<8f", hdr, 76, 1.0, *[float(np.linalg.norm(affine[:3, i])) for i in range(3)], 0, 0, 0, 0)
+            struct.pack_into("<f", hdr, 108, 352.0)
+            struct.pack_into("<2f", hdr, 112, 1.0, 0.0)
+            struct.pack_into("<2h", hdr, 252, 0, 1)           # qform 0, sform 1
+            for r in range(3):
+                struct.pack_into("<4f", hdr, 280 + 16 * r, *[float(x) for x in affine[r]])
+            hdr[344:348] = b"n+1\0"
+            with open(path, "wb") as f:
+                f.write(bytes(hdr) + b"\0" * 4 + np.asfortranarray(data.astype(dtype)).tobytes(order="F"))
+
+        rng = np.random.default_rng(0)
+        hu = (rng.random((12, 14, 10)) * 2000 - 1000).astype(np.float32)
+        seg = rng.integers(0, 4, size=hu.shape).astype(np.float32)
+        affine = np.diag([1.5, 1.5, 2.0, 1.0])
+        affine[:3, 3] = [-9.0, -10.0, -10.0]
+        write_nifti(tmp_path / "ct.nii", hu, affine, "<f4")
+        write_nifti(tmp_path / "seg.nii", seg, affine, "<i2")
+        drr = load.initialize_drr(str(tmp_path / "ct.nii"), str(tmp_path / "seg.nii"), "1,3", "AP", 20, 24, 1020.0, 2.0, 2.5,
+                                  1.0, -2.0, True, "trilinear", read_kwargs={}, drr_kwargs={"voxel_shift": 0.0}, device="cpu")
+        from xvr_amd.drr import DRR
+
+        assert isinstance(drr, DRR) and drr.renderer.renderer_name == "trilinear" and drr.renderer.voxel_shift == 0.0
+        assert (drr.detector.height, drr.detector.width, drr.detector.delx, drr.detector.dely) == (20, 24, 2.0, 2.5)
+        assert tuple(drr.density.shape) == hu.shape and float(drr.density.min()) >= 0.0
+        assert set(np.unique(drr.mask.numpy()).tolist()) <= {0.0, 1.0, 3.0}      # labels="1,3" keeps only those structures
+        from xvr_amd.pose import convert
+
+        pose = convert(torch.zeros(1, 3), torch.tensor([[0.0, 800.0, 0.0]]), parameterization="euler_angles", convention="ZXY")
+        src, tgt = drr.detector(pose, None)
+        assert src.shape == (1, 1, 3) and tgt.shape == (1, 20 * 24, 3)
+        drr.rescale_detector_(0.5)
+        assert (drr.detector.height, drr.detector.width) == (10, 12)
+    finally:
+        for k in [k for k in sys.modules if k == "diffdrr" or k.startswith("diffdrr.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
