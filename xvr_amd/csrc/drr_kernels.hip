@@ -9,6 +9,21 @@
 //
 // No MFMA anywhere: this is gather + interpolate, not a contraction.
 //
+// Contents, in file order:
+//   launch geometry: RenderArgs, xcd_remap, map_ray, ray_setup, trilinear taps
+//   trilinear forward (+jacobian): tri_march / tri_finish / k_trilinear_fwd
+//     sample-split forward for small launches: k_trilinear_fwd_split
+//     LDS-staged bricks (opt-in, slower): k_trilinear_fwd_lds
+//   trilinear re-march backward / atomic scatter fallback: k_trilinear_bwd
+//   voxel gradient as a gather: PoseLattice, k_gather_prep, k_gather_cull
+//     k_trilinear_gather_vol
+//     k_siddon_gather_vol
+//   pose-side backward from the jacobian: k_backward_from_jac
+//   Siddon traversal, forward / jacobian / backward / alpha-split: k_siddon
+//   ray generation and its adjoint: k_rays_fwd, k_rays_bwd, k_jac_to_cam
+//   host side: argument checks, launch helpers, split_factor, workspace layout
+//   C ABI entry points (extern "C")
+//
 // Semantics are those of oracle/diffdrr_restated.py (the restated diffdrr==0.6.0 algorithm; every
 // unpinned constant arrives through xvr_drr_spec).  Reference call sites being replaced:
 //   /root/reference/src/xvr/model/trainer.py:288   drr.renderer(volume, source, target, img, mask=seg)
