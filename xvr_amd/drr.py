@@ -15,8 +15,6 @@ from __future__ import annotations
 
 import torch
 
-import ctypes
-
 from . import _lib
 from .data import Subject
 from .detector import Detector, make_reorient
