@@ -146,6 +146,20 @@ int xvr_drr_rays_backward(const float* cam, int B, int H, int W, const float* gr
                           const float* grad_target, const float* grad_raylen, float* grad_cam, void* stream);
 
 /*
+ * Forward calls that generate their rays from the camera vector (cam [B][24] as in xvr_drr_rays_forward)
+ * instead of loading source / target / raylen: same arithmetic as xvr_drr_rays_forward followed by the
+ * forward call, bit for bit, without the [B][H*W][4] floats in between.  For callers that differentiate
+ * w.r.t. the pose only (the reference's registration loop; /root/reference/src/xvr/registrar/base.py:249):
+ * the backward is then xvr_drr_jac_to_camera_backward on the jacobian written here.
+ */
+int xvr_drr_trilinear_forward_camera(const float* volume, const float* mask, int D0, int D1, int D2, int C,
+                                     const float* cam, int B, int H, int W, const xvr_drr_spec* spec, float* out,
+                                     float* jac, unsigned long long* work, void* stream);
+int xvr_drr_siddon_forward_camera(const float* volume, const float* mask, int D0, int D1, int D2, int C,
+                                  const float* cam, int B, int H, int W, const xvr_drr_spec* spec, float* out,
+                                  float* jac, unsigned long long* work, void* stream);
+
+/*
  * Labels packed into the volume, for the mask -> channels renders of the training loop
  * (/root/reference/src/xvr/model/trainer.py:288, `renderer(..., mask=seg)`).  The label of a sample is the
  * label of its NEAREST voxel, which is always one of the 8 voxels the interpolation loads anyway; with the

@@ -96,6 +96,8 @@ EXPORTS = {
     "xvr_drr_hu_to_density": ([_P, ctypes.c_longlong, _P, ctypes.c_float, _P, _P], ctypes.c_int),
     "xvr_drr_rays_forward": ([_P, _I, _I, _I, _P, _P, _P, _P], ctypes.c_int),
     "xvr_drr_rays_backward": ([_P, _I, _I, _I, _P, _P, _P, _P, _P], ctypes.c_int),
+    "xvr_drr_trilinear_forward_camera": ([_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, ctypes.POINTER(CSpec), _P, _P, _P, _P], ctypes.c_int),
+    "xvr_drr_siddon_forward_camera": ([_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, ctypes.POINTER(CSpec), _P, _P, _P, _P], ctypes.c_int),
     "xvr_drr_pack_labels": ([_P, _P, ctypes.c_longlong, _P, _P], ctypes.c_int),
     "xvr_drr_jac_to_camera_workspace_bytes": ([_I, _I, _I], ctypes.c_size_t),
     "xvr_drr_jac_to_camera_backward": ([_P, _P, _P, _I, _I, _I, _P, _P, ctypes.c_size_t, _P], ctypes.c_int),

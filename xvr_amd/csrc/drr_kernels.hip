@@ -54,6 +54,7 @@ struct RenderArgs {
     const float* __restrict__ source;
     const float* __restrict__ target;
     const float* __restrict__ raylen;
+    const float* __restrict__ cam;  // nullable [B][24]: rays are generated from it (k_rays_fwd's arithmetic) instead of loaded
     int B, n;
     xvr_drr_spec sp;
     int grid_w, grid_h, tiles_x, blocks_per_pose;
@@ -127,10 +128,16 @@ __device__ __forceinline__ bool map_ray(const RenderArgs& A, int& b, int& r, int
             if (A.grid_w > 1 && A.grid_h > 1) {
                 const int pc = px0 + 1 < A.grid_w ? px0 + 1 : px0 - 1;
                 const int pr = py0 + 1 < A.grid_h ? py0 + 1 : py0 - 1;
-                const float* T = A.target + (size_t)b * A.n * 3;
-                const float z00 = T[((size_t)py0 * A.grid_w + px0) * 3 + 2];
-                const float zc = fabsf(T[((size_t)py0 * A.grid_w + pc) * 3 + 2] - z00);
-                const float zr = fabsf(T[((size_t)pr * A.grid_w + px0) * 3 + 2] - z00);
+                float zc, zr;   // how far the target moves along z per detector column / row
+                if (A.cam) {
+                    zc = fabsf(A.cam[24 * b + 7]);
+                    zr = fabsf(A.cam[24 * b + 6]);
+                } else {
+                    const float* T = A.target + (size_t)b * A.n * 3;
+                    const float z00 = T[((size_t)py0 * A.grid_w + px0) * 3 + 2];
+                    zc = fabsf(T[((size_t)py0 * A.grid_w + pc) * 3 + 2] - z00);
+                    zr = fabsf(T[((size_t)pr * A.grid_w + px0) * 3 + 2] - z00);
+                }
                 shape = zc > 2.f * zr ? 1 : (zr > 2.f * zc ? 2 : 0);
             }
         }
@@ -159,16 +166,34 @@ struct Ray {
 
 __device__ __forceinline__ void ray_setup(const RenderArgs& A, int b, int r, bool valid, Ray& R) {
     R.valid = valid;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) R.s[i] = A.source[3 * b + i];
-    float t[3] = {R.s[0], R.s[1], R.s[2]};
+    float t[3];
     R.L = 0.f;
-    if (valid) {
-        const float* tp = A.target + ((size_t)b * A.n + r) * 3;
-        t[0] = tp[0];
-        t[1] = tp[1];
-        t[2] = tp[2];
-        R.L = A.raylen[(size_t)b * A.n + r];
+    if (A.cam) {   // rays from the camera vector, with exactly k_rays_fwd's arithmetic (detector lattice only)
+        const float* c = A.cam + 24 * b;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) t[i] = R.s[i] = c[9 + i];
+        if (valid) {
+            const int pi = r / A.grid_w, pj = r - pi * A.grid_w;
+            const float fi = (float)pi, fj = (float)pj;
+            float l2 = 0.f;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                t[a] = fmaf(c[3 * a], fi, fmaf(c[3 * a + 1], fj, c[3 * a + 2]));
+                const float w = fmaf(c[12 + 3 * a], fi, fmaf(c[12 + 3 * a + 1], fj, c[12 + 3 * a + 2])) - c[21 + a];
+                l2 = fmaf(w, w, l2);
+            }
+            R.L = sqrtf(l2);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) t[i] = R.s[i] = A.source[3 * b + i];
+        if (valid) {
+            const float* tp = A.target + ((size_t)b * A.n + r) * 3;
+            t[0] = tp[0];
+            t[1] = tp[1];
+            t[2] = tp[2];
+            R.L = A.raylen[(size_t)b * A.n + r];
+        }
     }
     float lo = -INFINITY, hi = INFINITY;
     int ain = -1, aout = -1;
@@ -1718,8 +1743,9 @@ int fail(int code, const char* msg) {
 }
 
 int check_common(const float* volume, int D0, int D1, int D2, int C, const float* source, const float* target,
-                 const float* raylen, int B, int n, const xvr_drr_spec* sp) {
-    if (!volume || !source || !target || !raylen || !sp) return fail(XVR_DRR_E_ARG, "null pointer argument");
+                 const float* raylen, int B, int n, const xvr_drr_spec* sp, const float* cam = nullptr) {
+    if (!volume || !sp || (!cam && (!source || !target || !raylen))) return fail(XVR_DRR_E_ARG, "null pointer argument");
+    if (cam && !(sp->ray_grid_w > 1 && n / sp->ray_grid_w > 0)) return fail(XVR_DRR_E_ARG, "camera rays need a detector lattice");
     if (D0 < 2 || D1 < 2 || D2 < 2) return fail(XVR_DRR_E_ARG, "every volume dimension must be >= 2");
     if ((long long)D0 * D1 * D2 >= (1LL << 31)) return fail(XVR_DRR_E_UNSUPPORTED, "volume has >= 2^31 voxels");
     if (B <= 0 || n <= 0) return fail(XVR_DRR_E_ARG, "B and n must be positive");
@@ -1733,11 +1759,11 @@ int check_common(const float* volume, int D0, int D1, int D2, int C, const float
 
 void fill_args(RenderArgs& A, const float* volume, const float* mask, int D0, int D1, int D2, int C,
                const float* source, const float* target, const float* raylen, int B, int n,
-               const xvr_drr_spec* sp) {
+               const xvr_drr_spec* sp, const float* cam = nullptr) {
     A = RenderArgs{};
     A.volume = volume; A.mask = mask;
     A.D0 = D0; A.D1 = D1; A.D2 = D2; A.C = C;
-    A.source = source; A.target = target; A.raylen = raylen;
+    A.source = source; A.target = target; A.raylen = raylen; A.cam = cam;
     A.B = B; A.n = n; A.sp = *sp;
     A.grid_w = sp->ray_grid_w;
     static const int forced_shape = [] {
@@ -1919,11 +1945,11 @@ const char* xvr_drr_last_error(void) { return g_err; }
 // shared by the other translation units of the library (sim_kernels.hip); not part of the public header
 void xvr_drr_set_last_error(const char* msg) { snprintf(g_err, sizeof(g_err), "%s", msg ? msg : ""); }
 
-int xvr_drr_trilinear_forward(const float* volume, const float* mask, int D0, int D1, int D2, int C,
+static int trilinear_forward_impl(const float* volume, const float* mask, int D0, int D1, int D2, int C,
                               const float* source, const float* target, const float* raylen, int B, int n,
                               const xvr_drr_spec* sp, float* out, float* jac, unsigned long long* work,
-                              void* stream) {
-    int rc = check_common(volume, D0, D1, D2, C, source, target, raylen, B, n, sp);
+                              void* stream, const float* cam) {
+    int rc = check_common(volume, D0, D1, D2, C, source, target, raylen, B, n, sp, cam);
     if (rc) return rc;
     if (!out) return fail(XVR_DRR_E_ARG, "out is null");
     if (sp->n_points < 1) return fail(XVR_DRR_E_ARG, "n_points must be >= 1");
@@ -1931,7 +1957,7 @@ int xvr_drr_trilinear_forward(const float* volume, const float* mask, int D0, in
     const bool packed = !mask && C > 1;   // labels in the low mantissa bits of `volume` (xvr_drr_pack_labels)
     if (packed && C > (1 << LABEL_BITS)) return fail(XVR_DRR_E_ARG, "packed labels hold at most 16 channels");
     RenderArgs A;
-    fill_args(A, volume, mask, D0, D1, D2, C, source, target, raylen, B, n, sp);
+    fill_args(A, volume, mask, D0, D1, D2, C, source, target, raylen, B, n, sp, cam);
     A.out = out; A.jac = jac; A.work = work;
     const bool clip = sp->clip_to_volume != 0;
     const size_t lds = C > 1 || mask ? (size_t)C * WG * sizeof(float) : 0;
@@ -1966,6 +1992,22 @@ int xvr_drr_trilinear_forward(const float* volume, const float* mask, int D0, in
                          : launch(k_trilinear_fwd<true, 0, false>, A, 0, stream);
     return clip ? launch(k_trilinear_fwd<false, 0, true>, A, 0, stream)
                 : launch(k_trilinear_fwd<false, 0, false>, A, 0, stream);
+}
+
+int xvr_drr_trilinear_forward(const float* volume, const float* mask, int D0, int D1, int D2, int C,
+                           const float* source, const float* target, const float* raylen, int B, int n,
+                           const xvr_drr_spec* sp, float* out, float* jac, unsigned long long* work, void* stream) {
+    return trilinear_forward_impl(volume, mask, D0, D1, D2, C, source, target, raylen, B, n, sp, out, jac, work, stream, nullptr);
+}
+
+int xvr_drr_trilinear_forward_camera(const float* volume, const float* mask, int D0, int D1, int D2, int C,
+                                  const float* cam, int B, int H, int W, const xvr_drr_spec* sp, float* out, float* jac,
+                                  unsigned long long* work, void* stream) {
+    if (!cam || !sp) return fail(XVR_DRR_E_ARG, "null pointer argument");
+    if (H < 1 || W < 2 || (long long)H * W >= (1LL << 31)) return fail(XVR_DRR_E_ARG, "detector must be at least 1 x 2");
+    xvr_drr_spec local = *sp;
+    local.ray_grid_w = W;
+    return trilinear_forward_impl(volume, mask, D0, D1, D2, C, nullptr, nullptr, nullptr, B, H * W, &local, out, jac, work, stream, cam);
 }
 
 int xvr_drr_trilinear_backward(const float* volume, const float* mask, int D0, int D1, int D2, int C,
@@ -2018,17 +2060,17 @@ int xvr_drr_trilinear_backward(const float* volume, const float* mask, int D0, i
 #undef TRI_BWD
 }
 
-int xvr_drr_siddon_forward(const float* volume, const float* mask, int D0, int D1, int D2, int C,
+static int siddon_forward_impl(const float* volume, const float* mask, int D0, int D1, int D2, int C,
                            const float* source, const float* target, const float* raylen, int B, int n,
                            const xvr_drr_spec* sp, float* out, float* jac, unsigned long long* work,
-                           void* stream) {
-    int rc = check_common(volume, D0, D1, D2, C, source, target, raylen, B, n, sp);
+                           void* stream, const float* cam) {
+    int rc = check_common(volume, D0, D1, D2, C, source, target, raylen, B, n, sp, cam);
     if (rc) return rc;
     if (!out) return fail(XVR_DRR_E_ARG, "out is null");
     const bool packed = !mask && C > 1;   // labels in the low mantissa bits of `volume` (xvr_drr_pack_labels)
     if (packed && C > (1 << LABEL_BITS)) return fail(XVR_DRR_E_ARG, "packed labels hold at most 16 channels");
     RenderArgs A;
-    fill_args(A, volume, mask, D0, D1, D2, C, source, target, raylen, B, n, sp);
+    fill_args(A, volume, mask, D0, D1, D2, C, source, target, raylen, B, n, sp, cam);
     A.out = out; A.jac = jac; A.work = work;
     const size_t lds = C > 1 || mask ? (size_t)C * WG * sizeof(float) : 0;
     const bool ex = siddon_exact_geometry(sp);
@@ -2046,6 +2088,22 @@ int xvr_drr_siddon_forward(const float* volume, const float* mask, int D0, int D
     }
     if (jac) return (ex ? launch(k_siddon<1, false, false, false, true>, A, 0, stream) : launch(k_siddon<1, false, false, false, false>, A, 0, stream));
     return (ex ? launch(k_siddon<0, false, false, false, true>, A, 0, stream) : launch(k_siddon<0, false, false, false, false>, A, 0, stream));
+}
+
+int xvr_drr_siddon_forward(const float* volume, const float* mask, int D0, int D1, int D2, int C,
+                           const float* source, const float* target, const float* raylen, int B, int n,
+                           const xvr_drr_spec* sp, float* out, float* jac, unsigned long long* work, void* stream) {
+    return siddon_forward_impl(volume, mask, D0, D1, D2, C, source, target, raylen, B, n, sp, out, jac, work, stream, nullptr);
+}
+
+int xvr_drr_siddon_forward_camera(const float* volume, const float* mask, int D0, int D1, int D2, int C,
+                                  const float* cam, int B, int H, int W, const xvr_drr_spec* sp, float* out, float* jac,
+                                  unsigned long long* work, void* stream) {
+    if (!cam || !sp) return fail(XVR_DRR_E_ARG, "null pointer argument");
+    if (H < 1 || W < 2 || (long long)H * W >= (1LL << 31)) return fail(XVR_DRR_E_ARG, "detector must be at least 1 x 2");
+    xvr_drr_spec local = *sp;
+    local.ray_grid_w = W;
+    return siddon_forward_impl(volume, mask, D0, D1, D2, C, nullptr, nullptr, nullptr, B, H * W, &local, out, jac, work, stream, cam);
 }
 
 int xvr_drr_siddon_backward(const float* volume, const float* mask, int D0, int D1, int D2, int C,

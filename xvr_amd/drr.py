@@ -19,7 +19,7 @@ from . import _lib
 from .data import Subject
 from .detector import Detector, make_reorient
 from .pose import RigidTransform, convert
-from .renderers import Siddon, Trilinear, _ptr, _stream, _timed
+from .renderers import Siddon, Trilinear, _ptr, _stream, _timed, render_from_camera
 
 __all__ = ["DRR", "rays_from_camera"]
 
@@ -140,9 +140,17 @@ class DRR(torch.nn.Module):
                     *args, parameterization=parameterization, convention=convention)
                 batch_size = len(pose)
                 cam = torch.addmm(c, pose.matrix[:, :3, :].reshape(batch_size, 12), G.T)
-            source, target, img = rays_from_camera(cam, self.detector.height, self.detector.width)
-            kwargs["mask"] = self.mask if mask_to_channels else None
-            img = self.renderer(density, source, target, img, **kwargs)
+            spec_keys = {"n_points", "align_corners"} if self.renderer.renderer_name == "trilinear" else {"align_corners"}
+            if (not mask_to_channels and set(kwargs) <= spec_keys and not density.requires_grad and self.detector.width > 1
+                    and density.dtype == torch.float32 and density.dim() == 3):
+                # pose gradient only, one channel (the registration loop): the render kernel generates the rays
+                # itself and the backward is one fixed-order kernel -- no [B, n, 3] targets in between
+                img = render_from_camera(density, cam, self.renderer.make_spec(**kwargs), self.detector.height,
+                                         self.detector.width)
+            else:
+                source, target, img = rays_from_camera(cam, self.detector.height, self.detector.width)
+                kwargs["mask"] = self.mask if mask_to_channels else None
+                img = self.renderer(density, source, target, img, **kwargs)
         else:
             pose = args[0] if parameterization is None else convert(
                 *args, parameterization=parameterization, convention=convention)

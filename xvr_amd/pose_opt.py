@@ -1,12 +1,11 @@
 """Device-resident pose optimisation for the registration loop (include/xvr_pose.h).
 
 ``RegistrationStage`` runs one pyramid stage of ``_RegistrarBase.run_test_time_optimization``
-(/root/reference/src/xvr/registrar/base.py:245-280) as SIX C-ABI calls per iteration and no
+(/root/reference/src/xvr/registrar/base.py:245-280) as FIVE C-ABI calls per iteration and no
 autograd tape:
 
     pose -> camera            xvr_pose_camera_forward          (reg(): convert + detector + affine_inverse)
-    camera -> rays            xvr_drr_rays_forward
-    rays -> DRR + jacobian    xvr_drr_{trilinear,siddon}_forward
+    camera -> DRR + jacobian  xvr_drr_{trilinear,siddon}_forward_camera   (rays generated in the kernel)
     DRR -> similarity + grad  xvr_sim_ncc_forward_backward     (transform, imagesim, backward of both)
     grad -> camera            xvr_drr_jac_to_camera_backward   (loss.backward() through renderer and rays)
     camera -> pose, Adam, ReduceLROnPlateau, stopping rule     xvr_pose_opt_step
@@ -105,11 +104,10 @@ class RegistrationStage:
         self.max_iters = int(max_iters)
         self.rspec = drr.renderer.make_spec()
         self.cspec = make_cspec(tuple(drr.density.shape), self.rspec, self.W)
-        self.render_fn = (self.lib.xvr_drr_trilinear_forward if self.rspec.renderer == "trilinear"
-                          else self.lib.xvr_drr_siddon_forward)
+        self.render_fn = (self.lib.xvr_drr_trilinear_forward_camera if self.rspec.renderer == "trilinear"
+                          else self.lib.xvr_drr_siddon_forward_camera)
         f = dict(device=dev, dtype=torch.float32)
         self.cam, self.g_cam = torch.empty(B, 24, **f), torch.zeros(B, 24, **f)
-        self.source, self.target, self.raylen = torch.empty(B, 3, **f), torch.empty(B, n, 3, **f), torch.empty(B, n, **f)
         nbytes = self.lib.xvr_drr_jac_to_camera_workspace_bytes(B, self.H, self.W)
         self.j2c_ws = torch.zeros((nbytes + 3) // 4, **f)   # zero-filled once; every call leaves it ready for the next
         self.img, self.g_img = torch.empty(B, 1, self.H, self.W, **f), torch.empty(B, 1, self.H, self.W, **f)
@@ -121,17 +119,15 @@ class RegistrationStage:
                    "xvr_pose_opt_init")
         self.graph = None
 
-    # -- the six calls --------------------------------------------------------------------------
+    # -- the five calls --------------------------------------------------------------------------
     def render(self):
         lib, B, H, W, n, s = self.lib, self.B, self.H, self.W, self.n, _stream()
         vol = self.drr.density
         _lib.check(_timed("pose_camera_forward", lib.xvr_pose_camera_forward, _ptr(self.rot), _ptr(self.xyz), B, self.axes,
                           _ptr(self.G), _ptr(self.c), _ptr(self.cam), s), "xvr_pose_camera_forward")
-        _lib.check(_timed("rays_forward", lib.xvr_drr_rays_forward, _ptr(self.cam), B, H, W, _ptr(self.source),
-                          _ptr(self.target), _ptr(self.raylen), s), "xvr_drr_rays_forward")
-        _lib.check(_timed(f"{self.rspec.renderer}_forward+jac", self.render_fn, _ptr(vol), None, *vol.shape, 1,
-                          _ptr(self.source), _ptr(self.target), _ptr(self.raylen), B, n, ctypes.byref(self.cspec),
-                          _ptr(self.img), _ptr(self.jac), None, s), f"xvr_drr_{self.rspec.renderer}_forward")
+        _lib.check(_timed(f"{self.rspec.renderer}_forward+jac", self.render_fn, _ptr(vol), None, *vol.shape, 1, _ptr(self.cam), B, H, W,
+                          ctypes.byref(self.cspec), _ptr(self.img), _ptr(self.jac), None, s),
+                   f"xvr_drr_{self.rspec.renderer}_forward_camera")
 
     def iteration(self):
         lib, B, H, W, n = self.lib, self.B, self.H, self.W, self.n

@@ -25,7 +25,7 @@ import torch
 from . import _lib
 from .spec import RenderSpec
 
-__all__ = ["Siddon", "Trilinear", "render", "make_cspec"]
+__all__ = ["Siddon", "Trilinear", "render", "render_from_camera", "make_cspec"]
 
 
 def make_cspec(shape, spec: RenderSpec, ray_grid_w: int = 0) -> _lib.CSpec:
@@ -80,7 +80,7 @@ def _check_gpu_f32(name, t):
 
 
 # Device scratch for the backward pass (voxel-driven gather: packed rays + per-pose projection
-# constants), one buffer per device, grown on demand and reused across calls on the same stream.
+# constants), one buffer per (device, stream), grown on demand and reused across calls.
 # VOXEL_GATHER = False withholds it, which forces the atomic scatter fallback (tests, A/B runs).
 VOXEL_GATHER = True
 _WORKSPACES = {}
@@ -90,9 +90,10 @@ def _workspace(lib, B, n, shape, device):
     if not VOXEL_GATHER:
         return None, 0
     nbytes = lib.xvr_drr_backward_workspace_bytes(B, n, *shape)
-    ws = _WORKSPACES.get(device)
+    key = (device, torch.cuda.current_stream(device).cuda_stream)   # one scratch per stream: concurrent backwards
+    ws = _WORKSPACES.get(key)                                        # on two streams must not share it
     if ws is None or ws.numel() * 4 < nbytes:
-        ws = _WORKSPACES[device] = torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
+        ws = _WORKSPACES[key] = torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
     return ws, ws.numel() * 4
 
 
@@ -198,6 +199,58 @@ class _Render(torch.autograd.Function):
         g_target = gtgt if need_pose and ctx.needs_input_grad[2] else None
         g_img = glen.reshape(ctx.img_shape) if need_pose and ctx.needs_input_grad[3] else None
         return gvol, g_source, g_target, g_img, None, None, None, None, None
+
+
+class _RenderFromCamera(torch.autograd.Function):
+    """cam [B,24] -> DRRs [B,1,H*W] with the rays generated inside the render kernel; backward =
+    jacobian -> camera in one fixed-order kernel (xvr_drr_jac_to_camera_backward).  Pose gradient only,
+    one channel: what the reference's registration loop differentiates."""
+
+    @staticmethod
+    def forward(ctx, cam, volume, spec: RenderSpec, H: int, W: int):
+        lib = _lib.load()
+        cam_c, vol_c = cam.contiguous(), volume.contiguous()
+        B, n = cam_c.shape[0], H * W
+        cs = make_cspec(tuple(vol_c.shape), spec, W)
+        need = ctx.needs_input_grad[0]
+        out = torch.empty(B, 1, n, device=cam.device, dtype=torch.float32)
+        jac = torch.empty(B, n, _lib.JAC_STRIDE, device=cam.device, dtype=torch.float32) if need else None
+        fn = lib.xvr_drr_trilinear_forward_camera if spec.renderer == "trilinear" else lib.xvr_drr_siddon_forward_camera
+        rc = _timed(f"{spec.renderer}_forward" + ("+jac" if need else ""), fn, _ptr(vol_c), None, *vol_c.shape, 1, _ptr(cam_c),
+                    B, H, W, ctypes.byref(cs), _ptr(out), _ptr(jac), None, _stream())
+        _lib.check(rc, f"xvr_drr_{spec.renderer}_forward_camera")
+        ctx.save_for_backward(cam_c, jac)
+        ctx.hw = (H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        cam_c, jac = ctx.saved_tensors
+        H, W = ctx.hw
+        B = cam_c.shape[0]
+        g_cam = torch.empty_like(cam_c)
+        nbytes = lib.xvr_drr_jac_to_camera_workspace_bytes(B, H, W)
+        key = ("j2c", cam_c.device, torch.cuda.current_stream(cam_c.device).cuda_stream)
+        ws = _WORKSPACES.get(key)
+        if ws is None or ws.numel() * 4 < nbytes:   # zero-filled once; every call leaves it ready for the next
+            ws = _WORKSPACES[key] = torch.zeros((nbytes + 3) // 4, device=cam_c.device, dtype=torch.float32)
+        rc = _timed("jac_to_camera_backward", lib.xvr_drr_jac_to_camera_backward, _ptr(jac), _ptr(gout.contiguous()), _ptr(cam_c),
+                    B, H, W, _ptr(g_cam), _ptr(ws), ws.numel() * 4, _stream())
+        _lib.check(rc, "xvr_drr_jac_to_camera_backward")
+        return g_cam, None, None, None, None
+
+
+def render_from_camera(volume, cam, spec: RenderSpec, height: int, width: int):
+    """One-channel render straight from the camera vector of ``DRR.camera`` / ``pose_camera`` ([B,24]); the
+    volume is treated as a constant (no voxel gradient on this path)."""
+    _check_gpu_f32("volume", volume)
+    _check_gpu_f32("cam", cam)
+    if volume.dim() != 3 or cam.dim() != 2 or cam.shape[1] != 24:
+        raise ValueError("volume must be [D0, D1, D2] and cam [B, 24]")
+    if cam.shape[0] == 0:
+        return (cam.sum() * 0).expand(0, 1, height * width)
+    return _RenderFromCamera.apply(cam, volume, spec, int(height), int(width))
 
 
 def render(volume, source, target, img, spec: RenderSpec, mask=None, ray_grid_w: int = 0, n_channels=None, work=None):
