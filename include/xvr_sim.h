@@ -13,6 +13,8 @@
  *
  * One call computes the similarity of every image of the batch AND its exact gradient w.r.t. the raw
  * (un-transformed) moving image, including the terms through the global min / max of Standardize.
+ * A term whose weight is zero is not computed: beta = 1 is the multiscale NCC alone (the training loss,
+ * /root/reference/src/xvr/model/loss.py:16,27 -- fixed_sobel is then unused and may alias fixed).
  * All pointers are device pointers; kernels are enqueued on `stream`; returns 0 or a negative
  * XVR_DRR_E_* code (message via xvr_drr_last_error()).
  */
@@ -35,6 +37,9 @@ typedef struct xvr_sim_spec {
     int   per_image;      /* 0: Standardize by the min/max of the WHOLE batch tensor, as the reference's
                              transform does (identical for B = 1); 1: by each image's own min/max, so that
                              the images of a batch are independent problems (batched multi-start)        */
+    int   pre_transformed;/* 1: `moving` is already transformed (y = moving; mean / std / std_eps unused, no
+                             min/max terms in the gradient): the training loss, which transforms both images
+                             before it calls the similarity (/root/reference/src/xvr/model/trainer.py:215-218)  */
 } xvr_sim_spec;
 
 /* bytes of device scratch for a batch of B images of H x W */

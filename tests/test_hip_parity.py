@@ -938,3 +938,39 @@ def test_render_from_camera_is_rays_then_render_bit_for_bit(renderer, hw):
     # camera_affine(): the same numbers to fp32 rounding)
     img = drr(pose)
     _close(img.reshape(B, 1, -1), a, FWD_TOL, "DRR.forward vs render_from_camera")
+
+
+@pytest.mark.parametrize("shape", [(1, 40, 36), (5, 64, 64), (3, 33, 47)])
+@pytest.mark.parametrize("patch", [9, 3])
+def test_multiscale_ncc_module_dispatches_to_hip_and_matches_torch(shape, patch, monkeypatch):
+    """MultiscaleNormalizedCrossCorrelation2d([None, p], [.5, .5]) -- the training loss's similarity and half of
+    the registration's -- on CUDA float32 runs the fused kernels (beta = 1, pre-transformed); values and the
+    gradients w.r.t. BOTH images against the float64 torch formulation and the literal unfold oracle."""
+    from oracle.metrics_restated import multiscale_ncc as multiscale_ncc_unfold
+    from xvr_amd import metrics
+
+    B, H, W = shape
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(B, 1, H, W, generator=g).cuda().requires_grad_()
+    y = (0.6 * x.detach() + 0.4 * torch.rand(B, 1, H, W, generator=g).cuda()).requires_grad_()
+    w = torch.rand(B, generator=g).cuda() + 0.5
+    sim = metrics.MultiscaleNormalizedCrossCorrelation2d([None, patch], [0.5, 0.5])
+    out = sim(x, y)
+    (out * w).sum().backward()
+    gx, gy = x.grad.clone(), y.grad.clone()
+    x.grad = y.grad = None
+    monkeypatch.setattr(metrics.MultiscaleNormalizedCrossCorrelation2d, "FUSED", False)
+    ref = sim(x, y)
+    (ref * w).sum().backward()
+    assert torch.allclose(out, ref, rtol=2e-5, atol=2e-6), (out - ref).abs().max()
+    for a, b, name in ((gx, x.grad, "d/dx"), (gy, y.grad, "d/dy")):
+        assert (a - b).abs().max() <= 2e-4 * b.abs().max(), (name, (a - b).abs().max(), b.abs().max())
+    orc = multiscale_ncc_unfold(x.detach().cpu(), y.detach().cpu(), (None, patch), (0.5, 0.5))
+    assert torch.allclose(out.cpu(), orc.float(), rtol=2e-5, atol=2e-6)
+    # only one side needs a gradient: one kernel call, the other gradient is None
+    x2 = x.detach().clone()
+    out2 = metrics.MultiscaleNormalizedCrossCorrelation2d([None, patch], [0.5, 0.5])
+    monkeypatch.setattr(metrics.MultiscaleNormalizedCrossCorrelation2d, "FUSED", True)
+    y.grad = None
+    (out2(x2, y) * w).sum().backward()
+    assert torch.allclose(y.grad, gy, rtol=1e-6, atol=0)

@@ -39,6 +39,7 @@ class CSimSpec(ctypes.Structure):
         ("mncc_patch", ctypes.c_int),
         ("gncc_patch", ctypes.c_int),
         ("per_image", ctypes.c_int),
+        ("pre_transformed", ctypes.c_int),
     ]
 
 

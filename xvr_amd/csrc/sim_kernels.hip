@@ -149,7 +149,8 @@ __global__ __launch_bounds__(TB) void k_sim_prep(const float* __restrict__ m, co
     const float mn = dec(hd->enc_min), mx = dec(hd->enc_max);
     const float r = (mx - mn) + sp.std_eps;
     const float* M = m + (size_t)b * hw;
-    auto yof = [&](float v) { return (((v - mn) / r) - sp.mean) / sp.std; };
+    const bool pre = sp.pre_transformed != 0;   // the moving image is already transformed: y = m
+    auto yof = [&](float v) { return pre ? v : (((v - mn) / r) - sp.mean) / sp.std; };
     auto at = [&](int rr, int cc) { return (rr >= 0 && rr < H && cc >= 0 && cc < W) ? yof(M[rr * W + cc]) : 0.f; };
     double s[5] = {0, 0, 0, 0, 0};
     int cmin = 0, cmax = 0;
@@ -162,6 +163,7 @@ __global__ __launch_bounds__(TB) void k_sim_prep(const float* __restrict__ m, co
         s[0] += yy; s[1] += (double)yy * yy; s[2] += ff; s[3] += (double)ff * ff; s[4] += (double)ff * yy;
         cmin += v == mn;
         cmax += v == mx;
+        if (sp.beta >= 1.f) continue;   // no gradient-NCC term: nobody reads the Sobel pair
         const int rr = i / W, c = i - rr * W;
         const float a00 = at(rr - 1, c - 1), a01 = at(rr - 1, c), a02 = at(rr - 1, c + 1);
         const float a10 = at(rr, c - 1), a12 = at(rr, c + 1);
@@ -328,7 +330,7 @@ __global__ __launch_bounds__(TB) void k_sim_final(const float* __restrict__ m, c
     hd += sp.per_image ? b : 0;
     const float mn = dec(hd->enc_min), mx = dec(hd->enc_max);
     const float r = (mx - mn) + sp.std_eps;
-    const float a = 1.f / (r * sp.std);
+    const float a = sp.pre_transformed ? 1.f : 1.f / (r * sp.std);
     const double* A = acc + (size_t)b * N_ACC;
     const double n = (double)hw;
     const double muy = A[0] / n, muf = A[2] / n;
@@ -340,18 +342,20 @@ __global__ __launch_bounds__(TB) void k_sim_final(const float* __restrict__ m, c
         const int rr = i / W, cc = i - rr * W;
         const size_t k = (size_t)b * hw + i;
         const float yy = y[k], ff = f[k];
-        float G = Gy[k];
+        float G = sp.beta > 0.f ? Gy[k] : 0.f;   // (a term with zero weight is not computed at all)
         G += (float)(0.5 * sp.beta / n * ((ff - muf) / sg - cov * (yy - muy) / (vy * sg)));
         // Sobel^T: dL/dy[r,c] = sum_{u,v} K[u][v] * Gg[r - u + 1, c - v + 1]
         const float* gx = Gg + ((size_t)b * 2 + 0) * hw;
         const float* gy = Gg + ((size_t)b * 2 + 1) * hw;
         auto at = [&](const float* P, int r2, int c2) { return (r2 >= 0 && r2 < H && c2 >= 0 && c2 < W) ? P[r2 * W + c2] : 0.f; };
-        // Kx = [[1,0,-1],[2,0,-2],[1,0,-1]]
-        G += at(gx, rr + 1, cc + 1) - at(gx, rr + 1, cc - 1) + 2.f * (at(gx, rr, cc + 1) - at(gx, rr, cc - 1)) +
-             at(gx, rr - 1, cc + 1) - at(gx, rr - 1, cc - 1);
-        // Ky = [[1,2,1],[0,0,0],[-1,-2,-1]]
-        G += at(gy, rr + 1, cc + 1) + 2.f * at(gy, rr + 1, cc) + at(gy, rr + 1, cc - 1) -
-             (at(gy, rr - 1, cc + 1) + 2.f * at(gy, rr - 1, cc) + at(gy, rr - 1, cc - 1));
+        if (sp.beta < 1.f) {
+            // Kx = [[1,0,-1],[2,0,-2],[1,0,-1]]
+            G += at(gx, rr + 1, cc + 1) - at(gx, rr + 1, cc - 1) + 2.f * (at(gx, rr, cc + 1) - at(gx, rr, cc - 1)) +
+                 at(gx, rr - 1, cc + 1) - at(gx, rr - 1, cc - 1);
+            // Ky = [[1,2,1],[0,0,0],[-1,-2,-1]]
+            G += at(gy, rr + 1, cc + 1) + 2.f * at(gy, rr + 1, cc) + at(gy, rr + 1, cc - 1) -
+                 (at(gy, rr - 1, cc + 1) + 2.f * at(gy, rr - 1, cc) + at(gy, rr - 1, cc - 1));
+        }
         const float x = (m[k] - mn) / r;
         if (grad) grad[k] = a * G;
         s2[0] = (double)G * (1.0 - x);
@@ -479,7 +483,8 @@ int xvr_sim_ncc_forward_backward(const float* fixed, const float* fixed_sobel, c
     const unsigned groups = per_image ? (unsigned)B : 1u;
     const long long want = (n_mm + (long long)TB * 16 - 1) / ((long long)TB * 16);
     const unsigned rb = (unsigned)(want < 1 ? 1 : (want > 256 ? 256 : want));
-    hipLaunchKernelGGL(k_sim_minmax, dim3(rb, groups), dim3(TB), 0, stream, moving, n_mm, hd);
+    const bool pre = sp->pre_transformed != 0;   // no Standardize: no min/max, no gradient through them
+    if (!pre) hipLaunchKernelGGL(k_sim_minmax, dim3(rb, groups), dim3(TB), 0, stream, moving, n_mm, hd);
     unsigned* tickets = reinterpret_cast<unsigned*>(ws + L.tickets);
     const unsigned pb = (unsigned)((hw + TB - 1) / TB < (int)PREP_BLOCKS_MAX ? (hw + TB - 1) / TB : PREP_BLOCKS_MAX);
     hipLaunchKernelGGL(k_sim_prep, dim3(pb, B), dim3(TB), 0, stream, moving, fixed, H, W, hd, *sp, y, gyb, acc,
@@ -492,8 +497,11 @@ int xvr_sim_ncc_forward_backward(const float* fixed, const float* fixed_sobel, c
     jobs.j[0] = {fixed, y, 1, 0, p1, m1, 5, sc1, Gy, 1, 0};
     jobs.j[1] = {fixed_sobel, gyb, 2, 0, p2, m2, 6, sc2, Gg, 2, 0};
     jobs.j[2] = {fixed_sobel, gyb, 2, 1, p2, m2 + 4 * np2, 7, sc2, Gg, 2, 1};
-    const int pmin = p1 < p2 ? p1 : p2;
-    auto tiles = [&](int hh, int ww) { return dim3((ww + TILE - 1) / TILE, (hh + TILE - 1) / TILE, 3 * B); };
+    // a term with zero weight is not computed: beta = 1 drops the two gradient-NCC jobs, beta = 0 the local mNCC
+    int njobs = 3, pmin = p1 < p2 ? p1 : p2;
+    if (sp->beta >= 1.f) { njobs = 1; pmin = p1; }
+    else if (sp->beta <= 0.f) { jobs.j[0] = jobs.j[1]; jobs.j[1] = jobs.j[2]; njobs = 2; pmin = p2; }
+    auto tiles = [&](int hh, int ww) { return dim3((ww + TILE - 1) / TILE, (hh + TILE - 1) / TILE, njobs * B); };
     hipLaunchKernelGGL(k_sim_patch, tiles(H - pmin + 1, W - pmin + 1), dim3(TB), 0, stream, jobs, B, H, W, sp->ncc_eps, acc,
                        reinterpret_cast<double*>(ws + L.part_patch), tickets + B);
     hipLaunchKernelGGL(k_sim_patch_grad, tiles(H, W), dim3(TB), 0, stream, jobs, B, H, W);
@@ -501,7 +509,7 @@ int xvr_sim_ncc_forward_backward(const float* fixed, const float* fixed_sobel, c
                        *sp, grad_moving, reinterpret_cast<double*>(ws + L.part_final), tickets + 4 * B);
     const long long want2 = (n_mm + (long long)TB * 4 - 1) / ((long long)TB * 4);
     const unsigned gb = (unsigned)(want2 < 1 ? 1 : (want2 > 1024 ? 1024 : want2));
-    if (grad_moving) hipLaunchKernelGGL(k_sim_minmax_grad, dim3(gb, groups), dim3(TB), 0, stream, moving, n_mm, hd, *sp, grad_moving, acc, B, H, W, loss);
+    if (grad_moving && !pre) hipLaunchKernelGGL(k_sim_minmax_grad, dim3(gb, groups), dim3(TB), 0, stream, moving, n_mm, hd, *sp, grad_moving, acc, B, H, W, loss);
     else hipLaunchKernelGGL(k_sim_loss, dim3((B + 63) / 64), dim3(64), 0, stream, acc, B, H, W, *sp, loss);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return sim_fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));

@@ -65,7 +65,27 @@ class MultiscaleNormalizedCrossCorrelation2d(torch.nn.Module):
         self.patch_weights = list(patch_weights)
 
     def forward(self, x1, x2):
+        if self._hip_ok(x1, x2):
+            from .similarity import fused_mncc   # (imported late: similarity.py imports this module)
+
+            return fused_mncc(x1, x2, self.nccs[1].patch_size, self.nccs[1].eps)
         return sum(w * ncc(x1, x2) for w, ncc in zip(self.patch_weights, self.nccs))
+
+    # ``[None, p]`` with weights ``[0.5, 0.5]`` -- the configuration of both of xvr's loops
+    # (/root/reference/src/xvr/registrar/base.py:119-121, /root/reference/src/xvr/model/loss.py:16) -- on float32
+    # CUDA images of one channel goes through the fused HIP kernels (xvr_sim_ncc_forward_backward with
+    # beta = 1, pre_transformed = 1): one thread per patch from LDS tiles instead of fp64 box filters.
+    # FUSED = False keeps the torch formulation (the cross-check in tests).
+    FUSED = True
+
+    def _hip_ok(self, x1, x2):
+        if not (self.FUSED and len(self.nccs) == 2 and self.patch_weights == [0.5, 0.5]):
+            return False
+        p0, p1 = self.nccs[0].patch_size, self.nccs[1].patch_size
+        if p0 is not None or p1 is None or not (1 <= p1 <= 15) or self.nccs[0].eps != self.nccs[1].eps:
+            return False
+        return (x1.is_cuda and x2.is_cuda and x1.dtype == x2.dtype == torch.float32 and x1.shape == x2.shape and x1.dim() == 4
+                and x1.shape[1] == 1 and x1.shape[0] > 0 and min(x1.shape[2:]) >= p1)
 
 
 class Sobel(torch.nn.Module):

@@ -61,7 +61,7 @@ class FusedSimilarity(torch.nn.Module):
             raise RuntimeError("FusedSimilarity needs a float32 CUDA target of shape [B,1,H,W] (HIP kernels, no CPU path)")
         self.register_buffer("fixed", fixed.contiguous())
         self.register_buffer("fixed_sobel", Sobel(0.0).to(fixed.device)(fixed).contiguous())
-        self.spec = _lib.CSimSpec(mean, std, 1e-6, eps, beta, int(mncc_patch_size), int(gncc_patch_size), int(bool(per_image)))
+        self.spec = _lib.CSimSpec(mean, std, 1e-6, eps, beta, int(mncc_patch_size), int(gncc_patch_size), int(bool(per_image)), 0)
         B, _, H, W = fixed.shape
         nbytes = _lib.load().xvr_sim_workspace_bytes(B, H, W)
         self.register_buffer("workspace", torch.empty((nbytes + 3) // 4, device=fixed.device, dtype=torch.float32), persistent=False)
@@ -76,3 +76,42 @@ class FusedSimilarity(torch.nn.Module):
         if moving.shape != self.fixed.shape:
             raise ValueError(f"moving {tuple(moving.shape)} and fixed {tuple(self.fixed.shape)} differ")
         return _FusedNCC.apply(moving, self.fixed, self.fixed_sobel, self.spec, self.workspace)
+
+
+class _FusedMNCC(torch.autograd.Function):
+    """0.5 NCC(x, y) + 0.5 patch-NCC_p(x, y) per image for already transformed images; NCC is symmetric, so the
+    gradient w.r.t. either argument is the same kernel with the roles swapped."""
+
+    @staticmethod
+    def forward(ctx, x, y, patch, eps):
+        lib = _lib.load()
+        xc, yc = x.contiguous(), y.contiguous()
+        B, _, H, W = xc.shape
+        spec = _lib.CSimSpec(0.0, 1.0, 0.0, float(eps), 1.0, int(patch), int(patch), 0, 1)
+        nbytes = lib.xvr_sim_workspace_bytes(B, H, W)
+        ws = torch.empty((nbytes + 3) // 4, device=x.device, dtype=torch.float32)
+        loss = torch.empty(B, device=x.device, dtype=torch.float32)
+        gx = gy = None
+        if ctx.needs_input_grad[1] or not ctx.needs_input_grad[0]:
+            gy = torch.empty_like(yc) if ctx.needs_input_grad[1] else None
+            rc = _timed("mncc_forward_backward", lib.xvr_sim_ncc_forward_backward, _ptr(xc), _ptr(xc), _ptr(yc), B, H, W,
+                        ctypes.byref(spec), _ptr(loss), _ptr(gy), _ptr(ws), ws.numel() * 4, _stream())
+            _lib.check(rc, "xvr_sim_ncc_forward_backward")
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(xc)
+            rc = _timed("mncc_forward_backward", lib.xvr_sim_ncc_forward_backward, _ptr(yc), _ptr(yc), _ptr(xc), B, H, W,
+                        ctypes.byref(spec), _ptr(loss), _ptr(gx), _ptr(ws), ws.numel() * 4, _stream())
+            _lib.check(rc, "xvr_sim_ncc_forward_backward")
+        ctx.save_for_backward(gx, gy)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        gx, gy = ctx.saved_tensors
+        g = gout.reshape(-1, 1, 1, 1)
+        return (gx * g if gx is not None else None), (gy * g if gy is not None else None), None, None
+
+
+def fused_mncc(x, y, patch_size: int, eps: float = 1e-5):
+    """``MultiscaleNormalizedCrossCorrelation2d([None, p], [0.5, 0.5])(x, y)`` -> [B] through the HIP kernels."""
+    return _FusedMNCC.apply(x, y, int(patch_size), float(eps))
