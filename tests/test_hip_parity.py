@@ -974,3 +974,25 @@ def test_multiscale_ncc_module_dispatches_to_hip_and_matches_torch(shape, patch,
     y.grad = None
     (out2(x2, y) * w).sum().backward()
     assert torch.allclose(y.grad, gy, rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("shape", [(1, 40, 36), (4, 64, 64)])
+def test_gradient_ncc_module_dispatches_to_hip_and_matches_torch(shape, monkeypatch):
+    from xvr_amd import metrics
+
+    B, H, W = shape
+    g = torch.Generator().manual_seed(13)
+    x = torch.rand(B, 1, H, W, generator=g).cuda().requires_grad_()
+    y = (0.6 * x.detach() + 0.4 * torch.rand(B, 1, H, W, generator=g).cuda()).requires_grad_()
+    w = torch.rand(B, generator=g).cuda() + 0.5
+    sim = metrics.GradientNormalizedCrossCorrelation2d(11, 0.0).cuda()
+    out = sim(x, y)
+    (out * w).sum().backward()
+    gx, gy = x.grad.clone(), y.grad.clone()
+    x.grad = y.grad = None
+    monkeypatch.setattr(metrics.GradientNormalizedCrossCorrelation2d, "FUSED", False)
+    ref = sim(x, y)
+    (ref * w).sum().backward()
+    assert torch.allclose(out, ref, rtol=2e-5, atol=2e-6), (out - ref).abs().max()
+    for a, b, name in ((gx, x.grad, "d/dx"), (gy, y.grad, "d/dy")):
+        assert (a - b).abs().max() <= 2e-4 * b.abs().max(), (name, (a - b).abs().max(), b.abs().max())

@@ -118,7 +118,19 @@ class GradientNormalizedCrossCorrelation2d(NormalizedCrossCorrelation2d):
         super().__init__(patch_size, **kwargs)
         self.sobel = Sobel(sigma)
 
+    # A patch gradient-NCC without pre-blur -- the second half of the registration similarity,
+    # /root/reference/src/xvr/registrar/base.py:122 with the default sigma = 0 -- on float32 CUDA images of one
+    # channel goes through the fused HIP kernels (beta = 0, pre_transformed = 1).  FUSED = False: torch.
+    FUSED = True
+
     def forward(self, x1, x2):
+        p = self.patch_size
+        if (self.FUSED and p is not None and 1 <= p <= 15 and not self.sobel.sigma and x1.is_cuda and x2.is_cuda
+                and x1.dtype == x2.dtype == torch.float32 and x1.shape == x2.shape and x1.dim() == 4 and x1.shape[1] == 1
+                and x1.shape[0] > 0 and min(x1.shape[2:]) >= p):
+            from .similarity import fused_gncc
+
+            return fused_gncc(x1, x2, p, self.eps, self.sobel)
         return super().forward(self.sobel(x1), self.sobel(x2))
 
 

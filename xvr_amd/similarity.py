@@ -79,27 +79,30 @@ class FusedSimilarity(torch.nn.Module):
 
 
 class _FusedMNCC(torch.autograd.Function):
-    """0.5 NCC(x, y) + 0.5 patch-NCC_p(x, y) per image for already transformed images; NCC is symmetric, so the
-    gradient w.r.t. either argument is the same kernel with the roles swapped."""
+    """beta = 1: 0.5 NCC(x, y) + 0.5 patch-NCC_p(x, y) per image; beta = 0: patch-NCC_p of the Sobel pairs
+    (sx, sy = Sobel(x), Sobel(y), constants of the call), for already transformed images.  NCC is symmetric, so
+    the gradient w.r.t. either argument is the same kernel with the roles swapped."""
 
     @staticmethod
-    def forward(ctx, x, y, patch, eps):
+    def forward(ctx, x, y, patch, eps, beta=1.0, sx=None, sy=None):
         lib = _lib.load()
         xc, yc = x.contiguous(), y.contiguous()
         B, _, H, W = xc.shape
-        spec = _lib.CSimSpec(0.0, 1.0, 0.0, float(eps), 1.0, int(patch), int(patch), 0, 1)
+        spec = _lib.CSimSpec(0.0, 1.0, 0.0, float(eps), float(beta), int(patch), int(patch), 0, 1)
+        sx = xc if sx is None else sx.contiguous()   # (unused by the kernels when beta = 1)
+        sy = yc if sy is None else sy.contiguous()
         nbytes = lib.xvr_sim_workspace_bytes(B, H, W)
         ws = torch.empty((nbytes + 3) // 4, device=x.device, dtype=torch.float32)
         loss = torch.empty(B, device=x.device, dtype=torch.float32)
         gx = gy = None
         if ctx.needs_input_grad[1] or not ctx.needs_input_grad[0]:
             gy = torch.empty_like(yc) if ctx.needs_input_grad[1] else None
-            rc = _timed("mncc_forward_backward", lib.xvr_sim_ncc_forward_backward, _ptr(xc), _ptr(xc), _ptr(yc), B, H, W,
+            rc = _timed("mncc_forward_backward", lib.xvr_sim_ncc_forward_backward, _ptr(xc), _ptr(sx), _ptr(yc), B, H, W,
                         ctypes.byref(spec), _ptr(loss), _ptr(gy), _ptr(ws), ws.numel() * 4, _stream())
             _lib.check(rc, "xvr_sim_ncc_forward_backward")
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(xc)
-            rc = _timed("mncc_forward_backward", lib.xvr_sim_ncc_forward_backward, _ptr(yc), _ptr(yc), _ptr(xc), B, H, W,
+            rc = _timed("mncc_forward_backward", lib.xvr_sim_ncc_forward_backward, _ptr(yc), _ptr(sy), _ptr(xc), B, H, W,
                         ctypes.byref(spec), _ptr(loss), _ptr(gx), _ptr(ws), ws.numel() * 4, _stream())
             _lib.check(rc, "xvr_sim_ncc_forward_backward")
         ctx.save_for_backward(gx, gy)
@@ -109,9 +112,18 @@ class _FusedMNCC(torch.autograd.Function):
     def backward(ctx, gout):
         gx, gy = ctx.saved_tensors
         g = gout.reshape(-1, 1, 1, 1)
-        return (gx * g if gx is not None else None), (gy * g if gy is not None else None), None, None
+        return (gx * g if gx is not None else None), (gy * g if gy is not None else None), None, None, None, None, None
 
 
 def fused_mncc(x, y, patch_size: int, eps: float = 1e-5):
     """``MultiscaleNormalizedCrossCorrelation2d([None, p], [0.5, 0.5])(x, y)`` -> [B] through the HIP kernels."""
     return _FusedMNCC.apply(x, y, int(patch_size), float(eps))
+
+
+def fused_gncc(x, y, patch_size: int, eps: float, sobel):
+    """``GradientNormalizedCrossCorrelation2d(p, sigma=0)(x, y)`` -> [B] through the HIP kernels.  The kernels take
+    the Sobel pair of the image they treat as fixed ready-made (one conv2d each, only for a side that needs it)."""
+    with torch.no_grad():
+        sx = sobel(x)
+        sy = sobel(y) if x.requires_grad else None
+    return _FusedMNCC.apply(x, y, int(patch_size), float(eps), 0.0, sx, sy)
