@@ -87,6 +87,22 @@ int xvr_pose_opt_step(float* rot, float* xyz, int B, const xvr_pose_opt_spec* sp
                       float* grad_cam, const float* loss, xvr_pose_opt_state* state, float* history,
                       void* stream);
 
+/*
+ * Pose terms of the training loss (/root/reference/src/xvr/model/loss.py:27-48), which the reference evaluates
+ * with ~200 tiny framework launches per step.  Poses are row-major 4x4 matrices ([N][16]); sdd in mm.
+ *   xvr_pose_geodesic            DoubleGeodesicSE3(sdd)(a, b): out [3][N] = (angular, translational, double), all mm;
+ *                                grad_b [N][12] (nullable) = d double_n / d (R | t of b_n)
+ *   xvr_pose_multiview_forward   mvc [B (B - 1) / 2] = double geodesic between the true and the predicted relative
+ *                                pose b_j b_i^{-1} of every pair i < j, in torch.triu_indices(B, B, 1) order
+ *   xvr_pose_multiview_backward  grad_pred [B][12] = sum over pairs of grad_mvc[pair] * d mvc[pair] / d pred pose,
+ *                                added in a fixed order (no atomics)
+ */
+int xvr_pose_geodesic(const float* a, const float* b, int N, float sdd, float eps, float* out, float* grad_b, void* stream);
+int xvr_pose_multiview_forward(const float* true_pose, const float* pred_pose, int B, float sdd, float eps, float* mvc,
+                               void* stream);
+int xvr_pose_multiview_backward(const float* true_pose, const float* pred_pose, const float* grad_mvc, int B, float sdd,
+                                float eps, float* grad_pred, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -271,3 +271,40 @@ def test_fused_similarity_per_image_equals_one_image_at_a_time(shape):
         (lb * w[b]).sum().backward()
         assert torch.allclose(loss[b], lb[0], rtol=1e-6, atol=1e-7)
         assert torch.allclose(moving.grad[b], mb.grad[0], rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [2, 7, 40])
+def test_fused_pose_loss_terms_match_torch(B, monkeypatch):
+    """Double geodesic and multiview consistency of the training loss (xvr_pose_geodesic, xvr_pose_multiview_*)
+    against the torch formulation in xvr_amd.metrics / xvr_amd.loss: values and gradients w.r.t. the predicted pose."""
+    from xvr_amd import loss as loss_mod
+    from xvr_amd.training import get_random_pose
+
+    g = torch.Generator().manual_seed(5)
+    true = get_random_pose(135.0, 225.0, -45.0, 45.0, -15.0, 15.0, -150.0, 150.0, 450.0, 1000.0, -150.0, 150.0, B, generator=g).cuda()
+    rot, xyz = true.convert("euler_angles", "ZXY")
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(loss_mod.PoseRegressionLoss, "FUSED", fused)
+        r = (rot + 0.05 * torch.randn(B, 3, generator=torch.Generator().manual_seed(1)).cuda()).requires_grad_()
+        t = (xyz + 4.0 * torch.randn(B, 3, generator=torch.Generator().manual_seed(2)).cuda()).requires_grad_()
+        pred = convert(r, t, parameterization="euler_angles", convention="ZXY")
+        L = loss_mod.PoseRegressionLoss(1020.0, weight_mvc=0.5).cuda()
+        img = torch.rand(B, 1, 32, 32, generator=torch.Generator().manual_seed(3)).cuda()
+        mask = torch.rand(B, 3, 32, 32, generator=torch.Generator().manual_seed(4)).cuda() > 0.5
+        loss, mncc, dgeo, rgeo, tgeo, dice, mvc = L(img, mask, true, img * 0.9 + 0.01, mask, pred)
+        loss.mean().backward()
+        res[fused] = (loss.detach(), dgeo.detach(), rgeo.detach(), tgeo.detach(), mvc.detach(), r.grad.clone(), t.grad.clone())
+    names = ("loss", "dgeo", "rgeo", "tgeo", "mvc", "d/drot", "d/dxyz")
+    for a, b, name in zip(res[True], res[False], names):
+        assert a.shape == b.shape, name
+        assert torch.allclose(a, b, rtol=2e-4, atol=2e-4 * max(b.abs().max().item(), 1e-6)), (name, (a - b).abs().max(), b.abs().max())
+    # identical poses: zero distance, finite (zero) gradient
+    r = rot.clone().requires_grad_()
+    pred = convert(r, xyz, parameterization="euler_angles", convention="ZXY")
+    monkeypatch.setattr(loss_mod.PoseRegressionLoss, "FUSED", True)
+    L = loss_mod.PoseRegressionLoss(1020.0)
+    mv = L.multiview_consistency(true, pred)
+    mv.sum().backward()
+    assert float(mv.detach().max()) < 0.05 and torch.isfinite(r.grad).all()

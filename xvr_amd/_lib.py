@@ -104,6 +104,9 @@ EXPORTS = {
     "xvr_drr_jac_to_camera_backward": ([_P, _P, _P, _I, _I, _I, _P, _P, ctypes.c_size_t, _P], ctypes.c_int),
     "xvr_pose_camera_forward": ([_P, _P, _I, _AX, _P, _P, _P, _P], ctypes.c_int),
     "xvr_pose_camera_backward": ([_P, _P, _I, _AX, _P, _P, _P, _P, _P], ctypes.c_int),
+    "xvr_pose_geodesic": ([_P, _P, _I, ctypes.c_float, ctypes.c_float, _P, _P, _P], ctypes.c_int),
+    "xvr_pose_multiview_forward": ([_P, _P, _I, ctypes.c_float, ctypes.c_float, _P, _P], ctypes.c_int),
+    "xvr_pose_multiview_backward": ([_P, _P, _P, _I, ctypes.c_float, ctypes.c_float, _P, _P], ctypes.c_int),
     "xvr_pose_opt_state_bytes": ([], ctypes.c_size_t),
     "xvr_pose_opt_init": ([_P, _I, ctypes.c_float, ctypes.c_float, _P], ctypes.c_int),
     "xvr_pose_opt_step": ([_P, _P, _I, ctypes.POINTER(CPoseOptSpec), _P, _P, _P, _P, _P, _P], ctypes.c_int),

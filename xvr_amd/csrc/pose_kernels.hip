@@ -207,6 +207,132 @@ __global__ __launch_bounds__(64) void k_pose_opt_step(float* __restrict__ rot, f
     state[b] = s;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Double geodesic on SE(3) for the training loss (/root/reference/src/xvr/model/loss.py:27-28,41-48):
+//   R = Ra^T Rb,  angle = atan2(|axis part of R|, (tr R - 1) / 2),  ang = sdd / 2 * angle,
+//   trans = |ta - tb|,  d = sqrt(ang^2 + trans^2 + eps)
+// and the gradient of d w.r.t. (Rb, tb).  Matrices are row-major 4x4, top three rows used.
+// ---------------------------------------------------------------------------------------------
+struct Geo {
+    float ang, trans, d;
+};
+
+__device__ inline Geo geodesic(const float* Ra, const float* ta, const float* Rb, const float* tb, float sdd, float eps,
+                               float* gRb, float* gtb) {
+    float R[9];
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) R[a * 3 + b] = Ra[0 + a] * Rb[0 + b] + Ra[3 + a] * Rb[3 + b] + Ra[6 + a] * Rb[6 + b];
+    const float c = 0.5f * ((R[0] + R[4] + R[8]) - 1.f);
+    const float w21 = R[7] - R[5], w02 = R[2] - R[6], w10 = R[3] - R[1];
+    const float q = w21 * w21 + w02 * w02 + w10 * w10 + 1e-24f;
+    const float sn = 0.5f * sqrtf(q);
+    const float k = 0.5f * sdd;
+    Geo g;
+    g.ang = k * atan2f(sn, c);
+    const float d0 = ta[0] - tb[0], d1 = ta[1] - tb[1], d2 = ta[2] - tb[2];
+    g.trans = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+    g.d = sqrtf(g.ang * g.ang + g.trans * g.trans + eps);
+    if (gRb) {
+        const float ga = g.ang / g.d, gtau = g.trans / g.d;
+        const float den = sn * sn + c * c;
+        const float gs = ga * k * c / den, gc = -ga * k * sn / den;
+        // d/dR = gc / 2 * I + gs / (4 sn) * (R - R^T)
+        const float f = gs / (4.f * sn);
+        float GR[9];
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) GR[a * 3 + b] = f * (R[a * 3 + b] - R[b * 3 + a]) + (a == b ? 0.5f * gc : 0.f);
+        for (int r = 0; r < 3; ++r)
+            for (int b = 0; b < 3; ++b) gRb[r * 3 + b] = Ra[r * 3] * GR[b] + Ra[r * 3 + 1] * GR[3 + b] + Ra[r * 3 + 2] * GR[6 + b];
+        const float it = g.trans > 0.f ? gtau / g.trans : 0.f;
+        gtb[0] = -it * d0; gtb[1] = -it * d1; gtb[2] = -it * d2;
+    }
+    return g;
+}
+
+__device__ inline void load_rt(const float* M, float* R, float* t) {
+    for (int r = 0; r < 3; ++r) {
+        R[r * 3] = M[r * 4]; R[r * 3 + 1] = M[r * 4 + 1]; R[r * 3 + 2] = M[r * 4 + 2];
+        t[r] = M[r * 4 + 3];
+    }
+}
+
+// rel = A_j A_i^{-1} for rigid A: R = Rj Ri^T, t = tj - R ti
+__device__ inline void relative(const float* Ri, const float* ti, const float* Rj, const float* tj, float* R, float* t) {
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) R[a * 3 + b] = Rj[a * 3] * Ri[b * 3] + Rj[a * 3 + 1] * Ri[b * 3 + 1] + Rj[a * 3 + 2] * Ri[b * 3 + 2];
+    for (int a = 0; a < 3; ++a) t[a] = tj[a] - (R[a * 3] * ti[0] + R[a * 3 + 1] * ti[1] + R[a * 3 + 2] * ti[2]);
+}
+
+// out [3][N] = (ang, trans, d) of pose pairs (A_n, B_n); gB [N][12] = d d_n / d (R_b | t_b) (nullable)
+__global__ void k_geodesic(const float* __restrict__ A, const float* __restrict__ Bm, int N, float sdd, float eps,
+                           float* __restrict__ out, float* __restrict__ gB) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float Ra[9], ta[3], Rb[9], tb[3], gR[9], gt[3];
+    load_rt(A + (size_t)n * 16, Ra, ta);
+    load_rt(Bm + (size_t)n * 16, Rb, tb);
+    const Geo g = geodesic(Ra, ta, Rb, tb, sdd, eps, gB ? gR : nullptr, gt);
+    out[n] = g.ang; out[N + n] = g.trans; out[2 * N + n] = g.d;
+    if (gB) {
+        for (int i = 0; i < 9; ++i) gB[(size_t)n * 12 + i] = gR[i];
+        for (int i = 0; i < 3; ++i) gB[(size_t)n * 12 + 9 + i] = gt[i];
+    }
+}
+
+__device__ __forceinline__ int pair_index(int i, int j, int B) { return i * (2 * B - i - 1) / 2 + (j - i - 1); }
+
+// multiview consistency: for every pair i < j the double geodesic between the true and the predicted RELATIVE
+// pose A_j A_i^{-1}; mvc in the order of torch.triu_indices(B, B, 1)
+__global__ void k_multiview_fwd(const float* __restrict__ T, const float* __restrict__ P, int B, float sdd, float eps,
+                                float* __restrict__ mvc) {
+    const int i = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= B || j <= i) return;
+    float Ri[9], ti[3], Rj[9], tj[3], Rt[9], tt[3], Rp[9], tp[3];
+    load_rt(T + (size_t)i * 16, Ri, ti); load_rt(T + (size_t)j * 16, Rj, tj);
+    relative(Ri, ti, Rj, tj, Rt, tt);
+    load_rt(P + (size_t)i * 16, Ri, ti); load_rt(P + (size_t)j * 16, Rj, tj);
+    relative(Ri, ti, Rj, tj, Rp, tp);
+    mvc[pair_index(i, j, B)] = geodesic(Rt, tt, Rp, tp, sdd, eps, nullptr, nullptr).d;
+}
+
+// gradient w.r.t. the predicted poses: thread m adds up, in a fixed order, the terms of every pair that
+// contains pose m (no atomics).  gP [B][12] = (R | t) rows of pose m.
+__global__ void k_multiview_bwd(const float* __restrict__ T, const float* __restrict__ P, const float* __restrict__ gout,
+                                int B, float sdd, float eps, float* __restrict__ gP) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= B) return;
+    float accR[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, acct[3] = {0, 0, 0};
+    for (int u = 0; u < B; ++u) {
+        if (u == m) continue;
+        const int i = m < u ? m : u, j = m < u ? u : m;
+        float Ri[9], ti[3], Rj[9], tj[3], Rt[9], tt[3], Rp[9], tp[3], gR[9], gt[3];
+        load_rt(T + (size_t)i * 16, Ri, ti); load_rt(T + (size_t)j * 16, Rj, tj);
+        relative(Ri, ti, Rj, tj, Rt, tt);
+        load_rt(P + (size_t)i * 16, Ri, ti); load_rt(P + (size_t)j * 16, Rj, tj);   // from here on: the predicted pair
+        relative(Ri, ti, Rj, tj, Rp, tp);
+        geodesic(Rt, tt, Rp, tp, sdd, eps, gR, gt);
+        const float go = gout[pair_index(i, j, B)];
+        // tp = tj - Rp ti: the translation gradient also reaches Rp
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) gR[a * 3 + b] -= gt[a] * ti[b];
+        if (m == j) {          // Rp = Rj Ri^T: d/dRj = G Ri;  d/dtj = g_t
+            for (int a = 0; a < 3; ++a) {
+                for (int b = 0; b < 3; ++b)
+                    accR[a * 3 + b] += go * (gR[a * 3] * Ri[b] + gR[a * 3 + 1] * Ri[3 + b] + gR[a * 3 + 2] * Ri[6 + b]);
+                acct[a] += go * gt[a];
+            }
+        } else {               // d/dRi = G^T Rj;  d/dti = -Rp^T g_t
+            for (int a = 0; a < 3; ++a) {
+                for (int b = 0; b < 3; ++b)
+                    accR[a * 3 + b] += go * (gR[a] * Rj[b] + gR[3 + a] * Rj[3 + b] + gR[6 + a] * Rj[6 + b]);
+                acct[a] -= go * (Rp[a] * gt[0] + Rp[3 + a] * gt[1] + Rp[6 + a] * gt[2]);
+            }
+        }
+    }
+    for (int a = 0; a < 9; ++a) gP[(size_t)m * 12 + a] = accR[a];
+    for (int a = 0; a < 3; ++a) gP[(size_t)m * 12 + 9 + a] = acct[a];
+}
+
 bool axes_ok(const int* a) {
     if (!a) return false;
     for (int i = 0; i < 3; ++i)
@@ -260,4 +386,27 @@ extern "C" int xvr_pose_opt_step(float* rot, float* xyz, int B, const xvr_pose_o
     hipLaunchKernelGGL(k_pose_opt_step, dim3(B), dim3(64), 0, (hipStream_t)stream, rot, xyz, B, *spec, G,
                        grad_cam, loss, state, history);
     return launched("pose_opt_step");
+}
+
+extern "C" int xvr_pose_geodesic(const float* a, const float* b, int N, float sdd, float eps, float* out, float* grad_b,
+                                 void* stream) {
+    if (!a || !b || !out || N <= 0) return pfail(XVR_DRR_E_ARG, "bad argument");
+    hipLaunchKernelGGL(k_geodesic, dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream, a, b, N, sdd, eps, out, grad_b);
+    return launched("pose_geodesic");
+}
+
+extern "C" int xvr_pose_multiview_forward(const float* true_pose, const float* pred_pose, int B, float sdd, float eps,
+                                          float* mvc, void* stream) {
+    if (!true_pose || !pred_pose || !mvc || B < 2 || B > 46340) return pfail(XVR_DRR_E_ARG, "bad argument");
+    hipLaunchKernelGGL(k_multiview_fwd, dim3((B + 127) / 128, B), dim3(128), 0, (hipStream_t)stream, true_pose, pred_pose, B,
+                       sdd, eps, mvc);
+    return launched("pose_multiview_forward");
+}
+
+extern "C" int xvr_pose_multiview_backward(const float* true_pose, const float* pred_pose, const float* grad_mvc, int B,
+                                           float sdd, float eps, float* grad_pred, void* stream) {
+    if (!true_pose || !pred_pose || !grad_mvc || !grad_pred || B < 2 || B > 46340) return pfail(XVR_DRR_E_ARG, "bad argument");
+    hipLaunchKernelGGL(k_multiview_bwd, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, true_pose, pred_pose, grad_mvc, B,
+                       sdd, eps, grad_pred);
+    return launched("pose_multiview_backward");
 }

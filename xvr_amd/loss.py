@@ -12,6 +12,75 @@ import torch
 from .metrics import DoubleGeodesicSE3, MultiscaleNormalizedCrossCorrelation2d
 
 
+def _hip_poses(*poses) -> bool:
+    return all(p.matrix.is_cuda and p.matrix.dtype == torch.float32 for p in poses)
+
+
+class _Geodesic(torch.autograd.Function):
+    """DoubleGeodesicSE3(sdd)(a, b) in one HIP launch (xvr_pose_geodesic); differentiable w.r.t. b through the
+    double geodesic, which is all the training loss uses (angular / translational parts are returned for logging)."""
+
+    @staticmethod
+    def forward(ctx, a, b, sdd, eps):
+        from . import _lib
+        from .renderers import _ptr, _stream
+
+        lib = _lib.load()
+        N = a.shape[0]
+        a_c, b_c = a.contiguous(), b.contiguous()
+        out = torch.empty(3, N, device=a.device, dtype=torch.float32)
+        gb = torch.empty(N, 12, device=a.device, dtype=torch.float32) if ctx.needs_input_grad[1] else None
+        _lib.check(lib.xvr_pose_geodesic(_ptr(a_c), _ptr(b_c), N, float(sdd), float(eps), _ptr(out), _ptr(gb), _stream()),
+                   "xvr_pose_geodesic")
+        ctx.save_for_backward(gb)
+        ctx.mark_non_differentiable(out[0], out[1])
+        return out[0], out[1], out[2]
+
+    @staticmethod
+    def backward(ctx, _g_ang, _g_trans, g_d):
+        (gb,) = ctx.saved_tensors
+        grad = torch.zeros(gb.shape[0], 4, 4, device=gb.device, dtype=gb.dtype)
+        g = gb * g_d.reshape(-1, 1)
+        grad[:, :3, :3] = g[:, :9].reshape(-1, 3, 3)
+        grad[:, :3, 3] = g[:, 9:]
+        return None, grad, None, None
+
+
+class _Multiview(torch.autograd.Function):
+    """Multiview consistency over all pose pairs (xvr_pose_multiview_forward / _backward)."""
+
+    @staticmethod
+    def forward(ctx, true_m, pred_m, sdd, eps):
+        from . import _lib
+        from .renderers import _ptr, _stream
+
+        lib = _lib.load()
+        B = true_m.shape[0]
+        t_c, p_c = true_m.contiguous(), pred_m.contiguous()
+        mvc = torch.empty(B * (B - 1) // 2, device=true_m.device, dtype=torch.float32)
+        _lib.check(lib.xvr_pose_multiview_forward(_ptr(t_c), _ptr(p_c), B, float(sdd), float(eps), _ptr(mvc), _stream()),
+                   "xvr_pose_multiview_forward")
+        ctx.save_for_backward(t_c, p_c)
+        ctx.cfg = (float(sdd), float(eps))
+        return mvc
+
+    @staticmethod
+    def backward(ctx, g_mvc):
+        from . import _lib
+        from .renderers import _ptr, _stream
+
+        lib = _lib.load()
+        t_c, p_c = ctx.saved_tensors
+        B = t_c.shape[0]
+        gp = torch.empty(B, 12, device=t_c.device, dtype=torch.float32)
+        _lib.check(lib.xvr_pose_multiview_backward(_ptr(t_c), _ptr(p_c), _ptr(g_mvc.contiguous()), B, *ctx.cfg, _ptr(gp), _stream()),
+                   "xvr_pose_multiview_backward")
+        grad = torch.zeros(B, 4, 4, device=gp.device, dtype=gp.dtype)
+        grad[:, :3, :3] = gp[:, :9].reshape(B, 3, 3)
+        grad[:, :3, 3] = gp[:, 9:]
+        return None, grad, None, None
+
+
 class DiceMetric(torch.nn.Module):
     """2D Dice between two multi-channel label maps, background (channel 0) excluded; reduction none."""
 
@@ -33,6 +102,10 @@ class DiceLoss(torch.nn.Module):
 
 
 class PoseRegressionLoss(torch.nn.Module):
+    # the pose terms (double geodesic, multiview consistency over all pairs) as one HIP launch each on CUDA poses
+    # instead of ~200 tiny torch launches; False keeps the torch formulation (the cross-check in tests)
+    FUSED = True
+
     def __init__(self, sdd: float, weight_ncc: float = 1e0, weight_geo: float = 1e-2, weight_dice: float = 1e0,
                  weight_mvc: float = 1e-3):
         super().__init__()
@@ -45,7 +118,10 @@ class PoseRegressionLoss(torch.nn.Module):
     def forward(self, img, mask, pose, pred_img, pred_mask, pred_pose):
         mncc = self.imagesim(img, pred_img)
         dice = self.diceloss(mask, pred_mask)
-        rgeo, tgeo, dgeo = self.geodesic(pose, pred_pose)
+        if self.FUSED and _hip_poses(pose, pred_pose) and len(pose) > 0 and not pose.matrix.requires_grad:
+            rgeo, tgeo, dgeo = _Geodesic.apply(pose.matrix, pred_pose.matrix, self.geodesic.sdd, self.geodesic.eps)
+        else:
+            rgeo, tgeo, dgeo = self.geodesic(pose, pred_pose)
         loss = self.weight_ncc * (1 - mncc) + self.weight_dice * dice + self.weight_geo * dgeo
         mvc = self.multiview_consistency(pose, pred_pose)
         if self.weight_mvc > 0:
@@ -54,6 +130,8 @@ class PoseRegressionLoss(torch.nn.Module):
 
     def multiview_consistency(self, true_pose, pred_pose):
         assert (B := len(true_pose)) == len(pred_pose)
+        if self.FUSED and B >= 2 and _hip_poses(true_pose, pred_pose) and not true_pose.matrix.requires_grad:
+            return _Multiview.apply(true_pose.matrix, pred_pose.matrix, self.geodesic.sdd, self.geodesic.eps)
         idx, jdx = torch.triu_indices(B, B, offset=1)
         if len(idx) == 0:
             return torch.zeros(1, device=true_pose.matrix.device)
