@@ -34,9 +34,19 @@ def get_random_pose(alphamin, alphamax, betamin, betamax, gammamin, gammamax, tx
 
 def render_samples(drr, volume, seg, affinv, pose, img_threshold=0.10, mask_threshold=0.05):
     """-> (img [B,1,H,W], mask [B,C,H,W] bool, keep [B] bool)."""
-    source, target = drr.detector(pose, None)
-    img = (target - source).norm(dim=-1).unsqueeze(1)
-    source, target = affinv(source), affinv(target)
+    if (volume.is_cuda and getattr(drr, "fused_rays", False)
+            and affinv.matrix.data_ptr() == drr._affine_inverse.data_ptr()):   # the DRR's own inverse affine, not a subject's
+        # detector -> ray length -> inverse affine as ONE launch from the pose's camera vector (same numbers:
+        # tests/test_hip_parity.py::test_fused_ray_generation_matches_the_detector_path)
+        from .drr import rays_from_camera
+
+        G, c = drr._camera_affine_cached()
+        cam = torch.addmm(c, pose.matrix[:, :3, :].reshape(len(pose), 12), G.T)
+        source, target, img = rays_from_camera(cam, drr.detector.height, drr.detector.width)
+    else:
+        source, target = drr.detector(pose, None)
+        img = (target - source).norm(dim=-1).unsqueeze(1)
+        source, target = affinv(source), affinv(target)
     img = drr.renderer(volume, source, target, img, mask=seg)
     img = drr.reshape_transform(img, batch_size=len(pose))
     mask = img > 0
