@@ -1355,8 +1355,10 @@ __global__ __launch_bounds__(WG) void k_backward_from_jac(const float* __restric
 // k_trilinear_fwd_split) and the partial sums meet in LDS.  A voxel segment that straddles a cut is
 // credited to the same voxel from both sides (exact geometry: the voxel is the one between the planes),
 // so only the rounding of that one product differs from the unsplit walk.
+// (at most 5 wavefronts per SIMD: the walk is bound by the texture-address unit; 10.7 ms at C3 against 11.5 ms at
+//  the 8 its register count would allow and at 4)
 template <int MODE, int MASK, bool GPOSE, bool GVOL, bool EXACT, int SPLIT = 0>
-__global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAX : WG) void k_siddon(RenderArgs A) {
+__global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAX : WG) __attribute__((amdgpu_waves_per_eu(1, 5))) void k_siddon(RenderArgs A) {
     extern __shared__ float lds[];  // MASK: fwd -> channel accumulators, bwd -> upstream gradients; SPLIT: partial sums
     static_assert(!SPLIT || (MODE != 2 && !MASK && EXACT), "split walk: forward, unmasked, exact geometry");
     if (MODE == 2 && A.skip_unless_flag_gt && !(*A.skip_unless_flag_gt > __float_as_uint(GATHER_DEV_TOL))) return;
