@@ -308,3 +308,27 @@ def test_fused_pose_loss_terms_match_torch(B, monkeypatch):
     mv = L.multiview_consistency(true, pred)
     mv.sum().backward()
     assert float(mv.detach().max()) < 0.05 and torch.isfinite(r.grad).all()
+
+
+@pytest.mark.gpu
+def test_run_batch_with_one_target_per_pose():
+    """B different X-rays of one geometry registered in one batch: each equals its own single run."""
+    from xvr_amd.registrar import Registrar
+    vol, _ = make_phantom(64, n_ellipsoids=8, seed=8, device="cuda")
+    drr = DRR(read(vol, spacing=(2.0,) * 3, orientation="AP"), 1020.0, 96, 1.8, renderer="trilinear", reverse_x_axis=False,
+              voxel_shift=0.0).cuda()
+    rots = torch.tensor([[3.10, 0.05, -0.03], [3.20, -0.04, 0.02]])
+    xyzs = torch.tensor([[4.0, 700.0, -6.0], [-5.0, 690.0, 3.0]])
+    with torch.no_grad():
+        gts = drr(convert(rots.cuda(), xyzs.cuda(), parameterization="euler_angles", convention="ZXY"))
+    inits = convert(rots + 0.05, xyzs + 6.0, parameterization="euler_angles", convention="ZXY")
+    reg = Registrar(drr, scales="2,1", n_itrs="25,15", patience=4, max_n_plateaus=2)
+    batch = reg.run_batch(gts, inits)
+    for b in range(2):
+        single = reg.run(gts[b:b + 1], inits[b])
+        k = min(6, len(batch[b]["trajectory"]), len(single["trajectory"]))
+        np.testing.assert_allclose(np.array(batch[b]["trajectory"])[:k, :3], np.array(single["trajectory"])[:k, :3], atol=2e-3)
+        np.testing.assert_allclose(batch[b]["nccs"][:k], single["nccs"][:k], atol=2e-3)
+        assert abs(batch[b]["nccs"][-1] - single["nccs"][-1]) < 0.05 and batch[b]["nccs"][-1] > batch[b]["nccs"][0]
+    with pytest.raises(ValueError):
+        reg.run_batch(gts, convert(rots[:1].repeat(3, 1), xyzs[:1].repeat(3, 1), parameterization="euler_angles", convention="ZXY"))

@@ -188,7 +188,8 @@ class Registrar:
                     lrs=lrs, trajectory=traj, runtime=sum(times), drr=reg.drr)
 
     def run_batch(self, gt: torch.Tensor, init_poses: RigidTransform, intrinsics: dict | None = None) -> list:
-        """Multi-start in ONE batch: the B initial poses are B independent registrations of the same target,
+        """Multi-start in ONE batch: the B initial poses are B independent registrations of the same target
+        (``gt`` [1,1,H,W]) -- or of B different targets of the same geometry (``gt`` [B,1,H,W]) --,
         advanced together by the device-resident stage (xvr_amd/pose_opt.py) -- every pose has its own Adam
         moments, plateau scheduler, learning rates and stopping flag on the device, the similarity
         standardises every rendered image by its own min/max (``per_image``), and a stage ends when all poses
@@ -198,6 +199,8 @@ class Registrar:
         device = self.drr.density.device
         *_, height, width = gt.shape
         B = len(init_poses)
+        if gt.shape[0] not in (1, B):
+            raise ValueError(f"gt holds {gt.shape[0]} images for {B} poses: pass one target, or one per pose")
         if self.parameterization != "euler_angles" or device.type != "cuda":
             raise RuntimeError("run_batch needs the device-resident loop: Euler angles on a GPU")
         drr = deepcopy(self.drr)
@@ -218,9 +221,9 @@ class Registrar:
             if not FusedSimilarity.supported(h, w, self.mncc_patch_size, self.gncc_patch_size, self.sigma, self.equalize):
                 raise RuntimeError("run_batch needs the fused similarity (sigma = 0, no equalisation, patches <= 15)")
             transform = XrayTransforms(h, w, equalize=self.equalize)
-            img = transform(gt)
-            sim = FusedSimilarity(img.expand(B, -1, -1, -1).contiguous(), self.mncc_patch_size, self.gncc_patch_size, self.beta,
-                                  per_image=True)
+            img = torch.cat([transform(gt[b:b + 1]) for b in range(gt.shape[0])])   # every target standardised on its own
+            fixed = img.expand(B, -1, -1, -1) if img.shape[0] == 1 else img   # one target for all starts, or one per pose
+            sim = FusedSimilarity(fixed.contiguous(), self.mncc_patch_size, self.gncc_patch_size, self.beta, per_image=True)
             step_size_scalar *= 2 ** (stage - 1)
             if n_itr <= 0:
                 continue
@@ -237,8 +240,9 @@ class Registrar:
                 print(f"stage {stage}: iterations per pose {[len(r) for r in stage_run.results()]}")
         final = convert(rot, xyz, parameterization=self.parameterization, convention=self.convention)
         with torch.no_grad():
-            moving = transform(drr(final))
-            final_ncc = [self.imagesim(img, moving[b:b + 1]).sum().item() for b in range(B)]
+            # (XrayTransforms standardises over the whole tensor it is given: one image at a time, as in run())
+            final_ncc = [self.imagesim(transform(gt[b:b + 1] if gt.shape[0] == B and B > 1 else gt),
+                                       transform(drr(final[b]))).sum().item() for b in range(B)]
         out = []
         for b in range(B):
             per[b]["nccs"].append(final_ncc[b])
