@@ -1309,6 +1309,105 @@ __global__ __launch_bounds__(WG) void k_siddon_gather_vol(GatherArgs G) {
 }
 
 
+// Same gather with a 2 x 2 x 2 voxel block per lane (one wavefront per 8^3 brick, as the trilinear gather):
+// the per-pose window and the candidate's loads are paid once for eight voxels, the three planes per axis give
+// nine crossing alphas per candidate (the forward's expression, plane by plane), from which every voxel's
+// entry / exit are one max3 / min3.  A candidate costs ~57 VALU for 8 voxels instead of 8 x 19.
+__global__ __launch_bounds__(64) void k_siddon_gather_vol2(GatherArgs G) {
+    if (*G.flag > __float_as_uint(GATHER_DEV_TOL)) return;
+    int bx, by, bz;
+    brick_coords(blockIdx.x, G.D1, G.D2, G.bd, bx, by, bz);
+    const int tid = threadIdx.x;
+    const int vx = (bx * 4 + (tid >> 4)) * 2, vy = (by * 4 + ((tid >> 2) & 3)) * 2, vz = (bz * 4 + (tid & 3)) * 2;
+    const bool inb = vx < G.D0 && vy < G.D1 && vz < G.D2;
+    // the three planes per axis that bound the block's voxels, and the block centre, in x coordinates
+    float px[3], py[3], pz[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        px[k] = (float)(vx + k) + G.sp.plane0[0];
+        py[k] = (float)(vy + k) + G.sp.plane0[1];
+        pz[k] = (float)(vz + k) + G.sp.plane0[2];
+    }
+    const float cx = px[1], cy = py[1], cz = pz[1];
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int wd = 0; wd < G.words; ++wd) {
+        unsigned bits = G.cull[(size_t)blockIdx.x * G.words + wd];
+        while (bits) {
+            const int p = wd * 32 + __builtin_ctz(bits);
+            bits &= bits - 1;
+            const PoseLattice& P = G.poses[p];
+            const float s0 = P.s[0], s1 = P.s[1], s2 = P.s[2];
+            const float w0 = cx - s0, w1 = cy - s1, w2 = cz - s2;
+            const float av = P.nh[0] * w0 + P.nh[1] * w1 + P.nh[2] * w2;
+            const float da = P.dalpha;                        // half-range of alpha over the 2-voxel block
+            const float amin = av - da, amax = av + da;
+            const float nj = P.gc[0] * w0 + P.gc[1] * w1 + P.gc[2] * w2, dnj = P.hwc;
+            const float ni = P.gr[0] * w0 + P.gr[1] * w1 + P.gr[2] * w2, dni = P.hwr;
+            int jlo = 0, jhi = -1, ilo = 0, ihi = -1;
+            if (inb && amin > 1e-6f && amax >= 0.f && amin <= 1.f) {
+                const float i0 = 1.f / amin, i1 = 1.f / amax;
+                const float ja = (nj - dnj) * i0, jb = (nj - dnj) * i1, jc = (nj + dnj) * i0, jd = (nj + dnj) * i1;
+                const float ia = (ni - dni) * i0, ib = (ni - dni) * i1, ic = (ni + dni) * i0, id = (ni + dni) * i1;
+                const float jmn = fminf(fminf(ja, jb), fminf(jc, jd)) + P.gc0 - GATHER_WIN_MARGIN;
+                const float jmx = fmaxf(fmaxf(ja, jb), fmaxf(jc, jd)) + P.gc0 + GATHER_WIN_MARGIN;
+                const float imn = fminf(fminf(ia, ib), fminf(ic, id)) + P.gr0 - GATHER_WIN_MARGIN;
+                const float imx = fmaxf(fmaxf(ia, ib), fmaxf(ic, id)) + P.gr0 + GATHER_WIN_MARGIN;
+                jlo = (int)ceilf(fmaxf(jmn, 0.f));
+                jhi = (int)floorf(fminf(jmx, (float)(G.W - 1)));
+                ilo = (int)ceilf(fmaxf(imn, 0.f));
+                ihi = (int)floorf(fminf(imx, (float)(G.H - 1)));
+            } else if (inb && amin <= 1e-6f && amax >= 0.f) {
+                jhi = G.W - 1;   // the block reaches the source plane: no perspective bound -- visit every ray
+                ihi = G.H - 1;
+            }
+            float lx[3], ly[3], lz[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { lx[k] = px[k] - s0; ly[k] = py[k] - s1; lz[k] = pz[k] - s2; }
+            const float4* __restrict__ q = G.q + (size_t)p * G.n;
+            const float2* __restrict__ q2 = G.q2 + (size_t)p * G.n;
+            for (int i = ilo; i <= ihi; ++i) {
+                const float4* __restrict__ row = q + (size_t)i * G.W;
+                const float2* __restrict__ row2 = q2 + (size_t)i * G.W;
+                // two candidates per trip: the four loads are issued before either candidate is evaluated
+                for (int j = jlo; j <= jhi; j += 2) {
+                    const int j1 = j < jhi ? j + 1 : j;
+                    float4 tt[2] = {row[j], row[j1]};
+                    const float2 aa[2] = {row2[j], row2[j1]};
+                    if (j1 == j) tt[1].w = 0.f;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const float4 t = tt[h];
+                        const float2 ab = aa[h];
+                        // crossing alphas of the planes (forward's expression), then per axis the two voxel
+                        // intervals; the ray's own [alpha_lo, alpha_hi] is folded into the x intervals once
+                        const float x0 = lx[0] * t.x, x1 = lx[1] * t.x, x2 = lx[2] * t.x;
+                        const float y0 = ly[0] * t.y, y1 = ly[1] * t.y, y2 = ly[2] * t.y;
+                        const float z0 = lz[0] * t.z, z1 = lz[1] * t.z, z2 = lz[2] * t.z;
+                        const float xl[2] = {fmaxf(fminf(x0, x1), ab.x), fmaxf(fminf(x1, x2), ab.x)};
+                        const float xh[2] = {fminf(fmaxf(x0, x1), ab.y), fminf(fmaxf(x1, x2), ab.y)};
+                        const float yl[2] = {fminf(y0, y1), fminf(y1, y2)}, yh[2] = {fmaxf(y0, y1), fmaxf(y1, y2)};
+                        const float zl[2] = {fminf(z0, z1), fminf(z1, z2)}, zh[2] = {fmaxf(z0, z1), fmaxf(z1, z2)};
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const int a = e >> 2, b = (e >> 1) & 1, c = e & 1;
+                            const float en = fmaxf(fmaxf(xl[a], yl[b]), zl[c]);
+                            const float ex = fminf(fminf(xh[a], yh[b]), zh[c]);
+                            // (alphas live in [0, 1]: the [0, 1] clamp is the max with 0, folded into the subtract)
+                            acc[e] = fmaf(__builtin_amdgcn_fmed3f(ex - en, 0.f, 1.f), t.w, acc[e]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int x = vx + (e >> 2), y = vy + ((e >> 1) & 1), z = vz + (e & 1);
+        if (x < G.D0 && y < G.D1 && z < G.D2 && acc[e] != 0.f) G.gvol[((size_t)x * G.D1 + y) * G.D2 + z] += acc[e];
+    }
+}
+
+
 // =============================================================================================
 // pose-side backward from the saved jacobian (C == 1): elementwise + wave reduction
 // =============================================================================================
@@ -1898,7 +1997,11 @@ int launch_gather(bool siddon, const float* source, const float* target, const f
     G.q2 = reinterpret_cast<float2*>(ws + ws_q2_off(B, n));
     G.siddon = siddon ? 1 : 0;
     G.V = siddon ? 1 : gather_block();
-    if (siddon) { G.bd[0] = 4; G.bd[1] = 8; G.bd[2] = 8; }
+    // Siddon: 2x2x2 voxels per lane in 8^3 bricks unless XVR_DRR_SIDDON_GATHER_BLOCK=1 (A/B switch: one voxel per
+    // lane, 256 lanes on a 4 x 8 x 8 brick)
+    static const bool siddon_v1 = [] { const char* e = getenv("XVR_DRR_SIDDON_GATHER_BLOCK"); return e && e[0] == '1'; }();
+    if (siddon && siddon_v1) { G.bd[0] = 4; G.bd[1] = 8; G.bd[2] = 8; }
+    else if (siddon) { G.bd[0] = G.bd[1] = G.bd[2] = 8; }
     else { G.bd[0] = G.bd[1] = G.bd[2] = 4 * G.V; }
     G.cull = reinterpret_cast<unsigned*>(ws + ws_cull_off(B, n));
     G.words = (B + 31) / 32;
@@ -1912,7 +2015,8 @@ int launch_gather(bool siddon, const float* source, const float* target, const f
     if (bricks >= (1LL << 31)) return fail(XVR_DRR_E_UNSUPPORTED, "grid too large");
     hipLaunchKernelGGL(k_gather_cull, dim3((unsigned)((bricks + WG / 32 - 1) / (WG / 32))), dim3(WG), 0,
                        (hipStream_t)stream, G, (int)bricks);
-    if (siddon) hipLaunchKernelGGL(k_siddon_gather_vol, dim3((unsigned)bricks), dim3(WG), 0, (hipStream_t)stream, G);
+    if (siddon && siddon_v1) hipLaunchKernelGGL(k_siddon_gather_vol, dim3((unsigned)bricks), dim3(WG), 0, (hipStream_t)stream, G);
+    else if (siddon) hipLaunchKernelGGL(k_siddon_gather_vol2, dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
     else if (G.V == 2 && getenv("XVR_DRR_GATHER_ABLATE")) hipLaunchKernelGGL((k_trilinear_gather_vol<2, true>), dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
     else if (G.V == 2) hipLaunchKernelGGL(k_trilinear_gather_vol<2>, dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
     else hipLaunchKernelGGL(k_trilinear_gather_vol<1>, dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
