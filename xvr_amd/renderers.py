@@ -102,6 +102,7 @@ def _workspace(lib, B, n, shape, device):
 # The density seen by the render moves by <= 15 ulp (1.8e-6 relative).  False (or XVR_DRR_PACK_LABELS=0)
 # keeps the separate lookup in the mask volume.
 import os as _os
+import weakref
 
 PACK_LABELS = _os.environ.get("XVR_DRR_PACK_LABELS", "1") != "0"
 
@@ -109,15 +110,15 @@ PACK_LABELS = _os.environ.get("XVR_DRR_PACK_LABELS", "1") != "0"
 def _packed_volume(lib, volume, mask):
     """The label-carrying copy of ``volume``; cached ON the volume tensor object (an address-keyed cache goes
     stale when the allocator hands the same address to the next step's density)."""
-    key = (id(mask), mask.data_ptr(), mask._version, volume._version)
+    key = (mask.data_ptr(), mask._version, volume._version)
     hit = getattr(volume, "_xvr_packed", None)
-    if hit is not None and hit[0] == key:
+    if hit is not None and hit[0] == key and hit[2]() is mask:   # (weak reference: an id() can be recycled)
         return hit[1]
     packed = torch.empty_like(volume)
     rc = _timed("pack_labels", lib.xvr_drr_pack_labels, _ptr(volume), _ptr(mask), volume.numel(), _ptr(packed), _stream())
     _lib.check(rc, "xvr_drr_pack_labels")
     try:
-        volume._xvr_packed = (key, packed)
+        volume._xvr_packed = (key, packed, weakref.ref(mask))
     except AttributeError:   # pragma: no cover  (exotic tensor subclasses without a __dict__)
         pass
     return packed
