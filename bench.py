@@ -131,8 +131,9 @@ def main():
         density.grad = None
         rot.grad = None
         xyz.grad = None
-        pose = convert(rot, xyz, parameterization="euler_angles", convention="ZXY")
-        img = drr(pose, density=density, **kw)   # DRR.forward: rays -> render, [B,1,H,H]
+        # DRR.forward from the pose parameters (Euler ZXY, xvr's registration parameterisation): pose -> camera is
+        # one HIP launch, then rays -> render, [B,1,H,H]
+        img = drr(rot, xyz, parameterization="euler_angles", convention="ZXY", density=density, **kw)
         handle = None
         if world > 1:  # the exchange step of the path: every rank gets every rendered DRR (RCCL over xGMI)
             handle = dist.all_gather_into_tensor(gathered, img.detach(), async_op=True)
