@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define XVR_DRR_ABI_VERSION 1
+#define XVR_DRR_ABI_VERSION 2   /* 2: xvr_sim_spec grew (per_image, pre_transformed); camera-driven forwards, packed labels, xvr_pose.h */
 
 #define XVR_DRR_OK 0
 #define XVR_DRR_E_ARG (-1)     /* bad argument (null pointer, non-positive size, unsupported combo) */

@@ -8,7 +8,7 @@ from pathlib import Path
 
 from .build import LIB, build_library, is_stale
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 JAC_STRIDE = 8
 
 
