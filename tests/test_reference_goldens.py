@@ -177,3 +177,24 @@ def test_reference_initialize_drr_runs_over_the_shim(tmp_path):
         for k in [k for k in sys.modules if k == "diffdrr" or k.startswith("diffdrr.")]:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+def test_parse_scales_equals_the_reference_function():
+    """registrar/base.py cannot be imported here (matplotlib, torchvision, ...), but its pure helper
+    `_parse_scales` can be compiled on its own from the reference tree and compared call by call."""
+    import ast
+
+    import pytest
+
+    path = REF / "registrar" / "base.py"
+    if not path.exists():
+        pytest.skip("the reference tree is not present on this machine")
+    tree = ast.parse(path.read_text())
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "_parse_scales")
+    ns = {}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), str(path), "exec"), ns)
+    from xvr_amd.registrar import parse_scales
+
+    for scales, crop, height in (("8", 0, 2048), ("8,4", 0, 2048), ("24,12,6", 100, 1436), ("4,2,1", 50, 512)):
+        want = ns["_parse_scales"](scales.split(","), crop, height)     # the reference passes the split list (base.py:152)
+        assert parse_scales(scales, crop, height) == pytest.approx(want, rel=1e-12), (scales, crop, height)
