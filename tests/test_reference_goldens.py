@@ -198,3 +198,27 @@ def test_parse_scales_equals_the_reference_function():
     for scales, crop, height in (("8", 0, 2048), ("8,4", 0, 2048), ("24,12,6", 100, 1436), ("4,2,1", 50, 512)):
         want = ns["_parse_scales"](scales.split(","), crop, height)     # the reference passes the split list (base.py:152)
         assert parse_scales(scales, crop, height) == pytest.approx(want, rel=1e-12), (scales, crop, height)
+
+
+def test_standardize_and_equalize_equal_the_reference_classes():
+    """utils/preprocess.py imports torchvision (absent here), but its Standardize / Equalize classes are plain
+    torch: compiled on their own from the reference tree and compared with xvr_amd.metrics on random images."""
+    import ast
+
+    import pytest
+
+    path = REF / "utils" / "preprocess.py"
+    if not path.exists():
+        pytest.skip("the reference tree is not present on this machine")
+    tree = ast.parse(path.read_text())
+    classes = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name in ("Standardize", "Identity", "Equalize")]
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=classes, type_ignores=[]), str(path), "exec"), ns)
+    from xvr_amd.metrics import Equalize, XrayTransforms
+
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(3, 1, 24, 20, generator=g) * 7.0 - 1.0
+    std = ns["Standardize"]()(x)
+    assert torch.allclose(XrayTransforms(24, 20)(x), (std - 0.15) / 0.1, rtol=1e-6, atol=1e-6)
+    assert torch.allclose(Equalize()(std), ns["Equalize"]()(std), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(XrayTransforms(24, 20, equalize=True)(x), (ns["Equalize"]()(std) - 0.15) / 0.1, rtol=1e-5, atol=1e-5)
