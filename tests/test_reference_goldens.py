@@ -222,3 +222,32 @@ def test_standardize_and_equalize_equal_the_reference_classes():
     assert torch.allclose(XrayTransforms(24, 20)(x), (std - 0.15) / 0.1, rtol=1e-6, atol=1e-6)
     assert torch.allclose(Equalize()(std), ns["Equalize"]()(std), rtol=1e-5, atol=1e-6)
     assert torch.allclose(XrayTransforms(24, 20, equalize=True)(x), (ns["Equalize"]()(std) - 0.15) / 0.1, rtol=1e-5, atol=1e-5)
+
+
+def test_reference_antipode_helper_puts_the_source_on_the_other_side():
+    """model/inference.py:_construct_antipode (pure diffdrr.pose calls) compiled on its own over this package's
+    pose module.  For a C-arm pose (xyz = (0, d, 0)) it must carry the source to the far side of the patient --
+    (x, y, z) -> (x, -y, -z), a half turn about the left-right axis -- which only happens if the translation is
+    applied in the camera frame, x_world = R (x_cam + t): the convention xvr_amd.pose.convert was pinned on
+    (with x_world = R x_cam + t the source would not move at all).  Applying it twice is the identity."""
+    import ast
+
+    import pytest
+
+    path = REF / "model" / "inference.py"
+    if not path.exists():
+        pytest.skip("the reference tree is not present on this machine")
+    fn = next(n for n in ast.parse(path.read_text()).body if isinstance(n, ast.FunctionDef) and n.name == "_construct_antipode")
+    from xvr_amd.pose import RigidTransform, convert
+
+    ns = {"torch": torch, "RigidTransform": RigidTransform, "convert": convert}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), str(path), "exec"), ns)
+    rot = torch.tensor([[0.4, 0.2, -0.1], [2.9, -0.3, 0.05]])
+    xyz = torch.tensor([[0.0, 800.0, 0.0], [0.0, 650.0, 0.0]])
+    pose = convert(rot, xyz, parameterization="euler_angles", convention="ZXY")
+    anti = ns["_construct_antipode"](pose)
+    src, src_anti = pose.matrix[:, :3, 3], anti.matrix[:, :3, 3]          # camera origin in world coordinates
+    assert torch.allclose(src_anti, src * torch.tensor([1.0, -1.0, -1.0]), atol=1e-3), (src, src_anti)
+    assert torch.allclose(src.norm(dim=1), xyz[:, 1], atol=1e-3)           # the source orbits at distance d
+    back = ns["_construct_antipode"](anti)
+    assert torch.allclose(back.matrix, pose.matrix, atol=1e-4)
