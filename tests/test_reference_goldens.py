@@ -251,3 +251,38 @@ def test_reference_antipode_helper_puts_the_source_on_the_other_side():
     assert torch.allclose(src.norm(dim=1), xyz[:, 1], atol=1e-3)           # the source orbits at distance d
     back = ns["_construct_antipode"](anti)
     assert torch.allclose(back.matrix, pose.matrix, atol=1e-4)
+
+
+def test_preprocess_xray_equals_the_reference_function():
+    """io/xray.py imports pydicom and torchvision (absent here); its `_preprocess_xray` is plain torch apart from
+    `center_crop`, for which this package's own restatement is handed in: every non-crop branch is the reference's
+    own arithmetic, call by call."""
+    import ast
+    from typing import Callable
+
+    import pytest
+
+    path = REF / "io" / "xray.py"
+    if not path.exists():
+        pytest.skip("the reference tree is not present on this machine")
+    fn = next(n for n in ast.parse(path.read_text()).body if isinstance(n, ast.FunctionDef) and n.name == "_preprocess_xray")
+    from xvr_amd.data import center_crop, preprocess_xray
+
+    ns = {"torch": torch, "Callable": Callable, "center_crop": center_crop}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), str(path), "exec"), ns)
+    g = torch.Generator().manual_seed(2)
+    img4 = (torch.rand(1, 1, 37, 41, generator=g) * 4000).round()
+    img5 = (torch.rand(1, 1, 3, 20, 24, generator=g) * 4000).round()
+    for img in (img4, img5):
+        for crop in (0, 6):
+            for sub in (False, True):
+                for lin in (False, True):
+                    for red in ("max", "sum", 1, None):
+                        want = ns["_preprocess_xray"](img.clone(), crop, sub, lin, red)
+                        got = preprocess_xray(img.clone(), crop, sub, lin, red)
+                        assert got.shape == want.shape and torch.allclose(got, want, rtol=1e-6, atol=1e-7), (crop, sub, lin, red)
+    # center_crop: torchvision's rounding rule on odd differences
+    x = torch.arange(7 * 9, dtype=torch.float32).reshape(1, 1, 7, 9)
+    assert center_crop(x, (4, 4)).shape == (1, 1, 4, 4) and float(center_crop(x, (4, 4))[0, 0, 0, 0]) == float(x[0, 0, 2, 2])
+    with pytest.raises(ValueError):
+        preprocess_xray(img5, reducefn="median")
