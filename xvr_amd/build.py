@@ -8,20 +8,22 @@ from __future__ import annotations
 
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
-SRC = [PKG / "csrc" / "drr_kernels.hip", PKG / "csrc" / "sim_kernels.hip", PKG / "csrc" / "volume_kernels.hip",
-       PKG / "csrc" / "pose_kernels.hip"]
-HDR = [ROOT / "include" / "xvr_drr.h", ROOT / "include" / "xvr_sim.h", ROOT / "include" / "xvr_pose.h"]
+SRC = [PKG / "csrc" / f for f in ("drr_trilinear.hip", "drr_siddon.hip", "drr_gather.hip", "drr_rays.hip", "drr_api.hip",
+                                  "sim_kernels.hip", "volume_kernels.hip", "pose_kernels.hip")]
+HDR = [ROOT / "include" / "xvr_drr.h", ROOT / "include" / "xvr_sim.h", ROOT / "include" / "xvr_pose.h",
+       PKG / "csrc" / "drr_common.hiph"]
+OBJ = PKG / "lib" / "obj"
 LIB = PKG / "lib" / "libxvr_drr.so"
 
 HIPCC_FLAGS = [
     "--offload-arch=gfx950",
     "-O3",
     "-std=c++17",
-    "-shared",
     "-fPIC",
     "-munsafe-fp-atomics",  # fp32 atomic add in hardware (global_atomic_add_f32), no CAS loops
     f"-I{ROOT / 'include'}",
@@ -41,13 +43,31 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not Path(hipcc).exists():
         raise RuntimeError("hipcc not found: cannot build libxvr_drr.so (ROCm toolchain required)")
-    LIB.parent.mkdir(parents=True, exist_ok=True)
-    cmd = [hipcc, *HIPCC_FLAGS, "-o", str(LIB), *map(str, SRC)]
+    OBJ.mkdir(parents=True, exist_ok=True)
+    newest_header = max(p.stat().st_mtime for p in HDR if p.exists())
+
+    def compile_one(src: Path):
+        obj = OBJ / (src.stem + ".o")
+        if not force and obj.exists() and obj.stat().st_mtime > max(src.stat().st_mtime, newest_header):
+            return obj, None
+        cmd = [hipcc, *HIPCC_FLAGS, "-c", str(src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd))
+        proc = subprocess.run(cmd, capture_output=True, text=True)
+        return obj, (None if proc.returncode == 0 else f"{src.name}: hipcc failed ({proc.returncode}):\n{proc.stdout}\n{proc.stderr}")
+
+    # one translation unit per kernel family: compiled in parallel (a few workers: each clang takes ~1 GB), then linked
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        results = list(pool.map(compile_one, SRC))
+    errors = [e for _, e in results if e]
+    if errors:
+        raise RuntimeError("\n".join(errors))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *[str(o) for o, _ in results]]
     if verbose:
         print(" ".join(cmd))
     proc = subprocess.run(cmd, capture_output=True, text=True)
     if proc.returncode != 0:
-        raise RuntimeError(f"hipcc failed ({proc.returncode}):\n{proc.stdout}\n{proc.stderr}")
+        raise RuntimeError(f"hipcc link failed ({proc.returncode}):\n{proc.stdout}\n{proc.stderr}")
     return LIB
 
 

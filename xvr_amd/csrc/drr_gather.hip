@@ -1,0 +1,568 @@
+// MI355X (gfx950) differentiable-DRR kernels: the voxel gradient as an atomic-free, voxel-driven gather
+// (trilinear and Siddon), its per-pose preparation and per-brick cull.  DESIGN.md section 4.1.
+#include "drr_common.hiph"
+
+namespace {
+
+// =============================================================================================
+// Voxel gradient of the trilinear renderer WITHOUT atomics: a voxel-driven exact adjoint.
+//
+// fp32 atomics are the wrong tool on this chip (measured, profiles/r01_microbench_atomics.txt:
+// ~20 G scattered global atomic line-ops/s whatever the scope, ~190 G/s for LDS ds_add_f32
+// chip-wide), and the scatter has 8 of them per sample.  Instead one thread OWNS one voxel v and
+// gathers every sample that touches it.  Because a pose's rays end on a planar H x W lattice and all
+// rays share alpha_k, the samples of step k form a planar patch, so the few (pixel, step) pairs whose
+// sample lies inside v's unit box are found by projecting v onto the detector:
+//     alpha_v = n.(x_v - s)/h,  pixel (i*, j*) = G.(s + (x_v - s)/alpha_k - T00)
+// with a conservative window around (k*, i*, j*).  Each candidate's sample position is recomputed
+// with the SAME fmaf sequence as the forward from the SAME target array, so its weight
+// prod(1 - |p - v|) is bit-identical to the forward's interpolation weight: this is the exact
+// transpose of the forward gather, up to summation order -- and it is deterministic.
+// =============================================================================================
+
+__device__ __forceinline__ void cross3(const float* a, const float* b, float* o) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+__device__ __forceinline__ float dot3(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+// one block per (pose, 256 rays): packs q, measures how far the targets are from an exact lattice,
+// and (block 0 of each pose) derives the pose's projection constants.
+__global__ __launch_bounds__(WG) void k_gather_prep(GatherArgs G) {
+    const int b = blockIdx.y;
+    const int r = blockIdx.x * WG + threadIdx.x;
+    const float* T = G.target + (size_t)b * G.n * 3;
+    float t00[3], ec[3], er[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        t00[i] = T[i];
+        ec[i] = (T[(size_t)(G.W - 1) * 3 + i] - t00[i]) / (float)(G.W - 1);
+        er[i] = (T[(size_t)(G.H - 1) * G.W * 3 + i] - t00[i]) / (float)(G.H - 1);
+    }
+    const float pitch = fminf(sqrtf(dot3(ec, ec)), sqrtf(dot3(er, er)));
+    float dev = 0.f;
+    if (r < G.n) {
+        const int i = r / G.W, j = r - i * G.W;
+        const float tx = T[(size_t)r * 3], ty = T[(size_t)r * 3 + 1], tz = T[(size_t)r * 3 + 2];
+        dev = fmaxf(fabsf(tx - (t00[0] + j * ec[0] + i * er[0])),
+                    fmaxf(fabsf(ty - (t00[1] + j * ec[1] + i * er[1])), fabsf(tz - (t00[2] + j * ec[2] + i * er[2]))));
+        dev = pitch > 0.f ? dev / pitch : INFINITY;
+        if (!(dev == dev)) dev = INFINITY;
+        const float c = G.gout[(size_t)b * G.n + r] * G.raylen[(size_t)b * G.n + r] * G.sp.inv_denom;
+        // d exactly as the forward forms it, (t - s) + eps, so that the gather's fmaf chain below
+        // reproduces the forward's sample positions bit for bit
+        const float sx = G.source[3 * b], sy = G.source[3 * b + 1], sz = G.source[3 * b + 2];
+        const float ddx = (tx - sx) + G.sp.eps, ddy = (ty - sy) + G.sp.eps, ddz = (tz - sz) + G.sp.eps;
+        if (!G.siddon) {
+            G.q[(size_t)b * G.n + r] = make_float4(ddx, ddy, ddz, c);
+        } else {
+            // the ray's own integration interval, computed exactly as ray_setup() does for the forward
+            const float dd[3] = {ddx, ddy, ddz}, ss[3] = {sx, sy, sz};
+            float lo = -INFINITY, hi = INFINITY;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float a0 = (G.sp.lo[k] - ss[k]) / dd[k], a1 = (G.sp.hi[k] - ss[k]) / dd[k];
+                lo = fmaxf(lo, fminf(a0, a1));
+                hi = fminf(hi, fmaxf(a0, a1));
+            }
+            if (!(lo > 0.f)) lo = 0.f;
+            if (!(hi < 1.f)) hi = 1.f;
+            G.q[(size_t)b * G.n + r] = make_float4(1.f / ddx, 1.f / ddy, 1.f / ddz,
+                                                   G.gout[(size_t)b * G.n + r] * G.raylen[(size_t)b * G.n + r]);
+            G.q2[(size_t)b * G.n + r] = make_float2(lo, hi);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dev = fmaxf(dev, __shfl_xor(dev, o));
+    // only a wave that SEES a violation touches the flag (one word: 10^5 same-address atomics would
+    // serialise into more than a millisecond)
+    if ((threadIdx.x & 63) == 0 && dev > GATHER_DEV_TOL) atomicMax(G.flag, __float_as_uint(dev));
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        PoseLattice P = {};
+        float s[3], nrm[3], st[3], ts[3], tmp[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            s[i] = G.source[3 * b + i];
+            ts[i] = (t00[i] + G.sp.eps) - s[i];  // T00e - s
+            st[i] = -ts[i];
+        }
+        cross3(ec, er, nrm);
+        const float h = dot3(nrm, ts);  // n . (T00 - s)
+        cross3(er, nrm, tmp);
+        const float dc = dot3(ec, tmp);
+        float gc[3] = {tmp[0] / dc, tmp[1] / dc, tmp[2] / dc};
+        cross3(nrm, ec, tmp);
+        const float dr = dot3(er, tmp);
+        float gr[3] = {tmp[0] / dr, tmp[1] / dr, tmp[2] / dr};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            P.s[i] = s[i];
+            P.nh[i] = nrm[i] / h;
+            P.gc[i] = gc[i];
+            P.gr[i] = gr[i];
+            P.st[i] = ts[i];
+            P.ec[i] = ec[i];
+            P.er[i] = er[i];
+            P.dalpha += fabsf(P.nh[i]) / G.sp.a[i];
+            P.hwc += fabsf(gc[i]) / G.sp.a[i];
+            P.hwr += fabsf(gr[i]) / G.sp.a[i];
+        }
+        P.nh_norm = sqrtf(dot3(P.nh, P.nh));
+        P.gc_norm = sqrtf(dot3(gc, gc));
+        P.gr_norm = sqrtf(dot3(gr, gr));
+        P.gc0 = dot3(gc, st);
+        P.gr0 = dot3(gr, st);
+        const float chk = P.dalpha + P.hwc + P.hwr + P.gc0 + P.gr0;
+        if (!(chk == chk) || !(fabsf(chk) < 1e30f) || h == 0.f) atomicMax(G.flag, __float_as_uint(INFINITY));
+        G.poses[b] = P;
+    }
+}
+
+// A gather workgroup covers a brick of bd[0] x bd[1] x bd[2] voxels (trilinear: one wavefront per
+// compact (4V)^3 brick, each lane a V^3 block; siddon: 256 lanes on 4 x 8 x 8 voxels).
+__device__ __forceinline__ void brick_coords(int blk, int D1, int D2, const int* bd, int& bx, int& by, int& bz) {
+    const int nz = (D2 + bd[2] - 1) / bd[2], ny = (D1 + bd[1] - 1) / bd[1];
+    bz = blk % nz; blk /= nz;
+    by = blk % ny; bx = blk / ny;
+}
+
+// one thread per (brick, pose): can any sample of the pose fall inside the brick grown by one voxel?
+// (bounding sphere against the pose's sample pyramid, conservative).  32 poses per word.
+__global__ __launch_bounds__(WG) void k_gather_cull(GatherArgs G, int nbricks) {
+    const int brick = blockIdx.x * (WG / 32) + (threadIdx.x >> 5);
+    const int lane = threadIdx.x & 31;
+    if (brick >= nbricks) return;
+    int bx, by, bz;
+    brick_coords(brick, G.D1, G.D2, G.bd, bx, by, bz);
+    const float c[3] = {bx * G.bd[0] + 0.5f * (G.bd[0] - 1), by * G.bd[1] + 0.5f * (G.bd[1] - 1),
+                        bz * G.bd[2] + 0.5f * (G.bd[2] - 1)};
+    // half extent to the outermost voxel centre + 1 (interpolation support) + 0.5 (slack), in x units
+    const float hx = (0.5f * (G.bd[0] - 1) + 1.5f) / G.sp.a[0], hy = (0.5f * (G.bd[1] - 1) + 1.5f) / G.sp.a[1],
+                hz = (0.5f * (G.bd[2] - 1) + 1.5f) / G.sp.a[2];
+    const float R = sqrtf(hx * hx + hy * hy + hz * hz);
+    for (int wd = 0; wd < G.words; ++wd) {
+        const int p = wd * 32 + lane;
+        bool hit = false;
+        if (p < G.B) {
+            const PoseLattice& P = G.poses[p];
+            float w[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) w[i] = (c[i] - G.sp.b[i]) / G.sp.a[i] - P.s[i];
+            const float av = dot3(P.nh, w), da = R * P.nh_norm;
+            const float amin = av - da, amax = av + da;
+            if (amax >= G.sp.near_ && amin <= G.sp.far_) {
+                if (amin <= 1e-6f) {
+                    hit = true;  // the sphere reaches the source plane: no perspective bound, keep
+                } else {
+                    const float inv = 1.f / av;
+                    const float jc = fmaf(dot3(P.gc, w), inv, P.gc0), ic = fmaf(dot3(P.gr, w), inv, P.gr0);
+                    // a point of the sphere moves the pixel by at most R |g| / alpha (lateral) plus the
+                    // centre's own shift |j - gc0| * da / alpha (depth), with alpha >= amin
+                    const float ia = 1.f / amin;
+                    const float rj = (R * P.gc_norm + fabsf(jc - P.gc0) * da) * ia + 1.f;
+                    const float ri = (R * P.gr_norm + fabsf(ic - P.gr0) * da) * ia + 1.f;
+                    hit = jc + rj >= 0.f && jc - rj <= (float)(G.W - 1) && ic + ri >= 0.f && ic - ri <= (float)(G.H - 1);
+                }
+            }
+        }
+        const unsigned long long m = __ballot(hit);
+        const unsigned bits = (threadIdx.x & 32) ? (unsigned)(m >> 32) : (unsigned)m;
+        if (lane == 0) G.cull[(size_t)brick * G.words + wd] = bits;
+    }
+}
+
+// One lane owns a V x V x V block of voxels (V = 2: per-pose / per-step / per-row setup is paid once
+// for 8 voxels and the sample position is computed once per candidate); a workgroup covers a
+// (4V) x (8V) x (8V) brick so that its lanes' candidates share pixels.
+// max(1 - |d|, 0), the trilinear weight of a voxel at signed distance d, in ONE instruction: 1 - |d| never
+// exceeds 1, so the [0, 1] clamp equals the max and folds into the subtraction's clamp bit
+// (v_sub_f32 dst, 1.0, |d| clamp) -- the gather's inner loop is VALU-bound and has six of these per candidate.
+__device__ __forceinline__ float hat01(float d) { return __builtin_amdgcn_fmed3f(1.f - fabsf(d), 0.f, 1.f); }
+
+// (register budget set for 7 wavefronts per SIMD: 72 VGPRs, no spills, 14.4 ms at C2 against 14.6 at the 6 the
+//  compiler chose; 8 spills, 4 takes 17.7 ms)
+template <int V, bool NOLOAD = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_trilinear_gather_vol(GatherArgs G) {
+    if (*G.flag > __float_as_uint(GATHER_DEV_TOL)) return;  // not a lattice: the scatter kernel runs instead
+    constexpr float HS = V == 2 ? 1.5f : 1.0f;  // half-size of the block's interpolation support
+    constexpr float CO = V == 2 ? 0.5f : 0.0f;  // block centre relative to its first voxel
+    int bx, by, bz;
+    brick_coords(blockIdx.x, G.D1, G.D2, G.bd, bx, by, bz);
+    const int tid = threadIdx.x;  // one wavefront: 4 x 4 x 4 blocks
+    const int vx = (bx * 4 + (tid >> 4)) * V, vy = (by * 4 + ((tid >> 2) & 3)) * V, vz = (bz * 4 + (tid & 3)) * V;
+    const bool inb = vx < G.D0 && vy < G.D1 && vz < G.D2;
+    const float fv[3] = {(float)vx, (float)vy, (float)vz};
+    float xv[3];  // block centre in x coordinates
+#pragma unroll
+    for (int i = 0; i < 3; ++i) xv[i] = (fv[i] + CO - G.sp.b[i]) / G.sp.a[i];
+    const int N = G.sp.n_points;
+    const float near_ = G.sp.near_, far_ = G.sp.far_;
+    const float step = N > 1 ? (far_ - near_) / (float)(N - 1) : 0.f;
+    const float inv_step = step > 0.f ? 1.f / step : 0.f;
+    const float a0 = G.sp.a[0], a1 = G.sp.a[1], a2 = G.sp.a[2];
+    const float b0 = G.sp.b[0], b1 = G.sp.b[1], b2 = G.sp.b[2];
+    // p - v for the first voxel of the block (b - v is exact, and so is folding it into the fmaf for
+    // every |p| < 2^23: these are the forward's interpolation weights); the second voxel gets its own
+    // constant so that its weight is formed by the same single fmaf
+    const float bv0 = b0 - fv[0], bv1 = b1 - fv[1], bv2 = b2 - fv[2];
+    const float bw0 = bv0 - 1.f, bw1 = bv1 - 1.f, bw2 = bv2 - 1.f;
+    const float jmargin = GATHER_DEV_TOL + 0.01f;
+    float acc[V * V * V];
+#pragma unroll
+    for (int i = 0; i < V * V * V; ++i) acc[i] = 0.f;
+
+    for (int wd = 0; wd < G.words; ++wd) {
+        unsigned bits = G.cull[(size_t)blockIdx.x * G.words + wd];  // uniform: scalar load
+        while (bits) {
+            const int p = wd * 32 + __builtin_ctz(bits);
+            bits &= bits - 1;
+            const PoseLattice& P = G.poses[p];
+            const float s0 = P.s[0], s1 = P.s[1], s2 = P.s[2];
+            const float w0 = xv[0] - s0, w1 = xv[1] - s1, w2 = xv[2] - s2;
+            const float av = P.nh[0] * w0 + P.nh[1] * w1 + P.nh[2] * w2;
+            const float da = HS * P.dalpha;
+            int klo, khi;
+            if (step > 0.f) {
+                const float k0 = (av - da - near_) * inv_step, k1 = (av + da - near_) * inv_step;
+                klo = (int)ceilf(fmaxf(k0 - GATHER_K_SLACK, 0.f));
+                khi = (int)floorf(fminf(k1 + GATHER_K_SLACK, (float)(N - 1)));
+            } else {
+                klo = 0;
+                khi = (fabsf(av - near_) <= da) ? 0 : -1;
+            }
+            if (!inb || !(av == av)) khi = -1;
+            const float grw = P.gr[0] * w0 + P.gr[1] * w1 + P.gr[2] * w2;
+            const float4* __restrict__ q = G.q + (size_t)p * G.n;
+            const float Bx = fmaf(a0, s0, bv0), By = fmaf(a1, s1, bv1), Bz = fmaf(a2, s2, bv2);
+            for (int k = klo; k <= khi; ++k) {
+                const float al = linspace_at(k, N, near_, far_, step);
+                if (al > 1e-12f) {
+                    const float inv = 1.f / al;
+                    const float ic = fmaf(grw, inv, P.gr0);
+                    const float hi = fmaf(HS * P.hwr, inv, GATHER_WIN_MARGIN);
+                    const int ilo = (int)ceilf(fmaxf(ic - hi, 0.f));
+                    const int ihi = (int)floorf(fminf(ic + hi, (float)(G.H - 1)));
+                    // lattice model of the sample positions relative to the block centre, in index space:
+                    // Q0 + i Ur + j Uc.  Used ONLY to find which pixels to visit; the weights below come
+                    // from the real targets.
+                    const float ucx = al * a0 * P.ec[0], ucy = al * a1 * P.ec[1], ucz = al * a2 * P.ec[2];
+                    const float urx = al * a0 * P.er[0], ury = al * a1 * P.er[1], urz = al * a2 * P.er[2];
+                    const float q0x = fmaf(a0, fmaf(al, P.st[0], s0), b0) - (fv[0] + CO);
+                    const float q0y = fmaf(a1, fmaf(al, P.st[1], s1), b1) - (fv[1] + CO);
+                    const float q0z = fmaf(a2, fmaf(al, P.st[2], s2), b2) - (fv[2] + CO);
+                    // reciprocal of the per-column step, clamped: an axis the row does not move along
+                    // (|uc| ~ 0) then yields (-huge, +huge) when |q| < HS and an empty interval otherwise
+                    const float rx = fabsf(ucx) < 1e-9f ? 1e9f : 1.f / ucx;
+                    const float ry = fabsf(ucy) < 1e-9f ? 1e9f : 1.f / ucy;
+                    const float rz = fabsf(ucz) < 1e-9f ? 1e9f : 1.f / ucz;
+                    const float ax_ = HS * fabsf(rx), ay_ = HS * fabsf(ry), az_ = HS * fabsf(rz);
+                    const float Ax = al * a0, Ay = al * a1, Az = al * a2;
+                    for (int i = ilo; i <= ihi; ++i) {
+                        const float fi = (float)i;
+                        const float qx = fmaf(fi, urx, q0x), qy = fmaf(fi, ury, q0y), qz = fmaf(fi, urz, q0z);
+                        // exact j-interval on this row where |q + j Uc| < HS on all three axes
+                        const float mx = -qx * rx, my = -qy * ry, mz = -qz * rz;
+                        const float lo = fmaxf(fmaxf(mx - ax_, my - ay_), mz - az_);
+                        const float hiJ = fminf(fminf(mx + ax_, my + ay_), mz + az_);
+                        const int jlo = (int)ceilf(fmaxf(lo - jmargin, 0.f));
+                        const int jhi = (int)floorf(fminf(hiJ + jmargin, (float)(G.W - 1)));
+                        const float4* __restrict__ row = q + (size_t)i * G.W;
+                        // two candidates per trip: both 16-byte loads are issued before either is used
+                        for (int j = jlo; j <= jhi; j += 2) {
+                            const bool two = j < jhi;
+                            float4 ta, tb;
+                            if (NOLOAD) {  // ablation only (XVR_DRR_GATHER_ABLATE=1): same arithmetic, no memory
+                                ta = make_float4(q0x + (float)j, q0y, q0z, 1.f);
+                                tb = make_float4(q0x, q0y + (float)j, q0z, 1.f);
+                            } else {
+                                ta = row[j];
+                                tb = row[two ? j + 1 : j];
+                            }
+                            tb.w = two ? tb.w : 0.f;
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                const float4 t = h ? tb : ta;
+                                // signed distance of the sample from the block's first voxel, per axis:
+                                // a (s + alpha d) + b - v folded into one fma (within an ulp of the
+                                // forward's two-fma chain); the second voxel sits exactly 1 further
+                                const float dx = fmaf(Ax, t.x, Bx), dy = fmaf(Ay, t.y, By), dz = fmaf(Az, t.z, Bz);
+                                const float ux0 = hat01(dx);
+                                const float uy0 = hat01(dy);
+                                const float uz0 = hat01(dz) * t.w;
+                                if (V == 1) {
+                                    acc[0] = fmaf(ux0 * uy0, uz0, acc[0]);
+                                } else {
+                                    const float ux1 = hat01(dx - 1.f);
+                                    const float uy1 = hat01(dy - 1.f);
+                                    const float uz1 = hat01(dz - 1.f) * t.w;
+                                    // (packed v_pk_mul/fma_f32 on (z, z+1) pairs measured SLOWER, 15.9 vs 14.7 ms:
+                                    //  the pair building / broadcast moves cost more than the halved fma count)
+                                    const float p00 = ux0 * uy0, p01 = ux0 * uy1, p10 = ux1 * uy0, p11 = ux1 * uy1;
+                                    acc[0] = fmaf(p00, uz0, acc[0]);
+                                    acc[1 % (V * V * V)] = fmaf(p00, uz1, acc[1 % (V * V * V)]);
+                                    acc[2 % (V * V * V)] = fmaf(p01, uz0, acc[2 % (V * V * V)]);
+                                    acc[3 % (V * V * V)] = fmaf(p01, uz1, acc[3 % (V * V * V)]);
+                                    acc[4 % (V * V * V)] = fmaf(p10, uz0, acc[4 % (V * V * V)]);
+                                    acc[5 % (V * V * V)] = fmaf(p10, uz1, acc[5 % (V * V * V)]);
+                                    acc[6 % (V * V * V)] = fmaf(p11, uz0, acc[6 % (V * V * V)]);
+                                    acc[7 % (V * V * V)] = fmaf(p11, uz1, acc[7 % (V * V * V)]);
+                                }
+                            }
+                        }
+                    }
+                } else {
+                    // alpha_k = 0: every ray's sample sits on the source; all pixels are candidates for the
+                    // blocks whose support contains it (a source inside the volume only)
+                    const bool hit = fabsf(fmaf(a0, s0, b0) - (fv[0] + CO)) < HS && fabsf(fmaf(a1, s1, b1) - (fv[1] + CO)) < HS &&
+                                     fabsf(fmaf(a2, s2, b2) - (fv[2] + CO)) < HS;
+                    const int cnt = hit ? G.n : 0;
+                    for (int r = 0; r < cnt; ++r) {
+                        const float4 t = q[r];
+                        const float ix = fmaf(al, t.x, s0), iy = fmaf(al, t.y, s1), iz = fmaf(al, t.z, s2);
+#pragma unroll
+                        for (int e = 0; e < V * V * V; ++e) {
+                            const float ox = (float)(e >> 2 & 1), oy = (float)(e >> 1 & 1), oz = (float)(e & 1);
+                            const float ux = hat01(fmaf(a0, ix, bv0 - ox));
+                            const float uy = hat01(fmaf(a1, iy, bv1 - oy));
+                            const float uz = hat01(fmaf(a2, iz, bv2 - oz));
+                            acc[e] = fmaf(ux * uy * uz, t.w, acc[e]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < V * V * V; ++e) {
+        const int x = vx + (V == 2 ? (e >> 2 & 1) : 0), y = vy + (V == 2 ? (e >> 1 & 1) : 0), z = vz + (V == 2 ? (e & 1) : 0);
+        if (x < G.D0 && y < G.D1 && z < G.D2 && acc[e] != 0.f) G.gvol[((size_t)x * G.D1 + y) * G.D2 + z] += acc[e];
+    }
+}
+
+// Siddon voxel gradient as a gather (exact-geometry index map only: a = 1, b = shift - 1/2, so the
+// voxel a segment is credited to is the voxel whose box contains it).  d out / d V[v] for one ray is
+// L x (length of the ray inside v's box, clipped to the ray's own [alpha_lo, alpha_hi]); the box's
+// entry/exit alphas use the forward's expression ((plane + plane0) - s) * (1 / d), so they are the
+// very crossing values the forward traversal produced.
+__global__ __launch_bounds__(WG) void k_siddon_gather_vol(GatherArgs G) {
+    if (*G.flag > __float_as_uint(GATHER_DEV_TOL)) return;
+    int bx, by, bz;
+    brick_coords(blockIdx.x, G.D1, G.D2, G.bd, bx, by, bz);
+    // 256 lanes on 4 x 8 x 8 voxels (one voxel per lane: the per-pose setup dominates, so a larger
+    // workgroup that amortises the cull words and pose constants wins here -- 4^3 bricks measured 10 % slower)
+    const int tid = threadIdx.x;
+    const int vx = bx * 4 + (tid >> 6), vy = by * 8 + ((tid >> 3) & 7), vz = bz * 8 + (tid & 7);
+    const bool inb = vx < G.D0 && vy < G.D1 && vz < G.D2;
+    // planes of the voxel's box and its centre, in x coordinates
+    const float p0x = (float)vx + G.sp.plane0[0], p0y = (float)vy + G.sp.plane0[1], p0z = (float)vz + G.sp.plane0[2];
+    const float p1x = (float)(vx + 1) + G.sp.plane0[0], p1y = (float)(vy + 1) + G.sp.plane0[1],
+                p1z = (float)(vz + 1) + G.sp.plane0[2];
+    const float cx = p0x + 0.5f, cy = p0y + 0.5f, cz = p0z + 0.5f;
+    float acc = 0.f;
+    for (int wd = 0; wd < G.words; ++wd) {
+        unsigned bits = G.cull[(size_t)blockIdx.x * G.words + wd];
+        while (bits) {
+            const int p = wd * 32 + __builtin_ctz(bits);
+            bits &= bits - 1;
+            const PoseLattice& P = G.poses[p];
+            const float s0 = P.s[0], s1 = P.s[1], s2 = P.s[2];
+            const float w0 = cx - s0, w1 = cy - s1, w2 = cz - s2;
+            const float av = P.nh[0] * w0 + P.nh[1] * w1 + P.nh[2] * w2;
+            const float da = 0.5f * P.dalpha;
+            const float amin = av - da, amax = av + da;
+            // pixel = g0 + N / alpha with N in [N0 - dN, N0 + dN], alpha in [amin, amax]
+            const float nj = P.gc[0] * w0 + P.gc[1] * w1 + P.gc[2] * w2, dnj = 0.5f * P.hwc;
+            const float ni = P.gr[0] * w0 + P.gr[1] * w1 + P.gr[2] * w2, dni = 0.5f * P.hwr;
+            int jlo = 0, jhi = -1, ilo = 0, ihi = -1;
+            if (inb && amin > 1e-6f && amax >= 0.f && amin <= 1.f) {
+                const float i0 = 1.f / amin, i1 = 1.f / amax;
+                const float ja = (nj - dnj) * i0, jb = (nj - dnj) * i1, jc = (nj + dnj) * i0, jd = (nj + dnj) * i1;
+                const float ia = (ni - dni) * i0, ib = (ni - dni) * i1, ic = (ni + dni) * i0, id = (ni + dni) * i1;
+                const float jmn = fminf(fminf(ja, jb), fminf(jc, jd)) + P.gc0 - GATHER_WIN_MARGIN;
+                const float jmx = fmaxf(fmaxf(ja, jb), fmaxf(jc, jd)) + P.gc0 + GATHER_WIN_MARGIN;
+                const float imn = fminf(fminf(ia, ib), fminf(ic, id)) + P.gr0 - GATHER_WIN_MARGIN;
+                const float imx = fmaxf(fmaxf(ia, ib), fmaxf(ic, id)) + P.gr0 + GATHER_WIN_MARGIN;
+                jlo = (int)ceilf(fmaxf(jmn, 0.f));
+                jhi = (int)floorf(fminf(jmx, (float)(G.W - 1)));
+                ilo = (int)ceilf(fmaxf(imn, 0.f));
+                ihi = (int)floorf(fminf(imx, (float)(G.H - 1)));
+            } else if (inb && amin <= 1e-6f && amax >= 0.f) {
+                // the box reaches the source plane: no perspective bound -- visit every ray
+                jhi = G.W - 1;
+                ihi = G.H - 1;
+            }
+            const float lx = p0x - s0, ly = p0y - s1, lz = p0z - s2;
+            const float hx = p1x - s0, hy = p1y - s1, hz = p1z - s2;
+            const float4* __restrict__ q = G.q + (size_t)p * G.n;
+            const float2* __restrict__ q2 = G.q2 + (size_t)p * G.n;
+            for (int i = ilo; i <= ihi; ++i) {
+                for (int j = jlo; j <= jhi; ++j) {
+                    const float4 t = q[(size_t)i * G.W + j];
+                    const float2 ab = q2[(size_t)i * G.W + j];
+                    const float x0 = lx * t.x, x1 = hx * t.x, y0 = ly * t.y, y1 = hy * t.y, z0 = lz * t.z, z1 = hz * t.z;
+                    float en = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+                    float ex = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+                    en = fmaxf(en, ab.x);
+                    ex = fminf(ex, ab.y);
+                    acc = fmaf(fmaxf(ex - en, 0.f), t.w, acc);
+                }
+            }
+        }
+    }
+    if (inb && acc != 0.f) G.gvol[((size_t)vx * G.D1 + vy) * G.D2 + vz] += acc;
+}
+
+
+// Same gather with a 2 x 2 x 2 voxel block per lane (one wavefront per 8^3 brick, as the trilinear gather):
+// the per-pose window and the candidate's loads are paid once for eight voxels, the three planes per axis give
+// nine crossing alphas per candidate (the forward's expression, plane by plane), from which every voxel's
+// entry / exit are one max3 / min3.  A candidate costs ~57 VALU for 8 voxels instead of 8 x 19.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_siddon_gather_vol2(GatherArgs G) {
+    if (*G.flag > __float_as_uint(GATHER_DEV_TOL)) return;
+    int bx, by, bz;
+    brick_coords(blockIdx.x, G.D1, G.D2, G.bd, bx, by, bz);
+    const int tid = threadIdx.x;
+    const int vx = (bx * 4 + (tid >> 4)) * 2, vy = (by * 4 + ((tid >> 2) & 3)) * 2, vz = (bz * 4 + (tid & 3)) * 2;
+    const bool inb = vx < G.D0 && vy < G.D1 && vz < G.D2;
+    // the three planes per axis that bound the block's voxels, and the block centre, in x coordinates
+    float px[3], py[3], pz[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        px[k] = (float)(vx + k) + G.sp.plane0[0];
+        py[k] = (float)(vy + k) + G.sp.plane0[1];
+        pz[k] = (float)(vz + k) + G.sp.plane0[2];
+    }
+    const float cx = px[1], cy = py[1], cz = pz[1];
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int wd = 0; wd < G.words; ++wd) {
+        unsigned bits = G.cull[(size_t)blockIdx.x * G.words + wd];
+        while (bits) {
+            const int p = wd * 32 + __builtin_ctz(bits);
+            bits &= bits - 1;
+            const PoseLattice& P = G.poses[p];
+            const float s0 = P.s[0], s1 = P.s[1], s2 = P.s[2];
+            const float w0 = cx - s0, w1 = cy - s1, w2 = cz - s2;
+            const float av = P.nh[0] * w0 + P.nh[1] * w1 + P.nh[2] * w2;
+            const float da = P.dalpha;                        // half-range of alpha over the 2-voxel block
+            const float amin = av - da, amax = av + da;
+            const float nj = P.gc[0] * w0 + P.gc[1] * w1 + P.gc[2] * w2, dnj = P.hwc;
+            const float ni = P.gr[0] * w0 + P.gr[1] * w1 + P.gr[2] * w2, dni = P.hwr;
+            int jlo = 0, jhi = -1, ilo = 0, ihi = -1;
+            if (inb && amin > 1e-6f && amax >= 0.f && amin <= 1.f) {
+                const float i0 = 1.f / amin, i1 = 1.f / amax;
+                const float ja = (nj - dnj) * i0, jb = (nj - dnj) * i1, jc = (nj + dnj) * i0, jd = (nj + dnj) * i1;
+                const float ia = (ni - dni) * i0, ib = (ni - dni) * i1, ic = (ni + dni) * i0, id = (ni + dni) * i1;
+                const float jmn = fminf(fminf(ja, jb), fminf(jc, jd)) + P.gc0 - GATHER_WIN_MARGIN;
+                const float jmx = fmaxf(fmaxf(ja, jb), fmaxf(jc, jd)) + P.gc0 + GATHER_WIN_MARGIN;
+                const float imn = fminf(fminf(ia, ib), fminf(ic, id)) + P.gr0 - GATHER_WIN_MARGIN;
+                const float imx = fmaxf(fmaxf(ia, ib), fmaxf(ic, id)) + P.gr0 + GATHER_WIN_MARGIN;
+                jlo = (int)ceilf(fmaxf(jmn, 0.f));
+                jhi = (int)floorf(fminf(jmx, (float)(G.W - 1)));
+                ilo = (int)ceilf(fmaxf(imn, 0.f));
+                ihi = (int)floorf(fminf(imx, (float)(G.H - 1)));
+            } else if (inb && amin <= 1e-6f && amax >= 0.f) {
+                jhi = G.W - 1;   // the block reaches the source plane: no perspective bound -- visit every ray
+                ihi = G.H - 1;
+            }
+            float lx[3], ly[3], lz[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { lx[k] = px[k] - s0; ly[k] = py[k] - s1; lz[k] = pz[k] - s2; }
+            const float4* __restrict__ q = G.q + (size_t)p * G.n;
+            const float2* __restrict__ q2 = G.q2 + (size_t)p * G.n;
+            for (int i = ilo; i <= ihi; ++i) {
+                const float4* __restrict__ row = q + (size_t)i * G.W;
+                const float2* __restrict__ row2 = q2 + (size_t)i * G.W;
+                // two candidates per trip: the four loads are issued before either candidate is evaluated
+                for (int j = jlo; j <= jhi; j += 2) {
+                    const int j1 = j < jhi ? j + 1 : j;
+                    float4 tt[2] = {row[j], row[j1]};
+                    const float2 aa[2] = {row2[j], row2[j1]};
+                    if (j1 == j) tt[1].w = 0.f;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const float4 t = tt[h];
+                        const float2 ab = aa[h];
+                        // crossing alphas of the planes (forward's expression), then per axis the two voxel
+                        // intervals; the ray's own [alpha_lo, alpha_hi] is folded into the x intervals once
+                        const float x0 = lx[0] * t.x, x1 = lx[1] * t.x, x2 = lx[2] * t.x;
+                        const float y0 = ly[0] * t.y, y1 = ly[1] * t.y, y2 = ly[2] * t.y;
+                        const float z0 = lz[0] * t.z, z1 = lz[1] * t.z, z2 = lz[2] * t.z;
+                        const float xl[2] = {fmaxf(fminf(x0, x1), ab.x), fmaxf(fminf(x1, x2), ab.x)};
+                        const float xh[2] = {fminf(fmaxf(x0, x1), ab.y), fminf(fmaxf(x1, x2), ab.y)};
+                        const float yl[2] = {fminf(y0, y1), fminf(y1, y2)}, yh[2] = {fmaxf(y0, y1), fmaxf(y1, y2)};
+                        const float zl[2] = {fminf(z0, z1), fminf(z1, z2)}, zh[2] = {fmaxf(z0, z1), fmaxf(z1, z2)};
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const int a = e >> 2, b = (e >> 1) & 1, c = e & 1;
+                            const float en = fmaxf(fmaxf(xl[a], yl[b]), zl[c]);
+                            const float ex = fminf(fminf(xh[a], yh[b]), zh[c]);
+                            // (alphas live in [0, 1]: the [0, 1] clamp is the max with 0, folded into the subtract)
+                            acc[e] = fmaf(__builtin_amdgcn_fmed3f(ex - en, 0.f, 1.f), t.w, acc[e]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int x = vx + (e >> 2), y = vy + ((e >> 1) & 1), z = vz + (e & 1);
+        if (x < G.D0 && y < G.D1 && z < G.D2 && acc[e] != 0.f) G.gvol[((size_t)x * G.D1 + y) * G.D2 + z] += acc[e];
+    }
+}
+
+
+}  // namespace
+
+// Set up the workspace and launch prep -> cull -> gather.  The caller launches the scatter fallback
+// (with skip_unless_flag_gt = the returned flag) right behind it.
+int xvr_detail::launch_gather(bool siddon, const float* source, const float* target, const float* raylen, const float* grad_out,
+                  int B, int n, int gw, int D0, int D1, int D2, const xvr_drr_spec* sp, float* grad_volume,
+                  void* workspace, void* stream, unsigned** flag_out) {
+    char* ws = static_cast<char*>(workspace);
+    GatherArgs G = {};
+    G.source = source; G.target = target; G.raylen = raylen; G.gout = grad_out;
+    G.B = B; G.n = n; G.W = gw; G.H = n / gw; G.D0 = D0; G.D1 = D1; G.D2 = D2; G.sp = *sp;
+    G.flag = reinterpret_cast<unsigned*>(ws);
+    G.poses = reinterpret_cast<PoseLattice*>(ws + ws_pose_off());
+    G.q = reinterpret_cast<float4*>(ws + ws_q_off(B));
+    G.q2 = reinterpret_cast<float2*>(ws + ws_q2_off(B, n));
+    G.siddon = siddon ? 1 : 0;
+    G.V = siddon ? 1 : gather_block();
+    // Siddon: 2x2x2 voxels per lane in 8^3 bricks unless XVR_DRR_SIDDON_GATHER_BLOCK=1 (A/B switch: one voxel per
+    // lane, 256 lanes on a 4 x 8 x 8 brick)
+    static const bool siddon_v1 = [] { const char* e = getenv("XVR_DRR_SIDDON_GATHER_BLOCK"); return e && e[0] == '1'; }();
+    if (siddon && siddon_v1) { G.bd[0] = 4; G.bd[1] = 8; G.bd[2] = 8; }
+    else if (siddon) { G.bd[0] = G.bd[1] = G.bd[2] = 8; }
+    else { G.bd[0] = G.bd[1] = G.bd[2] = 4 * G.V; }
+    G.cull = reinterpret_cast<unsigned*>(ws + ws_cull_off(B, n));
+    G.words = (B + 31) / 32;
+    G.gvol = grad_volume;
+    *flag_out = G.flag;
+    hipError_t e = hipMemsetAsync(G.flag, 0, 16, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
+    hipLaunchKernelGGL(k_gather_prep, dim3((unsigned)((n + WG - 1) / WG), (unsigned)B), dim3(WG), 0,
+                       (hipStream_t)stream, G);
+    const long long bricks = n_bricks(D0, D1, D2, G.bd);
+    if (bricks >= (1LL << 31)) return fail(XVR_DRR_E_UNSUPPORTED, "grid too large");
+    hipLaunchKernelGGL(k_gather_cull, dim3((unsigned)((bricks + WG / 32 - 1) / (WG / 32))), dim3(WG), 0,
+                       (hipStream_t)stream, G, (int)bricks);
+    if (siddon && siddon_v1) hipLaunchKernelGGL(k_siddon_gather_vol, dim3((unsigned)bricks), dim3(WG), 0, (hipStream_t)stream, G);
+    else if (siddon) hipLaunchKernelGGL(k_siddon_gather_vol2, dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
+    else if (G.V == 2 && getenv("XVR_DRR_GATHER_ABLATE")) hipLaunchKernelGGL((k_trilinear_gather_vol<2, true>), dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
+    else if (G.V == 2) hipLaunchKernelGGL(k_trilinear_gather_vol<2>, dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
+    else hipLaunchKernelGGL(k_trilinear_gather_vol<1>, dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
+    return XVR_DRR_OK;
+}
+
+extern "C" {
+
+size_t xvr_drr_backward_workspace_bytes(int B, int n, int D0, int D1, int D2) {
+    if (B <= 0 || n <= 0 || D0 <= 0 || D1 <= 0 || D2 <= 0) return 0;
+    return ws_bytes(B, n, D0, D1, D2);
+}
+
+}  // extern "C"

@@ -1,0 +1,266 @@
+// MI355X (gfx950) differentiable-DRR kernels: the per-ray side -- pose gradient from the saved jacobian, ray generation
+// from the camera vector and its adjoint, jacobian -> camera in one fixed-order pass.
+#include "drr_common.hiph"
+
+namespace {
+
+// =============================================================================================
+// pose-side backward from the saved jacobian (C == 1): elementwise + wave reduction
+// =============================================================================================
+__global__ __launch_bounds__(WG) void k_backward_from_jac(const float* __restrict__ jac, const float* __restrict__ gout,
+                                                         int n, float* gsrc, float* __restrict__ gtgt,
+                                                         float* __restrict__ glen) {
+    __shared__ float part[3][WG / 64];
+    const int b = blockIdx.y;
+    const int r = blockIdx.x * WG + threadIdx.x;
+    float js[3] = {0.f, 0.f, 0.f};
+    if (r < n) {
+        const size_t ray = (size_t)b * n + r;
+        const float g = gout[ray];
+        const float4* jp = reinterpret_cast<const float4*>(jac + ray * XVR_DRR_JAC_STRIDE);
+        const float4 j0 = jp[0], j1 = jp[1];
+        js[0] = g * j0.y; js[1] = g * j0.z; js[2] = g * j0.w;
+        float* tp = gtgt + ray * 3;
+        tp[0] = g * j1.x; tp[1] = g * j1.y; tp[2] = g * j1.z;
+        if (glen) glen[ray] = g * j0.x;
+    }
+    // grad_source is shared by all rays of the pose: wave butterfly (DPP/shfl), then the 4 waves of
+    // the block through LDS, then ONE atomic per component per block
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float tot = wave_sum_f(js[i]);
+        if ((threadIdx.x & 63) == 0) part[i][threadIdx.x >> 6] = tot;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const float tot = part[threadIdx.x][0] + part[threadIdx.x][1] + part[threadIdx.x][2] + part[threadIdx.x][3];
+        if (tot != 0.f) atomic_add_f32(gsrc + 3 * b + threadIdx.x, tot);
+    }
+}
+
+// =============================================================================================
+// Ray generation fused into one pass (rows a2-a4 of SURVEY.md 8a): what xvr does with three torch
+// calls and ~40 launches -- drr.detector(pose, None), (target - source).norm(), affinv(source/target)
+// (src/xvr/model/trainer.py:283-285) -- is an affine map of the pixel index per pose:
+//     target_vox(i, j) = Mv (i, j, 1)^T,   raylen(i, j) = | Mw (i, j, 1)^T - s_w |
+// cam[b] = { Mv[3][3], s_v[3], Mw[3][3], s_w[3] } (24 floats, built by the host from the 4x4 pose).
+// =============================================================================================
+__global__ __launch_bounds__(WG) void k_rays_fwd(const float* __restrict__ cam, int H, int W, float* __restrict__ source,
+                                                 float* __restrict__ target, float* __restrict__ raylen) {
+    const int b = blockIdx.y, n = H * W;
+    const int r = blockIdx.x * WG + threadIdx.x;
+    const float* c = cam + 24 * b;
+    if (r == 0) { source[3 * b] = c[9]; source[3 * b + 1] = c[10]; source[3 * b + 2] = c[11]; }
+    if (r >= n) return;
+    const int i = r / W, j = r - i * W;
+    const float fi = (float)i, fj = (float)j;
+    float* t = target + ((size_t)b * n + r) * 3;
+    float l2 = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        t[a] = fmaf(c[3 * a], fi, fmaf(c[3 * a + 1], fj, c[3 * a + 2]));
+        const float w = fmaf(c[12 + 3 * a], fi, fmaf(c[12 + 3 * a + 1], fj, c[12 + 3 * a + 2])) - c[21 + a];
+        l2 = fmaf(w, w, l2);
+    }
+    raylen[(size_t)b * n + r] = sqrtf(l2);
+}
+
+// backward: 21 sums over a pose's rays (wave butterfly -> LDS across the 4 waves -> one atomic each per block)
+__global__ __launch_bounds__(WG) void k_rays_bwd(const float* __restrict__ cam, int H, int W, const float* __restrict__ g_source,
+                                                 const float* __restrict__ g_target, const float* __restrict__ g_raylen,
+                                                 float* g_cam) {
+    __shared__ float part[21][WG / 64];
+    const int b = blockIdx.y, n = H * W;
+    const int r = blockIdx.x * WG + threadIdx.x;
+    const float* c = cam + 24 * b;
+    float acc[21];
+#pragma unroll
+    for (int q = 0; q < 21; ++q) acc[q] = 0.f;
+    if (r < n) {
+        const int i = r / W, j = r - i * W;
+        const float pix[3] = {(float)i, (float)j, 1.f};
+        const float* gt = g_target + ((size_t)b * n + r) * 3;
+        float w[3], l2 = 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            w[a] = fmaf(c[12 + 3 * a], pix[0], fmaf(c[12 + 3 * a + 1], pix[1], c[12 + 3 * a + 2])) - c[21 + a];
+            l2 = fmaf(w[a], w[a], l2);
+        }
+        const float gl = g_raylen ? g_raylen[(size_t)b * n + r] : 0.f;
+        const float s = l2 > 0.f ? gl / sqrtf(l2) : 0.f;  // g_L * (unit direction) = s * w
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                acc[3 * a + m] = gt[a] * pix[m];           // d/d Mv[a][m]
+                acc[9 + 3 * a + m] = s * w[a] * pix[m];    // d/d Mw[a][m]
+            }
+            acc[18 + a] = -s * w[a];                        // d/d s_w[a]
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 21; ++q) {
+        const float tot = wave_sum_f(acc[q]);
+        if ((threadIdx.x & 63) == 0) part[q][threadIdx.x >> 6] = tot;
+    }
+    __syncthreads();
+    if (threadIdx.x < 21) {
+        const int q = threadIdx.x;
+        const float tot = part[q][0] + part[q][1] + part[q][2] + part[q][3];
+        // layout of g_cam mirrors cam: Mv 0..8, s_v 9..11, Mw 12..20, s_w 21..23
+        const int dst = q < 9 ? q : (q < 18 ? q + 3 : q + 3);
+        if (tot != 0.f) atomic_add_f32(g_cam + 24 * b + dst, tot);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 3 && g_source) atomic_add_f32(g_cam + 24 * b + 9 + threadIdx.x, g_source[3 * b + threadIdx.x]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// jacobian -> camera: k_backward_from_jac and k_rays_bwd in one pass, for callers that want d/d cam and
+// not the per-ray gradients (the registration loop).  grad_target / grad_raylen are never written, and
+// the 24 sums are ORDER-DETERMINISTIC: every block stores its partial sums, the block that finishes last
+// for a pose (ticket counter) adds them in block order and WRITES grad_cam[b] -- no float atomics, the
+// same bits on every run.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void k_jac_to_cam(const float* __restrict__ jac, const float* __restrict__ gout,
+                                                   const float* __restrict__ cam, int H, int W, float* partial,
+                                                   unsigned* counter, float* __restrict__ g_cam) {
+    __shared__ float part[24][WG / 64];
+    __shared__ float fin[24][WG + 1];
+    __shared__ bool last;
+    const int b = blockIdx.y, n = H * W, nblk = gridDim.x;
+    const int r = blockIdx.x * WG + threadIdx.x;
+    const float* c = cam + 24 * b;
+    float acc[24];
+#pragma unroll
+    for (int q = 0; q < 24; ++q) acc[q] = 0.f;
+    if (r < n) {
+        const size_t ray = (size_t)b * n + r;
+        const float g = gout[ray];
+        const float4* jp = reinterpret_cast<const float4*>(jac + ray * XVR_DRR_JAC_STRIDE);
+        const float4 j0 = jp[0], j1 = jp[1];
+        const int i = r / W, j = r - i * W;
+        const float pix[3] = {(float)i, (float)j, 1.f};
+        const float gt[3] = {g * j1.x, g * j1.y, g * j1.z};
+        float w[3], l2 = 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            w[a] = fmaf(c[12 + 3 * a], pix[0], fmaf(c[12 + 3 * a + 1], pix[1], c[12 + 3 * a + 2])) - c[21 + a];
+            l2 = fmaf(w[a], w[a], l2);
+        }
+        const float gl = g * j0.x;
+        const float sc = l2 > 0.f ? gl / sqrtf(l2) : 0.f;  // g_L * (unit direction) = sc * w
+        acc[9] = g * j0.y; acc[10] = g * j0.z; acc[11] = g * j0.w;   // d/d s_v = grad_source
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                acc[3 * a + m] = gt[a] * pix[m];             // d/d Mv[a][m]
+                acc[12 + 3 * a + m] = sc * w[a] * pix[m];    // d/d Mw[a][m]
+            }
+            acc[21 + a] = -sc * w[a];                         // d/d s_w[a]
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 24; ++q) {
+        const float tot = wave_sum_f(acc[q]);
+        if ((threadIdx.x & 63) == 0) part[q][threadIdx.x >> 6] = tot;
+    }
+    __syncthreads();
+    // Publishing without a device-wide fence (a release fence writes the XCD's whole L2 back: ~70 ns per
+    // block, serialised -- measured 4x slower than the kernel itself): the partials are stored and
+    // loaded with agent-scope atomics, which go to the level where the 8 XCDs are coherent; the
+    // barrier's wait for outstanding stores orders them before this block's ticket, and the block that
+    // draws the last ticket therefore reads everybody's partials.
+    float* mine = partial + ((size_t)b * nblk + blockIdx.x) * 24;
+    if (threadIdx.x < 24)
+        __hip_atomic_store(mine + threadIdx.x, (part[threadIdx.x][0] + part[threadIdx.x][1]) + (part[threadIdx.x][2] + part[threadIdx.x][3]),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();   // includes s_waitcnt vmcnt(0): the stores above have completed
+    if (threadIdx.x == 0)
+        last = __hip_atomic_fetch_add(counter + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nblk - 1);
+    __syncthreads();
+    if (!last) return;
+    // thread t adds rows t, t + 256, ... (all 24 columns, independent loads), then the 256 per-thread sums
+    // are added column by column in thread order
+    float t24[24];
+#pragma unroll
+    for (int q = 0; q < 24; ++q) t24[q] = 0.f;
+    const float* P = partial + (size_t)b * nblk * 24;
+    for (int k = threadIdx.x; k < nblk; k += WG) {
+#pragma unroll
+        for (int q = 0; q < 24; ++q)
+            t24[q] += __hip_atomic_load(P + (size_t)k * 24 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int q = 0; q < 24; ++q) fin[q][threadIdx.x] = t24[q];
+    __syncthreads();
+    if (threadIdx.x < 24) {
+        float t = 0.f;
+        for (int k = 0; k < WG; ++k) t += fin[threadIdx.x][k];
+        g_cam[24 * b + threadIdx.x] = t;
+    }
+    if (threadIdx.x == 0) counter[b] = 0;   // ready for the next call
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t xvr_drr_jac_to_camera_workspace_bytes(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    const size_t nblk = ((size_t)H * W + WG - 1) / WG;
+    return align256((size_t)B * sizeof(unsigned)) + (size_t)B * nblk * 24 * sizeof(float);
+}
+
+int xvr_drr_jac_to_camera_backward(const float* jac, const float* grad_out, const float* cam, int B, int H, int W,
+                                   float* grad_cam, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!jac || !grad_out || !cam || !grad_cam || !workspace) return fail(XVR_DRR_E_ARG, "null pointer argument");
+    if (B <= 0 || H <= 0 || W <= 0) return fail(XVR_DRR_E_ARG, "B, H, W must be positive");
+    if (workspace_bytes < xvr_drr_jac_to_camera_workspace_bytes(B, H, W)) return fail(XVR_DRR_E_ARG, "workspace too small");
+    if (reinterpret_cast<uintptr_t>(jac) & 15u) return fail(XVR_DRR_E_ARG, "jac must be 16-byte aligned");
+    const unsigned nblk = (unsigned)(((size_t)H * W + WG - 1) / WG);
+    char* ws = static_cast<char*>(workspace);
+    hipLaunchKernelGGL(k_jac_to_cam, dim3(nblk, (unsigned)B), dim3(WG), 0, (hipStream_t)stream, jac, grad_out, cam, H, W,
+                       reinterpret_cast<float*>(ws + align256((size_t)B * sizeof(unsigned))), reinterpret_cast<unsigned*>(ws),
+                       grad_cam);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
+    return XVR_DRR_OK;
+}
+
+int xvr_drr_rays_forward(const float* cam, int B, int H, int W, float* source, float* target, float* raylen,
+                         void* stream) {
+    if (!cam || !source || !target || !raylen) return fail(XVR_DRR_E_ARG, "null pointer argument");
+    if (B <= 0 || H <= 0 || W <= 0) return fail(XVR_DRR_E_ARG, "B, H, W must be positive");
+    dim3 grid((unsigned)(((long long)H * W + WG - 1) / WG), (unsigned)B);
+    hipLaunchKernelGGL(k_rays_fwd, grid, dim3(WG), 0, (hipStream_t)stream, cam, H, W, source, target, raylen);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
+    return XVR_DRR_OK;
+}
+
+int xvr_drr_rays_backward(const float* cam, int B, int H, int W, const float* grad_source, const float* grad_target,
+                          const float* grad_raylen, float* grad_cam, void* stream) {
+    if (!cam || !grad_target || !grad_cam) return fail(XVR_DRR_E_ARG, "null pointer argument");
+    if (B <= 0 || H <= 0 || W <= 0) return fail(XVR_DRR_E_ARG, "B, H, W must be positive");
+    dim3 grid((unsigned)(((long long)H * W + WG - 1) / WG), (unsigned)B);
+    hipLaunchKernelGGL(k_rays_bwd, grid, dim3(WG), 0, (hipStream_t)stream, cam, H, W, grad_source, grad_target,
+                       grad_raylen, grad_cam);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
+    return XVR_DRR_OK;
+}
+
+int xvr_drr_backward_from_jac(const float* jac, const float* grad_out, int B, int n, float* grad_source,
+                              float* grad_target, float* grad_raylen, void* stream) {
+    if (!jac || !grad_out || !grad_source || !grad_target) return fail(XVR_DRR_E_ARG, "null pointer argument");
+    if (B <= 0 || n <= 0) return fail(XVR_DRR_E_ARG, "B and n must be positive");
+    dim3 grid((unsigned)((n + WG - 1) / WG), (unsigned)B);
+    hipLaunchKernelGGL(k_backward_from_jac, grid, dim3(WG), 0, (hipStream_t)stream, jac, grad_out, n,
+                       grad_source, grad_target, grad_raylen);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
+    return XVR_DRR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,336 @@
+// MI355X (gfx950) differentiable-DRR kernels: Siddon exact traversal -- forward (+jacobian), alpha-split forward,
+// re-traversal backward (pose gradient and atomic-scatter voxel gradient).
+#include "drr_common.hiph"
+
+namespace {
+
+// =============================================================================================
+// Siddon: exact traversal as an incremental merge of the three per-axis plane-crossing sequences
+// (no sort, no materialised alpha list).  MODE 0: forward; 1: forward + jacobian; 2: backward.
+// =============================================================================================
+// EXACT: the index map is the exact-geometry one (a = 1, b = shift - 1/2), so the voxel a segment
+// belongs to is the voxel between the planes just crossed: it is tracked incrementally (+-1 on the
+// crossed axis) instead of being re-derived from every segment's midpoint.
+// SPLIT (forward, no mask, exact geometry only): 0 = one lane walks the whole ray; 1 / 2 = the ray's
+// alpha range is cut into NS equal slices walked by NS wavefronts of the workgroup (8x8 / 16x16 tiles, see
+// k_trilinear_fwd_split) and the partial sums meet in LDS.  A voxel segment that straddles a cut is
+// credited to the same voxel from both sides (exact geometry: the voxel is the one between the planes),
+// so only the rounding of that one product differs from the unsplit walk.
+// (at most 5 wavefronts per SIMD: the walk is bound by the texture-address unit; 10.7 ms at C3 against 11.5 ms at
+//  the 8 its register count would allow and at 4)
+template <int MODE, int MASK, bool GPOSE, bool GVOL, bool EXACT, int SPLIT = 0>
+__global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAX : WG) __attribute__((amdgpu_waves_per_eu(1, 5))) void k_siddon(RenderArgs A) {
+    extern __shared__ float lds[];  // MASK: fwd -> channel accumulators, bwd -> upstream gradients; SPLIT: partial sums
+    static_assert(!SPLIT || (MODE != 2 && !MASK && EXACT), "split walk: forward, unmasked, exact geometry");
+    if (MODE == 2 && A.skip_unless_flag_gt && !(*A.skip_unless_flag_gt > __float_as_uint(GATHER_DEV_TOL))) return;
+    int b, r, sl_l = 0, sl_w = 0, sl_n = 1;
+    const bool valid = SPLIT ? map_ray_split<SPLIT == 2>(A, b, r, sl_l, sl_w, sl_n) : map_ray(A, b, r, threadIdx.x);
+    const int tid = threadIdx.x;
+    Ray R;
+    ray_setup(A, b, r, valid, R);
+    const float* __restrict__ vol = A.volume;
+    const int D0 = A.D0, D1 = A.D1, D2 = A.D2;
+    constexpr bool BWD = MODE == 2;
+    constexpr bool DERIV = MODE == 1 || (BWD && GPOSE);
+
+    float g0 = 1.f;
+    if (MASK) {
+        for (int c = 0; c < A.C; ++c)
+            lds[c * WG + tid] = (BWD && valid) ? A.gout[((size_t)b * A.C + c) * A.n + r] : 0.f;
+    } else if (BWD) {
+        g0 = valid ? A.gout[(size_t)b * A.n + r] : 0.f;
+    }
+
+    float alo = R.amin, ahi = R.amax;
+    if (SPLIT) {   // cut k sits at fmaf(k / NS, amax - amin, amin): both neighbours compute it identically
+        const float a0 = R.amin, a1 = R.amax, inv = 1.f / (float)sl_n;
+        if (sl_w > 0) alo = fmaf((float)sl_w * inv, a1 - a0, a0);
+        if (sl_w < sl_n - 1) ahi = fmaf((float)(sl_w + 1) * inv, a1 - a0, a0);
+    }
+    bool live = valid && (ahi > alo) && (R.amax > R.amin);
+    // per axis: reciprocal direction, (plane0 - s) so that alpha(p) = ((float)p + ps) * inv_d -- the same
+    // value the sort formulation computes as ((p + plane0) - s) / d up to the reciprocal's rounding --,
+    // index of the next plane to cross, step, alpha of that plane.  No range check on p: a plane beyond
+    // the volume has alpha >= the axis' exit alpha >= ahi and is never selected before the loop ends.
+    float inv_d[3], an3[3];
+    int ip[3], stp[3];
+    bool on_plane = false;   // the walk starts on a plane (always at the entry face; at a cut: see plane_at_cut)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        inv_d[i] = 1.f / R.d[i];
+        const float f = fmaf(alo, R.d[i], R.s[i]) - A.sp.plane0[i];  // position in plane-index units
+        if (R.d[i] > 0.f) { stp[i] = 1; ip[i] = (int)floorf(f) + 1; }
+        else { stp[i] = -1; ip[i] = (int)ceilf(f) - 1; }
+        an3[i] = (((float)ip[i] + A.sp.plane0[i]) - R.s[i]) * inv_d[i];
+        if (an3[i] <= alo) {  // a plane at or behind the entry point (fp noise) is skipped
+            on_plane = true;
+            ip[i] += stp[i];
+            an3[i] = (((float)ip[i] + A.sp.plane0[i]) - R.s[i]) * inv_d[i];
+        } else if (SPLIT && sl_w > 0) {
+            // a slice must start at the FIRST plane beyond its cut by the same alpha arithmetic the previous
+            // slice ends with; the position-based guess above can be one plane late when the cut sits
+            // within an ulp of a plane
+            const float ap = (((float)(ip[i] - stp[i]) + A.sp.plane0[i]) - R.s[i]) * inv_d[i];
+            if (ap > alo) { ip[i] -= stp[i]; an3[i] = ap; }
+            else if (ap == alo) on_plane = true;
+        }
+        if (!live) an3[i] = INFINITY;
+    }
+    // EXACT: the current voxel along an axis is the one just before the next plane in travel direction
+    const int vo0 = stp[0] > 0 ? 1 : 0, vo1 = stp[1] > 0 ? 1 : 0, vo2 = stp[2] > 0 ? 1 : 0;
+
+    float acc = 0.f;                 // sum V * dalpha (C==1 fwd) / sum g V dalpha (bwd)
+    float As[3] = {0.f, 0.f, 0.f};   // sum dW (alpha-1)/d  per axis
+    float At[3] = {0.f, 0.f, 0.f};   // sum dW (-alpha)/d   per axis
+    float Wprev = 0.f;
+    int ax_prev = (SPLIT && sl_w > 0) ? -1 : R.ax_in;  // axis of the crossing that opened the current segment (-1: none)
+    float ac = alo;
+    unsigned cnt = 0;
+    // the work counter counts voxel segments: a slice that starts inside a voxel continues the previous
+    // slice's last segment
+    bool first_of_slice = SPLIT && sl_w > 0 && !on_plane;
+    const int max_iter = D0 + D1 + D2 + 8;
+
+    // Software pipeline, depth 1: the voxel (and label) of segment i is requested, then segment i-1 --
+    // whose load has had a whole traversal step to arrive -- is consumed.  The traversal itself never
+    // depends on loaded values, only the accumulation does.
+    bool have = false, exited = false;
+    float p_v = 0.f, p_seg = 0.f, p_ac = 0.f, p_lab = 0.f;
+    int p_ax = -1, p_off = 0;
+    bool p_inb = false;
+    float W = 0.f;
+
+    auto consume = [&]() {
+        const float v = p_v;
+        int lab = 0;
+        if (MASK) lab = p_inb ? min(max((int)p_lab, 0), A.C - 1) : 0;
+        W = v;
+        if (BWD) {
+            const float gk = MASK ? lds[lab * WG + tid] : g0;
+            W = gk * v;
+            if (GVOL && p_inb) {
+                const float c = gk * R.L * p_seg;
+                if (c != 0.f) atomic_add_f32(A.gvol + p_off, c);
+            }
+            acc = fmaf(W, p_seg, acc);
+        } else if (MASK) {
+            lds[lab * WG + tid] = fmaf(v, p_seg, lds[lab * WG + tid]);
+            if (MODE == 1) acc = fmaf(v, p_seg, acc);  // jacobian of the channel sum
+        } else {
+            acc = fmaf(v, p_seg, acc);
+        }
+        if (DERIV) {
+            const float dW = Wprev - W;  // d out / d alpha at the crossing that opened this segment
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float m = (p_ax == i) ? dW * inv_d[i] : 0.f;
+                As[i] = fmaf(m, p_ac - 1.f, As[i]);
+                At[i] = fmaf(m, -p_ac, At[i]);
+            }
+            Wprev = W;
+        }
+    };
+
+    for (int it = 0; it < max_iter; ++it) {
+        if (!live) break;
+        const float an = fminf(fminf(an3[0], an3[1]), fminf(an3[2], ahi));
+        int ix, iy, iz;
+        if (EXACT) {
+            ix = ip[0] - vo0; iy = ip[1] - vo1; iz = ip[2] - vo2;
+        } else {
+            const float mid = 0.5f * (ac + an);
+            ix = (int)rintf(fmaf(A.sp.a[0], fmaf(mid, R.d[0], R.s[0]), A.sp.b[0]));
+            iy = (int)rintf(fmaf(A.sp.a[1], fmaf(mid, R.d[1], R.s[1]), A.sp.b[1]));
+            iz = (int)rintf(fmaf(A.sp.a[2], fmaf(mid, R.d[2], R.s[2]), A.sp.b[2]));
+        }
+        const bool inb = (unsigned)ix < (unsigned)D0 && (unsigned)iy < (unsigned)D1 && (unsigned)iz < (unsigned)D2;
+        const int off = inb ? (ix * D1 + iy) * D2 + iz : 0;
+        const float v_new = vol[off];                       // always loadable (offset 0 when outside)
+        // MASK == 2: the label rides in the low mantissa bits of the voxel just loaded (xvr_drr_pack_labels)
+        const float lab_new = MASK == 2 ? (float)(__float_as_uint(v_new) & LABEL_MASK) : (MASK ? A.mask[off] : 0.f);
+        if (inb && !first_of_slice && (!SPLIT || an > ac)) ++cnt;
+        first_of_slice = false;
+        if (have) consume();
+        p_v = inb ? v_new : 0.f; p_seg = an - ac; p_ac = ac; p_ax = ax_prev; p_off = off; p_inb = inb; p_lab = lab_new;
+        have = true;
+        // advance every axis whose next plane has been reached (ties advance together), branch-free
+        const bool c0 = an3[0] <= an, c1 = an3[1] <= an, c2 = an3[2] <= an;
+        // A plane exactly AT a cut (routine: the cuts of opposite-face rays fall on the centre planes) is
+        // crossed by the slice that ends there: one more, zero-length, segment carries its jacobian term;
+        // the next slice starts behind the plane.
+        const bool plane_at_cut = SPLIT && sl_w < sl_n - 1 && (c0 || c1 || c2);
+        if (an >= ahi && !plane_at_cut) {
+            exited = true;
+            live = false;
+        } else {
+            ip[0] += c0 ? stp[0] : 0; ip[1] += c1 ? stp[1] : 0; ip[2] += c2 ? stp[2] : 0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) an3[i] = (((float)ip[i] + A.sp.plane0[i]) - R.s[i]) * inv_d[i];
+            ax_prev = c0 ? 0 : (c1 ? 1 : 2);
+            ac = an;
+        }
+    }
+    if (have) consume();
+    if (DERIV && exited && (!SPLIT || sl_w == sl_n - 1)) {  // exit crossing: beyond it W = 0
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float m = (R.ax_out == i) ? W * inv_d[i] : 0.f;
+            As[i] = fmaf(m, ahi - 1.f, As[i]);
+            At[i] = fmaf(m, -ahi, At[i]);
+        }
+    }
+
+    if (SPLIT) {
+        constexpr int TL = SPLIT == 2 ? 256 : 64;
+        if (sl_w > 0) {
+            float* p = lds + (size_t)(sl_w - 1) * 7 * TL + sl_l;
+            p[0] = acc;
+            if (MODE == 1) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { p[(1 + i) * TL] = As[i]; p[(4 + i) * TL] = At[i]; }
+            }
+        }
+        __syncthreads();
+        if (sl_w == 0) {
+            for (int v = 1; v < sl_n; ++v) {
+                const float* p = lds + (size_t)(v - 1) * 7 * TL + sl_l;
+                acc += p[0];
+                if (MODE == 1) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) { As[i] += p[(1 + i) * TL]; At[i] += p[(4 + i) * TL]; }
+                }
+            }
+        }
+    }
+    if (!BWD) {
+        if (valid && (!SPLIT || sl_w == 0)) {
+            if (MASK) {
+                for (int c = 0; c < A.C; ++c) A.out[((size_t)b * A.C + c) * A.n + r] = lds[c * WG + tid] * R.L;
+            } else {
+                A.out[(size_t)b * A.n + r] = acc * R.L;
+            }
+            if (MODE == 1) {
+                float4* jp = reinterpret_cast<float4*>(A.jac + ((size_t)b * A.n + r) * XVR_DRR_JAC_STRIDE);
+                jp[0] = make_float4(acc, R.L * As[0], R.L * As[1], R.L * As[2]);
+                jp[1] = make_float4(R.L * At[0], R.L * At[1], R.L * At[2], 0.f);
+            }
+        }
+        if (A.work) {
+            unsigned tot = wave_sum_u(cnt);
+            if ((tid & 63) == 0 && tot) atomicAdd(A.work, (unsigned long long)tot);
+        }
+    } else if (GPOSE) {
+        float js[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) js[i] = valid ? R.L * As[i] : 0.f;
+        if (valid) {
+            float* tp = A.gtgt + ((size_t)b * A.n + r) * 3;
+            tp[0] = R.L * At[0]; tp[1] = R.L * At[1]; tp[2] = R.L * At[2];
+            if (A.glen) A.glen[(size_t)b * A.n + r] = acc;
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float tot = wave_sum_f(js[i]);
+            if ((tid & 63) == 0 && tot != 0.f) atomic_add_f32(A.gsrc + 3 * b + i, tot);
+        }
+    }
+}
+
+
+}  // namespace
+
+extern "C" {
+
+static int siddon_forward_impl(const float* volume, const float* mask, int D0, int D1, int D2, int C,
+                           const float* source, const float* target, const float* raylen, int B, int n,
+                           const xvr_drr_spec* sp, float* out, float* jac, unsigned long long* work,
+                           void* stream, const float* cam) {
+    int rc = check_common(volume, D0, D1, D2, C, source, target, raylen, B, n, sp, cam);
+    if (rc) return rc;
+    if (!out) return fail(XVR_DRR_E_ARG, "out is null");
+    const bool packed = !mask && C > 1;   // labels in the low mantissa bits of `volume` (xvr_drr_pack_labels)
+    if (packed && C > (1 << LABEL_BITS)) return fail(XVR_DRR_E_ARG, "packed labels hold at most 16 channels");
+    RenderArgs A;
+    fill_args(A, volume, mask, D0, D1, D2, C, source, target, raylen, B, n, sp, cam);
+    A.out = out; A.jac = jac; A.work = work;
+    const size_t lds = C > 1 || mask ? (size_t)C * WG * sizeof(float) : 0;
+    const bool ex = siddon_exact_geometry(sp);
+    if (packed && jac) return (ex ? launch(k_siddon<1, 2, false, false, true>, A, lds, stream) : launch(k_siddon<1, 2, false, false, false>, A, lds, stream));
+    if (packed) return (ex ? launch(k_siddon<0, 2, false, false, true>, A, lds, stream) : launch(k_siddon<0, 2, false, false, false>, A, lds, stream));
+    if (mask && jac) return (ex ? launch(k_siddon<1, true, false, false, true>, A, lds, stream) : launch(k_siddon<1, true, false, false, false>, A, lds, stream));
+    if (mask) return (ex ? launch(k_siddon<0, true, false, false, true>, A, lds, stream) : launch(k_siddon<0, true, false, false, false>, A, lds, stream));
+    bool tile16 = false;
+    const int ns = ex ? split_factor(B, n, (long long)D0 * D1 * D2, true, &tile16) : 1;
+    if (ns > 1) {
+        if (jac) return tile16 ? launch_split(k_siddon<1, false, false, false, true, 2>, A, ns, true, 7, stream)
+                               : launch_split(k_siddon<1, false, false, false, true, 1>, A, ns, false, 7, stream);
+        return tile16 ? launch_split(k_siddon<0, false, false, false, true, 2>, A, ns, true, 7, stream)
+                      : launch_split(k_siddon<0, false, false, false, true, 1>, A, ns, false, 7, stream);
+    }
+    if (jac) return (ex ? launch(k_siddon<1, false, false, false, true>, A, 0, stream) : launch(k_siddon<1, false, false, false, false>, A, 0, stream));
+    return (ex ? launch(k_siddon<0, false, false, false, true>, A, 0, stream) : launch(k_siddon<0, false, false, false, false>, A, 0, stream));
+}
+
+int xvr_drr_siddon_forward(const float* volume, const float* mask, int D0, int D1, int D2, int C,
+                           const float* source, const float* target, const float* raylen, int B, int n,
+                           const xvr_drr_spec* sp, float* out, float* jac, unsigned long long* work, void* stream) {
+    return siddon_forward_impl(volume, mask, D0, D1, D2, C, source, target, raylen, B, n, sp, out, jac, work, stream, nullptr);
+}
+
+int xvr_drr_siddon_forward_camera(const float* volume, const float* mask, int D0, int D1, int D2, int C,
+                                  const float* cam, int B, int H, int W, const xvr_drr_spec* sp, float* out, float* jac,
+                                  unsigned long long* work, void* stream) {
+    if (!cam || !sp) return fail(XVR_DRR_E_ARG, "null pointer argument");
+    if (H < 1 || W < 2 || (long long)H * W >= (1LL << 31)) return fail(XVR_DRR_E_ARG, "detector must be at least 1 x 2");
+    xvr_drr_spec local = *sp;
+    local.ray_grid_w = W;
+    return siddon_forward_impl(volume, mask, D0, D1, D2, C, nullptr, nullptr, nullptr, B, H * W, &local, out, jac, work, stream, cam);
+}
+
+int xvr_drr_siddon_backward(const float* volume, const float* mask, int D0, int D1, int D2, int C,
+                            const float* source, const float* target, const float* raylen, int B, int n,
+                            const xvr_drr_spec* sp, const float* grad_out, float* grad_volume,
+                            float* grad_source, float* grad_target, float* grad_raylen, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+
+    int rc = check_common(volume, D0, D1, D2, C, source, target, raylen, B, n, sp);
+    if (rc) return rc;
+    if (!grad_out) return fail(XVR_DRR_E_ARG, "grad_out is null");
+    if (!mask && C != 1) return fail(XVR_DRR_E_ARG, "C must be 1 without a mask");
+    if ((grad_source == nullptr) != (grad_target == nullptr))
+        return fail(XVR_DRR_E_ARG, "grad_source and grad_target must be requested together");
+    if (grad_raylen && !grad_target) return fail(XVR_DRR_E_ARG, "grad_raylen needs grad_source/grad_target");
+    const bool gpose = grad_target != nullptr, gvol = grad_volume != nullptr;
+    if (!gpose && !gvol) return XVR_DRR_OK;
+    RenderArgs A;
+    fill_args(A, volume, mask, D0, D1, D2, C, source, target, raylen, B, n, sp);
+    A.gout = grad_out; A.gvol = grad_volume; A.gsrc = grad_source; A.gtgt = grad_target; A.glen = grad_raylen;
+    const size_t lds = mask ? (size_t)C * WG * sizeof(float) : 0;
+    // the gather needs the exact-geometry index map (voxel credited = voxel whose box holds the segment)
+    const bool exact_geom = siddon_exact_geometry(sp);
+    if (gvol && !mask && exact_geom && gather_usable(sp, n, workspace, workspace_bytes, B, D0, D1, D2)) {
+        unsigned* flag = nullptr;
+        rc = launch_gather(true, source, target, raylen, grad_out, B, n, sp->ray_grid_w, D0, D1, D2, sp, grad_volume,
+                           workspace, stream, &flag);
+        if (rc) return rc;
+        if (gpose) {
+            RenderArgs Ap = A;
+            Ap.gvol = nullptr;
+            rc = launch(k_siddon<2, false, true, false, true>, Ap, 0, stream);
+            if (rc) return rc;
+        }
+        RenderArgs Av = A;
+        Av.gsrc = nullptr; Av.gtgt = nullptr; Av.glen = nullptr;
+        Av.skip_unless_flag_gt = flag;
+        return launch(k_siddon<2, false, false, true, true>, Av, 0, stream);
+    }
+#define SID_BWD2(M, E)                                                                  \
+    (gpose ? (gvol ? launch(k_siddon<2, M, true, true, E>, A, lds, stream)              \
+                   : launch(k_siddon<2, M, true, false, E>, A, lds, stream))            \
+           : launch(k_siddon<2, M, false, true, E>, A, lds, stream))
+#define SID_BWD(M) (exact_geom ? SID_BWD2(M, true) : SID_BWD2(M, false))
+    return mask ? SID_BWD(true) : SID_BWD(false);
+#undef SID_BWD
+#undef SID_BWD2
+}
+}  // extern "C"

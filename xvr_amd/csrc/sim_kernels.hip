@@ -20,7 +20,7 @@
 #include "xvr_drr.h"
 #include "xvr_sim.h"
 
-extern "C" void xvr_drr_set_last_error(const char* msg);  // drr_kernels.hip
+extern "C" void xvr_drr_set_last_error(const char* msg);  // drr_api.hip
 
 namespace {
 

@@ -119,6 +119,8 @@ int vfail(int code, const char* msg) {
 
 }  // namespace
 
+namespace {
+
 // packed[i] = volume[i] with its low 4 mantissa bits replaced by the label min(max((int)mask[i], 0), 15)
 __global__ __launch_bounds__(TB) void k_pack_labels(const float* __restrict__ vol, const float* __restrict__ mask, long long n,
                                                     float* __restrict__ packed) {
@@ -137,6 +139,8 @@ __global__ __launch_bounds__(TB) void k_pack_labels(const float* __restrict__ vo
         packed[i] = __uint_as_float((__float_as_uint(vol[i]) & ~15u) | lab);
     }
 }
+
+}  // namespace
 
 extern "C" {
 
