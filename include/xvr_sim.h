@@ -32,8 +32,8 @@ typedef struct xvr_sim_spec {
     float std_eps;        /* Standardize: (x - min) / (max - min + std_eps)     (1e-6)               */
     float ncc_eps;        /* added to every variance                            (1e-5)               */
     float beta;           /* weight of the multiscale NCC vs the gradient NCC   (0.5)                */
-    int   mncc_patch;     /* patch size of the local term of the multiscale NCC (9)                  */
-    int   gncc_patch;     /* patch size of the gradient NCC                     (11)                 */
+    int   mncc_patch;     /* patch size of the local term of the multiscale NCC (9), in [2, 15]      */
+    int   gncc_patch;     /* patch size of the gradient NCC                     (11), in [2, 15]     */
     int   per_image;      /* 0: Standardize by the min/max of the WHOLE batch tensor, as the reference's
                              transform does (identical for B = 1); 1: by each image's own min/max, so that
                              the images of a batch are independent problems (batched multi-start)        */

@@ -1071,3 +1071,112 @@ def test_fuzz_random_configurations_against_the_oracle(seed):
     for name, (h, r) in named.items():
         tol = FWD_TOL if name == "out" else (GRAD_TOL if renderer == "trilinear" or name == "grad_volume" else 5 * GRAD_TOL)
         _close(h, r, tol, f"{name} [{what}]")
+
+
+@pytest.mark.parametrize("seed", list(range(30)))
+def test_fuzz_drr_module_end_to_end_against_the_oracle(seed):
+    """Randomised DRR modules (orientation, x-axis reversal, principal-point offsets, non-square pixels and detectors,
+    anisotropic CT spacing, every pose parameterisation) against the oracle's detector + renderer: the image from
+    both entry forms of DRR.forward (pose object -> camera by the affine map; Euler parameters -> one HIP launch) and
+    the gradient w.r.t. the pose parameters."""
+    import numpy as np
+
+    from oracle.diffdrr_restated import drr_from_pose
+    from xvr_amd.data import make_phantom, read
+    from xvr_amd.drr import DRR
+    from xvr_amd.pose import convert
+
+    rng = np.random.default_rng(5000 + seed)
+    size = int(rng.integers(12, 33))
+    vol, lab = make_phantom(size, n_ellipsoids=5, n_labels=3, seed=seed)
+    spacing = tuple(float(x) for x in rng.uniform(1.0, 3.0, size=3))
+    orientation = str(rng.choice(["AP", "PA"]))
+    rev = bool(rng.random() < 0.5)
+    H, W = int(rng.integers(2, 28)), int(rng.integers(2, 28))
+    sdd = float(rng.uniform(400.0, 1200.0))
+    delx, dely = float(rng.uniform(1.0, 4.0)), float(rng.uniform(1.0, 4.0))
+    x0, y0 = float(rng.uniform(-6, 6)), float(rng.uniform(-6, 6))
+    renderer = "trilinear" if rng.random() < 0.65 else "siddon"
+    shift = float(rng.choice([0.0, 0.5]))
+    sub = read(vol, lab, spacing=spacing, orientation=orientation)
+    drr = DRR(sub, sdd, H, delx, width=W, dely=dely, x0=x0, y0=y0, renderer=renderer, reverse_x_axis=rev, voxel_shift=shift).cuda()
+    B = int(rng.integers(1, 4))
+    rot = torch.tensor(rng.uniform(-1.0, 1.0, size=(B, 3)) * np.array([3.0, 0.6, 0.4]), dtype=torch.float32)
+    xyz = torch.tensor(np.stack([rng.uniform(-15, 15, B), rng.uniform(0.45, 0.8, B) * sdd, rng.uniform(-15, 15, B)], 1), dtype=torch.float32)
+    n_points = int(rng.integers(40, 200))
+    kw = {"n_points": n_points} if renderer == "trilinear" else {}
+    spec = drr.renderer._spec(**kw)
+    pose = convert(rot, xyz, parameterization="euler_angles", convention="ZXY")
+    ref = drr_from_pose(vol, sub.affine, pose.matrix, H, W, sdd, delx, dely, x0, y0, to_oracle_spec(spec), orientation=orientation,
+                        reverse_x_axis=rev)
+    what = f"seed {seed}: {renderer} shift {shift} {orientation} rev {rev} det {H}x{W} B {B} size {size}"
+    # entry form 1: a pose in a random parameterisation -> RigidTransform -> camera (affine map)
+    name = str(rng.choice(["axis_angle", "quaternion", "rotation_6d", "quaternion_adjugate", "se3_log_map", "matrix"]))
+    r2, t2 = pose.convert(name)
+    out1 = drr(r2.cuda(), t2.cuda(), parameterization=name, **kw)
+    assert out1.shape == (B, 1, H, W)
+    # (the fp32 round trip matrix -> parameters -> matrix moves the pose by ~1e-6 rad, lever arm ~1 m)
+    _close(out1, ref, 10 * FWD_TOL, f"DRR.forward({name}) [{what}]")
+    # entry form 2: Euler parameters (one HIP launch to the camera), with the gradient
+    r, t = rot.clone().cuda().requires_grad_(), xyz.clone().cuda().requires_grad_()
+    out2 = drr(r, t, parameterization="euler_angles", convention="ZXY", **kw)
+    # (end to end the two sides build their rays with different fp32 arithmetic -- camera vector vs detector grid,
+    #  then affine inverse -- a few ulp of position, which the sharp edges of a 12..32-voxel phantom amplify)
+    _close(out2, ref, 3 * FWD_TOL, f"DRR.forward(euler) [{what}]")
+    w = torch.rand(B, 1, H, W, generator=torch.Generator().manual_seed(seed))
+    (out2 * w.cuda()).sum().backward()
+    ro, to = rot.clone().requires_grad_(), xyz.clone().requires_grad_()
+    (drr_from_pose(vol, sub.affine, convert(ro, to, parameterization="euler_angles", convention="ZXY").matrix, H, W, sdd, delx, dely,
+                   x0, y0, to_oracle_spec(spec), orientation=orientation, reverse_x_axis=rev) * w).sum().backward()
+    tol = 5e-3 if renderer == "trilinear" else 5e-2     # (Siddon: one tie-broken crossing can carry a percent of the sum)
+    _close(r.grad, ro.grad, tol, f"d/d rotation [{what}]")
+    _close(t.grad, to.grad, tol, f"d/d translation [{what}]")
+    # masked render through the module
+    refm = drr_from_pose(vol, sub.affine, pose.matrix, H, W, sdd, delx, dely, x0, y0, to_oracle_spec(spec), orientation=orientation,
+                         reverse_x_axis=rev, mask=lab)
+    outm = drr(pose.cuda() if False else convert(rot.cuda(), xyz.cuda(), parameterization="euler_angles", convention="ZXY"),
+               mask_to_channels=True, **kw)
+    _close(outm.sum(1), refm.sum(1), FWD_TOL, f"mask_to_channels, channel sum [{what}]")
+    assert ((outm.cpu() - refm).abs() > FWD_TOL * refm.abs().max()).sum().item() <= 6, f"mask_to_channels [{what}]"
+
+
+@pytest.mark.parametrize("seed", list(range(30)))
+def test_fuzz_fused_similarity_against_torch(seed):
+    """Randomised fused similarity (image size incl. the smallest a patch allows, patch sizes 2..15, beta incl. the two
+    pure terms, batch with whole-tensor or per-image standardisation) against the torch formulation: value and
+    gradient w.r.t. the raw moving image."""
+    import numpy as np
+
+    from xvr_amd.metrics import GradientNormalizedCrossCorrelation2d, MultiscaleNormalizedCrossCorrelation2d, XrayTransforms
+    from xvr_amd.similarity import FusedSimilarity
+
+    rng = np.random.default_rng(7000 + seed)
+    p1, p2 = int(rng.integers(2, 16)), int(rng.integers(2, 16))
+    H, W = int(rng.integers(max(p1, p2), 70)), int(rng.integers(max(p1, p2), 70))
+    B = int(rng.integers(1, 5))
+    beta = float(rng.choice([0.0, 1.0, 0.5, rng.uniform(0.05, 0.95)]))
+    per_image = bool(rng.random() < 0.4)
+    g = torch.Generator().manual_seed(seed)
+    base = torch.rand(B, 1, H, W, generator=g)
+    fixed_raw = (base * rng.uniform(0.5, 5.0)).cuda()
+    moving = ((0.5 * base + 0.5 * torch.rand(B, 1, H, W, generator=g)) * rng.uniform(0.5, 50.0) + rng.uniform(-3, 3)).cuda().requires_grad_()
+    tf = XrayTransforms(H, W)
+    MultiscaleNormalizedCrossCorrelation2d.FUSED, GradientNormalizedCrossCorrelation2d.FUSED = False, False
+    try:
+        fixed = torch.cat([tf(fixed_raw[b:b + 1]) for b in range(B)]) if per_image else tf(fixed_raw)
+        sim = FusedSimilarity(fixed, p1, p2, beta, per_image=per_image)
+        w = torch.rand(B, generator=g).cuda() + 0.5 if per_image else torch.ones(B).cuda()
+        loss = sim(moving)
+        (loss * w).sum().backward()
+        got = moving.grad.clone()
+        moving.grad = None
+        s1 = MultiscaleNormalizedCrossCorrelation2d([None, p1], [0.5, 0.5])
+        s2 = GradientNormalizedCrossCorrelation2d(p2, 0.0).cuda()
+        y = torch.cat([tf(moving[b:b + 1]) for b in range(B)]) if per_image else tf(moving)
+        ref = beta * s1(fixed, y) + (1 - beta) * s2(fixed, y)
+        (ref * w).sum().backward()
+    finally:
+        MultiscaleNormalizedCrossCorrelation2d.FUSED, GradientNormalizedCrossCorrelation2d.FUSED = True, True
+    what = f"seed {seed}: {B}x{H}x{W} patches {p1},{p2} beta {beta:.2f} per_image {per_image}"
+    assert torch.allclose(loss, ref, rtol=5e-5, atol=5e-6), (what, (loss - ref).abs().max())
+    assert (got - moving.grad).abs().max() <= 5e-4 * moving.grad.abs().max() + 1e-9, (what, (got - moving.grad).abs().max(), moving.grad.abs().max())

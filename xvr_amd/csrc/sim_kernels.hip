@@ -458,7 +458,8 @@ int xvr_sim_ncc_forward_backward(const float* fixed, const float* fixed_sobel, c
     if (!fixed || !fixed_sobel || !moving || !sp || !loss || !workspace) return sim_fail(XVR_DRR_E_ARG, "null pointer argument");
     if (B <= 0 || H <= 0 || W <= 0) return sim_fail(XVR_DRR_E_ARG, "B, H, W must be positive");
     const int p1 = sp->mncc_patch, p2 = sp->gncc_patch;
-    if (p1 < 1 || p2 < 1 || p1 > MAXP || p2 > MAXP) return sim_fail(XVR_DRR_E_UNSUPPORTED, "patch size must be in [1, 15]");
+    // (a 1 x 1 patch has no variance: its NCC is 0 / eps, i.e. rounding noise over eps -- left to the caller)
+    if (p1 < 2 || p2 < 2 || p1 > MAXP || p2 > MAXP) return sim_fail(XVR_DRR_E_UNSUPPORTED, "patch size must be in [2, 15]");
     if (H < p1 || W < p1 || H < p2 || W < p2) return sim_fail(XVR_DRR_E_ARG, "image smaller than a patch");
     const Layout L = layout(B, H, W, p1, p2);
     if (workspace_bytes < L.total) return sim_fail(XVR_DRR_E_ARG, "workspace too small");

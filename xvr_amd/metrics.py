@@ -82,7 +82,7 @@ class MultiscaleNormalizedCrossCorrelation2d(torch.nn.Module):
         if not (self.FUSED and len(self.nccs) == 2 and self.patch_weights == [0.5, 0.5]):
             return False
         p0, p1 = self.nccs[0].patch_size, self.nccs[1].patch_size
-        if p0 is not None or p1 is None or not (1 <= p1 <= 15) or self.nccs[0].eps != self.nccs[1].eps:
+        if p0 is not None or p1 is None or not (2 <= p1 <= 15) or self.nccs[0].eps != self.nccs[1].eps:
             return False
         return (x1.is_cuda and x2.is_cuda and x1.dtype == x2.dtype == torch.float32 and x1.shape == x2.shape and x1.dim() == 4
                 and x1.shape[1] == 1 and x1.shape[0] > 0 and min(x1.shape[2:]) >= p1)
@@ -125,7 +125,7 @@ class GradientNormalizedCrossCorrelation2d(NormalizedCrossCorrelation2d):
 
     def forward(self, x1, x2):
         p = self.patch_size
-        if (self.FUSED and p is not None and 1 <= p <= 15 and not self.sobel.sigma and x1.is_cuda and x2.is_cuda
+        if (self.FUSED and p is not None and 2 <= p <= 15 and not self.sobel.sigma and x1.is_cuda and x2.is_cuda
                 and x1.dtype == x2.dtype == torch.float32 and x1.shape == x2.shape and x1.dim() == 4 and x1.shape[1] == 1
                 and x1.shape[0] > 0 and min(x1.shape[2:]) >= p):
             from .similarity import fused_gncc

@@ -69,7 +69,7 @@ class FusedSimilarity(torch.nn.Module):
     @staticmethod
     def supported(height, width, mncc_patch_size, gncc_patch_size, sigma, equalize) -> bool:
         big = max(mncc_patch_size, gncc_patch_size)
-        return ((not equalize) and (not sigma) and 1 <= min(mncc_patch_size, gncc_patch_size) and big <= 15
+        return ((not equalize) and (not sigma) and 2 <= min(mncc_patch_size, gncc_patch_size) and big <= 15
                 and min(height, width) >= big and torch.cuda.is_available())
 
     def forward(self, moving: torch.Tensor) -> torch.Tensor:
