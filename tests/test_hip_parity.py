@@ -1180,3 +1180,30 @@ def test_fuzz_fused_similarity_against_torch(seed):
     what = f"seed {seed}: {B}x{H}x{W} patches {p1},{p2} beta {beta:.2f} per_image {per_image}"
     assert torch.allclose(loss, ref, rtol=5e-5, atol=5e-6), (what, (loss - ref).abs().max())
     assert (got - moving.grad).abs().max() <= 5e-4 * moving.grad.abs().max() + 1e-9, (what, (got - moving.grad).abs().max(), moving.grad.abs().max())
+
+
+@pytest.mark.parametrize("renderer", ["trilinear", "siddon"])
+@pytest.mark.parametrize("B", [33, 70])
+def test_voxel_gather_with_more_than_one_cull_word(renderer, B):
+    """More than 32 poses: the per-brick cull bitmask spans several words.  Gather = scatter = oracle."""
+    import numpy as np
+
+    from xvr_amd import renderers
+    from xvr_amd.spec import RenderSpec
+
+    rng = np.random.default_rng(B)
+    rot = tuple(tuple(float(a) for a in rng.uniform(-180, 180, size=3) * np.array([1.0, 0.3, 0.2])) for _ in range(B))
+    xyz = tuple((float(rng.uniform(-6, 6)), float(rng.uniform(60, 140)), float(rng.uniform(-6, 6))) for _ in range(B))
+    case = make_case(shape=(18, 22, 20), height=14, width=12, sdd=260.0, delx=2.5, seed=B, rot=rot, xyz=xyz)
+    spec = RenderSpec(renderer=renderer, n_points=40) if renderer == "trilinear" else RenderSpec(renderer="siddon")
+    w = torch.rand(B, 1, 14 * 12, generator=torch.Generator().manual_seed(B))
+    grads = []
+    for flag in (True, False):
+        renderers.VOXEL_GATHER = flag
+        try:
+            grads.append(_hip_render(case, spec, grid_w=12, grads=True, w=w)[1])
+        finally:
+            renderers.VOXEL_GATHER = True
+    ref = _oracle_render(case, spec, grads=True, w=w)[1]
+    _close(grads[0], grads[1], 5e-5, "gather vs scatter")
+    _close(grads[0], ref, GRAD_TOL, "gather vs oracle")
