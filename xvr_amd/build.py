@@ -44,6 +44,18 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
     if not Path(hipcc).exists():
         raise RuntimeError("hipcc not found: cannot build libxvr_drr.so (ROCm toolchain required)")
     OBJ.mkdir(parents=True, exist_ok=True)
+    # one builder at a time: the ranks of a multi-GPU launch import the package simultaneously, and a stale library
+    # must not be rebuilt by eight processes into the same files
+    import fcntl
+
+    with open(OBJ / ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not is_stale():      # somebody else built it while we waited
+            return LIB
+        return _build_locked(hipcc, force, verbose)
+
+
+def _build_locked(hipcc: str, force: bool, verbose: bool) -> Path:
     newest_header = max(p.stat().st_mtime for p in HDR if p.exists())
 
     def compile_one(src: Path):
@@ -62,12 +74,14 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
     errors = [e for _, e in results if e]
     if errors:
         raise RuntimeError("\n".join(errors))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *[str(o) for o, _ in results]]
+    tmp = LIB.with_suffix(".so.tmp")
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(tmp), *[str(o) for o, _ in results]]
     if verbose:
         print(" ".join(cmd))
     proc = subprocess.run(cmd, capture_output=True, text=True)
     if proc.returncode != 0:
         raise RuntimeError(f"hipcc link failed ({proc.returncode}):\n{proc.stdout}\n{proc.stderr}")
+    tmp.replace(LIB)   # atomically: a process that is loading the old library keeps a complete file
     return LIB
 
 
