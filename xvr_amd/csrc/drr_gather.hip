@@ -108,6 +108,22 @@ __global__ __launch_bounds__(WG) void k_gather_prep(GatherArgs G) {
             P.hwc += fabsf(gc[i]) / G.sp.a[i];
             P.hwr += fabsf(gr[i]) / G.sp.a[i];
         }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float Nj = P.nh[j] / G.sp.a[j], Gj = gr[j] / G.sp.a[j];
+            // (an axis almost parallel to the sample planes would give a huge breakpoint whose bound is a difference
+            //  of huge numbers: skipped -- any subset of the breakpoints, with 0, still bounds from above)
+            if (fabsf(Nj) > 1e-3f * P.dalpha) {
+                const float lam = Gj / Nj;
+                float c = 0.f;
+                for (int i = 0; i < 3; ++i) c += fabsf(gr[i] / G.sp.a[i] - lam * (P.nh[i] / G.sp.a[i]));
+                P.rl[j] = lam;
+                P.rc[j] = c;
+            } else {
+                P.rl[j] = 0.f;
+                P.rc[j] = 1e30f;
+            }
+        }
         P.nh_norm = sqrtf(dot3(P.nh, P.nh));
         P.gc_norm = sqrtf(dot3(gc, gc));
         P.gr_norm = sqrtf(dot3(gr, gr));
@@ -240,9 +256,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7))) void
                 if (al > 1e-12f) {
                     const float inv = 1.f / al;
                     const float ic = fmaf(grw, inv, P.gr0);
-                    const float hi = fmaf(HS * P.hwr, inv, GATHER_WIN_MARGIN);
-                    const int ilo = (int)ceilf(fmaxf(ic - hi, 0.f));
-                    const int ihi = (int)floorf(fminf(ic + hi, (float)(G.H - 1)));
+                    // exact extent, along the detector's row axis, of the block's slice at this alpha (PoseLattice.rl/rc):
+                    // the whole-cube window has 45 % empty rows
+                    const float dlt = al - av;
+                    const float up = fminf(fminf(fmaf(P.rl[0], dlt, HS * P.rc[0]), fmaf(P.rl[1], dlt, HS * P.rc[1])),
+                                           fminf(fmaf(P.rl[2], dlt, HS * P.rc[2]), HS * P.hwr));
+                    const float dn = fminf(fminf(fmaf(-P.rl[0], dlt, HS * P.rc[0]), fmaf(-P.rl[1], dlt, HS * P.rc[1])),
+                                           fminf(fmaf(-P.rl[2], dlt, HS * P.rc[2]), HS * P.hwr));
+                    const int ilo = (int)ceilf(fmaxf(ic - fmaf(fmaxf(dn, 0.f), inv, GATHER_WIN_MARGIN), 0.f));
+                    const int ihi = (int)floorf(fminf(ic + fmaf(fmaxf(up, 0.f), inv, GATHER_WIN_MARGIN), (float)(G.H - 1)));
                     // lattice model of the sample positions relative to the block centre, in index space:
                     // Q0 + i Ur + j Uc.  Used ONLY to find which pixels to visit; the weights below come
                     // from the real targets.
