@@ -457,6 +457,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
     }
     const float cx = px[1], cy = py[1], cz = pz[1];
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float ea0 = 1.f / G.sp.a[0], ea1 = 1.f / G.sp.a[1], ea2 = 1.f / G.sp.a[2];   // half a block, in x coordinates
     for (int wd = 0; wd < G.words; ++wd) {
         unsigned bits = G.cull[(size_t)blockIdx.x * G.words + wd];
         while (bits) {
@@ -468,17 +469,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
             const float av = P.nh[0] * w0 + P.nh[1] * w1 + P.nh[2] * w2;
             const float da = P.dalpha;                        // half-range of alpha over the 2-voxel block
             const float amin = av - da, amax = av + da;
-            const float nj = P.gc[0] * w0 + P.gc[1] * w1 + P.gc[2] * w2, dnj = P.hwc;
-            const float ni = P.gr[0] * w0 + P.gr[1] * w1 + P.gr[2] * w2, dni = P.hwr;
+            const float nj = P.gc[0] * w0 + P.gc[1] * w1 + P.gc[2] * w2;
+            const float ni = P.gr[0] * w0 + P.gr[1] * w1 + P.gr[2] * w2;
             int jlo = 0, jhi = -1, ilo = 0, ihi = -1;
             if (inb && amin > 1e-6f && amax >= 0.f && amin <= 1.f) {
-                const float i0 = 1.f / amin, i1 = 1.f / amax;
-                const float ja = (nj - dnj) * i0, jb = (nj - dnj) * i1, jc = (nj + dnj) * i0, jd = (nj + dnj) * i1;
-                const float ia = (ni - dni) * i0, ib = (ni - dni) * i1, ic = (ni + dni) * i0, id = (ni + dni) * i1;
-                const float jmn = fminf(fminf(ja, jb), fminf(jc, jd)) + P.gc0 - GATHER_WIN_MARGIN;
-                const float jmx = fmaxf(fmaxf(ja, jb), fmaxf(jc, jd)) + P.gc0 + GATHER_WIN_MARGIN;
-                const float imn = fminf(fminf(ia, ib), fminf(ic, id)) + P.gr0 - GATHER_WIN_MARGIN;
-                const float imx = fmaxf(fmaxf(ia, ib), fmaxf(ic, id)) + P.gr0 + GATHER_WIN_MARGIN;
+                // the block is convex and in front of the source: its projection is the hull of its 8 projected
+                // corners, whose bounding box is the exact pixel window (the (n +- dn) / alpha box over the alpha range
+                // pairs extremes that no single point attains)
+                const float en0 = P.nh[0] * ea0, en1 = P.nh[1] * ea1, en2 = P.nh[2] * ea2;
+                const float ec0 = P.gc[0] * ea0, ec1 = P.gc[1] * ea1, ec2 = P.gc[2] * ea2;
+                const float er0 = P.gr[0] * ea0, er1 = P.gr[1] * ea1, er2 = P.gr[2] * ea2;
+                float jmn = INFINITY, jmx = -INFINITY, imn = INFINITY, imx = -INFINITY;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float sx = (c & 4) ? 1.f : -1.f, sy = (c & 2) ? 1.f : -1.f, sz = (c & 1) ? 1.f : -1.f;
+                    const float inv = 1.f / (av + sx * en0 + sy * en1 + sz * en2);
+                    const float jv = (nj + sx * ec0 + sy * ec1 + sz * ec2) * inv, iv = (ni + sx * er0 + sy * er1 + sz * er2) * inv;
+                    jmn = fminf(jmn, jv); jmx = fmaxf(jmx, jv);
+                    imn = fminf(imn, iv); imx = fmaxf(imx, iv);
+                }
+                jmn += P.gc0 - GATHER_WIN_MARGIN; jmx += P.gc0 + GATHER_WIN_MARGIN;
+                imn += P.gr0 - GATHER_WIN_MARGIN; imx += P.gr0 + GATHER_WIN_MARGIN;
                 jlo = (int)ceilf(fmaxf(jmn, 0.f));
                 jhi = (int)floorf(fminf(jmx, (float)(G.W - 1)));
                 ilo = (int)ceilf(fmaxf(imn, 0.f));
