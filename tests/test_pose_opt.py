@@ -332,3 +332,69 @@ def test_run_batch_with_one_target_per_pose():
         assert abs(batch[b]["nccs"][-1] - single["nccs"][-1]) < 0.05 and batch[b]["nccs"][-1] > batch[b]["nccs"][0]
     with pytest.raises(ValueError):
         reg.run_batch(gts, convert(rots[:1].repeat(3, 1), xyzs[:1].repeat(3, 1), parameterization="euler_angles", convention="ZXY"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_fuzz_opt_step_against_torch_adam(seed):
+    """Randomised optimiser specs (Euler convention, Adam betas / eps, ascent or descent, plateau factor / patience /
+    threshold, learning rates) on random camera gradients and loss curves, against torch.optim.Adam +
+    ReduceLROnPlateau stepped pose by pose."""
+    from xvr_amd.pose_opt import STATE_DTYPE, axes_of
+    lib = _lib.load()
+    rng = np.random.default_rng(900 + seed)
+    drr = _drr("cuda", orientation=str(rng.choice(["AP", "PA"])))
+    G, c = drr.camera_affine()
+    conv = str(rng.choice(["ZXY", "XYZ", "ZYX", "ZXZ", "YZX"]))
+    B, T = int(rng.integers(1, 5)), 40
+    b1, b2, eps = float(rng.uniform(0.7, 0.95)), float(rng.uniform(0.9, 0.9999)), float(10 ** rng.uniform(-9, -6))
+    maximize = bool(rng.random() < 0.5)
+    factor, patience, thr = float(rng.uniform(0.1, 0.7)), int(rng.integers(0, 4)), float(10 ** rng.uniform(-5, -2))
+    lr_rot, lr_xyz = float(10 ** rng.uniform(-3, -1)), float(10 ** rng.uniform(-1, 0.5))
+    max_pl = int(rng.integers(2, 5))
+    g = torch.Generator().manual_seed(seed)
+    rot0 = (torch.rand(B, 3, generator=g) - 0.5) * 2.0
+    xyz0 = (torch.rand(B, 3, generator=g) - 0.5) * 50 + torch.tensor([0.0, 800.0, 0.0])
+    gcams = torch.randn(T, B, 24, generator=g) * torch.logspace(-3, 0, 24)
+    losses = torch.stack([torch.cumsum(torch.randn(T, generator=g) * 0.01 + (0.004 if maximize else -0.004) * (torch.arange(T) < 12 + 5 * b), 0)
+                          for b in range(B)], dim=1).float()
+    mode = "max"   # the reference's scheduler watches a similarity it maximises (base.py:229-235)
+    ref_rows = []
+    for b in range(B):
+        rot = rot0[b:b + 1].clone().cuda().requires_grad_()
+        xyz = xyz0[b:b + 1].clone().cuda().requires_grad_()
+        opt = torch.optim.Adam([{"params": [rot], "lr": lr_rot}, {"params": [xyz], "lr": lr_xyz}], betas=(b1, b2), eps=eps, maximize=maximize)
+        sch = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, factor=factor, patience=patience, threshold=thr, mode=mode)
+        n_pl, cur, rows = 0, float("inf"), []
+        for t in range(T):
+            opt.zero_grad()
+            cam = drr.camera(convert(rot, xyz, parameterization="euler_angles", convention=conv))
+            (cam * gcams[t, b:b + 1].cuda()).sum().backward()
+            opt.step()
+            sch.step(losses[t, b].item())
+            lr = sch.get_last_lr()
+            rows.append(torch.cat([rot.detach(), xyz.detach()], 1).reshape(-1).cpu().tolist() + [losses[t, b].item(), *lr])
+            if lr[0] < cur:
+                cur, n_pl = lr[0], n_pl + 1
+            if n_pl == max_pl:
+                break
+        ref_rows.append(np.array(rows))
+    rot, xyz = rot0.clone().cuda(), xyz0.clone().cuda()
+    spec = _lib.CPoseOptSpec(axes_of(conv), b1, b2, eps, int(maximize), factor, patience, thr, 1e-8, max_pl, T)
+    state = torch.zeros(B * STATE_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    hist = torch.zeros(B, T, _lib.POSE_HISTORY_COLS, device="cuda")
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    assert lib.xvr_pose_opt_init(P(state), B, lr_rot, lr_xyz, None) == 0
+    for t in range(T):
+        gc = gcams[t].clone().cuda()
+        assert lib.xvr_pose_opt_step(P(rot), P(xyz), B, ctypes.byref(spec), P(G), P(gc), P(losses[t].cuda().contiguous()), P(state), P(hist), None) == 0
+    st = np.frombuffer(state.cpu().numpy().tobytes(), dtype=STATE_DTYPE)
+    h = hist.cpu().numpy()
+    what = f"seed {seed}: {conv} betas {b1:.3f},{b2:.4f} eps {eps:.1e} max {maximize} factor {factor:.2f} patience {patience} thr {thr:.1e}"
+    for b in range(B):
+        want = ref_rows[b]
+        assert int(st["iter"][b]) == len(want), (what, b, int(st["iter"][b]), len(want))
+        got = h[b, : len(want)]
+        np.testing.assert_allclose(got[:, 6:], want[:, 6:], rtol=2e-6, err_msg=what)
+        np.testing.assert_allclose(got[:, :3], want[:, :3], rtol=0, atol=2e-3 * lr_rot * T + 1e-5, err_msg=what)
+        np.testing.assert_allclose(got[:, 3:6], want[:, 3:6], rtol=0, atol=2e-3 * lr_xyz * T + 1e-3, err_msg=what)
