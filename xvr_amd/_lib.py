@@ -4,6 +4,7 @@ be loaded, every render call raises."""
 from __future__ import annotations
 
 import ctypes
+import os
 from pathlib import Path
 
 from .build import LIB, build_library, is_stale
@@ -120,7 +121,9 @@ class HipLibraryError(RuntimeError):
 
 
 def library_path() -> Path:
-    return LIB
+    # XVR_DRR_LIBRARY: load another build of the same ABI (the diagnostic builds of tools/gather_stats.py)
+    override = os.environ.get("XVR_DRR_LIBRARY")
+    return Path(override) if override else LIB
 
 
 def load(build_if_missing: bool = True) -> ctypes.CDLL:
@@ -128,22 +131,23 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if build_if_missing and is_stale():
+    path = library_path()
+    if path == LIB and build_if_missing and is_stale():
         try:
             build_library()
         except RuntimeError as e:
             if not LIB.exists():
                 raise HipLibraryError(f"libxvr_drr.so is missing and could not be built: {e}") from e
-    if not LIB.exists():
-        raise HipLibraryError(f"{LIB} not found; run `python -m xvr_amd.build` (needs hipcc)")
+    if not path.exists():
+        raise HipLibraryError(f"{path} not found; run `python -m xvr_amd.build` (needs hipcc)")
     try:
-        lib = ctypes.CDLL(str(LIB))
+        lib = ctypes.CDLL(str(path))
     except OSError as e:
-        raise HipLibraryError(f"cannot load {LIB}: {e}") from e
+        raise HipLibraryError(f"cannot load {path}: {e}") from e
     for name, (argtypes, restype) in EXPORTS.items():
         fn = getattr(lib, name, None)
         if fn is None:
-            raise HipLibraryError(f"{LIB} does not export {name}")
+            raise HipLibraryError(f"{path} does not export {name}")
         fn.argtypes, fn.restype = argtypes, restype
     if lib.xvr_drr_abi_version() != ABI_VERSION:
         raise HipLibraryError(f"ABI mismatch: library {lib.xvr_drr_abi_version()} != binding {ABI_VERSION}")

@@ -2,6 +2,17 @@
 // (trilinear and Siddon), its per-pose preparation and per-brick cull.  DESIGN.md section 4.1.
 #include "drr_common.hiph"
 
+#ifdef XVR_GATHER_STATS
+// Diagnostic build only (tools/gather_stats.py compiles it into a separate library): loop-trip counters of the
+// trilinear gather.  0 (lane, pose) visits . 1 steps k . 2 rows . 3 rows with an empty pixel interval . 4 candidates .
+// 5 unused . 6 wavefront-level inner trips . 7 wavefront-level pose iterations
+__device__ unsigned long long g_gather_stats[8];
+#define XVR_STAT(i, n) (st[i] += (n))
+#define XVR_STAT_WAVE(i) do { if ((threadIdx.x & 63) == __builtin_ctzll(__ballot(1))) st[i]++; } while (0)
+#else
+#define XVR_STAT(i, n) ((void)0)
+#define XVR_STAT_WAVE(i) ((void)0)
+#endif
 namespace {
 
 // =============================================================================================
@@ -224,6 +235,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7))) void
     const float bv0 = b0 - fv[0], bv1 = b1 - fv[1], bv2 = b2 - fv[2];
     const float bw0 = bv0 - 1.f, bw1 = bv1 - 1.f, bw2 = bv2 - 1.f;
     const float jmargin = GATHER_DEV_TOL + 0.01f;
+#ifdef XVR_GATHER_STATS
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     float acc[V * V * V];
 #pragma unroll
     for (int i = 0; i < V * V * V; ++i) acc[i] = 0.f;
@@ -248,11 +262,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7))) void
                 khi = (fabsf(av - near_) <= da) ? 0 : -1;
             }
             if (!inb || !(av == av)) khi = -1;
+            XVR_STAT(0, inb ? 1 : 0);
+            XVR_STAT_WAVE(7);
             const float grw = P.gr[0] * w0 + P.gr[1] * w1 + P.gr[2] * w2;
             const float4* __restrict__ q = G.q + (size_t)p * G.n;
             const float Bx = fmaf(a0, s0, bv0), By = fmaf(a1, s1, bv1), Bz = fmaf(a2, s2, bv2);
             for (int k = klo; k <= khi; ++k) {
                 const float al = linspace_at(k, N, near_, far_, step);
+                XVR_STAT(1, 1);
                 if (al > 1e-12f) {
                     const float inv = 1.f / al;
                     const float ic = fmaf(grw, inv, P.gr0);
@@ -290,9 +307,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7))) void
                         const int jlo = (int)ceilf(fmaxf(lo - jmargin, 0.f));
                         const int jhi = (int)floorf(fminf(hiJ + jmargin, (float)(G.W - 1)));
                         const float4* __restrict__ row = q + (size_t)i * G.W;
+                        XVR_STAT(2, 1);
+                        XVR_STAT(3, jlo > jhi ? 1 : 0);
                         // two candidates per trip: both 16-byte loads are issued before either is used
                         for (int j = jlo; j <= jhi; j += 2) {
                             const bool two = j < jhi;
+                            XVR_STAT(4, two ? 2 : 1);
+                            XVR_STAT_WAVE(6);
                             float4 ta, tb;
                             if (NOLOAD) {  // ablation only (XVR_DRR_GATHER_ABLATE=1): same arithmetic, no memory
                                 ta = make_float4(q0x + (float)j, q0y, q0z, 1.f);
@@ -355,6 +376,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7))) void
             }
         }
     }
+#ifdef XVR_GATHER_STATS
+    for (int i = 0; i < 8; ++i)
+        if (st[i]) atomicAdd(&g_gather_stats[i], st[i]);
+#endif
 #pragma unroll
     for (int e = 0; e < V * V * V; ++e) {
         const int x = vx + (V == 2 ? (e >> 2 & 1) : 0), y = vy + (V == 2 ? (e >> 1 & 1) : 0), z = vz + (V == 2 ? (e & 1) : 0);
@@ -592,6 +617,17 @@ int xvr_detail::launch_gather(bool siddon, const float* source, const float* tar
 }
 
 extern "C" {
+
+#ifdef XVR_GATHER_STATS
+int xvr_drr_debug_gather_stats(unsigned long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_gather_stats), 64) != hipSuccess) return XVR_DRR_E_LAUNCH;
+    if (reset) {
+        const unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_gather_stats), zero, 64) != hipSuccess) return XVR_DRR_E_LAUNCH;
+    }
+    return XVR_DRR_OK;
+}
+#endif
 
 size_t xvr_drr_backward_workspace_bytes(int B, int n, int D0, int D1, int D2) {
     if (B <= 0 || n <= 0 || D0 <= 0 || D1 <= 0 || D2 <= 0) return 0;
