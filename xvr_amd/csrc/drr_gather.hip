@@ -167,7 +167,6 @@ __global__ __launch_bounds__(WG) void k_gather_cull(GatherArgs G, int nbricks) {
     // half extent to the outermost voxel centre + 1 (interpolation support) + 0.5 (slack), in x units
     const float hx = (0.5f * (G.bd[0] - 1) + 1.5f) / G.sp.a[0], hy = (0.5f * (G.bd[1] - 1) + 1.5f) / G.sp.a[1],
                 hz = (0.5f * (G.bd[2] - 1) + 1.5f) / G.sp.a[2];
-    const float R = sqrtf(hx * hx + hy * hy + hz * hz);
     for (int wd = 0; wd < G.words; ++wd) {
         const int p = wd * 32 + lane;
         bool hit = false;
@@ -176,20 +175,30 @@ __global__ __launch_bounds__(WG) void k_gather_cull(GatherArgs G, int nbricks) {
             float w[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) w[i] = (c[i] - G.sp.b[i]) / G.sp.a[i] - P.s[i];
-            const float av = dot3(P.nh, w), da = R * P.nh_norm;
+            // the brick with its interpolation support is a box: alpha range from its L1 extent, and -- when it lies in
+            // front of the source -- its pixel footprint is the bounding box of its 8 projected corners (exact for a
+            // convex body); one pixel of slack covers the lattice tolerance
+            const float en0 = P.nh[0] * hx, en1 = P.nh[1] * hy, en2 = P.nh[2] * hz;
+            const float av = dot3(P.nh, w), da = fabsf(en0) + fabsf(en1) + fabsf(en2);
             const float amin = av - da, amax = av + da;
             if (amax >= G.sp.near_ && amin <= G.sp.far_) {
                 if (amin <= 1e-6f) {
-                    hit = true;  // the sphere reaches the source plane: no perspective bound, keep
+                    hit = true;  // the box reaches the source plane: no perspective bound, keep
                 } else {
-                    const float inv = 1.f / av;
-                    const float jc = fmaf(dot3(P.gc, w), inv, P.gc0), ic = fmaf(dot3(P.gr, w), inv, P.gr0);
-                    // a point of the sphere moves the pixel by at most R |g| / alpha (lateral) plus the
-                    // centre's own shift |j - gc0| * da / alpha (depth), with alpha >= amin
-                    const float ia = 1.f / amin;
-                    const float rj = (R * P.gc_norm + fabsf(jc - P.gc0) * da) * ia + 1.f;
-                    const float ri = (R * P.gr_norm + fabsf(ic - P.gr0) * da) * ia + 1.f;
-                    hit = jc + rj >= 0.f && jc - rj <= (float)(G.W - 1) && ic + ri >= 0.f && ic - ri <= (float)(G.H - 1);
+                    const float nj = dot3(P.gc, w), ni = dot3(P.gr, w);
+                    const float ec0 = P.gc[0] * hx, ec1 = P.gc[1] * hy, ec2 = P.gc[2] * hz;
+                    const float er0 = P.gr[0] * hx, er1 = P.gr[1] * hy, er2 = P.gr[2] * hz;
+                    float jmn = INFINITY, jmx = -INFINITY, imn = INFINITY, imx = -INFINITY;
+#pragma unroll
+                    for (int cc = 0; cc < 8; ++cc) {
+                        const float sx = (cc & 4) ? 1.f : -1.f, sy = (cc & 2) ? 1.f : -1.f, sz = (cc & 1) ? 1.f : -1.f;
+                        const float inv = 1.f / (av + sx * en0 + sy * en1 + sz * en2);
+                        const float jv = (nj + sx * ec0 + sy * ec1 + sz * ec2) * inv, iv = (ni + sx * er0 + sy * er1 + sz * er2) * inv;
+                        jmn = fminf(jmn, jv); jmx = fmaxf(jmx, jv);
+                        imn = fminf(imn, iv); imx = fmaxf(imx, iv);
+                    }
+                    hit = jmx + P.gc0 + 1.f >= 0.f && jmn + P.gc0 - 1.f <= (float)(G.W - 1) &&
+                          imx + P.gr0 + 1.f >= 0.f && imn + P.gr0 - 1.f <= (float)(G.H - 1);
                 }
             }
         }
