@@ -7,7 +7,9 @@ import ctypes
 import os
 from pathlib import Path
 
-from .build import LIB, build_library, is_stale
+import warnings
+
+from .build import LIB, HipccMissing, build_library, is_stale
 
 ABI_VERSION = 2
 JAC_STRIDE = 8
@@ -133,11 +135,17 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
         return _lib
     path = library_path()
     if path == LIB and build_if_missing and is_stale():
+        # A stale library is only ever used when there is NO compiler on this machine (and then loudly): a compile or
+        # link error must not leave the binding running over yesterday's kernels.
         try:
             build_library()
-        except RuntimeError as e:
+        except HipccMissing as e:
             if not LIB.exists():
                 raise HipLibraryError(f"libxvr_drr.so is missing and could not be built: {e}") from e
+            warnings.warn(f"{LIB} is older than its sources and hipcc is not available to rebuild it: loading the stale "
+                          "library", RuntimeWarning, stacklevel=2)
+        except RuntimeError as e:
+            raise HipLibraryError(f"libxvr_drr.so is stale and its rebuild failed: {e}") from e
     if not path.exists():
         raise HipLibraryError(f"{path} not found; run `python -m xvr_amd.build` (needs hipcc)")
     try:

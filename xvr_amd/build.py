@@ -42,6 +42,15 @@ def build_diagnostic_library(define: str, out: Path) -> Path:
     return out
 
 
+class HipccMissing(RuntimeError):
+    """The ROCm compiler is not on this machine (as opposed to: it is, and the sources do not compile)."""
+
+
+def find_hipcc():
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    return hipcc if Path(hipcc).exists() else None
+
+
 def is_stale() -> bool:
     if not LIB.exists():
         return True
@@ -52,9 +61,9 @@ def is_stale() -> bool:
 def build_library(force: bool = False, verbose: bool = False) -> Path:
     if not force and not is_stale():
         return LIB
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    if not Path(hipcc).exists():
-        raise RuntimeError("hipcc not found: cannot build libxvr_drr.so (ROCm toolchain required)")
+    hipcc = find_hipcc()
+    if hipcc is None:
+        raise HipccMissing("hipcc not found: cannot build libxvr_drr.so (ROCm toolchain required)")
     OBJ.mkdir(parents=True, exist_ok=True)
     # one builder at a time: the ranks of a multi-GPU launch import the package simultaneously, and a stale library
     # must not be rebuilt by eight processes into the same files

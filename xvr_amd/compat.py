@@ -1,7 +1,12 @@
-"""``install_as_diffdrr()``: make ``import diffdrr...`` resolve to this package, so unmodified xvr code
-(``from diffdrr.drr import DRR``, ``from diffdrr.pose import convert`` ...) runs on the MI355X path.
+"""``install_as_diffdrr()``: make ``import diffdrr...`` resolve to this package, so that xvr's render-path
+imports (``from diffdrr.drr import DRR``, ``from diffdrr.pose import convert`` ...) land on the MI355X path.
 
-Only the names xvr actually imports are mapped:
+Scope: the RENDER-PATH names only.  ``diffdrr.visualization`` (``plot_drr``,
+``plot_mask``), ``diffdrr.utils.resample`` and ``diffdrr.data.load_example_ct`` are NOT provided -- plotting and
+example data are outside SURVEY.md section 8 -- so the reference modules that import them at module scope
+(``registrar/base.py:12``, ``model/trainer.py:8``, ``model/inference.py:3``) do not import over this shim as they
+stand; ``renderer/load.py``, ``model/sampler.py`` and ``model/loss.py`` do (tests/test_reference_goldens.py).
+Mapped:
 
     diffdrr.drr            DRR
     diffdrr.data           read, transform_hu_to_density

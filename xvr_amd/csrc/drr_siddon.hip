@@ -151,7 +151,8 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAX : WG) __attribute__((amdgpu_
         if (inb && !first_of_slice && (!SPLIT || an > ac)) ++cnt;
         first_of_slice = false;
         if (have) consume();
-        p_v = inb ? v_new : 0.f; p_seg = an - ac; p_ac = ac; p_ax = ax_prev; p_off = off; p_inb = inb; p_lab = lab_new;
+        // (packed labels: the label bits are cleared from the value -- a voxel of density exactly 0 contributes exactly 0)
+        p_v = inb ? (MASK == 2 ? __uint_as_float(__float_as_uint(v_new) & ~LABEL_MASK) : v_new) : 0.f; p_seg = an - ac; p_ac = ac; p_ax = ax_prev; p_off = off; p_inb = inb; p_lab = lab_new;
         have = true;
         // advance every axis whose next plane has been reached (ties advance together), branch-free
         const bool c0 = an3[0] <= an, c1 = an3[1] <= an, c2 = an3[2] <= an;

@@ -78,14 +78,26 @@ __device__ __forceinline__ void tri_march(const RenderArgs& A, const Ray& R, con
         for (int h = 0; h < 2; ++h) {
             if (!act[h]) continue;
             const Taps& t = T[h];
+            int lab = 0;
+            if (MASK == 2) {
+                // the label first, then the label bits are cleared from the taps: a voxel of density exactly 0 (all of
+                // the air after transform_hu_to_density) must interpolate to exactly 0, as in the reference, not to a
+                // denormal L * 2^-149 that would flip xvr's `img > 0` foreground test (trainer.py:292-302)
+                lab = packed_label(P[h], pxs[h], pys[h], pzs[h], D0, D1, D2, A.C);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    P[h][q].x = __uint_as_float(__float_as_uint(P[h][q].x) & ~LABEL_MASK);
+                    P[h][q].y = __uint_as_float(__float_as_uint(P[h][q].y) & ~LABEL_MASK);
+                }
+            } else if (MASK == 1) {
+                lab = nearest_label(A.mask, pxs[h], pys[h], pzs[h], D0, D1, D2, A.C);
+            }
             const float v0 = fmaf(t.pz1, P[h][0].y, t.pz0 * P[h][0].x), v1 = fmaf(t.pz1, P[h][1].y, t.pz0 * P[h][1].x);
             const float v2 = fmaf(t.pz1, P[h][2].y, t.pz0 * P[h][2].x), v3 = fmaf(t.pz1, P[h][3].y, t.pz0 * P[h][3].x);
             const float r0 = fmaf(t.wy1, v1, t.wy0 * v0), r1 = fmaf(t.wy1, v3, t.wy0 * v2);
             const float v = fmaf(t.wx1, r1, t.wx0 * r0);
             ++cnt;
             if (MASK) {
-                const int lab = MASK == 2 ? packed_label(P[h], pxs[h], pys[h], pzs[h], D0, D1, D2, A.C)
-                                          : nearest_label(A.mask, pxs[h], pys[h], pzs[h], D0, D1, D2, A.C);
                 lds[lab * WG + tid] += v;
                 if (JAC) S += v;  // the jacobian saved with a mask is that of the channel SUM
             } else {

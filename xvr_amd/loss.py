@@ -33,8 +33,12 @@ class _Geodesic(torch.autograd.Function):
         _lib.check(lib.xvr_pose_geodesic(_ptr(a_c), _ptr(b_c), N, float(sdd), float(eps), _ptr(out), _ptr(gb), _stream()),
                    "xvr_pose_geodesic")
         ctx.save_for_backward(gb)
-        ctx.mark_non_differentiable(out[0], out[1])
-        return out[0], out[1], out[2]
+        # the SAME tensor objects must be marked and returned (marking a temporary view has no effect): the fused
+        # kernel carries the gradient of the combined distance only, so the angular and translational terms are
+        # honestly non-differentiable here instead of silently dropping an incoming gradient
+        ang, trans, dist = out.unbind(0)
+        ctx.mark_non_differentiable(ang, trans)
+        return ang, trans, dist
 
     @staticmethod
     def backward(ctx, _g_ang, _g_trans, g_d):

@@ -185,7 +185,20 @@ class Registrar:
             final_ncc = self.imagesim(img, transform(reg())).sum().item()
         nccs.append(final_ncc)
         return dict(final_pose=RigidTransform(reg.pose.matrix.detach()), init_pose=init_pose, nccs=nccs, times=times,
-                    lrs=lrs, trajectory=traj, runtime=sum(times), drr=reg.drr)
+                    lrs=lrs, trajectory=self._rows_as_euler_zxy(traj), runtime=sum(times), drr=reg.drr)
+
+    def _rows_as_euler_zxy(self, rows):
+        """Trajectory rows (rotation parameters + translation in THIS registrar's parameterisation, one row per
+        iteration) -> the reference's logging convention: ``pose.convert("euler_angles", "ZXY")`` whatever the
+        optimisation variables are (/root/reference/src/xvr/registrar/base.py:200-203, 262-266).  One batched
+        conversion for the whole trajectory instead of ~60 tiny launches per iteration."""
+        if not rows:
+            return []
+        if self.parameterization == "euler_angles" and self.convention == "ZXY":
+            return [list(r) for r in rows]
+        t = torch.as_tensor(rows, dtype=torch.float32)
+        pose = convert(t[:, :-3], t[:, -3:], parameterization=self.parameterization, convention=self.convention)
+        return torch.cat(pose.convert("euler_angles", "ZXY"), dim=-1).tolist()
 
     def run_batch(self, gt: torch.Tensor, init_poses: RigidTransform, intrinsics: dict | None = None) -> list:
         """Multi-start in ONE batch: the B initial poses are B independent registrations of the same target
@@ -247,21 +260,30 @@ class Registrar:
         for b in range(B):
             per[b]["nccs"].append(final_ncc[b])
             out.append(dict(final_pose=RigidTransform(final.matrix[b:b + 1].detach()), init_pose=init_poses[b], nccs=per[b]["nccs"],
-                            times=per[b]["times"], lrs=per[b]["lrs"], trajectory=per[b]["traj"], runtime=sum(per[b]["times"]),
+                            times=per[b]["times"], lrs=per[b]["lrs"], trajectory=self._rows_as_euler_zxy(per[b]["traj"]),
+                            runtime=sum(per[b]["times"]),
                             drr=drr))
         return out
 
     def parameters_dict(self, result: dict, intrinsics: dict | None = None, volume=None, mask=None, xray=None,
                         registrar_type: str = "fixed") -> dict:
         """The ``parameters.pt`` dictionary of the reference (/root/reference/src/xvr/registrar/base.py:355-394):
-        same keys, 4x4 CPU poses, and the trajectory as the rows of the reference's DataFrame
-        (r1, r2, r3, tx, ty, tz, ncc, times, lr_rot, lr_xyz) -- a list of dicts here, pandas is optional."""
+        same keys, 4x4 CPU poses, and the trajectory as the reference's ``_make_csv`` builds it (base.py:172-187,
+        410-422): a pandas DataFrame with columns r1, r2, r3, tx, ty, tz (Euler ZXY, whatever the optimisation's
+        parameterisation), ncc, times, lr_rot, lr_xyz -- or the same rows as a list of dicts where pandas is absent."""
         d = result["drr"].detector
         cols = ["r1", "r2", "r3", "tx", "ty", "tz", "ncc", "times", "lr_rot", "lr_xyz"]
-        init = result["init_pose"].convert(self.parameterization, self.convention)
+        init = result["init_pose"].convert("euler_angles", "ZXY")
         rows = [torch.cat(init, dim=-1).reshape(-1).tolist()] + result["trajectory"]
+        if any(len(r) != 6 for r in rows):
+            raise ValueError("trajectory rows must be (r1, r2, r3, tx, ty, tz)")
         n = min(len(rows), len(result["nccs"]), len(result["times"]), len(result["lrs"]))
-        traj = [dict(zip(cols, [*rows[i], result["nccs"][i], result["times"][i], *result["lrs"][i]])) for i in range(n)]
+        table = [[*rows[i], result["nccs"][i], result["times"][i], *result["lrs"][i]] for i in range(n)]
+        try:
+            import pandas as pd
+            traj = pd.DataFrame(table, columns=cols)
+        except ImportError:   # pragma: no cover
+            traj = [dict(zip(cols, r)) for r in table]
         intr = intrinsics or dict(sdd=d.sdd, height=d.height, width=d.width, delx=d.delx, dely=d.dely, x0=d.x0, y0=d.y0)
         return {
             "drr": {"volume": volume, "mask": mask, "labels": None, "orientation": self.drr.subject.orientation, **intr,
