@@ -1,0 +1,230 @@
+"""GPU parity tests at the geometries BASELINE.json names.
+
+* C1 -- the reference's own CPU-runnable case: DeepFluoro geometry, 128 x 128 detector, delx 2.1764375 mm,
+  sdd 1020 mm, batch_size 4, n_points 500, DeepFluoro pose ranges
+  (/root/reference/scripts/deepfluoro/train/de_novo.sh:24-32).  HIP (through the C ABI) against the oracle:
+  forward and all four gradients, both renderers, through the DRR module.
+* C2 / C3 at full size (512^3 -> 256^2): the voxel gradient of a whole B = 116 batch (4 cull words) by the gather
+  against the atomic scatter (both HIP), a per-voxel comparison with oracle autograd for two poses, and the Siddon pose
+  gradient against central differences.
+
+Tolerances: forward 1e-4 * max, gradients 2e-3 * max (fp32 both sides, see tests/test_hip_parity.py); full-size
+Siddon forward 1e-3 * max (~1500 fp32 crossings per ray).
+"""
+import pytest
+import torch
+
+from conftest import to_oracle_spec
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL = 1e-4
+GRAD_TOL = 2e-3
+
+
+def _close(a, b, tol, what=""):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    scale = max(b.abs().max().item(), 1e-12)
+    err = (a - b).abs().max().item() / scale
+    assert err <= tol, f"{what}: rel err {err:.3e} > {tol:.1e} (scale {scale:.3e})"
+
+
+def _close_per_ray(a, b, tol, what, outliers=2e-4, outlier_tol=5e-2):
+    """Per-ray gradients of a trilinear march are sums of ONE-SIDED derivatives: the interpolant's gradient jumps at
+    every voxel boundary, and of the 3e7 samples of a C1 batch a few thousand land within an ulp of one, where the cell
+    (hence the derivative) is decided by the last bit of two different fp32 evaluation orders (grid_sample's
+    un-normalisation vs the kernel's fused index map).  Such a sample moves its own ray's gradient by up to
+    L/N * |jump|; sums over rays (source, pose, voxels) average it away.  So: all but a fraction `outliers` of the rays
+    within `tol` of the largest entry, and no ray further than `outlier_tol`."""
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    scale = max(b.abs().max().item(), 1e-12)
+    err = ((a - b).abs() / scale).reshape(-1)
+    frac = (err > tol).double().mean().item()
+    assert frac <= outliers, f"{what}: {frac:.2e} of the entries beyond {tol:.1e} (allowed {outliers:.1e})"
+    assert err.max().item() <= outlier_tol, f"{what}: worst entry {err.max().item():.3e} > {outlier_tol:.1e}"
+
+
+def deepfluoro_poses(batch, seed):
+    from xvr_amd.training import get_random_pose
+
+    g = torch.Generator().manual_seed(seed)
+    return get_random_pose(135.0, 225.0, -45.0, 45.0, -15.0, 15.0, -150.0, 150.0, 450.0, 1000.0, -150.0, 150.0,
+                           batch, generator=g)
+
+
+# ----------------------------------------------------------------------------------------------
+# C1: DeepFluoro geometry, 128 x 128, batch 4
+# ----------------------------------------------------------------------------------------------
+C1 = dict(sdd=1020.0, height=128, delx=2.1764375, batch=4, n_points=500)
+
+
+@pytest.mark.parametrize("renderer", ["trilinear", "siddon"])
+def test_c1_deepfluoro_geometry_forward_and_all_gradients(renderer):
+    from oracle.diffdrr_restated import drr_from_pose
+    from xvr_amd.data import make_phantom, read
+    from xvr_amd.drr import DRR
+    from xvr_amd.pose import convert
+
+    # an anisotropic stand-in for the DeepFluoro CT (the real one is not in the image): 176 x 160 x 192 voxels
+    vol, _ = make_phantom((176, 160, 192), n_ellipsoids=24, seed=7)
+    # CT-like smoothness (scanner PSF): three box blurs; the sharp-edged phantom only makes the one-sided-derivative
+    # ties of _close_per_ray larger, it does not change what is tested
+    for _ in range(3):
+        vol = torch.nn.functional.avg_pool3d(vol[None, None], 3, stride=1, padding=1)[0, 0]
+    vol = vol.contiguous()
+    sub = read(vol, spacing=(1.6, 1.8, 1.5), orientation="AP")
+    H = C1["height"]
+    drr = DRR(sub, C1["sdd"], H, C1["delx"], renderer=renderer, reverse_x_axis=True).cuda()
+    pose0 = deepfluoro_poses(C1["batch"], seed=0)
+    rot0, xyz0 = pose0.convert("euler_angles", "ZXY")
+    kw = {"n_points": C1["n_points"]} if renderer == "trilinear" else {}
+    w = torch.rand(C1["batch"], 1, H, H, generator=torch.Generator().manual_seed(5))
+
+    rot, xyz = rot0.clone().cuda().requires_grad_(True), xyz0.clone().cuda().requires_grad_(True)
+    density = drr.density.clone().requires_grad_(True)
+    out = drr(rot, xyz, parameterization="euler_angles", convention="ZXY", density=density, **kw)
+    (out * w.cuda()).sum().backward()
+
+    r, t = rot0.clone().requires_grad_(True), xyz0.clone().requires_grad_(True)
+    v = vol.clone().requires_grad_(True)
+    spec = to_oracle_spec(drr.renderer._spec(**kw))
+    ref = drr_from_pose(v, sub.affine, convert(r, t, parameterization="euler_angles", convention="ZXY").matrix, H, H, C1["sdd"],
+                        C1["delx"], C1["delx"], 0.0, 0.0, spec, orientation="AP", reverse_x_axis=True, chunk=4096)
+    (ref * w).sum().backward()
+    assert out.shape == ref.shape == (C1["batch"], 1, H, H)
+    assert (ref > 0).float().mean().item() > 0.3          # the poses do look at the phantom
+    _close(out, ref, FWD_TOL, "C1 forward")
+    if renderer == "trilinear":
+        _close(density.grad, v.grad, GRAD_TOL, "C1 d/d volume")
+    else:
+        # Siddon credits a whole segment to ONE voxel: where a ray crosses two planes within an ulp of each other (it
+        # passes through a voxel edge) the order of the two crossings, hence the voxel credited for the sliver's
+        # neighbours, is decided by the last bit.  The float32 and float64 evaluations of the ORACLE ITSELF differ by
+        # 2.4e-3 of the largest entry on four boundary voxels of this very case (7e-7 of the voxels beyond 2e-3); the
+        # HIP traversal is a third evaluation order.  So: all but 1e-5 of the voxels within tolerance, none beyond 2e-2.
+        _close_per_ray(density.grad, v.grad, GRAD_TOL, "C1 d/d volume", outliers=1e-5, outlier_tol=2e-2)
+    _close(rot.grad, r.grad, 5e-3, "C1 d/d rotation")
+    _close(xyz.grad, t.grad, 5e-3, "C1 d/d translation")
+
+    # the exploded call sequence of the trainer (detector -> ray length -> inverse affine -> renderer), with the
+    # gradients of source / target / ray length themselves
+    from oracle.diffdrr_restated import _apply, rays_from_pose, render as oracle_render
+    with torch.no_grad():
+        pose = convert(rot0, xyz0, parameterization="euler_angles", convention="ZXY")
+        s_w, t_w = rays_from_pose(pose.matrix, H, H, C1["sdd"], C1["delx"], C1["delx"], 0.0, 0.0, "AP", True)
+        L = (t_w - s_w).norm(dim=-1).unsqueeze(1)
+        affinv = torch.linalg.inv(sub.affine)[None]
+        s_v, t_v = _apply(affinv, s_w), _apply(affinv, t_w)
+    hs, ht, hl = (x.clone().cuda().requires_grad_(True) for x in (s_v, t_v, L))
+    hout = drr.renderer(drr.density, hs, ht, hl, **kw)
+    (hout * w.reshape(C1["batch"], 1, -1).cuda()).sum().backward()
+    os_, ot, ol = (x.clone().requires_grad_(True) for x in (s_v, t_v, L))
+    oout = oracle_render(vol, os_, ot, ol, spec, chunk=4096)
+    (oout * w.reshape(C1["batch"], 1, -1)).sum().backward()
+    _close(hout, oout, FWD_TOL, "C1 renderer() forward")
+    _close(hs.grad, os_.grad, GRAD_TOL, "C1 d/d source")
+    _close_per_ray(ht.grad, ot.grad, GRAD_TOL, "C1 d/d target")
+    _close(hl.grad, ol.grad, GRAD_TOL, "C1 d/d ray length")
+
+
+# ----------------------------------------------------------------------------------------------
+# C2 / C3 at full size
+# ----------------------------------------------------------------------------------------------
+def _bench_setup(renderer, B, size=512, det=256):
+    from xvr_amd.data import make_phantom, read
+    from xvr_amd.drr import DRR
+
+    vol, _ = make_phantom(size, n_ellipsoids=16, seed=3, device="cuda")
+    sub = read(vol.cpu(), orientation="AP")
+    drr = DRR(sub, 1020.0, det, 1.08821875 * 256 / det, renderer=renderer, reverse_x_axis=False).cuda()
+    rot, xyz = deepfluoro_poses(B, seed=0).convert("euler_angles", "ZXY")
+    return vol, sub, drr, rot, xyz
+
+
+@pytest.mark.parametrize("renderer", ["trilinear", "siddon"])
+def test_full_size_batch_116_voxel_gradient_gather_equals_scatter(renderer, monkeypatch):
+    """The whole benchmark batch (116 poses = 4 cull words) at 512^3 -> 256^2: the voxel-driven gather against the
+    ray-driven atomic scatter, voxel by voxel.  Two HIP kernels that share no code beyond the ray set-up."""
+    from xvr_amd import renderers
+
+    vol, sub, drr, rot, xyz = _bench_setup(renderer, 116)
+    kw = {"n_points": 500} if renderer == "trilinear" else {}
+    w = torch.rand(116, 1, 256, 256, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2))
+
+    def voxel_gradient():
+        density = drr.density.clone().requires_grad_(True)
+        out = drr(rot.cuda(), xyz.cuda(), parameterization="euler_angles", convention="ZXY", density=density, **kw)
+        (out * w).sum().backward()
+        return density.grad
+
+    g_gather = voxel_gradient()
+    monkeypatch.setattr(renderers, "VOXEL_GATHER", False)
+    g_scatter = voxel_gradient()
+    assert g_gather.abs().max().item() > 0
+    # the scatter adds with fp32 atomics in arbitrary order: ~1e-5 of the largest voxel gradient
+    _close(g_gather, g_scatter, 2e-4, f"{renderer}: gather vs scatter at B = 116")
+    # voxels no ray of any pose comes near have gradient exactly zero on both paths
+    assert ((g_gather == 0) == (g_scatter == 0)).float().mean().item() > 0.9999
+
+
+@pytest.mark.parametrize("renderer", ["trilinear", "siddon"])
+def test_full_size_voxel_gradient_matches_oracle_autograd_per_voxel(renderer):
+    """Two benchmark poses at 512^3 -> 256^2: d/d volume from the HIP gather against autograd through the oracle
+    (grid_sample's own backward on the CPU), every one of the 1.3e8 voxels."""
+    from oracle.diffdrr_restated import drr_from_pose
+    from xvr_amd.pose import convert
+
+    B = 2
+    vol, sub, drr, rot, xyz = _bench_setup(renderer, B)
+    kw = {"n_points": 500} if renderer == "trilinear" else {}
+    w = torch.rand(B, 1, 256, 256, generator=torch.Generator().manual_seed(2))
+    density = drr.density.clone().requires_grad_(True)
+    out = drr(rot.cuda(), xyz.cuda(), parameterization="euler_angles", convention="ZXY", density=density, **kw)
+    (out * w.cuda()).sum().backward()
+    v = vol.cpu().clone().requires_grad_(True)
+    spec = to_oracle_spec(drr.renderer._spec(**kw))
+    pose = convert(rot, xyz, parameterization="euler_angles", convention="ZXY")
+    ref = drr_from_pose(v, sub.affine, pose.matrix, 256, 256, 1020.0, 1.08821875, 1.08821875, 0.0, 0.0, spec,
+                        orientation="AP", reverse_x_axis=False, chunk=16384)
+    (ref * w).sum().backward()
+    _close(out, ref, FWD_TOL if renderer == "trilinear" else 1e-3, "full-size forward")
+    if renderer == "trilinear":
+        _close(density.grad, v.grad, GRAD_TOL, "full-size d/d volume, per voxel")
+    else:   # Siddon: whole segments change voxel where a ray passes within an ulp of a voxel edge (see the C1 test above)
+        _close_per_ray(density.grad, v.grad, GRAD_TOL, "full-size d/d volume, per voxel", outliers=1e-5, outlier_tol=2e-2)
+
+
+def test_full_size_siddon_pose_gradient_matches_finite_differences():
+    """d loss / d (rot, xyz) through DRR.forward (Siddon) at 512^3 -> 256^2 against central differences of the HIP
+    forward.  The Siddon image is continuous and piecewise smooth in the pose (its derivative is through the plane
+    crossings only); on a smooth volume the kinks are O(h) and central differences see the same slope."""
+    from xvr_amd.data import read
+    from xvr_amd.drr import DRR
+    from xvr_amd.pose import convert
+
+    ax = torch.arange(512, dtype=torch.float32, device="cuda")
+    vol = torch.zeros(512, 512, 512, device="cuda")
+    for cx, cy, cz, sg, rho in ((200.0, 260.0, 250.0, 60.0, 1.0), (330.0, 220.0, 300.0, 45.0, 0.7), (256.0, 300.0, 180.0, 80.0, 0.5)):
+        vol += rho * (torch.exp(-((ax - cx) / sg) ** 2)[:, None, None] * torch.exp(-((ax - cy) / sg) ** 2)[None, :, None]
+                      * torch.exp(-((ax - cz) / sg) ** 2)[None, None, :])
+    drr = DRR(read(vol.cpu(), orientation="AP"), 1020.0, 256, 1.08821875, renderer="siddon", reverse_x_axis=False).cuda()
+    u = torch.linspace(0, 1, 256, device="cuda", dtype=torch.float64)
+    w = (0.6 + 0.4 * torch.cos(3.0 * u))[:, None] * (0.5 + 0.5 * torch.sin(2.0 * u + 0.3))[None, :]
+    rot0 = torch.tensor([[3.05, 0.1, -0.05]], device="cuda")
+    xyz0 = torch.tensor([[10.0, 720.0, -15.0]], device="cuda")
+
+    def loss(rot, xyz):
+        pose = convert(rot, xyz, parameterization="euler_angles", convention="ZXY")
+        return (drr(pose).double() * w).sum()
+
+    rot, xyz = rot0.clone().requires_grad_(True), xyz0.clone().requires_grad_(True)
+    loss(rot, xyz).backward()
+    for p, g, h in ((rot0, rot.grad, 2e-3), (xyz0, xyz.grad, 0.5)):
+        for i in range(3):
+            e = torch.zeros_like(p)
+            e[0, i] = h
+            if p is rot0:
+                fd = (loss(rot0 + e, xyz0) - loss(rot0 - e, xyz0)).item() / (2 * h)
+            else:
+                fd = (loss(rot0, xyz0 + e) - loss(rot0, xyz0 - e)).item() / (2 * h)
+            assert abs(g[0, i].item() - fd) <= 0.02 * max(abs(fd), 0.05 * abs(g).max().item()), (i, g[0, i].item(), fd)

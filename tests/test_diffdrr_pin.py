@@ -1,0 +1,96 @@
+"""Consumes ``tests/golden/diffdrr_pin.npz`` -- outputs of the REAL diffdrr (the package xvr renders through,
+/root/reference/uv.lock:955-977) on committed inputs, written by ``tools/pin_against_diffdrr.py`` on a machine where
+the package is installed -- and holds the oracle (CPU) and the HIP kernels (GPU) to them with the knob set the tool
+recorded.  The file cannot be produced in the build container (no diffdrr, no network): until somebody runs the tool
+these tests skip and parity stays "unpinned" (DESIGN.md section 2); once it exists they are the pin."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+PIN = Path(__file__).resolve().parent / "golden" / "diffdrr_pin.npz"
+needs_pin = pytest.mark.skipif(not PIN.exists(), reason="tests/golden/diffdrr_pin.npz absent: run tools/pin_against_diffdrr.py where diffdrr is installed")
+
+TAGS = [(r, s) for r in ("trilinear", "siddon") for s in (0.5, 0.0)]
+CASES = ["case11", "case12", "c1"]
+
+
+def _load():
+    z = np.load(PIN, allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
+def _case(z, name):
+    return {k: torch.from_numpy(z[f"in_{name}_{k}"]) for k in ("volume", "mask", "source", "target", "img")}
+
+
+def _rel(a, b):
+    return ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-12)).item()
+
+
+def test_pin_tool_is_importable_and_refuses_to_run_without_diffdrr():
+    """The recipe itself is kept healthy here: it parses, and without the package it stops with a clear message."""
+    import importlib.util
+    import sys
+
+    spec = importlib.util.spec_from_file_location("pin_against_diffdrr", PIN.parents[2] / "tools" / "pin_against_diffdrr.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert callable(mod.main) and len(list(mod.knob_grid("trilinear"))) == 24 and len(list(mod.knob_grid("siddon"))) == 12
+    c1 = mod.c1_case()
+    assert c1["target"].shape == (1, 128 * 128, 3) and c1["img"].shape == (1, 1, 128 * 128)
+    if importlib.util.find_spec("diffdrr") is None:
+        old = sys.argv
+        sys.argv = ["pin_against_diffdrr.py"]
+        try:
+            with pytest.raises(SystemExit, match="diffdrr is not importable"):
+                mod.main()
+        finally:
+            sys.argv = old
+
+
+@needs_pin
+@pytest.mark.parametrize("renderer,shift", TAGS)
+def test_oracle_reproduces_the_real_diffdrr(renderer, shift):
+    from oracle.diffdrr_restated import RenderSpec, render
+
+    z = _load()
+    tag = f"{renderer}_shift{shift}"
+    spec = RenderSpec(renderer=renderer, voxel_shift=shift, n_points=60, **json.loads(str(z[tag + "_knobs"])))
+    for name in CASES:
+        c = _case(z, name)
+        v, s, t = (c[k].clone().requires_grad_(True) for k in ("volume", "source", "target"))
+        out = render(v, s, t, c["img"], spec)
+        (out * torch.from_numpy(z[f"{tag}_{name}_w"])).sum().backward()
+        assert _rel(out, torch.from_numpy(z[f"{tag}_{name}_out"])) <= 1e-4
+        for g, key in ((v.grad, "gvol"), (s.grad, "gsrc"), (t.grad, "gtgt")):
+            assert _rel(g, torch.from_numpy(z[f"{tag}_{name}_{key}"])) <= 2e-3, key
+        outm = render(c["volume"], c["source"], c["target"], c["img"], spec, c["mask"])
+        assert _rel(outm, torch.from_numpy(z[f"{tag}_{name}_mask_out"])) <= 1e-4
+
+
+@needs_pin
+@pytest.mark.gpu
+@pytest.mark.parametrize("renderer,shift", TAGS)
+def test_hip_reproduces_the_real_diffdrr(renderer, shift):
+    from xvr_amd.renderers import render
+    from xvr_amd.spec import RenderSpec
+
+    z = _load()
+    tag = f"{renderer}_shift{shift}"
+    knobs = json.loads(str(z[tag + "_knobs"]))
+    knobs.pop("per_ray_clamp", None)   # the HIP traversal is per ray by construction
+    spec = RenderSpec(renderer=renderer, voxel_shift=shift, n_points=60, **knobs)
+    for name in CASES:
+        c = {k: v.cuda() for k, v in _case(z, name).items()}
+        v, s, t = (c[k].clone().requires_grad_(True) for k in ("volume", "source", "target"))
+        gw = 128 if name == "c1" else 10
+        out = render(v, s, t, c["img"], spec, ray_grid_w=gw)
+        (out * torch.from_numpy(z[f"{tag}_{name}_w"]).cuda()).sum().backward()
+        assert _rel(out.cpu(), torch.from_numpy(z[f"{tag}_{name}_out"])) <= 1e-4
+        for g, key in ((v.grad, "gvol"), (s.grad, "gsrc"), (t.grad, "gtgt")):
+            assert _rel(g.cpu(), torch.from_numpy(z[f"{tag}_{name}_{key}"])) <= 2e-3, key
+        outm = render(c["volume"], c["source"], c["target"], c["img"], spec, c["mask"], ray_grid_w=gw)
+        assert _rel(outm.cpu(), torch.from_numpy(z[f"{tag}_{name}_mask_out"])) <= 1e-4

@@ -177,7 +177,9 @@ def test_voxel_gather_equals_atomic_scatter_and_oracle(kw, hw):
         finally:
             renderers.VOXEL_GATHER = True
     ref = _oracle_render(case, spec, grads=True, w=w)[1]
-    _close(grads[0], grads[1], 2e-5, "gather vs scatter")
+    # same weights up to the last bit or two of the sample position (the gather forms a (s + alpha d) + b - v as one fma
+    # on the pre-scaled direction a * d), different summation order, fp32 atomics on the scatter side
+    _close(grads[0], grads[1], 4e-5, "gather vs scatter")
     _close(grads[0], ref, GRAD_TOL, "gather vs oracle")
 
 

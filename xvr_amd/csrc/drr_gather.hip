@@ -66,7 +66,10 @@ __global__ __launch_bounds__(WG) void k_gather_prep(GatherArgs G) {
         const float sx = G.source[3 * b], sy = G.source[3 * b + 1], sz = G.source[3 * b + 2];
         const float ddx = (tx - sx) + G.sp.eps, ddy = (ty - sy) + G.sp.eps, ddz = (tz - sz) + G.sp.eps;
         if (!G.siddon) {
-            G.q[(size_t)b * G.n + r] = make_float4(ddx, ddy, ddz, c);
+            // a * d: the gather forms a (s + alpha d) + b - v as fma(alpha, a d, a s + b - v) (a = 1 for the default index map)
+            float4* row = G.q + (size_t)b * G.qn + (size_t)i * G.qs;
+            row[j] = make_float4(G.sp.a[0] * ddx, G.sp.a[1] * ddy, G.sp.a[2] * ddz, c);
+            if (j == G.W - 1) row[G.W] = make_float4(0.f, 0.f, 0.f, 0.f);
         } else {
             // the ray's own integration interval, computed exactly as ray_setup() does for the forward
             const float dd[3] = {ddx, ddy, ddz}, ss[3] = {sx, sy, sz};
@@ -134,6 +137,15 @@ __global__ __launch_bounds__(WG) void k_gather_prep(GatherArgs G) {
                 P.rl[j] = 0.f;
                 P.rc[j] = 1e30f;
             }
+        }
+        const float HSv = G.V == 2 ? 1.5f : 1.0f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            P.e0[i] = G.sp.a[i] * ts[i];
+            P.era[i] = G.sp.a[i] * er[i];
+            const float eca = G.sp.a[i] * ec[i];
+            P.rec[i] = fabsf(eca) < 1e-9f ? 1e9f : 1.f / eca;
+            P.hsr[i] = HSv * fabsf(P.rec[i]);
         }
         P.nh_norm = sqrtf(dot3(P.nh, P.nh));
         P.gc_norm = sqrtf(dot3(gc, gc));
@@ -216,9 +228,15 @@ __global__ __launch_bounds__(WG) void k_gather_cull(GatherArgs G, int nbricks) {
 // (v_sub_f32 dst, 1.0, |d| clamp) -- the gather's inner loop is VALU-bound and has six of these per candidate.
 __device__ __forceinline__ float hat01(float d) { return __builtin_amdgcn_fmed3f(1.f - fabsf(d), 0.f, 1.f); }
 
+// linspace_at() with both halves evaluated and one select (same values, no exec-masked branches in the inner loops)
+__device__ __forceinline__ float linspace_sel(int k, int N, float near_, float far_, float step) {
+    const float lo = fmaf(step, (float)k, near_), hi = far_ - step * (float)(N - 1 - k);
+    return (k < N / 2 || N == 1) ? lo : hi;
+}
+
 // (register budget set for 7 wavefronts per SIMD: 72 VGPRs, no spills, 14.4 ms at C2 against 14.6 at the 6 the
 //  compiler chose; 8 spills, 4 takes 17.7 ms)
-template <int V, bool NOLOAD = false>
+template <int V>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_trilinear_gather_vol(GatherArgs G) {
     if (*G.flag > __float_as_uint(GATHER_DEV_TOL)) return;  // not a lattice: the scatter kernel runs instead
     constexpr float HS = V == 2 ? 1.5f : 1.0f;  // half-size of the block's interpolation support
@@ -274,7 +292,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7))) void
             XVR_STAT(0, inb ? 1 : 0);
             XVR_STAT_WAVE(7);
             const float grw = P.gr[0] * w0 + P.gr[1] * w1 + P.gr[2] * w2;
-            const float4* __restrict__ q = G.q + (size_t)p * G.n;
+            const float4* __restrict__ q = G.q + (size_t)p * G.qn;
             const float Bx = fmaf(a0, s0, bv0), By = fmaf(a1, s1, bv1), Bz = fmaf(a2, s2, bv2);
             for (int k = klo; k <= khi; ++k) {
                 const float al = linspace_at(k, N, near_, far_, step);
@@ -305,7 +323,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7))) void
                     const float ry = fabsf(ucy) < 1e-9f ? 1e9f : 1.f / ucy;
                     const float rz = fabsf(ucz) < 1e-9f ? 1e9f : 1.f / ucz;
                     const float ax_ = HS * fabsf(rx), ay_ = HS * fabsf(ry), az_ = HS * fabsf(rz);
-                    const float Ax = al * a0, Ay = al * a1, Az = al * a2;
+                    const float Ax = al, Ay = al, Az = al;   // (q holds a * d)
                     for (int i = ilo; i <= ihi; ++i) {
                         const float fi = (float)i;
                         const float qx = fmaf(fi, urx, q0x), qy = fmaf(fi, ury, q0y), qz = fmaf(fi, urz, q0z);
@@ -315,7 +333,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7))) void
                         const float hiJ = fminf(fminf(mx + ax_, my + ay_), mz + az_);
                         const int jlo = (int)ceilf(fmaxf(lo - jmargin, 0.f));
                         const int jhi = (int)floorf(fminf(hiJ + jmargin, (float)(G.W - 1)));
-                        const float4* __restrict__ row = q + (size_t)i * G.W;
+                        const float4* __restrict__ row = q + (size_t)i * G.qs;
                         XVR_STAT(2, 1);
                         XVR_STAT(3, jlo > jhi ? 1 : 0);
                         // two candidates per trip: both 16-byte loads are issued before either is used
@@ -323,14 +341,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7))) void
                             const bool two = j < jhi;
                             XVR_STAT(4, two ? 2 : 1);
                             XVR_STAT_WAVE(6);
-                            float4 ta, tb;
-                            if (NOLOAD) {  // ablation only (XVR_DRR_GATHER_ABLATE=1): same arithmetic, no memory
-                                ta = make_float4(q0x + (float)j, q0y, q0z, 1.f);
-                                tb = make_float4(q0x, q0y + (float)j, q0z, 1.f);
-                            } else {
-                                ta = row[j];
-                                tb = row[two ? j + 1 : j];
-                            }
+                            float4 ta = row[j], tb = row[two ? j + 1 : j];
                             tb.w = two ? tb.w : 0.f;
 #pragma unroll
                             for (int h = 0; h < 2; ++h) {
@@ -368,16 +379,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7))) void
                     // blocks whose support contains it (a source inside the volume only)
                     const bool hit = fabsf(fmaf(a0, s0, b0) - (fv[0] + CO)) < HS && fabsf(fmaf(a1, s1, b1) - (fv[1] + CO)) < HS &&
                                      fabsf(fmaf(a2, s2, b2) - (fv[2] + CO)) < HS;
-                    const int cnt = hit ? G.n : 0;
+                    const int cnt = hit ? G.qn : 0;   // (the rows' closing elements carry weight 0)
                     for (int r = 0; r < cnt; ++r) {
                         const float4 t = q[r];
-                        const float ix = fmaf(al, t.x, s0), iy = fmaf(al, t.y, s1), iz = fmaf(al, t.z, s2);
 #pragma unroll
                         for (int e = 0; e < V * V * V; ++e) {
                             const float ox = (float)(e >> 2 & 1), oy = (float)(e >> 1 & 1), oz = (float)(e & 1);
-                            const float ux = hat01(fmaf(a0, ix, bv0 - ox));
-                            const float uy = hat01(fmaf(a1, iy, bv1 - oy));
-                            const float uz = hat01(fmaf(a2, iz, bv2 - oz));
+                            const float ux = hat01(fmaf(al, t.x, Bx - ox));
+                            const float uy = hat01(fmaf(al, t.y, By - oy));
+                            const float uz = hat01(fmaf(al, t.z, Bz - oz));
                             acc[e] = fmaf(ux * uy * uz, t.w, acc[e]);
                         }
                     }
@@ -392,6 +402,264 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7))) void
 #pragma unroll
     for (int e = 0; e < V * V * V; ++e) {
         const int x = vx + (V == 2 ? (e >> 2 & 1) : 0), y = vy + (V == 2 ? (e >> 1 & 1) : 0), z = vz + (V == 2 ? (e & 1) : 0);
+        if (x < G.D0 && y < G.D1 && z < G.D2 && acc[e] != 0.f) G.gvol[((size_t)x * G.D1 + y) * G.D2 + z] += acc[e];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same gather with the loop nest FLATTENED per lane (round 2; DESIGN.md section 4.1, tools/sim_gather_divergence.py).
+//
+// In the nested kernel above the 64 lanes of a wavefront walk step -> row -> pixel loops whose trip counts differ per
+// lane: at the benchmark geometry a wavefront's inner trip fills 47 of its 128 candidate slots and a (wavefront, pose)
+// visit costs 27 inner trips where the lanes' own work is 12 (10.3 if no lane ever idled).  Here every pose is done in
+// two phases:
+//   A  the lane enumerates its non-empty lattice rows -- (step k, row i, first pixel, count) -- with the cheap part of
+//      the old nest (step set-up from per-pose constants: ~45 instructions instead of ~130; row set-up unchanged) and
+//      appends one 32-bit entry per row to ITS column of an LDS table (lane-private: no barrier, no atomics);
+//   B  one flat loop: every lane pulls its own next entry whenever its row is exhausted and evaluates two candidates
+//      per trip, so a trip is short only for lanes that have run out of rows altogether: 16.3 trips per visit.
+// The candidate arithmetic (gather_pair) is the nested kernel's, bit for bit; only the ORDER in which a lane adds its
+// candidates is the same too (rows in step-major order), so both kernels produce identical sums.
+// Entry = first ray of the run (22 bits: detectors up to 2048^2) | count << 22 (5 bits) | (k - klo) << 27 (5 bits); a row
+// that does not fit (table full -- 2 % of the visits have a lane with more than 20 rows --, > 31 pixels, > 31 steps) is
+// evaluated on the spot by the old inner loop.
+// ---------------------------------------------------------------------------------------------
+constexpr int TAB_ROWS = 11;   // 11 x 64 lanes x 8 B = 5.5 KiB of LDS per wavefront: 28 wavefronts per CU fit in 160 KiB
+constexpr unsigned TAB_R0_BITS = 24, TAB_N_BITS = 8;   // entry.x = first element of the run in q | count << 24; entry.y = alpha_k
+constexpr unsigned TAB_MAX_RAYS = 1u << TAB_R0_BITS;
+
+// two candidates against the lane's 2x2x2 block; signed distance of the sample from the block's first voxel per axis:
+// a (s + alpha d) + b - v folded into one fma (within an ulp of the forward's two-fma chain); the second voxel sits
+// exactly 1 further.  (packed v_pk_mul/fma_f32 on (z, z+1) pairs measured SLOWER in round 1)
+__device__ __forceinline__ void gather_pair(const float4 ta, const float4 tb, const float Ax, const float Ay, const float Az,
+                                            const float Bx, const float By, const float Bz, float (&acc)[8]) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float4 t = h ? tb : ta;
+        const float dx = fmaf(Ax, t.x, Bx), dy = fmaf(Ay, t.y, By), dz = fmaf(Az, t.z, Bz);
+        const float ux0 = hat01(dx), uy0 = hat01(dy), uz0 = hat01(dz) * t.w;
+        const float ux1 = hat01(dx - 1.f), uy1 = hat01(dy - 1.f), uz1 = hat01(dz - 1.f) * t.w;
+        const float p00 = ux0 * uy0, p01 = ux0 * uy1, p10 = ux1 * uy0, p11 = ux1 * uy1;
+        acc[0] = fmaf(p00, uz0, acc[0]);
+        acc[1] = fmaf(p00, uz1, acc[1]);
+        acc[2] = fmaf(p01, uz0, acc[2]);
+        acc[3] = fmaf(p01, uz1, acc[3]);
+        acc[4] = fmaf(p10, uz0, acc[4]);
+        acc[5] = fmaf(p10, uz1, acc[5]);
+        acc[6] = fmaf(p11, uz0, acc[6]);
+        acc[7] = fmaf(p11, uz1, acc[7]);
+    }
+}
+
+#ifdef XVR_GATHER_ABLATE   // diagnostic build only (tools/gather_stats.py --ablate): same arithmetic, no memory traffic
+#define XVR_LOAD_Q(ptr, k) make_float4((float)(k) * 0.25f, 0.5f, 0.75f, 1.f)
+#else
+#define XVR_LOAD_Q(ptr, k) ((ptr)[k])
+#endif
+
+__device__ __forceinline__ void gather_row(const float4* __restrict__ row, const int n, const float Ax, const float Ay, const float Az,
+                                           const float Bx, const float By, const float Bz, float (&acc)[8]) {
+    for (int j = 0; j < n; j += 2) {
+        const bool two = j + 1 < n;
+        const float4 ta = XVR_LOAD_Q(row, j);
+        float4 tb = XVR_LOAD_Q(row, two ? j + 1 : j);
+        tb.w = two ? tb.w : 0.f;
+        gather_pair(ta, tb, Ax, Ay, Az, Bx, By, Bz, acc);
+    }
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_trilinear_gather_tab(GatherArgs G) {
+    if (*G.flag > __float_as_uint(GATHER_DEV_TOL)) return;  // not a lattice: the scatter kernel runs instead
+    __shared__ uint2 tab[TAB_ROWS * 64];
+    constexpr float HS = 1.5f, CO = 0.5f;
+    int bx, by, bz;
+    brick_coords(blockIdx.x, G.D1, G.D2, G.bd, bx, by, bz);
+    const int tid = threadIdx.x;  // one wavefront: 4 x 4 x 4 blocks of 2 x 2 x 2 voxels
+    const int vx = (bx * 4 + (tid >> 4)) * 2, vy = (by * 4 + ((tid >> 2) & 3)) * 2, vz = (bz * 4 + (tid & 3)) * 2;
+    const bool inb = vx < G.D0 && vy < G.D1 && vz < G.D2;
+    const float fv[3] = {(float)vx, (float)vy, (float)vz};
+    float xv[3];  // block centre in x coordinates
+#pragma unroll
+    for (int i = 0; i < 3; ++i) xv[i] = (fv[i] + CO - G.sp.b[i]) / G.sp.a[i];
+    const int N = G.sp.n_points;
+    const float near_ = G.sp.near_, far_ = G.sp.far_;
+    const float step = N > 1 ? (far_ - near_) / (float)(N - 1) : 0.f;
+    const float inv_step = step > 0.f ? 1.f / step : 0.f;
+    const float a0 = G.sp.a[0], a1 = G.sp.a[1], a2 = G.sp.a[2];
+    const float b0 = G.sp.b[0], b1 = G.sp.b[1], b2 = G.sp.b[2];
+    const float bv0 = b0 - fv[0], bv1 = b1 - fv[1], bv2 = b2 - fv[2];
+    const float jmargin = GATHER_DEV_TOL + 0.01f;
+    const float Hm1 = (float)(G.H - 1), Wm1 = (float)(G.W - 1);
+#ifdef XVR_GATHER_STATS
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+
+    for (int wd = 0; wd < G.words; ++wd) {
+        unsigned bits = G.cull[(size_t)blockIdx.x * G.words + wd];  // uniform: scalar load
+        while (bits) {
+            const int p = wd * 32 + __builtin_ctz(bits);
+            bits &= bits - 1;
+            const PoseLattice& P = G.poses[p];
+            const float s0 = P.s[0], s1 = P.s[1], s2 = P.s[2];
+            const float w0 = xv[0] - s0, w1 = xv[1] - s1, w2 = xv[2] - s2;
+            const float av = P.nh[0] * w0 + P.nh[1] * w1 + P.nh[2] * w2;
+            const float da = HS * P.dalpha;
+            int klo, khi;
+            if (step > 0.f) {
+                const float k0 = (av - da - near_) * inv_step, k1 = (av + da - near_) * inv_step;
+                klo = (int)ceilf(fmaxf(k0 - GATHER_K_SLACK, 0.f));
+                khi = (int)floorf(fminf(k1 + GATHER_K_SLACK, (float)(N - 1)));
+            } else {
+                klo = 0;
+                khi = (fabsf(av - near_) <= da) ? 0 : -1;
+            }
+            if (!inb || !(av == av)) khi = -1;
+            XVR_STAT(0, inb ? 1 : 0);
+            XVR_STAT_WAVE(7);
+            const float grw = P.gr[0] * w0 + P.gr[1] * w1 + P.gr[2] * w2;
+            const float4* __restrict__ q = G.q + (size_t)p * G.qn;
+            // a s + b - v for the block's first voxel (the weights' constant) and for its centre (the windows')
+            const float Bx = fmaf(a0, s0, bv0), By = fmaf(a1, s1, bv1), Bz = fmaf(a2, s2, bv2);
+            const float Cx = Bx - CO, Cy = By - CO, Cz = Bz - CO;
+            const float rcx = HS * P.rc[0], rcy = HS * P.rc[1], rcz = HS * P.rc[2], rcw = HS * P.hwr;
+
+            // per-step constants of the window arithmetic (used ONLY to find which pixels to visit; the weights come from
+            // the real targets): row range [ilo, ihi] and the lattice model Q0 + i Ur + j Uc of the sample positions
+            // relative to the block centre, in index space, with Uc = alpha * (a ec)
+            struct StepC { float q0x, q0y, q0z, urx, ury, urz, rx, ry, rz, ax_, ay_, az_; int ilo, ihi; };
+            auto step_setup = [&](const float al, StepC& S) {
+                const float inv = __builtin_amdgcn_rcpf(al);   // windows only (1 ulp): the weights never see it
+                const float ic = fmaf(grw, inv, P.gr0);
+                // exact extent, along the detector's row axis, of the block's slice at this alpha (PoseLattice.rl/rc)
+                const float dlt = al - av;
+                const float up = fminf(fminf(fmaf(P.rl[0], dlt, rcx), fmaf(P.rl[1], dlt, rcy)), fminf(fmaf(P.rl[2], dlt, rcz), rcw));
+                const float dn = fminf(fminf(fmaf(-P.rl[0], dlt, rcx), fmaf(-P.rl[1], dlt, rcy)), fminf(fmaf(-P.rl[2], dlt, rcz), rcw));
+                S.ilo = (int)ceilf(fmaxf(ic - fmaf(fmaxf(dn, 0.f), inv, GATHER_WIN_MARGIN), 0.f));
+                S.ihi = (int)floorf(fminf(ic + fmaf(fmaxf(up, 0.f), inv, GATHER_WIN_MARGIN), Hm1));
+                S.q0x = fmaf(al, P.e0[0], Cx); S.q0y = fmaf(al, P.e0[1], Cy); S.q0z = fmaf(al, P.e0[2], Cz);
+                S.urx = al * P.era[0]; S.ury = al * P.era[1]; S.urz = al * P.era[2];
+                S.rx = inv * P.rec[0]; S.ry = inv * P.rec[1]; S.rz = inv * P.rec[2];      // 1 / Uc
+                // HS / |Uc| plus the lattice tolerance: half-width of the pixel interval per axis
+                S.ax_ = fmaf(inv, P.hsr[0], jmargin); S.ay_ = fmaf(inv, P.hsr[1], jmargin); S.az_ = fmaf(inv, P.hsr[2], jmargin);
+            };
+            // exact pixel interval [jlo, jhi] of row i where |q + j Uc| < HS on all three axes (empty: jhi < jlo)
+            auto row_setup = [&](const StepC& S, const int i, int& jlo, int& jhi) {
+                const float fi = (float)i;
+                const float qx = fmaf(fi, S.urx, S.q0x), qy = fmaf(fi, S.ury, S.q0y), qz = fmaf(fi, S.urz, S.q0z);
+                const float mx = -qx * S.rx, my = -qy * S.ry, mz = -qz * S.rz;
+                const float lo = fmaxf(fmaxf(mx - S.ax_, my - S.ay_), mz - S.az_);
+                const float hiJ = fminf(fminf(mx + S.ax_, my + S.ay_), mz + S.az_);
+                jlo = (int)ceilf(fmaxf(lo, 0.f));
+                jhi = (int)floorf(fminf(hiJ, Wm1));
+            };
+
+            // ---- phase A: enumerate the non-empty rows of every step into the lane's column of the table.  Nothing here
+            // touches the accumulators.  A lane that meets a row it cannot enter (table full, more than 30 pixels, more
+            // than 31 steps, a step at alpha = 0) remembers where and leaves: the slow path below takes over from there.
+            int cnt = 0;
+            int k_ovf = INT32_MAX, i_ovf = 0;
+            for (int k = klo; k <= khi && k_ovf == INT32_MAX; ++k) {
+                const float al = linspace_sel(k, N, near_, far_, step);
+                XVR_STAT(1, 1);
+                if (!(al > 1e-12f)) { k_ovf = k; i_ovf = INT32_MIN; break; }
+                StepC S;
+                step_setup(al, S);
+                for (int i = S.ilo; i <= S.ihi; ++i) {
+                    int jlo, jhi;
+                    row_setup(S, i, jlo, jhi);
+                    int n = jhi - jlo + 1;
+                    XVR_STAT(2, 1);
+                    XVR_STAT(3, n <= 0 ? 1 : 0);
+                    XVR_STAT(4, n > 0 ? n : 0);
+                    // an even number of candidates per row, so that phase B takes two per trip without a tail case: the extra
+                    // element is the next pixel (outside the exact interval: all eight weights are exactly 0) or the all-zero
+                    // element that closes every row of q
+                    n += n & 1;
+                    // (straight-line: no break / continue -- a lane that has overflown just stops entering rows)
+                    const bool want = n > 0 && k_ovf == INT32_MAX;
+                    const bool fits = want && cnt < TAB_ROWS && n < (1 << TAB_N_BITS);
+                    if (fits) tab[cnt * 64 + tid] = make_uint2((unsigned)(i * G.qs + jlo) | ((unsigned)n << TAB_R0_BITS), __float_as_uint(al));
+                    cnt += fits ? 1 : 0;
+                    i_ovf = (want && !fits) ? i : i_ovf;
+                    k_ovf = (want && !fits) ? k : k_ovf;
+                }
+            }
+
+            // ---- phase B: one flat loop over the lane's rows, two candidates per trip (rows in the table are even)
+            {
+                int idx = 0, rem = 0;
+                const float4* __restrict__ ptr = q;
+                float al = 0.f;
+                uint2 e_next = tab[tid];   // (unused when the lane has no rows)
+                // pull the lane's next row; false when it has none left.  The entry after it is requested right away, so
+                // its LDS latency is hidden behind the row's candidates.
+                auto next_row = [&]() -> bool {
+                    if (idx >= cnt) return false;
+                    const uint2 e = e_next;
+                    ++idx;
+                    e_next = tab[(idx < TAB_ROWS ? idx : TAB_ROWS - 1) * 64 + tid];
+                    rem = (int)(e.x >> TAB_R0_BITS);
+                    al = __uint_as_float(e.y);
+                    ptr = q + (e.x & (TAB_MAX_RAYS - 1u));
+                    return true;
+                };
+                bool live = next_row();
+                while (live) {
+                    XVR_STAT_WAVE(6);
+                    const float4 ta = XVR_LOAD_Q(ptr, 0), tb = XVR_LOAD_Q(ptr, 1);
+                    gather_pair(ta, tb, al, al, al, Bx, By, Bz, acc);
+                    ptr += 2;
+                    rem -= 2;
+                    if (rem <= 0) live = next_row();
+                }
+            }
+
+            // ---- slow path (rare: ~2 % of the wavefront visits have such a lane): the rows phase A could not enter, by the
+            // nested loops of the round-1 kernel
+            if (__any(k_ovf != INT32_MAX)) {
+                for (int k = k_ovf; k <= khi; ++k) {   // (k_ovf = INT32_MAX: no trip)
+                    const float al = linspace_sel(k, N, near_, far_, step);
+                    if (al > 1e-12f) {
+                        StepC S;
+                        step_setup(al, S);
+                        const int ifirst = (k == k_ovf && i_ovf != INT32_MIN) ? i_ovf : S.ilo;
+                        for (int i = ifirst; i <= S.ihi; ++i) {
+                            int jlo, jhi;
+                            row_setup(S, i, jlo, jhi);
+                            XVR_STAT(5, jhi >= jlo ? 1 : 0);
+                            if (jhi >= jlo) gather_row(q + (size_t)i * G.qs + jlo, jhi - jlo + 1, al, al, al, Bx, By, Bz, acc);
+                        }
+                    } else {
+                        // alpha_k = 0: every ray's sample sits on the source; all pixels are candidates for the blocks
+                        // whose support contains it (a source inside the volume only)
+                        const bool hit = fabsf(Cx) < HS && fabsf(Cy) < HS && fabsf(Cz) < HS;
+                        const int nall = hit ? G.qn : 0;   // (the rows' closing elements carry weight 0)
+                        for (int r = 0; r < nall; ++r) {
+                            const float4 t = q[r];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float ox = (float)(e >> 2 & 1), oy = (float)(e >> 1 & 1), oz = (float)(e & 1);
+                                const float ux = hat01(fmaf(al, t.x, Bx - ox));
+                                const float uy = hat01(fmaf(al, t.y, By - oy));
+                                const float uz = hat01(fmaf(al, t.z, Bz - oz));
+                                acc[e] = fmaf(ux * uy * uz, t.w, acc[e]);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+#ifdef XVR_GATHER_STATS
+    for (int i = 0; i < 8; ++i)
+        if (st[i]) atomicAdd(&g_gather_stats[i], st[i]);
+#endif
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int x = vx + (e >> 2 & 1), y = vy + (e >> 1 & 1), z = vz + (e & 1);
         if (x < G.D0 && y < G.D1 && z < G.D2 && acc[e] != 0.f) G.gvol[((size_t)x * G.D1 + y) * G.D2 + z] += acc[e];
     }
 }
@@ -596,9 +864,14 @@ int xvr_detail::launch_gather(bool siddon, const float* source, const float* tar
     G.q = reinterpret_cast<float4*>(ws + ws_q_off(B));
     G.q2 = reinterpret_cast<float2*>(ws + ws_q2_off(B, n));
     G.siddon = siddon ? 1 : 0;
+    G.qs = siddon ? gw : gw + 1;
+    G.qn = siddon ? n : (n / gw) * (gw + 1);
     G.V = siddon ? 1 : gather_block();
     // Siddon: 2x2x2 voxels per lane in 8^3 bricks unless XVR_DRR_SIDDON_GATHER_BLOCK=1 (A/B switch: one voxel per
     // lane, 256 lanes on a 4 x 8 x 8 brick)
+    // trilinear: the per-lane flattened (table) kernel unless XVR_DRR_GATHER_TABLE=0 (A/B switch: the round-1 nested kernel;
+    // both are exact and give identical sums)
+    static const bool use_table = [] { const char* e = getenv("XVR_DRR_GATHER_TABLE"); return !(e && e[0] == '0'); }();
     static const bool siddon_v1 = [] { const char* e = getenv("XVR_DRR_SIDDON_GATHER_BLOCK"); return e && e[0] == '1'; }();
     if (siddon && siddon_v1) { G.bd[0] = 4; G.bd[1] = 8; G.bd[2] = 8; }
     else if (siddon) { G.bd[0] = G.bd[1] = G.bd[2] = 8; }
@@ -617,7 +890,7 @@ int xvr_detail::launch_gather(bool siddon, const float* source, const float* tar
                        (hipStream_t)stream, G, (int)bricks);
     if (siddon && siddon_v1) hipLaunchKernelGGL(k_siddon_gather_vol, dim3((unsigned)bricks), dim3(WG), 0, (hipStream_t)stream, G);
     else if (siddon) hipLaunchKernelGGL(k_siddon_gather_vol2, dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
-    else if (G.V == 2 && getenv("XVR_DRR_GATHER_ABLATE")) hipLaunchKernelGGL((k_trilinear_gather_vol<2, true>), dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
+    else if (G.V == 2 && use_table && (unsigned)G.qn <= TAB_MAX_RAYS) hipLaunchKernelGGL(k_trilinear_gather_tab, dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
     else if (G.V == 2) hipLaunchKernelGGL(k_trilinear_gather_vol<2>, dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
     else hipLaunchKernelGGL(k_trilinear_gather_vol<1>, dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
     e = hipGetLastError();
