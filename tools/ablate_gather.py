@@ -1,0 +1,23 @@
+"""Loads-ablated diagnostic build of the trilinear table gather (-DXVR_GATHER_ABLATE: same arithmetic, candidates made up
+in registers instead of loaded; results are WRONG by construction -- a separate library, never the product's): how
+much of the kernel's time is memory.  python tools/ablate_gather.py build | run"""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+LIB = ROOT / "xvr_amd" / "lib" / "libxvr_drr_ablate.so"
+LIB2 = ROOT / "xvr_amd" / "lib" / "libxvr_drr_ablate2.so"
+if sys.argv[1:] == ["build"]:
+    from xvr_amd.build import build_diagnostic_library
+    print(build_diagnostic_library("XVR_GATHER_ABLATE=1", LIB))
+    print(build_diagnostic_library("XVR_GATHER_ABLATE=2", LIB2))
+else:
+    for name, env in (("product", {}), ("loads ablated", {"XVR_DRR_LIBRARY": str(LIB)}), ("half the loads", {"XVR_DRR_LIBRARY": str(LIB2)})):
+        out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "6", "--warmup", "2", "--no-cpu-baseline"],
+                             env=dict(os.environ, **env), capture_output=True, text=True)
+        d = json.loads(out.stdout.strip().splitlines()[-1])
+        print(f"{name}: voxel gradient {d['kernels']['trilinear_backward[vol]']['avg_ms']:.3f} ms", flush=True)

@@ -97,6 +97,7 @@ def main():
     hist_steps = np.zeros(8, int)
     hist_rows = np.zeros(16, int)
     hist_visit_rows = np.zeros(64, int)
+    tile_sizes = []
     lane_trips_by_pose, lane_rows_by_pose, keep_by_pose = [], [], []
     for p, L in enumerate(P):
         w = xv - L["s"]
@@ -136,6 +137,7 @@ def main():
         wave_trips_sum = np.zeros(len(bricks), int)
         wave_steps = np.zeros(len(bricks), int)
         lane_cands = np.zeros(nst.shape, int)
+        bb = [np.full(len(bricks), 10**9), np.full(len(bricks), -1), np.full(len(bricks), 10**9), np.full(len(bricks), -1)]
         rowslot = np.zeros(len(bricks), int)
         for it in range(int(maxst.max()) if maxst.size else 0):
             k = klo + it
@@ -184,6 +186,12 @@ def main():
                 lane_cands += nc
                 lane_rows += ract
                 lane_nonempty_rows += ract & (nc > 0)
+                has = ract & (nc > 0)
+                big = 10**9
+                bb[0] = np.minimum(bb[0], np.where(has, i, big).min(axis=1))
+                bb[1] = np.maximum(bb[1], np.where(has, i, -1).max(axis=1))
+                bb[2] = np.minimum(bb[2], np.where(has, jlo, big).min(axis=1))
+                bb[3] = np.maximum(bb[3], np.where(has, jhi + 1, -1).max(axis=1))
             rowslot += step_trips.max(axis=1)            # (lane = (block, row) organisation: not priced further)
             wave_act = act.any(axis=1)
             wave_steps += wave_act
@@ -203,6 +211,8 @@ def main():
         tot["lane_trip_max"] += int(lane_total_trips.max(axis=1).sum())   # everything flattened per lane
         hist_steps += np.bincount(np.minimum(nst[nst > 0], 7), minlength=8)
         lane_trips_by_pose.append(lane_total_trips)
+        ok = bb[1] >= 0
+        tile_sizes.extend(((bb[1] - bb[0] + 1) * (bb[3] - bb[2] + 1))[ok].tolist())
         lane_rows_by_pose.append(lane_nonempty_rows)
         keep_by_pose.append(visited)
         hist_visit_rows += np.bincount(np.minimum(lane_nonempty_rows[nst > 0], 63), minlength=64)
@@ -217,13 +227,16 @@ def main():
     print(f"per wave-pose: steps {tot['w_steps'] / wp:.2f}, row iterations {tot['w_rows'] / wp:.2f}, inner trips {tot['w_trips'] / wp:.2f} "
           f"(ideal, all lanes busy: {tot['cands'] / 2 / 64 / wp:.2f}; lanes' own trips, mean {tot['lane_trips'] / 64 / wp:.2f})")
     print(f"  flattened (k,row) per lane: row iterations {tot['flat_rows'] / wp:.2f}; everything flattened per lane: trips {tot['lane_trip_max'] / wp:.2f}")
+    ts = np.array(tile_sizes)
+    print("pixel bounding box of a wavefront's candidates per pose (elements of 16 B): mean %.0f, median %.0f, 90 %% %.0f, 99 %% %.0f, max %d; fit in 256 / 320 / 384 / 448 / 512: %s" % (
+        ts.mean(), np.median(ts), np.percentile(ts, 90), np.percentile(ts, 99), ts.max(), [round(float((ts <= c).mean()), 3) for c in (256, 320, 384, 448, 512)]))
     LT = np.stack(lane_trips_by_pose)      # [poses, bricks, 64]
     KP = np.stack(keep_by_pose)            # [poses, bricks]
     cum = np.cumsum(hist_visit_rows) / hist_visit_rows.sum()
     print("non-empty rows per (lane,pose) visit: mean %.2f; P(<=8) %.3f P(<=12) %.3f P(<=16) %.3f P(<=20) %.3f P(<=24) %.3f P(<=32) %.3f" % (
         (hist_visit_rows * np.arange(64)).sum() / hist_visit_rows.sum(), cum[8], cum[12], cum[16], cum[20], cum[24], cum[32]))
     LR = np.stack(lane_rows_by_pose)
-    for T in (12, 16, 24, 32):
+    for T in (8, 10, 12, 13, 16, 24, 32):
         print(f"  table of {T}: wave-poses with an overflowing lane {((LR.max(axis=2) > T) & KP).sum() / KP.sum():.3f}")
     for batch in (1, 2, 4, 8):
         tot_b = 0

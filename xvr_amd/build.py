@@ -30,12 +30,13 @@ HIPCC_FLAGS = [
 ]
 
 
-def build_diagnostic_library(define: str, out: Path) -> Path:
-    """A separate library with one extra -D (e.g. XVR_GATHER_STATS) for the measuring tools under tools/; never loaded
-    by the package itself."""
+def build_diagnostic_library(define, out: Path) -> Path:
+    """A separate library with extra -D's (e.g. XVR_GATHER_STATS; a string or a list of them) for the measuring tools
+    under tools/; never loaded by the package itself."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     out.parent.mkdir(parents=True, exist_ok=True)
-    cmd = [hipcc, *HIPCC_FLAGS, f"-D{define}", "-shared", "-o", str(out), *map(str, SRC)]
+    defines = [define] if isinstance(define, str) else list(define)
+    cmd = [hipcc, *HIPCC_FLAGS, *[f"-D{d}" for d in defines], "-shared", "-o", str(out), *map(str, SRC)]
     proc = subprocess.run(cmd, capture_output=True, text=True)
     if proc.returncode != 0:
         raise RuntimeError(f"hipcc failed ({proc.returncode}):\n{proc.stdout}\n{proc.stderr}")

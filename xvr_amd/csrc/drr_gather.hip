@@ -420,11 +420,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7))) void
 //      per trip, so a trip is short only for lanes that have run out of rows altogether: 16.3 trips per visit.
 // The candidate arithmetic (gather_pair) is the nested kernel's, bit for bit; only the ORDER in which a lane adds its
 // candidates is the same too (rows in step-major order), so both kernels produce identical sums.
-// Entry = first ray of the run (22 bits: detectors up to 2048^2) | count << 22 (5 bits) | (k - klo) << 27 (5 bits); a row
-// that does not fit (table full -- 2 % of the visits have a lane with more than 20 rows --, > 31 pixels, > 31 steps) is
-// evaluated on the spot by the old inner loop.
+// Entry (8 bytes) = first element of the run in q | count << 24, alpha_k; a lane that meets a row it cannot enter (table
+// full: 5 % of the visits have a lane with more than 13 rows) remembers where and the nested loops of the round-1 kernel
+// take over from there once phase B is done.
+// Where the time goes (C2, tools/ablate_gather.py): 11.9 ms, of which 8.7 ms with the candidate loads ablated and 10.6 ms
+// with half of them -- the 16-byte loads cost 3.2 ms ADDITIVELY (the L1's 64 B/clk/CU return path, not latency).  Built on
+// that, measured, NOT adopted (all parity-green): a depth-one software pipeline of the loads in two register sets
+// (11.7-12.0 ms: nothing to hide); the wavefront's pixel bounding box copied once per pose into an LDS tile by
+// global_load_lds, candidates then read pairwise from LDS and evaluated in packed fp32 (15.3-18.8 ms over four table / tile
+// splits at 4 wavefronts per SIMD: the per-pose bounding-box reductions, the drained tile load and the lost occupancy cost
+// far more than the L1 traffic they remove); rounds instead of the nested slow path (12.2 ms).
 // ---------------------------------------------------------------------------------------------
-constexpr int TAB_ROWS = 11;   // 11 x 64 lanes x 8 B = 5.5 KiB of LDS per wavefront: 28 wavefronts per CU fit in 160 KiB
+#ifndef XVR_TAB_ROWS   // (both overridable for the tuning builds of tools/tune_gather.py)
+#define XVR_TAB_ROWS 13
+#endif
+#ifndef XVR_TAB_WAVES
+#define XVR_TAB_WAVES 6
+#endif
+// 13 x 64 lanes x 8 B = 6.5 KiB of LDS per wavefront: 24 wavefronts per CU (6 per SIMD) fit in 160 KiB; measured flat from
+// (7 per SIMD, 11 rows) to (6, 13) and (5, 15), 5-8 % worse at (8, 9) and (4, 19)
+constexpr int TAB_ROWS = XVR_TAB_ROWS;
 constexpr unsigned TAB_R0_BITS = 24, TAB_N_BITS = 8;   // entry.x = first element of the run in q | count << 24; entry.y = alpha_k
 constexpr unsigned TAB_MAX_RAYS = 1u << TAB_R0_BITS;
 
@@ -451,7 +466,9 @@ __device__ __forceinline__ void gather_pair(const float4 ta, const float4 tb, co
     }
 }
 
-#ifdef XVR_GATHER_ABLATE   // diagnostic build only (tools/gather_stats.py --ablate): same arithmetic, no memory traffic
+#if defined(XVR_GATHER_ABLATE) && XVR_GATHER_ABLATE == 2   // diagnostic build: half the loads (the pair's second = its first)
+#define XVR_LOAD_Q(ptr, k) ((ptr)[0])
+#elif defined(XVR_GATHER_ABLATE)   // diagnostic build only (tools/ablate_gather.py): same arithmetic, no memory traffic
 #define XVR_LOAD_Q(ptr, k) make_float4((float)(k) * 0.25f, 0.5f, 0.75f, 1.f)
 #else
 #define XVR_LOAD_Q(ptr, k) ((ptr)[k])
@@ -468,7 +485,7 @@ __device__ __forceinline__ void gather_row(const float4* __restrict__ row, const
     }
 }
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_trilinear_gather_tab(GatherArgs G) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(XVR_TAB_WAVES, XVR_TAB_WAVES))) void k_trilinear_gather_tab(GatherArgs G) {
     if (*G.flag > __float_as_uint(GATHER_DEV_TOL)) return;  // not a lattice: the scatter kernel runs instead
     __shared__ uint2 tab[TAB_ROWS * 64];
     constexpr float HS = 1.5f, CO = 0.5f;
@@ -742,6 +759,9 @@ __global__ __launch_bounds__(WG) void k_siddon_gather_vol(GatherArgs G) {
 // the per-pose window and the candidate's loads are paid once for eight voxels, the three planes per axis give
 // nine crossing alphas per candidate (the forward's expression, plane by plane), from which every voxel's
 // entry / exit are one max3 / min3.  A candidate costs ~57 VALU for 8 voxels instead of 8 x 19.
+// (Round 2 measured the per-lane FLATTENED window loop here too -- lane-private (row, column) cursor, same arithmetic:
+//  13.5 ms against 12.2 ms.  Fewer trips, but the lanes of a wavefront drift onto different detector rows, and the four
+//  loads of a trip then touch that many more cache lines; the nested loops keep the wavefront on one row at a time.)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_siddon_gather_vol2(GatherArgs G) {
     if (*G.flag > __float_as_uint(GATHER_DEV_TOL)) return;
     int bx, by, bz;
