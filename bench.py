@@ -36,7 +36,7 @@ TAP_BYTES_PER_SAMPLE = 32   # 8 taps x 4 B; the voxel backward ac
 # which profiled kernels make up each timed C-ABI call (one call may launch several kernels)
 TRAFFIC_KERNELS = {
     "trilinear_forward": ["k_trilinear_fwd"],
-    "trilinear_backward": ["k_trilinear_gather_vol", "k_gather_prep", "k_gather_cull", "k_trilinear_bwd"],
+    "trilinear_backward": ["k_trilinear_gather_tab", "k_trilinear_gather_vol", "k_gather_prep", "k_gather_cull", "k_trilinear_bwd"],
     "siddon_forward": ["k_siddon<"],
     "siddon_backward": ["k_siddon_gather_vol", "k_gather_prep", "k_gather_cull", "k_siddon<"],
     "backward_from_jac": ["k_backward_from_jac"],
@@ -87,7 +87,10 @@ def main():
     ap.add_argument("--renderer", default="trilinear", choices=["trilinear", "siddon"])
     ap.add_argument("--no-voxel-grad", action="store_true", help="pose-only backward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --batch poses per rank (default); strong: --batch poses in total, split over the ranks")
     ap.add_argument("--cpu-rays", type=int, default=16384, help="rays of one DRR rendered by the CPU baseline")
+    ap.add_argument("--no-c1-plumbing", action="store_true", help="skip the whole-DRR configs[0] leg of the CPU baseline")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--single-device", action="store_true",
                     help="testing hook: every rank uses cuda:0 (with --backend gloo), to exercise the N > 1 code path on a 1-GPU box")
@@ -114,18 +117,34 @@ def main():
     from xvr_amd.pose import convert
 
     B, H = args.batch, args.det
+    if args.scaling == "strong":   # the same B poses whatever the number of ranks: contiguous shares (distributed.shard_bounds)
+        from xvr_amd.distributed import shard_bounds
+        lo, hi = shard_bounds(B, rank, world)
+        B_total, B = B, hi - lo
+        if B <= 0:
+            raise SystemExit(f"--scaling strong: rank {rank} of {world} has no pose out of {B_total}")
+    else:
+        lo, B_total = 0, world * B
     vol, _ = make_phantom(args.size, n_ellipsoids=64, seed=0, device=dev)
     subject = read(vol, orientation="AP")
     delx = 1.08821875 * 256 / H  # scripts/v1-submission/pelvis/train/patient_specific.sh:31-33
     kw = {"n_points": args.n_points} if args.renderer == "trilinear" else {}
     drr = DRR(subject, 1020.0, H, delx, renderer=args.renderer, reverse_x_axis=False).to(dev)
     density = drr.density.clone().requires_grad_(not args.no_voxel_grad)
-    pose0 = deepfluoro_poses(B, seed=rank)
-    rot, xyz = pose0.convert("euler_angles", "ZXY")
+    if args.scaling == "strong":
+        rot, xyz = (t[lo:lo + B] for t in deepfluoro_poses(B_total, seed=0).convert("euler_angles", "ZXY"))
+    else:
+        rot, xyz = deepfluoro_poses(B, seed=rank).convert("euler_angles", "ZXY")
     rot = rot.to(dev).requires_grad_(True)
     xyz = xyz.to(dev).requires_grad_(True)
     w = torch.rand(B, 1, H, H, device=dev)
-    gathered = torch.empty(world * B, 1, H, H, device=dev) if world > 1 else None
+    # the exchange step: every rank ends up with every DRR.  Equal shares go through all_gather_into_tensor; the unequal
+    # shares of a strong-scaling split through all_gather on a list
+    even = args.scaling == "weak" or B_total % world == 0
+    gathered = torch.empty(B_total, 1, H, H, device=dev) if world > 1 else None
+    if world > 1 and not even:
+        from xvr_amd.distributed import shard_bounds as _sb
+        gathered = [torch.empty(_sb(B_total, r, world)[1] - _sb(B_total, r, world)[0], 1, H, H, device=dev) for r in range(world)]
 
     def step():
         density.grad = None
@@ -136,7 +155,8 @@ def main():
         img = drr(rot, xyz, parameterization="euler_angles", convention="ZXY", density=density, **kw)
         handle = None
         if world > 1:  # the exchange step of the path: every rank gets every rendered DRR (RCCL over xGMI)
-            handle = dist.all_gather_into_tensor(gathered, img.detach(), async_op=True)
+            handle = (dist.all_gather_into_tensor(gathered, img.detach(), async_op=True) if even
+                      else dist.all_gather(gathered, img.detach().contiguous(), async_op=True))
         (img * w).sum().backward()
         if handle is not None:
             handle.wait()
@@ -199,6 +219,17 @@ def main():
         "bytes_per_unit": bytes_per_unit, "avg_launch_ms": dom["avg_ms"],
         "nominal_units_per_launch": nominal_units or None,
     }
+    # Three ways to price the same launch, side by side: `frac` = counted algorithmic taps (the kernel
+    # skips, exactly, the samples that only read padding); `nominal_frac` = SURVEY 8d's nominal B*H*W*N samples -- it can
+    # exceed 1 because more than half of them lie outside the volume; `hbm_physical` = what the memory side actually
+    # moved (FETCH_SIZE + WRITE_SIZE of the committed rocprofv3 PMC passes; FETCH_SIZE under-counts wide coalesced reads
+    # by 2x on gfx950 and is uncalibrated for 4-16 B gathers: the x2 figure is the upper bound)
+    if nominal_units:
+        roofline["nominal_frac"] = nominal_units * bytes_per_unit / (dom["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+    if roofline["traffic"]:
+        phys = roofline["traffic"] / (dom["avg_ms"] * 1e-3) / 1e9
+        roofline["hbm_physical"] = {"GBps": phys, "frac": phys / HBM_PEAK_GBS, "frac_if_fetch_undercounts_2x": 2 * phys / HBM_PEAK_GBS,
+                                    "source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; separate passes)"}
 
     # the forward+backward PAIR priced as one unit (64 B per sample with the voxel gradient,
     # 32 B without), over the summed HIP-event time of every kernel of a step
@@ -211,15 +242,15 @@ def main():
 
     result = {
         "metric": "DRRs/sec (fwd+bwd) 512³ CT→256² detector; achieved HBM GB/s vs peak",
-        "value": world * B * args.steps / elapsed, "unit": "DRRs/s",
+        "value": B_total * args.steps / elapsed, "unit": "DRRs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
             "workload": f"single {args.size}^3 CT, {args.renderer} fwd+bwd(pose{'' if args.no_voxel_grad else '+voxel'}), "
-                        f"{H}x{H} detector, batch_size={B} per GPU"
+                        f"{H}x{H} detector, batch_size={B} per GPU" + (f" ({B_total} in total, strong scaling)" if args.scaling == "strong" else "")
                         + (f", n_points={args.n_points}" if args.renderer == "trilinear" else ""),
-            "global_batch": world * B, "parallelism": f"pose-sharded x{world}, replicated volume, all-gather of DRRs"
+            "global_batch": B_total, "parallelism": f"pose-sharded x{world}, replicated volume, all-gather of DRRs"
             if world > 1 else "single GPU",
         },
         "roofline": roofline, "kernels": kernels,
@@ -233,17 +264,58 @@ def main():
         dist.destroy_process_group()
 
 
+def host_cpu():
+    """(model name, physical cores, hardware threads) of this host, from /proc/cpuinfo."""
+    model, cores, threads = "unknown", set(), 0
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            key, _, val = line.partition(":")
+            key, val = key.strip(), val.strip()
+            if key == "model name":
+                model = val
+            elif key == "processor":
+                threads += 1
+            elif key == "physical id":
+                phys = val
+            elif key == "core id":
+                core = val
+            elif not key and phys is not None:
+                cores.add((phys, core))
+        if phys is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    return model, (len(cores) or threads or (os.cpu_count() or 1)), (threads or (os.cpu_count() or 1))
+
+
+def _timed_reps(run, min_reps=3, budget_s=12.0, max_reps=8):
+    run()  # warm-up (page in the volume, thread pool)
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < min_reps or (time.perf_counter() - t_start < budget_s and len(times) < max_reps):
+        t0 = time.perf_counter()
+        run()
+        times.append(time.perf_counter() - t0)
+    return times
+
+
 def cpu_baseline(vol, drr, rot, xyz, spec, args):
     """The oracle (torch-ops restatement of the reference's CPU render path: linspace -> grid_sample ->
-    sum, autograd backward to pose and voxels) on this host's cores, on a bounded sample: the first
-    `cpu_rays` rays of pose 0 of the same workload, scaled to whole DRRs."""
+    sum, autograd backward to pose and voxels) on this host's cores.  Two bounded legs:
+      * `value`: the benchmark's own workload -- `cpu_rays` centre rays of pose 0, scaled to whole DRRs (same unit as the
+        headline; >= 3 repetitions, the median is reported);
+      * `c1_plumbing`: BASELINE.json configs[0] run WHOLE, as the reference would on its CPU path: DeepFluoro geometry,
+        128 x 128 detector, delx 2.1764375, batch_size 4, n_points 500 (scripts/deepfluoro/train/de_novo.sh:24-32), forward +
+        backward to pose and voxels, in 128 x 128 DRRs per second."""
     import dataclasses
+    import statistics
 
-    from oracle.diffdrr_restated import RenderSpec as OSpec, render as oracle_render
+    from oracle.diffdrr_restated import RenderSpec as OSpec, drr_from_pose, render as oracle_render
     from xvr_amd.pose import convert
 
-    ncores = os.cpu_count() or 1
-    torch.set_num_threads(ncores)
+    model, ncores, nthreads = host_cpu()
+    torch.set_num_threads(nthreads)
     H = args.det
     nrays = min(args.cpu_rays, H * H)
     with torch.no_grad():
@@ -260,31 +332,45 @@ def cpu_baseline(vol, drr, rot, xyz, spec, args):
     ospec = OSpec(**dataclasses.asdict(spec))
 
     def run():
-        out = oracle_render(vol_c, s_c, t_c, L_c, ospec, chunk=4096)
+        vol_c.grad = None
+        out = oracle_render(vol_c, s_c, t_c, L_c, ospec, chunk=16384)
         out.sum().backward()
 
-    run()  # warm-up (page in the volume, thread pool)
-    vol_c.grad = None
-    t0 = time.perf_counter()
-    reps = 0
-    while reps < 1 or (time.perf_counter() - t0 < 10.0 and reps < 8):
-        run()
-        vol_c.grad = None
-        reps += 1
-    dt = (time.perf_counter() - t0) / reps
-    model = "unknown"
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                model = line.split(":", 1)[1].strip()
-                break
-    except OSError:
-        pass
-    return {
-        "value": (nrays / (H * H)) / dt, "unit": "DRRs/s", "cores": torch.get_num_threads(), "kind": "port",
-        "sample": f"{nrays} centre rays of one {H}x{H} DRR of the same workload, fwd+bwd, {reps} reps of {dt:.2f} s "
-                  f"(torch {torch.__version__} CPU ops, {ncores} threads, {model})",
+    times = _timed_reps(run)
+    dt = statistics.median(times)
+    result = {
+        "value": (nrays / (H * H)) / dt, "unit": "DRRs/s", "cores": ncores, "threads": torch.get_num_threads(), "kind": "port",
+        "sample": f"{nrays} centre rays of one {H}x{H} DRR of the same workload, fwd+bwd, median of {len(times)} reps "
+                  f"({min(times):.2f}-{max(times):.2f} s; torch {torch.__version__} CPU ops, {torch.get_num_threads()} threads on "
+                  f"{ncores} physical cores, {model})",
     }
+    if args.renderer == "trilinear" and not args.no_c1_plumbing:
+        # configs[0], whole DRRs, over a volume of the benchmark's size class cropped to what fits a CPU run in seconds
+        Hc, Bc = 128, 4
+        sub_vol = vol.detach().cpu()[::2, ::2, ::2].contiguous()   # 2 mm voxels: the same field of view, 1/8 of the voxels
+        affine = torch.diag(torch.tensor([2.0, 2.0, 2.0, 1.0]))
+        affine[:3, 3] = -(affine[:3, :3] @ ((torch.tensor(sub_vol.shape, dtype=torch.float32) - 1) / 2))
+        rc, tc = deepfluoro_poses(Bc, seed=0).convert("euler_angles", "ZXY")
+        rc.requires_grad_(True)
+        tc.requires_grad_(True)
+        v1 = sub_vol.clone().requires_grad_(True)
+        c1spec = dataclasses.replace(ospec, n_points=500)
+
+        def run_c1():
+            v1.grad = rc.grad = tc.grad = None
+            pose_c = convert(rc, tc, parameterization="euler_angles", convention="ZXY")
+            img = drr_from_pose(v1, affine, pose_c.matrix, Hc, Hc, 1020.0, 2.1764375, 2.1764375, 0.0, 0.0, c1spec,
+                                orientation="AP", reverse_x_axis=True, chunk=8192)
+            img.sum().backward()
+
+        t1 = _timed_reps(run_c1, budget_s=8.0)
+        d1 = statistics.median(t1)
+        result["c1_plumbing"] = {
+            "value": Bc / d1, "unit": "128x128 DRRs/s", "reps": len(t1), "seconds_per_batch": d1,
+            "config": f"DeepFluoro geometry, trilinear, 128x128, delx 2.1764375, sdd 1020, batch_size {Bc}, n_points 500, "
+                      f"{tuple(sub_vol.shape)} volume at 2 mm, fwd+bwd(pose+voxel), whole DRRs",
+        }
+    return result
 
 
 if __name__ == "__main__":

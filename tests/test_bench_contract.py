@@ -31,3 +31,37 @@ def test_bench_json_contract(renderer):
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["avg_launch_ms"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "DRRs/s" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
+    assert c["threads"] >= c["cores"] and "median of" in c["sample"]
+    if renderer == "trilinear":
+        assert r["nominal_frac"] >= r["frac"]            # nominal samples >= volume-touching samples
+        p1 = c["c1_plumbing"]                            # BASELINE.json configs[0], whole DRRs, on the CPU
+        assert p1["value"] > 0 and p1["reps"] >= 3 and "128x128" in p1["config"] and "batch_size 4" in p1["config"]
+
+
+def _torchrun_bench(extra, port):
+    """bench.py's N > 1 branch on ONE GPU: two ranks, gloo rendezvous, both on cuda:0 (--single-device)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "64",
+           "--det", "32", "--n-points", "80", "--backend", "gloo", "--single-device", *extra]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout          # rank 0 alone prints
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_weak_scaling_contract():
+    d = _torchrun_bench(["--batch", "4"], 29611)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8
+    assert abs(d["value"] - 8 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    assert "cpu_baseline" not in d and "pose-sharded x2" in d["config"]["parallelism"]
+    assert d["roofline"]["units_per_launch"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch", [6, 5], ids=["even-split", "ragged-split"])
+def test_bench_two_ranks_strong_scaling_contract(batch):
+    d = _torchrun_bench(["--batch", str(batch), "--scaling", "strong"], 29612 + batch)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["global_batch"] == batch
+    assert abs(d["value"] - batch * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]

@@ -3,6 +3,7 @@ import gzip
 import struct
 
 import numpy as np
+import pytest
 import torch
 
 from xvr_amd.data import make_phantom, read, read_nifti, transform_hu_to_density
@@ -77,3 +78,42 @@ def test_phantom_is_seeded_and_labelled():
     b, _ = make_phantom(24, n_labels=4, seed=3)
     assert torch.equal(a, b) and a.min() >= 0 and a.max() <= 1
     assert set(la.unique().tolist()) <= {0.0, 1.0, 2.0, 3.0} and la.max() >= 1
+
+
+def test_training_checkpoint_has_the_reference_schema(tmp_path):
+    """NNNN.pth: the keys, file name pattern and reload rules of /root/reference/src/xvr/model/trainer.py:318-332 and
+    /root/reference/src/xvr/model/utils.py:132-150,176-183."""
+    from datetime import datetime
+
+    from xvr_amd.training import CHECKPOINT_KEYS, load_checkpoint, restore_from_checkpoint, save_checkpoint
+
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 13))
+    opt = torch.optim.Adam(net.parameters(), lr=3e-4)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: 1.0 / (1 + s))
+    for _ in range(3):
+        net(torch.randn(4, 8)).square().mean().backward()
+        opt.step()
+        sched.step()
+        opt.zero_grad()
+    config = dict(volpath="ct.nii.gz", sdd=1020.0, height=128, delx=2.1764375, renderer="trilinear", batch_size=116,
+                  n_grad_accum_itrs=4, lr=3e-4)
+    path, nxt = save_checkpoint(tmp_path, net, opt, sched, itr=1000, model_number=7, config=config)
+    assert path.name == "0007.pth" and nxt == 8
+    raw = torch.load(path, weights_only=False)
+    assert tuple(raw) == CHECKPOINT_KEYS and isinstance(raw["date"], datetime) and raw["config"] == config
+
+    ckpt, start_itr, number = load_checkpoint(path, reuse_optimizer=True)
+    assert (start_itr, number) == (1000, 7)
+    assert load_checkpoint(path, reuse_optimizer=False)[1:] == (0, 0) and load_checkpoint(None) == (None, 0, 0)
+    net2 = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 13))
+    opt2 = torch.optim.Adam(net2.parameters(), lr=1.0)
+    sched2 = torch.optim.lr_scheduler.LambdaLR(opt2, lambda s: 1.0 / (1 + s))
+    restore_from_checkpoint(ckpt, net2, opt2, sched2, reuse_optimizer=True)
+    x = torch.randn(5, 8)
+    assert torch.equal(net(x), net2(x))
+    assert opt2.state_dict()["state"][0]["step"] == opt.state_dict()["state"][0]["step"]
+    assert sched2.last_epoch == sched.last_epoch == 3 and abs(opt2.param_groups[0]["lr"] - opt.param_groups[0]["lr"]) < 1e-12
+    torch.save({"model_state_dict": {}}, tmp_path / "bad.pth")
+    with pytest.raises(KeyError, match="missing"):
+        load_checkpoint(tmp_path / "bad.pth")

@@ -25,3 +25,17 @@ def test_multistart_registration_two_ranks():
     # starts are 100+ mm off; the end point moves by a few mm from run to run (atomic-order noise, amplified by
     # Adam's sign-like first steps, mostly along the poorly conditioned source-detector axis)
     assert float(found[0].group(2)) > 0.9 and float(found[0].group(4)) < 20.0
+
+
+@pytest.mark.gpu
+def test_training_step_one_volume_per_rank_two_ranks():
+    """configs[4] in miniature: every rank renders its own CT, the stand-in regressor's gradients are all-reduced every 4
+    steps as one bucket, and the ranks end up with identical weights."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", str(ROOT / "tools" / "train_step_multigpu.py"), "--backend", "gloo", "--single-device",
+           "--size", "48", "--det", "32", "--batch", "6", "--steps", "8", "--warmup", "1", "--params", "200000"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("rank ")]
+    assert len(lines) == 2, out.stdout
+    assert all("weights identical across ranks: True" in l and "every 4 steps" in l for l in lines)

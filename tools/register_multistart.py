@@ -56,5 +56,8 @@ errs0 = [geo(true_pose, inits[i])[2].item() for i in range(args.starts)]
 print(f"rank {rank}/{world}: refined {len(local)} starts; best ncc {score.item():.4f} from rank {best_rank}; "
       f"pose error {err:.2f} mm (starts were {min(errs0):.1f}-{max(errs0):.1f} mm off); "
       f"{sum(len(r['trajectory']) for r in local)} iterations in {wall:.2f} s{' (batched)' if args.batched else ''}", flush=True)
+# per-rank timeline: what this rank spent on each of its starts (no communication until the final 68-byte all-gather)
+for n, r in enumerate(local):
+    print(f"  rank {rank} start {n}: {len(r['trajectory'])} iterations, {r['runtime']:.2f} s, ncc {r['nccs'][0]:.3f} -> {r['nccs'][-1]:.3f}", flush=True)
 if world > 1:
     dist.destroy_process_group()

@@ -57,3 +57,59 @@ def render_samples(drr, volume, seg, affinv, pose, img_threshold=0.10, mask_thre
         keep = mask[:, 1:].sum(dim=1, keepdim=True)
         keep = (keep > 0).to(img).flatten(1).mean(1) > mask_threshold
     return img, mask, keep
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# training checkpoints: the reference's ``NNNN.pth`` schema
+# ---------------------------------------------------------------------------------------------------------------
+CHECKPOINT_KEYS = ("model_state_dict", "optimizer_state_dict", "scheduler_state_dict", "itr", "model_number", "date", "config")
+
+
+def save_checkpoint(outpath, model, optimizer, scheduler, itr: int, model_number: int, config: dict):
+    """Write ``{outpath}/{model_number:04d}.pth`` with exactly the keys of the reference's ``Trainer._checkpoint``
+    (/root/reference/src/xvr/model/trainer.py:318-332): model / optimizer / scheduler state dicts, ``itr``,
+    ``model_number``, ``date`` (a ``datetime``) and the trainer's ``config`` dict.  Returns (path, model_number + 1) --
+    the reference increments its counter after every save.  Works for any ``torch.nn.Module`` regressor (the timm
+    network itself is out of scope; a file written by the reference loads here and vice versa)."""
+    from datetime import datetime
+    from pathlib import Path
+
+    path = Path(outpath) / f"{model_number:04d}.pth"
+    path.parent.mkdir(parents=True, exist_ok=True)
+    torch.save({
+        "model_state_dict": model.state_dict(),
+        "optimizer_state_dict": optimizer.state_dict(),
+        "scheduler_state_dict": scheduler.state_dict(),
+        "itr": itr,
+        "model_number": model_number,
+        "date": datetime.now(),
+        "config": config,
+    }, path)
+    return path, model_number + 1
+
+
+def load_checkpoint(ckptpath, reuse_optimizer: bool = False):
+    """The reference's ``_load_checkpoint`` (/root/reference/src/xvr/model/utils.py:176-183): -> (ckpt, start_itr,
+    model_number); the iteration and file counters restart from 0 unless the optimizer is being reused."""
+    if ckptpath is None:
+        return None, 0, 0
+    ckpt = torch.load(ckptpath, weights_only=False)   # (holds a datetime and the config dict, as the reference's files do)
+    missing = [k for k in CHECKPOINT_KEYS if k not in ckpt]
+    if missing:
+        raise KeyError(f"{ckptpath}: not an xvr training checkpoint, missing {missing}")
+    if reuse_optimizer:
+        return ckpt, ckpt["itr"], ckpt["model_number"]
+    return ckpt, 0, 0
+
+
+def restore_from_checkpoint(ckpt, model, optimizer=None, scheduler=None, reuse_optimizer: bool = False):
+    """What ``initialize_modules`` does with a loaded checkpoint (/root/reference/src/xvr/model/utils.py:132-150): the
+    model weights always, optimizer and scheduler state only when ``reuse_optimizer``."""
+    if ckpt is None:
+        return
+    model.load_state_dict(ckpt["model_state_dict"])
+    if reuse_optimizer:
+        if optimizer is not None:
+            optimizer.load_state_dict(ckpt["optimizer_state_dict"])
+        if scheduler is not None:
+            scheduler.load_state_dict(ckpt["scheduler_state_dict"])
