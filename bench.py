@@ -138,13 +138,11 @@ def main():
     rot = rot.to(dev).requires_grad_(True)
     xyz = xyz.to(dev).requires_grad_(True)
     w = torch.rand(B, 1, H, H, device=dev)
-    # the exchange step: every rank ends up with every DRR.  Equal shares go through all_gather_into_tensor; the unequal
-    # shares of a strong-scaling split through all_gather on a list
-    even = args.scaling == "weak" or B_total % world == 0
-    gathered = torch.empty(B_total, 1, H, H, device=dev) if world > 1 else None
-    if world > 1 and not even:
-        from xvr_amd.distributed import shard_bounds as _sb
-        gathered = [torch.empty(_sb(B_total, r, world)[1] - _sb(B_total, r, world)[0], 1, H, H, device=dev) for r in range(world)]
+    # the exchange step: every rank ends up with every DRR (one all_gather_into_tensor).  The unequal shares of a ragged
+    # strong-scaling split are padded to the largest share: no backend gathers uneven tensors in one collective
+    Bmax = B if args.scaling == "weak" else -(-B_total // world)
+    gathered = torch.empty(world * Bmax, 1, H, H, device=dev) if world > 1 else None
+    send = torch.zeros(Bmax, 1, H, H, device=dev) if world > 1 and Bmax != B else None
 
     def step():
         density.grad = None
@@ -155,8 +153,9 @@ def main():
         img = drr(rot, xyz, parameterization="euler_angles", convention="ZXY", density=density, **kw)
         handle = None
         if world > 1:  # the exchange step of the path: every rank gets every rendered DRR (RCCL over xGMI)
-            handle = (dist.all_gather_into_tensor(gathered, img.detach(), async_op=True) if even
-                      else dist.all_gather(gathered, img.detach().contiguous(), async_op=True))
+            if send is not None:
+                send[:B].copy_(img.detach())
+            handle = dist.all_gather_into_tensor(gathered, img.detach() if send is None else send, async_op=True)
         (img * w).sum().backward()
         if handle is not None:
             handle.wait()
@@ -315,7 +314,7 @@ def cpu_baseline(vol, drr, rot, xyz, spec, args):
     from xvr_amd.pose import convert
 
     model, ncores, nthreads = host_cpu()
-    torch.set_num_threads(nthreads)
+    torch.set_num_threads(ncores)     # one thread per physical core (SMT siblings only add contention to grid_sample's backward)
     H = args.det
     nrays = min(args.cpu_rays, H * H)
     with torch.no_grad():

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define XVR_DRR_ABI_VERSION 2   /* 2: xvr_sim_spec grew (per_image, pre_transformed); camera-driven forwards, packed labels, xvr_pose.h */
+#define XVR_DRR_ABI_VERSION 3   /* 3: xvr_drr_spec.volume_layout + xvr_drr_pack_ypairs; 2: xvr_sim_spec grew, camera-driven forwards, packed labels, xvr_pose.h */
 
 #define XVR_DRR_OK 0
 #define XVR_DRR_E_ARG (-1)     /* bad argument (null pointer, non-positive size, unsupported combo) */
@@ -60,6 +60,8 @@ typedef struct xvr_drr_spec {
     /* launch shaping (performance only, never changes results) */
     int32_t ray_grid_w;    /* >0: the n rays form an (n / ray_grid_w) x ray_grid_w row-major detector and
                               lanes are mapped to 8x8 pixel tiles; 0: rays are mapped linearly             */
+    int32_t volume_layout; /* trilinear forward, one channel: 0 = `volume` is [D0][D1][D2]; 1 = it is the y-pair
+                              interleaved copy written by xvr_drr_pack_ypairs (same results, bit for bit)  */
 } xvr_drr_spec;
 
 int xvr_drr_abi_version(void);
@@ -171,6 +173,17 @@ int xvr_drr_siddon_forward_camera(const float* volume, const float* mask, int D0
  * take the original volume and mask.
  */
 int xvr_drr_pack_labels(const float* volume, const float* mask, long long n, float* packed, void* stream);
+
+/*
+ * y-pair interleaved copy of a volume for the trilinear forward (spec.volume_layout = 1):
+ *     pairs[x][yp][z] = (V[x][yp - 1][z], V[x][yp][z]),  yp = 0 .. D1, zero outside the volume
+ * i.e. [D0][D1 + 1][D2][2] floats = xvr_drr_ypairs_bytes().  One 16-byte load at (x, floor(y) + 1, z) then returns the
+ * four taps (y, z), (y + 1, z), (y, z + 1), (y + 1, z + 1): a sample costs two gather instructions instead of four, and
+ * the march is bound by the texture-address rate per instruction.  Twice the memory of the
+ * volume; built in one streaming pass; the forward's arithmetic is unchanged (identical output bits).
+ */
+size_t xvr_drr_ypairs_bytes(int D0, int D1, int D2);
+int xvr_drr_pack_ypairs(const float* volume, int D0, int D1, int D2, float* pairs, void* stream);
 
 /*
  * Jacobian -> camera in one pass (= xvr_drr_backward_from_jac followed by xvr_drr_rays_backward, without

@@ -117,6 +117,45 @@ def test_sample_split_forward_and_jacobian(ns, kw, grid, monkeypatch):
         _close(h, r, GRAD_TOL, f"{name} ns={ns}")
 
 
+@pytest.mark.parametrize("kw", [dict(n_points=120), dict(n_points=90, voxel_shift=0.0, step_mode="n_minus_1"),
+                                dict(n_points=100, norm_dims_offset=-1), dict(n_points=80, near=0.2, far=0.9),
+                                dict(n_points=70, clip_to_volume=True)], ids=_id)
+@pytest.mark.parametrize("shape", [(40, 44, 48), (33, 31, 29)], ids=["even", "odd"])
+def test_ypair_volume_layout_is_bit_identical(kw, shape, monkeypatch):
+    """Large one-channel trilinear launches march the y-pair interleaved copy of the volume (xvr_drr_pack_ypairs: two
+    16-byte gathers per sample instead of four 8-byte ones).  Same taps, same arithmetic: the image and the jacobian-borne
+    pose gradients must be IDENTICAL to the natural layout's, bit for bit -- also where rays leave the volume (the copy's
+    zero rows) and for odd sizes."""
+    from xvr_amd import renderers
+    from xvr_amd.renderers import render
+    from xvr_amd.spec import RenderSpec
+
+    spec = RenderSpec(renderer="trilinear", **kw)
+    case = make_case(seed=31, shape=shape, height=128, width=128, delx=0.45, rot=((170.0, 10.0, 5.0),) * 4 + ((20.0, -20.0, -8.0),) * 4,
+                     xyz=((5.0, 300.0, -4.0), (-3.0, 200.0, 6.0), (0.0, 30.0, 0.0), (40.0, 250.0, 10.0)) * 2)
+    assert 8 * (128 * 128 // 64) >= renderers.YPAIR_MIN_WAVEFRONTS
+    w = torch.rand(8, 1, 128 * 128, generator=torch.Generator().manual_seed(3)).cuda()
+    res = []
+    for flag in (True, False):
+        monkeypatch.setattr(renderers, "YPAIR_LAYOUT", flag)
+        vol, src, tgt, img = (case[k].cuda() for k in ("volume", "source", "target", "img"))
+        for t in (src, tgt, img):
+            t.requires_grad_(True)
+        renderers.PROFILER = []
+        out = render(vol, src, tgt, img, spec, ray_grid_w=128)
+        names = [e[0] for e in renderers.PROFILER]
+        renderers.PROFILER = None
+        assert ("pack_ypairs" in names) == flag                       # the layout really was (not) used
+        (out * w).sum().backward()
+        res.append((out.detach(), src.grad, tgt.grad, img.grad))
+    for a, b, name in zip(res[0], res[1], ("out", "grad_source", "grad_target", "grad_img")):
+        if name == "grad_source":      # (summed over rays with float atomics in arbitrary order)
+            _close(a, b, 1e-5, name)
+        else:
+            assert torch.equal(a, b), name
+    _close(res[0][0], _oracle_render(case, spec), FWD_TOL, "forward vs oracle")
+
+
 @pytest.mark.parametrize("packed", [True, False], ids=["packed-labels", "mask-lookup"])
 @pytest.mark.parametrize("kw", [s for s in SPECS if not s.get("clip_to_volume")], ids=_id)
 def test_forward_with_mask_matches_oracle(kw, packed, monkeypatch):
@@ -181,6 +220,72 @@ def test_voxel_gather_equals_atomic_scatter_and_oracle(kw, hw):
     # on the pre-scaled direction a * d), different summation order, fp32 atomics on the scatter side
     _close(grads[0], grads[1], 4e-5, "gather vs scatter")
     _close(grads[0], ref, GRAD_TOL, "gather vs oracle")
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n_points=40, clip_to_volume=True), dict(n_points=33, clip_to_volume=True, voxel_shift=0.0, step_mode="n_minus_1"),
+    dict(n_points=45, clip_to_volume=True, near=0.1, far=0.95), dict(n_points=50, clip_to_volume=True, norm_dims_offset=-1),
+    dict(n_points=1, clip_to_volume=True),
+], ids=_id)
+@pytest.mark.parametrize("hw", [(24, 24), (17, 33), (2, 2)])
+def test_clip_to_volume_voxel_gather_equals_atomic_scatter_and_oracle(kw, hw):
+    """clip_to_volume rescales alpha per ray, so the samples of a step are not on one plane: the pixel-major gather
+    (k_trilinear_gather_px<CLIP>) against the atomic scatter (same weights, other summation order) and the oracle."""
+    from xvr_amd import renderers
+    from xvr_amd.spec import RenderSpec
+
+    spec = RenderSpec(renderer="trilinear", **kw)
+    case = make_case(seed=23, shape=(20, 24, 28), height=hw[0], width=hw[1], delx=1.5 * 24 / max(hw))
+    w = torch.rand(2, 1, hw[0] * hw[1], generator=torch.Generator().manual_seed(5))
+    grads = []
+    for flag in (True, False):
+        renderers.VOXEL_GATHER = flag
+        try:
+            grads.append(_hip_render(case, spec, grid_w=hw[1], grads=True, w=w)[1])
+        finally:
+            renderers.VOXEL_GATHER = True
+    _close(grads[0], grads[1], 4e-5, "gather vs scatter")
+    _close(grads[0], _oracle_render(case, spec, grads=True, w=w)[1], GRAD_TOL, "gather vs oracle")
+
+
+@pytest.mark.parametrize("kw", [dict(n_points=60), dict(n_points=45, voxel_shift=0.0), dict(n_points=50, norm_dims_offset=-1),
+                                dict(n_points=40, near=0.2, far=0.9)], ids=_id)
+@pytest.mark.parametrize("uniform", [False, True], ids=["per-channel-gradient", "same-gradient-for-all-channels"])
+def test_masked_voxel_gather_equals_atomic_scatter_and_oracle(kw, uniform):
+    """mask -> channels.  A gradient that differs between channels is looked up per sample by its label
+    (k_trilinear_gather_px<MASK>); one that is the same for all channels -- the backward of xvr's `img.sum(dim=1)`,
+    /root/reference/src/xvr/model/trainer.py:292-293 -- reaches the voxels as if there were no mask and takes the plain
+    gather.  Both against the atomic scatter and the oracle."""
+    from xvr_amd import renderers
+    from xvr_amd.renderers import render
+    from xvr_amd.spec import RenderSpec
+
+    spec = RenderSpec(renderer="trilinear", **kw)
+    case = make_case(seed=29, shape=(20, 24, 28), height=22, width=26, delx=1.5)
+    n = 22 * 26
+    w3 = torch.rand(2, 3, n, generator=torch.Generator().manual_seed(6))
+
+    def hip_grad():
+        vol, src, tgt, img = (case[k].cuda() for k in ("volume", "source", "target", "img"))
+        vol.requires_grad_(True)
+        out = render(vol, src, tgt, img, spec, case["mask"].cuda(), ray_grid_w=26)
+        loss = (out.sum(dim=1, keepdim=True) * w3[:, :1].cuda()).sum() if uniform else (out * w3.cuda()).sum()
+        loss.backward()
+        return vol.grad
+
+    grads = []
+    for flag in (True, False):
+        renderers.VOXEL_GATHER = flag
+        try:
+            grads.append(hip_grad())
+        finally:
+            renderers.VOXEL_GATHER = True
+    from oracle.diffdrr_restated import render as oracle_render
+    v = case["volume"].clone().requires_grad_(True)
+    out = oracle_render(v, case["source"], case["target"], case["img"], to_oracle_spec(spec), case["mask"])
+    ((out.sum(dim=1, keepdim=True) * w3[:, :1]).sum() if uniform else (out * w3).sum()).backward()
+    _close(grads[0], grads[1], 4e-5, "gather vs scatter")
+    _close(grads[0], v.grad, GRAD_TOL, "gather vs oracle")
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(voxel_shift=0.0), dict(norm_dims_offset=1)], ids=_id)

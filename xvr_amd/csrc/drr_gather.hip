@@ -60,7 +60,8 @@ __global__ __launch_bounds__(WG) void k_gather_prep(GatherArgs G) {
                     fmaxf(fabsf(ty - (t00[1] + j * ec[1] + i * er[1])), fabsf(tz - (t00[2] + j * ec[2] + i * er[2]))));
         dev = pitch > 0.f ? dev / pitch : INFINITY;
         if (!(dev == dev)) dev = INFINITY;
-        const float c = G.gout[(size_t)b * G.n + r] * G.raylen[(size_t)b * G.n + r] * G.sp.inv_denom;
+        // (mask -> channels: the upstream gradient depends on the sample's label and is looked up per candidate)
+        float c = (G.mask ? 1.f : G.gout[(size_t)b * G.n + r]) * G.raylen[(size_t)b * G.n + r] * G.sp.inv_denom;
         // d exactly as the forward forms it, (t - s) + eps, so that the gather's fmaf chain below
         // reproduces the forward's sample positions bit for bit
         const float sx = G.source[3 * b], sy = G.source[3 * b + 1], sz = G.source[3 * b + 2];
@@ -70,6 +71,22 @@ __global__ __launch_bounds__(WG) void k_gather_prep(GatherArgs G) {
             float4* row = G.q + (size_t)b * G.qn + (size_t)i * G.qs;
             row[j] = make_float4(G.sp.a[0] * ddx, G.sp.a[1] * ddy, G.sp.a[2] * ddz, c);
             if (j == G.W - 1) row[G.W] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (G.clip) {
+                // the ray's own [alpha_min, alpha_max], computed exactly as ray_setup() does for the forward; the image is
+                // scaled by their span
+                const float dd[3] = {ddx, ddy, ddz}, ss[3] = {sx, sy, sz};
+                float lo = -INFINITY, hi = INFINITY;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float a0 = (G.sp.lo[k] - ss[k]) / dd[k], a1 = (G.sp.hi[k] - ss[k]) / dd[k];
+                    lo = fmaxf(lo, fminf(a0, a1));
+                    hi = fminf(hi, fmaxf(a0, a1));
+                }
+                if (!(lo > 0.f)) lo = 0.f;
+                if (!(hi < 1.f)) hi = 1.f;
+                row[j].w = c * fmaxf(hi - lo, 0.f);
+                G.q2[(size_t)b * G.n + r] = make_float2(lo, hi);
+            }
         } else {
             // the ray's own integration interval, computed exactly as ray_setup() does for the forward
             const float dd[3] = {ddx, ddy, ddz}, ss[3] = {sx, sy, sz};
@@ -193,7 +210,7 @@ __global__ __launch_bounds__(WG) void k_gather_cull(GatherArgs G, int nbricks) {
             const float en0 = P.nh[0] * hx, en1 = P.nh[1] * hy, en2 = P.nh[2] * hz;
             const float av = dot3(P.nh, w), da = fabsf(en0) + fabsf(en1) + fabsf(en2);
             const float amin = av - da, amax = av + da;
-            if (amax >= G.sp.near_ && amin <= G.sp.far_) {
+            if (amax >= G.cull_lo && amin <= G.cull_hi) {
                 if (amin <= 1e-6f) {
                     hit = true;  // the box reaches the source plane: no perspective bound, keep
                 } else {
@@ -681,6 +698,147 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(XVR_TAB_WAVE
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pixel-major voxel gather for the renders the lattice-of-planes kernels above cannot take (round 2):
+//   CLIP  spec.clip_to_volume: alpha_k = alpha_min(ray) + u_k (alpha_max - alpha_min)(ray) -- the samples of a step no longer
+//         lie on one plane, so there is no per-step row table; the image is scaled by the ray's span.
+//   MASK  mask -> channels with a gradient that differs between channels: the upstream value of a sample is
+//         gout[b][label(sample)][ray], looked up per candidate (a gradient that is the same for all channels -- all xvr
+//         ever produces, trainer.py:292-293 -- is the unmasked gradient and takes the table kernel).
+// One lane owns a 2x2x2 voxel block; per pose the pixel window is the bounding box of the 8 projected corners of the
+// block's interpolation support (as in k_siddon_gather_vol2); per pixel the ray is clipped against that support box
+// (slab test) and only the samples inside are evaluated -- with the forward's own alpha and position arithmetic, so the
+// weights are the forward's interpolation weights.  Before these kernels both cases fell back to the fp32-atomic scatter
+// (443 ms per C2 batch).
+// ---------------------------------------------------------------------------------------------
+template <bool CLIP, bool MASK>
+__global__ __launch_bounds__(64) void k_trilinear_gather_px(GatherArgs G) {
+    if (*G.flag > __float_as_uint(GATHER_DEV_TOL)) return;  // not a lattice: the scatter kernel runs instead
+    constexpr float HS = 1.5f, CO = 0.5f;
+    int bx, by, bz;
+    brick_coords(blockIdx.x, G.D1, G.D2, G.bd, bx, by, bz);
+    const int tid = threadIdx.x;
+    const int vx = (bx * 4 + (tid >> 4)) * 2, vy = (by * 4 + ((tid >> 2) & 3)) * 2, vz = (bz * 4 + (tid & 3)) * 2;
+    const bool inb = vx < G.D0 && vy < G.D1 && vz < G.D2;
+    const float fv[3] = {(float)vx, (float)vy, (float)vz};
+    const float a0 = G.sp.a[0], a1 = G.sp.a[1], a2 = G.sp.a[2];
+    float xv[3];  // block centre in x coordinates
+#pragma unroll
+    for (int i = 0; i < 3; ++i) xv[i] = (fv[i] + CO - G.sp.b[i]) / G.sp.a[i];
+    const float ea0 = HS / a0, ea1 = HS / a1, ea2 = HS / a2;   // half-size of the support, in x coordinates
+    const int N = G.sp.n_points;
+    const float near_ = G.sp.near_, far_ = G.sp.far_;
+    const float step = N > 1 ? (far_ - near_) / (float)(N - 1) : 0.f;
+    const float inv_step = step > 0.f ? 1.f / step : 0.f;
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+
+    for (int wd = 0; wd < G.words; ++wd) {
+        unsigned bits = G.cull[(size_t)blockIdx.x * G.words + wd];
+        while (bits) {
+            const int p = wd * 32 + __builtin_ctz(bits);
+            bits &= bits - 1;
+            const PoseLattice& P = G.poses[p];
+            const float s0 = P.s[0], s1 = P.s[1], s2 = P.s[2];
+            const float w0 = xv[0] - s0, w1 = xv[1] - s1, w2 = xv[2] - s2;
+            const float av = P.nh[0] * w0 + P.nh[1] * w1 + P.nh[2] * w2;
+            const float en0 = P.nh[0] * ea0, en1 = P.nh[1] * ea1, en2 = P.nh[2] * ea2;
+            const float da = fabsf(en0) + fabsf(en1) + fabsf(en2);
+            const float amin = av - da, amax = av + da;   // alpha range of the support box on this pose's sample planes
+            int jlo = 0, jhi = -1, ilo = 0, ihi = -1;
+            if (inb && amin > 1e-6f && amax >= G.cull_lo && amin <= G.cull_hi) {
+                // convex and in front of the source: the pixel window is the bounding box of the 8 projected corners
+                const float nj = P.gc[0] * w0 + P.gc[1] * w1 + P.gc[2] * w2;
+                const float ni = P.gr[0] * w0 + P.gr[1] * w1 + P.gr[2] * w2;
+                const float ec0 = P.gc[0] * ea0, ec1 = P.gc[1] * ea1, ec2 = P.gc[2] * ea2;
+                const float er0 = P.gr[0] * ea0, er1 = P.gr[1] * ea1, er2 = P.gr[2] * ea2;
+                float jmn = INFINITY, jmx = -INFINITY, imn = INFINITY, imx = -INFINITY;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float sx = (c & 4) ? 1.f : -1.f, sy = (c & 2) ? 1.f : -1.f, sz = (c & 1) ? 1.f : -1.f;
+                    const float inv = 1.f / (av + sx * en0 + sy * en1 + sz * en2);
+                    const float jv = (nj + sx * ec0 + sy * ec1 + sz * ec2) * inv, iv = (ni + sx * er0 + sy * er1 + sz * er2) * inv;
+                    jmn = fminf(jmn, jv); jmx = fmaxf(jmx, jv);
+                    imn = fminf(imn, iv); imx = fmaxf(imx, iv);
+                }
+                jlo = (int)ceilf(fmaxf(jmn + P.gc0 - GATHER_WIN_MARGIN, 0.f));
+                jhi = (int)floorf(fminf(jmx + P.gc0 + GATHER_WIN_MARGIN, (float)(G.W - 1)));
+                ilo = (int)ceilf(fmaxf(imn + P.gr0 - GATHER_WIN_MARGIN, 0.f));
+                ihi = (int)floorf(fminf(imx + P.gr0 + GATHER_WIN_MARGIN, (float)(G.H - 1)));
+            } else if (inb && amin <= 1e-6f && amax >= G.cull_lo) {
+                jhi = G.W - 1;   // the box reaches the source plane: no perspective bound -- visit every ray
+                ihi = G.H - 1;
+            }
+            const float4* __restrict__ q = G.q + (size_t)p * G.qn;
+            const float2* __restrict__ q2 = G.q2 + (size_t)p * G.n;
+            // a s + b - v for the block's first voxel (the weights' constant) and for its centre (the slab test's)
+            const float Bx = fmaf(a0, s0, G.sp.b[0] - fv[0]), By = fmaf(a1, s1, G.sp.b[1] - fv[1]), Bz = fmaf(a2, s2, G.sp.b[2] - fv[2]);
+            const float Cx = Bx - CO, Cy = By - CO, Cz = Bz - CO;
+            for (int i = ilo; i <= ihi; ++i) {
+                for (int j = jlo; j <= jhi; ++j) {
+                    const float4 t = q[(size_t)i * G.qs + j];   // a * d, (g *) L / N (* span)
+                    float lo = 0.f, span = 1.f;
+                    if (CLIP) {
+                        const float2 ab = q2[(size_t)i * G.W + j];
+                        lo = ab.x;
+                        span = ab.y - ab.x;      // exactly the forward's (amax - amin)
+                    }
+                    // alphas where the ray is inside the support box: |C + alpha t| < HS on all three axes (an axis the ray
+                    // does not move along: inside for every alpha or for none)
+                    const float ix = fabsf(t.x) < 1e-12f ? copysignf(1e12f, t.x) : 1.f / t.x;
+                    const float iy = fabsf(t.y) < 1e-12f ? copysignf(1e12f, t.y) : 1.f / t.y;
+                    const float iz = fabsf(t.z) < 1e-12f ? copysignf(1e12f, t.z) : 1.f / t.z;
+                    const float x0 = (-HS - Cx) * ix, x1 = (HS - Cx) * ix, y0 = (-HS - Cy) * iy, y1 = (HS - Cy) * iy;
+                    const float z0 = (-HS - Cz) * iz, z1 = (HS - Cz) * iz;
+                    const float e0 = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+                    const float e1 = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+                    // -> sample indices (u = near + k step; alpha = lo + u * span under CLIP, u otherwise)
+                    int klo = 0, khi = -1;
+                    if (e1 >= e0 && (!CLIP || span > 0.f)) {
+                        const float u0 = CLIP ? (e0 - lo) / span : e0, u1 = CLIP ? (e1 - lo) / span : e1;
+                        if (step > 0.f) {
+                            klo = (int)ceilf(fmaxf((u0 - near_) * inv_step - 1.f, 0.f));      // one step of slack each side: the
+                            khi = (int)floorf(fminf((u1 - near_) * inv_step + 1.f, (float)(N - 1)));   // weights decide, not the window
+                        } else {
+                            khi = 0;
+                        }
+                    }
+                    for (int k = klo; k <= khi; ++k) {
+                        const float u = linspace_at(k, N, near_, far_, step);
+                        const float al = CLIP ? fmaf(u, span, lo) : u;   // the forward's alpha, bit for bit
+                        const float dx = fmaf(al, t.x, Bx), dy = fmaf(al, t.y, By), dz = fmaf(al, t.z, Bz);
+                        float cw = t.w;
+                        if (MASK) {
+                            // the channel of the sample = the label of its nearest voxel (0 outside the volume), as the forward
+                            const int lx = (int)rintf(dx + fv[0]), ly = (int)rintf(dy + fv[1]), lz = (int)rintf(dz + fv[2]);
+                            const bool in = (unsigned)lx < (unsigned)G.D0 && (unsigned)ly < (unsigned)G.D1 && (unsigned)lz < (unsigned)G.D2;
+                            const int lab = in ? min(max((int)G.mask[((size_t)lx * G.D1 + ly) * G.D2 + lz], 0), G.C - 1) : 0;
+                            cw *= G.gout[((size_t)p * G.C + lab) * G.n + (size_t)i * G.W + j];
+                        }
+                        const float ux0 = hat01(dx), uy0 = hat01(dy), uz0 = hat01(dz) * cw;
+                        const float ux1 = hat01(dx - 1.f), uy1 = hat01(dy - 1.f), uz1 = hat01(dz - 1.f) * cw;
+                        const float p00 = ux0 * uy0, p01 = ux0 * uy1, p10 = ux1 * uy0, p11 = ux1 * uy1;
+                        acc[0] = fmaf(p00, uz0, acc[0]);
+                        acc[1] = fmaf(p00, uz1, acc[1]);
+                        acc[2] = fmaf(p01, uz0, acc[2]);
+                        acc[3] = fmaf(p01, uz1, acc[3]);
+                        acc[4] = fmaf(p10, uz0, acc[4]);
+                        acc[5] = fmaf(p10, uz1, acc[5]);
+                        acc[6] = fmaf(p11, uz0, acc[6]);
+                        acc[7] = fmaf(p11, uz1, acc[7]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int x = vx + (e >> 2 & 1), y = vy + (e >> 1 & 1), z = vz + (e & 1);
+        if (x < G.D0 && y < G.D1 && z < G.D2 && acc[e] != 0.f) G.gvol[((size_t)x * G.D1 + y) * G.D2 + z] += acc[e];
+    }
+}
+
 // Siddon voxel gradient as a gather (exact-geometry index map only: a = 1, b = shift - 1/2, so the
 // voxel a segment is credited to is the voxel whose box contains it).  d out / d V[v] for one ray is
 // L x (length of the ray inside v's box, clipped to the ray's own [alpha_lo, alpha_hi]); the box's
@@ -874,9 +1032,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 // (with skip_unless_flag_gt = the returned flag) right behind it.
 int xvr_detail::launch_gather(bool siddon, const float* source, const float* target, const float* raylen, const float* grad_out,
                   int B, int n, int gw, int D0, int D1, int D2, const xvr_drr_spec* sp, float* grad_volume,
-                  void* workspace, void* stream, unsigned** flag_out) {
+                  void* workspace, void* stream, unsigned** flag_out, const float* mask, int C) {
     char* ws = static_cast<char*>(workspace);
     GatherArgs G = {};
+    G.mask = siddon ? nullptr : mask;
+    G.C = C;
+    G.clip = (!siddon && sp->clip_to_volume) ? 1 : 0;
+    // alphas any sample can take: [near, far] on the shared planes; under clip alpha = amin + u (amax - amin) with
+    // 0 <= amin, amin + span <= 1, i.e. within [min(0, near), max(1, far)]
+    G.cull_lo = G.clip ? fminf(0.f, sp->near_) : sp->near_;
+    G.cull_hi = G.clip ? fmaxf(1.f, sp->far_) : sp->far_;
+    if (siddon) { G.cull_lo = 0.f; G.cull_hi = 1.f; }
     G.source = source; G.target = target; G.raylen = raylen; G.gout = grad_out;
     G.B = B; G.n = n; G.W = gw; G.H = n / gw; G.D0 = D0; G.D1 = D1; G.D2 = D2; G.sp = *sp;
     G.flag = reinterpret_cast<unsigned*>(ws);
@@ -895,7 +1061,10 @@ int xvr_detail::launch_gather(bool siddon, const float* source, const float* tar
     static const bool siddon_v1 = [] { const char* e = getenv("XVR_DRR_SIDDON_GATHER_BLOCK"); return e && e[0] == '1'; }();
     if (siddon && siddon_v1) { G.bd[0] = 4; G.bd[1] = 8; G.bd[2] = 8; }
     else if (siddon) { G.bd[0] = G.bd[1] = G.bd[2] = 8; }
-    else { G.bd[0] = G.bd[1] = G.bd[2] = 4 * G.V; }
+    else {
+        if (G.clip || G.mask) G.V = 2;   // (the pixel-major kernel is written for 2x2x2 blocks)
+        G.bd[0] = G.bd[1] = G.bd[2] = 4 * G.V;
+    }
     G.cull = reinterpret_cast<unsigned*>(ws + ws_cull_off(B, n));
     G.words = (B + 31) / 32;
     G.gvol = grad_volume;
@@ -910,6 +1079,9 @@ int xvr_detail::launch_gather(bool siddon, const float* source, const float* tar
                        (hipStream_t)stream, G, (int)bricks);
     if (siddon && siddon_v1) hipLaunchKernelGGL(k_siddon_gather_vol, dim3((unsigned)bricks), dim3(WG), 0, (hipStream_t)stream, G);
     else if (siddon) hipLaunchKernelGGL(k_siddon_gather_vol2, dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
+    else if (G.clip && G.mask) hipLaunchKernelGGL((k_trilinear_gather_px<true, true>), dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
+    else if (G.clip) hipLaunchKernelGGL((k_trilinear_gather_px<true, false>), dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
+    else if (G.mask) hipLaunchKernelGGL((k_trilinear_gather_px<false, true>), dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
     else if (G.V == 2 && use_table && (unsigned)G.qn <= TAB_MAX_RAYS) hipLaunchKernelGGL(k_trilinear_gather_tab, dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
     else if (G.V == 2) hipLaunchKernelGGL(k_trilinear_gather_vol<2>, dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
     else hipLaunchKernelGGL(k_trilinear_gather_vol<1>, dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);

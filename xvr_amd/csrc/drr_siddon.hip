@@ -249,6 +249,7 @@ static int siddon_forward_impl(const float* volume, const float* mask, int D0, i
     int rc = check_common(volume, D0, D1, D2, C, source, target, raylen, B, n, sp, cam);
     if (rc) return rc;
     if (!out) return fail(XVR_DRR_E_ARG, "out is null");
+    if (sp->volume_layout != 0) return fail(XVR_DRR_E_UNSUPPORTED, "siddon takes the natural volume layout");
     const bool packed = !mask && C > 1;   // labels in the low mantissa bits of `volume` (xvr_drr_pack_labels)
     if (packed && C > (1 << LABEL_BITS)) return fail(XVR_DRR_E_ARG, "packed labels hold at most 16 channels");
     RenderArgs A;

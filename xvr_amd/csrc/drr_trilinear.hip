@@ -37,7 +37,7 @@ struct TriAcc {  // per-lane sums of one ray (or of one slice of its samples)
 
 // Samples kbeg..kend (wave-uniform bounds; lanes mask themselves with their own K) of the lane's ray.
 // MASK: 0 = one channel; 1 = labels from a separate mask volume; 2 = labels packed into the volume's taps
-template <bool JAC, int MASK, bool CLIP>
+template <bool JAC, int MASK, bool CLIP, bool YP = false>
 __device__ __forceinline__ void tri_march(const RenderArgs& A, const Ray& R, const KRange K, const int kbeg, const int kend,
                                           const float step, float* lds, const int tid, TriAcc& acc) {
     const int N = A.sp.n_points;
@@ -56,6 +56,7 @@ __device__ __forceinline__ void tri_march(const RenderArgs& A, const Ray& R, con
         float u[2], al[2], pxs[2], pys[2], pzs[2];
         Taps T[2];
         fpair P[2][4];
+        int yoff[2][2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int k = kk + h;
@@ -65,14 +66,26 @@ __device__ __forceinline__ void tri_march(const RenderArgs& A, const Ray& R, con
             pxs[h] = fmaf(A.sp.a[0], fmaf(al[h], R.d[0], R.s[0]), A.sp.b[0]);
             pys[h] = fmaf(A.sp.a[1], fmaf(al[h], R.d[1], R.s[1]), A.sp.b[1]);
             pzs[h] = fmaf(A.sp.a[2], fmaf(al[h], R.d[2], R.s[2]), A.sp.b[2]);
-            make_taps(pxs[h], pys[h], pzs[h], D0, D1, D2, T[h]);  // offsets are clamped: always loadable
+            if (YP) make_taps_yp(pxs[h], pys[h], pzs[h], D0, D1, D2, T[h], yoff[h]);
+            else make_taps(pxs[h], pys[h], pzs[h], D0, D1, D2, T[h]);  // offsets are clamped: always loadable
         }
         // unconditional (offsets are clamped into the volume): a branch here would split the loads into
         // two exec-masked blocks with a full vmcnt(0) drain between them
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
+            if (YP) {
+                // y-pair interleaved copy: two 16-byte loads instead of four 8-byte ones; re-filed as the four (z, z + 1)
+                // pairs of rows (x0,y0) (x0,y1) (x1,y0) (x1,y1), so that everything below is the same arithmetic
 #pragma unroll
-            for (int q = 0; q < 4; ++q) P[h][q] = load_pair(vol + T[h].base[q]);
+                for (int q = 0; q < 2; ++q) {
+                    const fquad Q = load_quad(vol + yoff[h][q]);
+                    P[h][2 * q] = fpair{Q.x, Q.z};
+                    P[h][2 * q + 1] = fpair{Q.y, Q.w};
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) P[h][q] = load_pair(vol + T[h].base[q]);
+            }
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -171,7 +184,7 @@ __device__ __forceinline__ void tri_finish(const RenderArgs& A, const Ray& R, co
 // more resident wavefronts only thrash the L1/L2 -- the variant without the jacobian needs 64 VGPRs, ran at
 // 8 wavefronts per SIMD and took 8.2 ms where the (heavier) jacobian variant at 6 took 7.0; capped, both take
 // ~7.0 ms (measured flat from 3 to 6, worse at 2 and at 8).
-template <bool JAC, int MASK, bool CLIP>
+template <bool JAC, int MASK, bool CLIP, bool YP = false>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, 4))) void k_trilinear_fwd(RenderArgs A) {
     extern __shared__ float lds[];  // MASK: per-lane channel accumulators [C][WG]
     int b, r;
@@ -188,7 +201,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, 4))) void
         for (int c = 0; c < A.C; ++c) lds[c * WG + tid] = 0.f;
     }
     TriAcc acc;
-    tri_march<JAC, MASK, CLIP>(A, R, K, kbeg, kend, step, lds, tid, acc);
+    tri_march<JAC, MASK, CLIP, YP>(A, R, K, kbeg, kend, step, lds, tid, acc);
     if (valid) tri_finish<JAC, MASK, CLIP>(A, R, b, r, lds, tid, acc);
     if (A.work) {
         unsigned tot = wave_sum_u(acc.cnt);
@@ -581,6 +594,10 @@ static int trilinear_forward_impl(const float* volume, const float* mask, int D0
     if (!(sp->far_ >= sp->near_)) return fail(XVR_DRR_E_ARG, "far must be >= near");
     const bool packed = !mask && C > 1;   // labels in the low mantissa bits of `volume` (xvr_drr_pack_labels)
     if (packed && C > (1 << LABEL_BITS)) return fail(XVR_DRR_E_ARG, "packed labels hold at most 16 channels");
+    if (sp->volume_layout != 0 && sp->volume_layout != 1) return fail(XVR_DRR_E_ARG, "unknown volume_layout");
+    if (sp->volume_layout == 1 && (mask || C != 1)) return fail(XVR_DRR_E_UNSUPPORTED, "the y-pair layout serves one-channel renders");
+    if (sp->volume_layout == 1 && (long long)D0 * (D1 + 1) * D2 * 2 >= (1LL << 31))
+        return fail(XVR_DRR_E_UNSUPPORTED, "y-pair copy has >= 2^31 elements");
     RenderArgs A;
     fill_args(A, volume, mask, D0, D1, D2, C, source, target, raylen, B, n, sp, cam);
     A.out = out; A.jac = jac; A.work = work;
@@ -603,6 +620,12 @@ static int trilinear_forward_impl(const float* volume, const float* mask, int D0
     if (use_lds && !clip && A.grid_w > 0) {
         const size_t bytes = (size_t)(LDS_HDR + LDS_BRICK_CAP) * sizeof(float);
         return jac ? launch(k_trilinear_fwd_lds<true>, A, bytes, stream) : launch(k_trilinear_fwd_lds<false>, A, bytes, stream);
+    }
+    if (sp->volume_layout == 1) {   // `volume` is the y-pair interleaved copy: the unsplit kernel, whatever the launch size
+        if (jac) return clip ? launch(k_trilinear_fwd<true, 0, true, true>, A, 0, stream)
+                             : launch(k_trilinear_fwd<true, 0, false, true>, A, 0, stream);
+        return clip ? launch(k_trilinear_fwd<false, 0, true, true>, A, 0, stream)
+                    : launch(k_trilinear_fwd<false, 0, false, true>, A, 0, stream);
     }
     bool tile16 = false;
     const int ns = split_factor(B, n, (long long)D0 * D1 * D2, false, &tile16);
@@ -644,6 +667,7 @@ int xvr_drr_trilinear_backward(const float* volume, const float* mask, int D0, i
     if (rc) return rc;
     if (!grad_out) return fail(XVR_DRR_E_ARG, "grad_out is null");
     if (sp->n_points < 1) return fail(XVR_DRR_E_ARG, "n_points must be >= 1");
+    if (sp->volume_layout != 0) return fail(XVR_DRR_E_ARG, "the backward takes the natural volume layout");
     if (!mask && C != 1) return fail(XVR_DRR_E_ARG, "C must be 1 without a mask");
     if ((grad_source == nullptr) != (grad_target == nullptr))
         return fail(XVR_DRR_E_ARG, "grad_source and grad_target must be requested together");
@@ -656,25 +680,29 @@ int xvr_drr_trilinear_backward(const float* volume, const float* mask, int D0, i
     const bool clip = sp->clip_to_volume != 0;
     const size_t lds = mask ? (size_t)C * WG * sizeof(float) : 0;
 
-    // Voxel gradient by the atomic-free voxel-driven gather when the rays are a detector lattice
-    // (no mask, no per-ray alpha rescaling); the scatter kernel stays as the general fallback and is
-    // launched right behind it, reading the lattice flag on the device (no host sync).
-    const bool gather = gvol && !mask && !clip && gather_usable(sp, n, workspace, workspace_bytes, B, D0, D1, D2);
+    // Voxel gradient by the atomic-free voxel-driven gather when the rays are a detector lattice: the per-lane flattened
+    // table kernel for the plain render, the pixel-major kernel under clip_to_volume and / or a mask; the scatter kernel
+    // stays as the general fallback and is launched right behind it, reading the lattice flag on the device (no host sync).
+    const bool gather = gvol && gather_usable(sp, n, workspace, workspace_bytes, B, D0, D1, D2);
     if (gather) {
         unsigned* flag = nullptr;
         rc = launch_gather(false, source, target, raylen, grad_out, B, n, sp->ray_grid_w, D0, D1, D2, sp, grad_volume,
-                           workspace, stream, &flag);
+                           workspace, stream, &flag, mask, C);
         if (rc) return rc;
-        if (gpose) {  // the pose part does not depend on how the voxel part is done
-            RenderArgs Ap = A;
-            Ap.gvol = nullptr;
-            rc = launch(k_trilinear_bwd<false, false, true, false>, Ap, 0, stream);
-            if (rc) return rc;
-        }
-        RenderArgs Av = A;
+        RenderArgs Ap = A, Av = A;
+        Ap.gvol = nullptr;
         Av.gsrc = nullptr; Av.gtgt = nullptr; Av.glen = nullptr;
         Av.skip_unless_flag_gt = flag;
-        return launch(k_trilinear_bwd<false, false, false, true>, Av, 0, stream);
+#define TRI_BWD_ONE(M, CL, GP, GV, ARGS) launch(k_trilinear_bwd<M, CL, GP, GV>, ARGS, lds, stream)
+#define TRI_BWD_PAIR(M, CL)                                                                   \
+        do {                                                                                  \
+            if (gpose) { rc = TRI_BWD_ONE(M, CL, true, false, Ap); if (rc) return rc; }       \
+            return TRI_BWD_ONE(M, CL, false, true, Av);                                       \
+        } while (0)
+        if (mask) { if (clip) TRI_BWD_PAIR(true, true); else TRI_BWD_PAIR(true, false); }
+        if (clip) TRI_BWD_PAIR(false, true); else TRI_BWD_PAIR(false, false);
+#undef TRI_BWD_PAIR
+#undef TRI_BWD_ONE
     }
 #define TRI_BWD(M, CL)                                                                         \
     (gpose ? (gvol ? launch(k_trilinear_bwd<M, CL, true, true>, A, lds, stream)                \

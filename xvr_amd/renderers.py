@@ -28,7 +28,7 @@ from .spec import RenderSpec
 __all__ = ["Siddon", "Trilinear", "render", "render_from_camera", "make_cspec"]
 
 
-def make_cspec(shape, spec: RenderSpec, ray_grid_w: int = 0) -> _lib.CSpec:
+def make_cspec(shape, spec: RenderSpec, ray_grid_w: int = 0, volume_layout: int = 0) -> _lib.CSpec:
     spec.validate()
     a, b = spec.index_map(shape)
     c = _lib.CSpec()
@@ -43,6 +43,7 @@ def make_cspec(shape, spec: RenderSpec, ray_grid_w: int = 0) -> _lib.CSpec:
     c.inv_denom = 1.0 / (spec.n_points if spec.step_mode == "n_points" else spec.n_points - 1)
     c.clip_to_volume = int(spec.clip_to_volume)
     c.ray_grid_w = int(ray_grid_w)
+    c.volume_layout = int(volume_layout)
     return c
 
 
@@ -124,6 +125,36 @@ def _packed_volume(lib, volume, mask):
     return packed
 
 
+# One-channel trilinear renders of LARGE launches march a y-pair interleaved copy of the volume (xvr_drr_pack_ypairs): two
+# 16-byte gathers per sample instead of four 8-byte ones -- the march is bound by the texture-address rate per gather
+# instruction -- with identical output bits.  Costs twice the volume's memory (cached ON the volume tensor object, keyed by
+# its version counter; rebuilt in one 0.3 ms pass when the voxels change).  False (or XVR_DRR_YPAIRS=0): natural layout.
+YPAIR_LAYOUT = _os.environ.get("XVR_DRR_YPAIRS", "1") != "0"
+YPAIR_MIN_WAVEFRONTS = 2048     # smaller launches take the sample-split kernels on the natural layout
+
+
+def _ypair_volume(lib, volume):
+    D0, D1, D2 = volume.shape
+    key = volume._version
+    hit = getattr(volume, "_xvr_ypairs", None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    pairs = hit[1] if hit is not None else torch.empty(lib.xvr_drr_ypairs_bytes(D0, D1, D2) // 4, device=volume.device, dtype=torch.float32)
+    rc = _timed("pack_ypairs", lib.xvr_drr_pack_ypairs, _ptr(volume), D0, D1, D2, _ptr(pairs), _stream())
+    _lib.check(rc, "xvr_drr_pack_ypairs")
+    try:
+        volume._xvr_ypairs = (key, pairs)
+    except AttributeError:   # pragma: no cover
+        pass
+    return pairs
+
+
+def _use_ypairs(spec, volume, B, n, mask, C):
+    D0, D1, D2 = volume.shape
+    return (YPAIR_LAYOUT and spec.renderer == "trilinear" and mask is None and C == 1 and B * ((n + 63) // 64) >= YPAIR_MIN_WAVEFRONTS
+            and D0 * (D1 + 1) * D2 * 2 < 2 ** 31 and min(D0, D1, D2) >= 2)
+
+
 class _Render(torch.autograd.Function):
     """forward: one fused sweep (with the per-ray jacobian when a pose gradient may be needed);
     backward: elementwise-from-jacobian for the pose, a re-march with scatter for the voxels."""
@@ -138,13 +169,14 @@ class _Render(torch.autograd.Function):
         tgt_c = target.contiguous()
         len_c = img.reshape(B, n).contiguous()
         msk_c = mask.contiguous() if mask is not None else None
-        cs = make_cspec((D0, D1, D2), spec, ray_grid_w)
+        ypairs = _use_ypairs(spec, vol_c, B, n, msk_c, C)
+        cs = make_cspec((D0, D1, D2), spec, ray_grid_w, volume_layout=1 if ypairs else 0)
         need_pose = any(ctx.needs_input_grad[1:4])
         use_jac = need_pose  # with a mask: the jacobian of the channel sum (see backward)
         out = torch.empty(B, C, n, device=volume.device, dtype=torch.float32)
         jac = torch.empty(B, n, _lib.JAC_STRIDE, device=volume.device, dtype=torch.float32) if use_jac else None
         fn = lib.xvr_drr_trilinear_forward if spec.renderer == "trilinear" else lib.xvr_drr_siddon_forward
-        vol_f, msk_f = vol_c, msk_c
+        vol_f, msk_f = (_ypair_volume(lib, vol_c) if ypairs else vol_c), msk_c
         if msk_c is not None and PACK_LABELS and 2 <= C <= 16 and vol_c.data_ptr() % 16 == 0 and msk_c.data_ptr() % 16 == 0:
             vol_f, msk_f = _packed_volume(lib, vol_c, msk_c), None     # labels ride in the taps
         rc = _timed(f"{spec.renderer}_forward" + ("+jac" if use_jac else ""), fn,
@@ -190,6 +222,10 @@ class _Render(torch.autograd.Function):
             pose_here = need_pose and not from_jac
             ws, ws_bytes = (_workspace(lib, B, n, (D0, D1, D2), dev) if need_vol else (None, 0))
             tag = ("pose" if pose_here else "") + ("+vol" if need_vol else "")
+            if msk_c is not None and uniform and not pose_here:
+                # every sample lands in exactly one channel, so a gradient that is the same for all channels (the backward
+                # of xvr's `img.sum(dim=1)`) reaches the voxels as if there were no mask: the plain one-channel gather
+                msk_c, C, gout = None, 1, g_uniform
             rc = _timed(f"{spec.renderer}_backward[{tag.strip('+')}]", fn,
                         _ptr(vol_c), _ptr(msk_c), D0, D1, D2, C, _ptr(src_c), _ptr(tgt_c), _ptr(len_c), B, n,
                         ctypes.byref(cs), _ptr(gout), _ptr(gvol),
@@ -212,12 +248,14 @@ class _RenderFromCamera(torch.autograd.Function):
         lib = _lib.load()
         cam_c, vol_c = cam.contiguous(), volume.contiguous()
         B, n = cam_c.shape[0], H * W
-        cs = make_cspec(tuple(vol_c.shape), spec, W)
+        ypairs = _use_ypairs(spec, vol_c, B, n, None, 1)
+        cs = make_cspec(tuple(vol_c.shape), spec, W, volume_layout=1 if ypairs else 0)
         need = ctx.needs_input_grad[0]
         out = torch.empty(B, 1, n, device=cam.device, dtype=torch.float32)
         jac = torch.empty(B, n, _lib.JAC_STRIDE, device=cam.device, dtype=torch.float32) if need else None
         fn = lib.xvr_drr_trilinear_forward_camera if spec.renderer == "trilinear" else lib.xvr_drr_siddon_forward_camera
-        rc = _timed(f"{spec.renderer}_forward" + ("+jac" if need else ""), fn, _ptr(vol_c), None, *vol_c.shape, 1, _ptr(cam_c),
+        rc = _timed(f"{spec.renderer}_forward" + ("+jac" if need else ""), fn, _ptr(_ypair_volume(lib, vol_c) if ypairs else vol_c), None,
+                    *vol_c.shape, 1, _ptr(cam_c),
                     B, H, W, ctypes.byref(cs), _ptr(out), _ptr(jac), None, _stream())
         _lib.check(rc, f"xvr_drr_{spec.renderer}_forward_camera")
         ctx.save_for_backward(cam_c, jac)
