@@ -57,6 +57,17 @@ int xvr_sim_ncc_forward_backward(const float* fixed, const float* fixed_sobel, c
                                  float* loss, float* grad_moving,
                                  void* workspace, size_t workspace_bytes, void* stream);
 
+/*
+ * The Gaussian pre-blur of GradientNormalizedCrossCorrelation2d(patch, sigma > 0)
+ * (/root/reference/src/xvr/registrar/base.py:122): 5 taps exp(-x^2 / (2 sigma^2)), x = -2..2, normalised, separable,
+ * reflect padding by 2 -- and its exact transpose (adjoint = 1), which is the blur's backward.  The similarity of a
+ * configuration with sigma > 0 is then  beta * mNCC(fixed, y) + (1 - beta) * gNCC(blur(fixed), blur(y))  with both NCC
+ * terms from xvr_sim_ncc_forward_backward (beta = 1 / beta = 0, pre_transformed) and the second gradient passed back
+ * through the adjoint.
+ *   in, out, scratch  [B][H][W] each (out may alias in; scratch may not), H, W >= 3
+ */
+int xvr_sim_gaussian_blur5(const float* in, float* out, float* scratch, int B, int H, int W, float sigma, int adjoint, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -398,3 +398,127 @@ def test_fuzz_opt_step_against_torch_adam(seed):
         np.testing.assert_allclose(got[:, 6:], want[:, 6:], rtol=2e-6, err_msg=what)
         np.testing.assert_allclose(got[:, :3], want[:, :3], rtol=0, atol=2e-3 * lr_rot * T + 1e-5, err_msg=what)
         np.testing.assert_allclose(got[:, 3:6], want[:, 3:6], rtol=0, atol=2e-3 * lr_xyz * T + 1e-3, err_msg=what)
+
+
+# ----------------------------------------------------------------------------------------------
+# similarity configurations beyond the single fused call: sigma > 0, Equalize
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 3, 3), (2, 5, 7), (1, 4, 33), (3, 40, 36)])
+@pytest.mark.parametrize("sigma", [0.6, 1.0, 2.5])
+def test_gaussian_blur_kernels_match_torch_forward_and_adjoint(shape, sigma):
+    """xvr_sim_gaussian_blur5 against the reflect-pad + two conv2d of the reference's Sobel pre-blur, and its adjoint against
+    autograd through that torch formulation (every image size down to the 3 x 3 minimum of a 2-pixel reflection)."""
+    from xvr_amd.metrics import Sobel
+    from xvr_amd.similarity import gaussian_blur5
+
+    B, H, W = shape
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(B, 1, H, W, generator=g)
+    w = torch.rand(B, 1, H, W, generator=g)
+    ref_mod = Sobel(sigma)
+    xr = x.clone().requires_grad_(True)
+    ref = ref_mod._blur(xr)
+    (ref * w).sum().backward()
+    xh = x.cuda().requires_grad_(True)
+    out = gaussian_blur5(xh, sigma)
+    (out * w.cuda()).sum().backward()
+    assert torch.allclose(out.cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(xh.grad.cpu(), xr.grad, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sigma", [0.8, 1.5])
+def test_gradient_ncc_with_pre_blur_runs_in_hip_and_matches_torch_and_the_oracle(sigma, monkeypatch):
+    from oracle import metrics_restated as mref
+    from xvr_amd import metrics, renderers
+
+    B, H, W = 2, 48, 40
+    g = torch.Generator().manual_seed(13)
+    x = torch.rand(B, 1, H, W, generator=g).cuda().requires_grad_()
+    y = (0.6 * x.detach() + 0.4 * torch.rand(B, 1, H, W, generator=g).cuda()).requires_grad_()
+    w = torch.rand(B, generator=g).cuda() + 0.5
+    sim = metrics.GradientNormalizedCrossCorrelation2d(11, sigma).cuda()
+    renderers.PROFILER = []
+    out = sim(x, y)
+    names = {e[0] for e in renderers.PROFILER}
+    renderers.PROFILER = None
+    assert {"gaussian_blur5", "mncc_forward_backward"} <= names          # the HIP kernels did run
+    (out * w).sum().backward()
+    gx, gy = x.grad.clone(), y.grad.clone()
+    x.grad = y.grad = None
+    monkeypatch.setattr(metrics.GradientNormalizedCrossCorrelation2d, "FUSED", False)
+    ref = sim(x, y)
+    (ref * w).sum().backward()
+    assert torch.allclose(out, ref, rtol=2e-5, atol=2e-6), (out - ref).abs().max()
+    for a, b, name in ((gx, x.grad, "d/dx"), (gy, y.grad, "d/dy")):
+        assert (a - b).abs().max() <= 2e-4 * b.abs().max(), (name, (a - b).abs().max(), b.abs().max())
+    # the literal unfold formulation (oracle), value AND gradient
+    xo, yo = x.detach().cpu().double().requires_grad_(True), y.detach().cpu().double().requires_grad_(True)
+    oref = mref.gradient_ncc(xo, yo, 11, sigma)
+    (oref * w.cpu().double()).sum().backward()
+    assert torch.allclose(out.detach().cpu().double(), oref.detach(), atol=5e-5)
+    assert (gx.cpu().double() - xo.grad).abs().max() <= 2e-3 * xo.grad.abs().max()
+    assert (gy.cpu().double() - yo.grad).abs().max() <= 2e-3 * yo.grad.abs().max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 40, 36), (2, 64, 64)])
+@pytest.mark.parametrize("beta", [0.5, 0.2])
+def test_fused_similarity_gradient_matches_autograd_through_the_oracle(shape, beta):
+    """The fused call's GRADIENT w.r.t. the raw DRR, directly against autograd through the literal oracle formulation
+    (XrayTransforms restated line by line + the unfold-based patch NCC family, oracle/metrics_restated.py) in float64."""
+    from oracle import metrics_restated as mref
+    from xvr_amd.metrics import XrayTransforms
+    from xvr_amd.similarity import FusedSimilarity
+
+    B, H, W = shape
+    g = torch.Generator().manual_seed(41)
+    fixed_raw = torch.rand(B, 1, H, W, generator=g) * 40
+    # (a unique minimum and maximum: the oracle's x.min() / x.max() then have one sub-gradient, like the kernels')
+    moving = 0.7 * fixed_raw + 12 * torch.rand(B, 1, H, W, generator=g)
+    fixed = XrayTransforms(H, W)(fixed_raw)
+    sim = FusedSimilarity(fixed.cuda(), 9, 11, beta)
+    mv = moving.cuda().requires_grad_(True)
+    loss = sim(mv)
+    loss.sum().backward()
+    mo = moving.double().requires_grad_(True)
+    yo = mref.xray_transforms(mo, H, W)
+    oref = beta * mref.multiscale_ncc(fixed.double(), yo) + (1 - beta) * mref.gradient_ncc(fixed.double(), yo, 11, 0.0)
+    oref.sum().backward()
+    assert torch.allclose(loss.cpu().double(), oref.detach(), atol=5e-5)
+    err = (mv.grad.cpu().double() - mo.grad).abs().max() / mo.grad.abs().max()
+    assert err <= 2e-3, err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(sigma=1.0), dict(equalize=True), dict(sigma=0.8, equalize=True)], ids=["sigma", "equalize", "both"])
+def test_device_loop_and_run_batch_take_every_similarity_configuration(kw):
+    """sigma > 0 and Equalize used to be refused by the device-resident loop and by run_batch (torch fallback only): now
+    the stage differentiates a GeneralSimilarity (HIP NCC + blur kernels, torch transforms) between the render and the
+    optimiser step.  The device loop must follow the plain autograd loop, and the batched starts their one-by-one runs."""
+    from xvr_amd.registrar import Registrar
+    vol, _ = make_phantom(64, n_ellipsoids=8, seed=8, device="cuda")
+    drr = DRR(read(vol, spacing=(2.0,) * 3, orientation="AP"), 1020.0, 64, 2.8, renderer="trilinear", reverse_x_axis=False,
+              voxel_shift=0.0).cuda()
+    rot0, xyz0 = torch.tensor([[3.10, 0.05, -0.03]]), torch.tensor([[4.0, 700.0, -6.0]])
+    with torch.no_grad():
+        gt = drr(convert(rot0.cuda(), xyz0.cuda(), parameterization="euler_angles", convention="ZXY"))
+    g = torch.Generator().manual_seed(2)
+    drot, dxyz = (torch.rand(2, 3, generator=g) - 0.5) * 0.16, (torch.rand(2, 3, generator=g) - 0.5) * 24.0
+    inits = convert(rot0 + drot, xyz0 + dxyz, parameterization="euler_angles", convention="ZXY")
+    common = dict(scales="2,1", n_itrs="25,15", patience=4, max_n_plateaus=2, **kw)
+    dev = Registrar(drr, device_loop=True, **common)
+    ref = Registrar(drr, device_loop=False, fused=False, use_graph=False, **common)
+    a, b = dev.run(gt, inits[0]), ref.run(gt, inits[0])
+    k = min(6, len(a["trajectory"]), len(b["trajectory"]))
+    np.testing.assert_allclose(np.array(a["nccs"][:k]), np.array(b["nccs"][:k]), atol=3e-3)
+    np.testing.assert_allclose(np.array(a["trajectory"])[:k, :3], np.array(b["trajectory"])[:k, :3], atol=3e-3)
+    assert a["nccs"][-1] > a["nccs"][0] + 0.02
+    batch = dev.run_batch(gt, inits)
+    assert len(batch) == 2
+    for n in range(2):
+        single = dev.run(gt, inits[n])
+        k = min(6, len(batch[n]["trajectory"]), len(single["trajectory"]))
+        np.testing.assert_allclose(np.array(batch[n]["nccs"][:k]), np.array(single["nccs"][:k]), atol=3e-3)
+        assert batch[n]["nccs"][-1] > batch[n]["nccs"][0]

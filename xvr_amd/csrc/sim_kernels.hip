@@ -444,7 +444,72 @@ Layout layout(int B, int H, int W, int p1, int p2) {
 
 }  // namespace
 
+namespace {
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {   // torch's "reflect" padding (no edge repeat); needs n >= 3 for 2 pixels
+    i = i < 0 ? -i : i;
+    return i >= n ? 2 * (n - 1) - i : i;
+}
+
+// One axis of the 5-tap Gaussian pre-blur of GradientNormalizedCrossCorrelation2d(p, sigma > 0): reflect padding by 2, valid
+// correlation.  ADJ = false: out[p] = sum_t k[t] in[reflect(p + t - 2)].  ADJ = true: the exact transpose (what autograd
+// gives for the pad + conv pair): out[r] = sum over (p, t) with reflect(p + t - 2) = r of k[t] in[p] -- gathered, one thread
+// per element, no atomics.
+template <bool ADJ>
+__global__ __launch_bounds__(TB) void k_blur5(const float* __restrict__ in, float* __restrict__ out, long long total, int H, int W, int axis,
+                                              float k0, float k1, float k2, float k3, float k4) {
+    const long long e = (long long)blockIdx.x * TB + threadIdx.x;
+    if (e >= total) return;
+    const int w = (int)(e % W), h = (int)((e / W) % H);
+    const long long base = e - (axis ? w : (long long)h * W);    // element 0 of this row / column
+    const int n = axis ? W : H, pos = axis ? w : h;
+    const long long stride = axis ? 1 : W;
+    const float k[5] = {k0, k1, k2, k3, k4};
+    float acc = 0.f;
+    if (!ADJ) {
+#pragma unroll
+        for (int t = 0; t < 5; ++t) acc = fmaf(k[t], in[base + (long long)reflect_idx(pos + t - 2, n) * stride], acc);
+    } else {
+        // sources p = m - t + 2 for every m that reflects onto pos: m = pos, m = -pos (pos = 1, 2), m = 2 (n - 1) - pos
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            const int d = t - 2;
+            int pp = pos - d;                                     // m = pos
+            if (pp >= 0 && pp < n) acc = fmaf(k[t], in[base + (long long)pp * stride], acc);
+            pp = -pos - d;                                        // m = -pos < 0
+            if (pos > 0 && pp >= 0 && pp < n && -pos >= -2) acc = fmaf(k[t], in[base + (long long)pp * stride], acc);
+            pp = 2 * (n - 1) - pos - d;                           // m = 2 (n - 1) - pos > n - 1
+            if (pos < n - 1 && pp >= 0 && pp < n && n - 1 - pos <= 2) acc = fmaf(k[t], in[base + (long long)pp * stride], acc);
+        }
+    }
+    out[e] = acc;
+}
+
+}  // namespace
+
 extern "C" {
+
+int xvr_sim_gaussian_blur5(const float* in, float* out, float* scratch, int B, int H, int W, float sigma, int adjoint, void* stream_) {
+    if (!in || !out || !scratch) return sim_fail(XVR_DRR_E_ARG, "null pointer argument");
+    if (B <= 0 || H < 3 || W < 3) return sim_fail(XVR_DRR_E_ARG, "reflect padding by 2 needs images of at least 3 x 3");
+    if (!(sigma > 0.f)) return sim_fail(XVR_DRR_E_ARG, "sigma must be positive");
+    float k[5], sum = 0.f;
+    for (int t = 0; t < 5; ++t) { k[t] = expf(-0.5f * ((float)(t - 2) / sigma) * ((float)(t - 2) / sigma)); sum += k[t]; }
+    for (int t = 0; t < 5; ++t) k[t] /= sum;
+    const long long total = (long long)B * H * W;
+    const unsigned blocks = (unsigned)((total + TB - 1) / TB);
+    hipStream_t stream = (hipStream_t)stream_;
+    // forward: along W, then along H (the order of the reference's two conv2d calls); the adjoint runs them in reverse
+    if (!adjoint) {
+        hipLaunchKernelGGL(k_blur5<false>, dim3(blocks), dim3(TB), 0, stream, in, scratch, total, H, W, 1, k[0], k[1], k[2], k[3], k[4]);
+        hipLaunchKernelGGL(k_blur5<false>, dim3(blocks), dim3(TB), 0, stream, (const float*)scratch, out, total, H, W, 0, k[0], k[1], k[2], k[3], k[4]);
+    } else {
+        hipLaunchKernelGGL(k_blur5<true>, dim3(blocks), dim3(TB), 0, stream, in, scratch, total, H, W, 0, k[0], k[1], k[2], k[3], k[4]);
+        hipLaunchKernelGGL(k_blur5<true>, dim3(blocks), dim3(TB), 0, stream, (const float*)scratch, out, total, H, W, 1, k[0], k[1], k[2], k[3], k[4]);
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? XVR_DRR_OK : sim_fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
+}
 
 size_t xvr_sim_workspace_bytes(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return 0;

@@ -125,11 +125,15 @@ class GradientNormalizedCrossCorrelation2d(NormalizedCrossCorrelation2d):
 
     def forward(self, x1, x2):
         p = self.patch_size
-        if (self.FUSED and p is not None and 2 <= p <= 15 and not self.sobel.sigma and x1.is_cuda and x2.is_cuda
+        if (self.FUSED and p is not None and 2 <= p <= 15 and x1.is_cuda and x2.is_cuda
                 and x1.dtype == x2.dtype == torch.float32 and x1.shape == x2.shape and x1.dim() == 4 and x1.shape[1] == 1
-                and x1.shape[0] > 0 and min(x1.shape[2:]) >= p):
+                and x1.shape[0] > 0 and min(x1.shape[2:]) >= max(p, 3)):
             from .similarity import fused_gncc
 
+            if self.sobel.sigma and self.sobel.sigma > 0:   # pre-blur as a HIP kernel pair, then the plain Sobel pair
+                if getattr(self, "_sobel0", None) is None:
+                    self._sobel0 = Sobel(0.0).to(x1.device)
+                return fused_gncc(x1, x2, p, self.eps, self._sobel0, self.sobel.sigma)
             return fused_gncc(x1, x2, p, self.eps, self.sobel)
         return super().forward(self.sobel(x1), self.sobel(x2))
 
@@ -187,14 +191,23 @@ class XrayTransforms(torch.nn.Module):
     every rendered DRR each iteration (/root/reference/src/xvr/utils/preprocess.py:5-31; call sites
     /root/reference/src/xvr/registrar/base.py:213-218,250, /root/reference/src/xvr/model/trainer.py:207,216)."""
 
-    def __init__(self, height: int, width: int | None = None, mean: float = 0.15, std: float = 0.1, equalize: bool = False):
+    def __init__(self, height: int, width: int | None = None, mean: float = 0.15, std: float = 0.1, equalize: bool = False,
+                 per_image: bool = False):
         super().__init__()
         self.equalize = Equalize() if equalize else None
         self.height, self.width = height, height if width is None else width
         self.mean, self.std = mean, std
+        # per_image: every image of the batch standardised by its OWN min / max (the reference's transform takes them
+        # over the whole tensor, which is the same thing for the single image it is ever given); batched multi-start
+        # needs the images of a batch to be independent problems
+        self.per_image = per_image
 
     def forward(self, x):
-        x = (x - x.min()) / (x.max() - x.min() + 1e-6)
+        if self.per_image:
+            lo, hi = x.amin(dim=(1, 2, 3), keepdim=True), x.amax(dim=(1, 2, 3), keepdim=True)
+            x = (x - lo) / (hi - lo + 1e-6)
+        else:
+            x = (x - x.min()) / (x.max() - x.min() + 1e-6)
         if self.equalize is not None:
             x = self.equalize(x)
         if tuple(x.shape[-2:]) != (self.height, self.width):

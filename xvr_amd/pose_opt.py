@@ -94,6 +94,10 @@ class RegistrationStage:
         self.drr, self.sim, self.rot, self.xyz = drr, sim, rot, xyz
         self.B = B = rot.shape[0]
         self.H, self.W = drr.detector.height, drr.detector.width
+        # `sim`: a FusedSimilarity (one C-ABI call per iteration), or any callable raw DRRs [B,1,H,W] -> similarity [B]
+        # built from differentiable torch ops (a GeneralSimilarity: Equalize, sigma > 0, patches > 15 ...), which is then
+        # differentiated by autograd between the render and the optimiser step -- still no host sync, still capturable
+        self.sim_is_fused = hasattr(sim, "fixed_sobel")
         if tuple(sim.fixed.shape) != (B, 1, self.H, self.W):
             raise ValueError(f"similarity target {tuple(sim.fixed.shape)} does not match {B} poses at {self.H}x{self.W}")
         n = self.n = self.H * self.W
@@ -133,9 +137,17 @@ class RegistrationStage:
         lib, B, H, W, n = self.lib, self.B, self.H, self.W, self.n
         self.render()
         s, sim = _stream(), self.sim
-        _lib.check(_timed("ncc_forward_backward", lib.xvr_sim_ncc_forward_backward, _ptr(sim.fixed), _ptr(sim.fixed_sobel),
-                          _ptr(self.img), B, H, W, ctypes.byref(sim.spec), _ptr(self.loss), _ptr(self.g_img),
-                          _ptr(sim.workspace), sim.workspace.numel() * 4, s), "xvr_sim_ncc_forward_backward")
+        if self.sim_is_fused:
+            _lib.check(_timed("ncc_forward_backward", lib.xvr_sim_ncc_forward_backward, _ptr(sim.fixed), _ptr(sim.fixed_sobel),
+                              _ptr(self.img), B, H, W, ctypes.byref(sim.spec), _ptr(self.loss), _ptr(self.g_img),
+                              _ptr(sim.workspace), sim.workspace.numel() * 4, s), "xvr_sim_ncc_forward_backward")
+        else:
+            with torch.enable_grad():
+                img = self.img.detach().requires_grad_(True)
+                loss = sim(img)
+                (g,) = torch.autograd.grad(loss.sum(), img)
+            self.loss.copy_(loss.detach().reshape(B))
+            self.g_img.copy_(g)
         _lib.check(_timed("jac_to_camera_backward", lib.xvr_drr_jac_to_camera_backward, _ptr(self.jac), _ptr(self.g_img),
                           _ptr(self.cam), B, H, W, _ptr(self.g_cam), _ptr(self.j2c_ws), self.j2c_ws.numel() * 4, s),
                    "xvr_drr_jac_to_camera_backward")

@@ -32,7 +32,7 @@ from .metrics import (GradientNormalizedCrossCorrelation2d, MultiscaleNormalized
 from .pose import RigidTransform, convert
 from .pose_opt import RegistrationStage
 from .registration import Registration
-from .similarity import FusedSimilarity
+from .similarity import FusedSimilarity, GeneralSimilarity
 
 
 def parse_scales(scales, crop: int, height: int):
@@ -106,9 +106,12 @@ class Registrar:
             graphed = self.use_graph and device.type == "cuda"
             lr_rot = self.lr_rot / step_size_scalar
             lr_xyz = self.lr_xyz / step_size_scalar
-            if (self.device_loop if self.device_loop is not None else True) and use_fused and n_itr > 0 \
-                    and self.parameterization == "euler_angles":
-                stage_run = RegistrationStage(reg.drr, fused_sim, reg.rotation.data, reg.translation.data, self.convention,
+            device_loop = (self.device_loop if self.device_loop is not None else True) and device.type == "cuda" and n_itr > 0 \
+                and self.parameterization == "euler_angles" and (self.fused if self.fused is not None else True)
+            if device_loop:
+                sim_obj = fused_sim if use_fused else GeneralSimilarity(img, transform, self.mncc_patch_size, self.gncc_patch_size,
+                                                                       self.sigma, self.beta)
+                stage_run = RegistrationStage(reg.drr, sim_obj, reg.rotation.data, reg.translation.data, self.convention,
                                               lr_rot, lr_xyz, self.patience, self.threshold, self.max_n_plateaus,
                                               max_iters=n_itr)
                 _, stage_times = stage_run.run(n_itr, self.check_every, use_graph=graphed)
@@ -231,12 +234,14 @@ class Registrar:
         for stage, (scale, n_itr) in enumerate(zip(scales, self.n_itrs), start=1):
             drr.rescale_detector_(scale)
             h, w = drr.detector.height, drr.detector.width
-            if not FusedSimilarity.supported(h, w, self.mncc_patch_size, self.gncc_patch_size, self.sigma, self.equalize):
-                raise RuntimeError("run_batch needs the fused similarity (sigma = 0, no equalisation, patches <= 15)")
             transform = XrayTransforms(h, w, equalize=self.equalize)
             img = torch.cat([transform(gt[b:b + 1]) for b in range(gt.shape[0])])   # every target standardised on its own
             fixed = img.expand(B, -1, -1, -1) if img.shape[0] == 1 else img   # one target for all starts, or one per pose
-            sim = FusedSimilarity(fixed.contiguous(), self.mncc_patch_size, self.gncc_patch_size, self.beta, per_image=True)
+            if FusedSimilarity.supported(h, w, self.mncc_patch_size, self.gncc_patch_size, self.sigma, self.equalize):
+                sim = FusedSimilarity(fixed.contiguous(), self.mncc_patch_size, self.gncc_patch_size, self.beta, per_image=True)
+            else:   # Equalize / sigma > 0 / large patches: the same loop, the similarity composed of HIP NCC kernels + torch ops
+                sim = GeneralSimilarity(fixed.contiguous(), XrayTransforms(h, w, equalize=self.equalize, per_image=True),
+                                        self.mncc_patch_size, self.gncc_patch_size, self.sigma, self.beta)
             step_size_scalar *= 2 ** (stage - 1)
             if n_itr <= 0:
                 continue

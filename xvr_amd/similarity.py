@@ -78,6 +78,28 @@ class FusedSimilarity(torch.nn.Module):
         return _FusedNCC.apply(moving, self.fixed, self.fixed_sobel, self.spec, self.workspace)
 
 
+class GeneralSimilarity(torch.nn.Module):
+    """``sim(moving_raw [B,1,H,W]) -> [B]`` for the configurations the single fused call does not cover -- ``equalize``,
+    ``sigma > 0``, patches beyond 15 -- as the reference composes them (/root/reference/src/xvr/registrar/base.py:115-123,
+    250-251): XrayTransforms (optionally per image) then beta * mNCC + (1 - beta) * gNCC.  The NCC terms and the Gaussian
+    pre-blur still run in the HIP kernels (through ``xvr_amd.metrics``' dispatch); Standardize / Equalize / Normalize are
+    torch ops, differentiated by autograd.  Plugs into ``RegistrationStage`` wherever a ``FusedSimilarity`` does."""
+
+    def __init__(self, fixed, transform, mncc_patch_size=9, gncc_patch_size=11, sigma=0.0, beta=0.5):
+        super().__init__()
+        from .metrics import GradientNormalizedCrossCorrelation2d, MultiscaleNormalizedCrossCorrelation2d
+
+        self.register_buffer("fixed", fixed.contiguous())
+        self.transform = transform
+        self.beta = beta
+        self.sim1 = MultiscaleNormalizedCrossCorrelation2d([None, mncc_patch_size], [0.5, 0.5])
+        self.sim2 = GradientNormalizedCrossCorrelation2d(gncc_patch_size, sigma).to(fixed.device)
+
+    def forward(self, moving):
+        y = self.transform(moving)
+        return self.beta * self.sim1(self.fixed, y) + (1 - self.beta) * self.sim2(self.fixed, y)
+
+
 class _FusedMNCC(torch.autograd.Function):
     """beta = 1: 0.5 NCC(x, y) + 0.5 patch-NCC_p(x, y) per image; beta = 0: patch-NCC_p of the Sobel pairs
     (sx, sy = Sobel(x), Sobel(y), constants of the call), for already transformed images.  NCC is symmetric, so
@@ -115,14 +137,49 @@ class _FusedMNCC(torch.autograd.Function):
         return (gx * g if gx is not None else None), (gy * g if gy is not None else None), None, None, None, None, None
 
 
+class _Blur5(torch.autograd.Function):
+    """5-tap separable Gaussian blur with reflect padding (xvr_sim_gaussian_blur5); backward = its exact transpose."""
+
+    @staticmethod
+    def forward(ctx, x, sigma):
+        ctx.sigma = float(sigma)
+        return _Blur5._run(x, ctx.sigma, 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _Blur5._run(g, ctx.sigma, 1), None
+
+    @staticmethod
+    def _run(x, sigma, adjoint):
+        lib = _lib.load()
+        xc = x.contiguous()
+        H, W = xc.shape[-2:]
+        out, scratch = torch.empty_like(xc), torch.empty_like(xc)
+        rc = _timed("gaussian_blur5", lib.xvr_sim_gaussian_blur5, _ptr(xc), _ptr(out), _ptr(scratch), xc.numel() // (H * W), H, W,
+                    ctypes.c_float(sigma), adjoint, _stream())
+        _lib.check(rc, "xvr_sim_gaussian_blur5")
+        return out
+
+
+def gaussian_blur5(x, sigma: float):
+    """The pre-blur of ``GradientNormalizedCrossCorrelation2d(p, sigma > 0)`` as a HIP kernel pair (float32 CUDA, H, W >= 3)."""
+    if not x.is_cuda or x.dtype != torch.float32:
+        raise RuntimeError("gaussian_blur5 needs a float32 CUDA tensor (HIP kernel, no CPU path)")
+    return _Blur5.apply(x, float(sigma))
+
+
 def fused_mncc(x, y, patch_size: int, eps: float = 1e-5):
     """``MultiscaleNormalizedCrossCorrelation2d([None, p], [0.5, 0.5])(x, y)`` -> [B] through the HIP kernels."""
     return _FusedMNCC.apply(x, y, int(patch_size), float(eps))
 
 
-def fused_gncc(x, y, patch_size: int, eps: float, sobel):
-    """``GradientNormalizedCrossCorrelation2d(p, sigma=0)(x, y)`` -> [B] through the HIP kernels.  The kernels take
-    the Sobel pair of the image they treat as fixed ready-made (one conv2d each, only for a side that needs it)."""
+def fused_gncc(x, y, patch_size: int, eps: float, sobel, sigma: float = 0.0):
+    """``GradientNormalizedCrossCorrelation2d(p, sigma)(x, y)`` -> [B] through the HIP kernels.  The kernels take
+    the Sobel pair of the image they treat as fixed ready-made (one conv2d each, only for a side that needs it).
+    ``sigma > 0``: both images go through the 5-tap Gaussian pre-blur first (``gaussian_blur5``, differentiable);
+    ``sobel`` must then be the plain 3x3 pair."""
+    if sigma and sigma > 0:
+        x, y = gaussian_blur5(x, sigma), gaussian_blur5(y, sigma)
     with torch.no_grad():
         sx = sobel(x)
         sy = sobel(y) if x.requires_grad else None
