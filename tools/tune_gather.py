@@ -11,7 +11,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 
-VARIANTS = [(7, 11), (6, 13), (5, 15), (8, 9), (4, 19)]
+VARIANTS = [(6, 13), (5, 15), (7, 11)]
 
 
 def lib(w, t):

@@ -446,7 +446,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7))) void
 // (11.7-12.0 ms: nothing to hide); the wavefront's pixel bounding box copied once per pose into an LDS tile by
 // global_load_lds, candidates then read pairwise from LDS and evaluated in packed fp32 (15.3-18.8 ms over four table / tile
 // splits at 4 wavefronts per SIMD: the per-pose bounding-box reductions, the drained tile load and the lost occupancy cost
-// far more than the L1 traffic they remove); rounds instead of the nested slow path (12.2 ms).
+// far more than the L1 traffic they remove); rounds instead of the nested slow path (12.2 ms); the two candidates of a
+// trip through explicit packed fp32 (v_pk_fma/mul/add_f32 on component-wise pairs, one accumulator set per candidate:
+// 40 VALU instructions per trip instead of 47, yet 12.1-13.0 ms -- a v_pk_*_f32 costs two plain issues on gfx950, so the
+// instruction count is not the time; the compiler's own pairing of the eight accumulations is as far as packing goes).
 // ---------------------------------------------------------------------------------------------
 #ifndef XVR_TAB_ROWS   // (both overridable for the tuning builds of tools/tune_gather.py)
 #define XVR_TAB_ROWS 13
