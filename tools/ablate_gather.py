@@ -1,6 +1,8 @@
-"""Loads-ablated diagnostic build of the trilinear table gather (-DXVR_GATHER_ABLATE: same arithmetic, candidates made up
-in registers instead of loaded; results are WRONG by construction -- a separate library, never the product's): how
-much of the kernel's time is memory.  python tools/ablate_gather.py build | run"""
+"""Loads-ablated diagnostic builds of the trilinear table gather (-DXVR_GATHER_ABLATE: candidates made up in registers
+instead of loaded; results are WRONG by construction -- separate libraries, never the product's).  CAUTION when reading
+the numbers (round 2 learnt this the hard way): with constant candidates the compiler hoists their arithmetic out of the
+trip, so "ablated = 8.7 ms, half the loads = 10.6 ms" is an UPPER bound on what memory costs, not the cost -- a variant
+that really loaded a quarter of the bytes was slower.  python tools/ablate_gather.py build | run"""
 import json
 import os
 import subprocess

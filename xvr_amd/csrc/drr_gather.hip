@@ -440,15 +440,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7))) void
 // Entry (8 bytes) = first element of the run in q | count << 24, alpha_k; a lane that meets a row it cannot enter (table
 // full: 5 % of the visits have a lane with more than 13 rows) remembers where and the nested loops of the round-1 kernel
 // take over from there once phase B is done.
-// Where the time goes (C2, tools/ablate_gather.py): 11.9 ms, of which 8.7 ms with the candidate loads ablated and 10.6 ms
-// with half of them -- the 16-byte loads cost 3.2 ms ADDITIVELY (the L1's 64 B/clk/CU return path, not latency).  Built on
-// that, measured, NOT adopted (all parity-green): a depth-one software pipeline of the loads in two register sets
-// (11.7-12.0 ms: nothing to hide); the wavefront's pixel bounding box copied once per pose into an LDS tile by
-// global_load_lds, candidates then read pairwise from LDS and evaluated in packed fp32 (15.3-18.8 ms over four table / tile
-// splits at 4 wavefronts per SIMD: the per-pose bounding-box reductions, the drained tile load and the lost occupancy cost
-// far more than the L1 traffic they remove); rounds instead of the nested slow path (12.2 ms); the two candidates of a
-// trip through explicit packed fp32 (v_pk_fma/mul/add_f32 on component-wise pairs, one accumulator set per candidate:
-// 40 VALU instructions per trip instead of 47, yet 12.1-13.0 ms -- a v_pk_*_f32 costs two plain issues on gfx950, so the
+// Where the time goes (C2): the kernel is VALU-issue bound -- 8.4e9 wave-instructions of which the packed ones cost two
+// issues, ~80 % of the issue slots of an 11.8 ms launch (profiles/r02_trilinear_rocprof_summary.md), at 41 of 64 lanes.
+// A loads-ablated build (tools/ablate_gather.py) runs in 8.7 ms and one with half the loads in 10.6 ms, but that is NOT
+// the memory cost: with constant candidates the compiler hoists their arithmetic out of the trip.  The honest test of the
+// memory hypothesis was a variant that takes the sample positions from the lattice constants and loads only the 4-byte
+// weights (one 8-byte load per trip instead of two 16-byte ones): 13.2 ms -- slower, for its extra per-row arithmetic.
+// Built, measured, NOT adopted (all parity-green): that lattice-position variant; a depth-one software pipeline of the
+// loads in two register sets (11.7-12.0 ms: nothing to hide); the wavefront's pixel bounding box copied once per pose
+// into an LDS tile by global_load_lds with the candidates read pairwise from LDS (15.3-18.8 ms over four table / tile
+// splits at 4 wavefronts per SIMD); rounds instead of the nested slow path (12.2 ms); the two candidates of a trip
+// through explicit packed fp32 (v_pk_fma/mul/add_f32 on component-wise pairs, one accumulator set per candidate: 40
+// VALU instructions per trip instead of 47, yet 12.1-13.0 ms -- a v_pk_*_f32 costs two plain issues on gfx950, so the
 // instruction count is not the time; the compiler's own pairing of the eight accumulations is as far as packing goes).
 // ---------------------------------------------------------------------------------------------
 #ifndef XVR_TAB_ROWS   // (both overridable for the tuning builds of tools/tune_gather.py)
