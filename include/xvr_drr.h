@@ -69,6 +69,10 @@ const char* xvr_drr_last_error(void);
 
 /* Bytes of device scratch the backward entry points can use (see `workspace` below). */
 size_t xvr_drr_backward_workspace_bytes(int B, int n, int D0, int D1, int D2);
+/* The same for xvr_drr_siddon_backward under `spec`: a NON-exact index map (norm_dims_offset != 0, align_corners) gathers
+ * per plane cell into eight sums first and needs 32 bytes per voxel more; with only the smaller size such a spec falls
+ * back to the atomic scatter. */
+size_t xvr_drr_siddon_backward_workspace_bytes(int B, int n, int D0, int D1, int D2, const xvr_drr_spec* spec);
 
 /*
  * Trilinear ray-marching forward.  Replaces Trilinear.forward(volume, source, target, img, mask=...).

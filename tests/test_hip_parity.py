@@ -288,11 +288,15 @@ def test_masked_voxel_gather_equals_atomic_scatter_and_oracle(kw, uniform):
     _close(grads[0], v.grad, GRAD_TOL, "gather vs oracle")
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(voxel_shift=0.0), dict(norm_dims_offset=1)], ids=_id)
+@pytest.mark.parametrize("kw", [dict(), dict(voxel_shift=0.0), dict(norm_dims_offset=1), dict(norm_dims_offset=-1),
+                                dict(voxel_shift=0.0, norm_dims_offset=1), dict(align_corners=True, norm_dims_offset=1),
+                                dict(align_corners=True)], ids=_id)
 @pytest.mark.parametrize("hw", [(24, 24), (17, 33), (2, 2)])
 def test_siddon_voxel_gather_equals_atomic_scatter_and_oracle(kw, hw):
-    """Same for Siddon: d out / d V[v] = L x (ray length inside v's box).  norm_dims_offset=1 is not the
-    exact-geometry index map, so the library must keep the scatter for it (and still be right)."""
+    """Same for Siddon: d out / d V[v] = L x (ray length inside v's box).  A non-exact index map (norm_dims_offset != 0,
+    align_corners: the variants SURVEY.md Appendix A recalls for upstream) credits a segment to the voxel its MIDPOINT
+    rounds to: gathered per plane cell into eight sums (k_siddon_gather_cells), then folded onto the voxels -- against the
+    atomic scatter, which walks the rays with the same midpoint arithmetic."""
     from xvr_amd import renderers
     from xvr_amd.spec import RenderSpec
 

@@ -90,6 +90,7 @@ EXPORTS = {
     "xvr_drr_abi_version": ([], ctypes.c_int),
     "xvr_drr_last_error": ([], ctypes.c_char_p),
     "xvr_drr_backward_workspace_bytes": ([_I, _I, _I, _I, _I], ctypes.c_size_t),
+    "xvr_drr_siddon_backward_workspace_bytes": ([_I, _I, _I, _I, _I, ctypes.POINTER(CSpec)], ctypes.c_size_t),
     "xvr_drr_trilinear_forward": (_FWD, ctypes.c_int),
     "xvr_drr_trilinear_backward": (_BWD, ctypes.c_int),
     "xvr_drr_siddon_forward": (_FWD, ctypes.c_int),

@@ -102,6 +102,7 @@ __global__ __launch_bounds__(WG) void k_gather_prep(GatherArgs G) {
             G.q[(size_t)b * G.n + r] = make_float4(1.f / ddx, 1.f / ddy, 1.f / ddz,
                                                    G.gout[(size_t)b * G.n + r] * G.raylen[(size_t)b * G.n + r]);
             G.q2[(size_t)b * G.n + r] = make_float2(lo, hi);
+            if (G.cells) G.q[(size_t)G.B * G.n + (size_t)b * G.n + r] = make_float4(ddx, ddy, ddz, 0.f);   // d itself, for the midpoints
         }
     }
 #pragma unroll
@@ -919,6 +920,117 @@ __global__ __launch_bounds__(WG) void k_siddon_gather_vol(GatherArgs G) {
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// Siddon voxel gradient for NON-exact index maps (norm_dims_offset = +-1, align_corners = True: the variants SURVEY.md
+// Appendix A recalls for upstream), round 2.  The voxel a segment is credited to is rint(a x_mid + b) of its MIDPOINT, which
+// inside plane cell c is c + olo or c + olo + 1 per axis (the map drifts by less than a voxel over the volume:
+// siddon_cell_offsets).  One lane owns one CELL and gathers, as k_siddon_gather_vol does for a voxel, the length of every
+// ray inside it -- but splits it over 8 sums by where the forward's own midpoint arithmetic sends the segment.  The sums go
+// to a [cell][8] scratch; k_siddon_cells_to_voxels then adds, for every voxel, the eight (cell, octant) entries that
+// name it.  No atomics, deterministic; before this the non-exact maps took the fp32-atomic scatter (151 ms per C3 batch).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void k_siddon_gather_cells(GatherArgs G) {
+    if (*G.flag > __float_as_uint(GATHER_DEV_TOL)) return;
+    int bx, by, bz;
+    brick_coords(blockIdx.x, G.D1, G.D2, G.bd, bx, by, bz);
+    const int tid = threadIdx.x;   // 256 lanes on 4 x 8 x 8 cells
+    const int vx = bx * 4 + (tid >> 6), vy = by * 8 + ((tid >> 3) & 7), vz = bz * 8 + (tid & 7);
+    const bool inb = vx < G.D0 && vy < G.D1 && vz < G.D2;
+    const float p0x = (float)vx + G.sp.plane0[0], p0y = (float)vy + G.sp.plane0[1], p0z = (float)vz + G.sp.plane0[2];
+    const float p1x = (float)(vx + 1) + G.sp.plane0[0], p1y = (float)(vy + 1) + G.sp.plane0[1],
+                p1z = (float)(vz + 1) + G.sp.plane0[2];
+    const float cx = p0x + 0.5f, cy = p0y + 0.5f, cz = p0z + 0.5f;
+    const float a0 = G.sp.a[0], a1 = G.sp.a[1], a2 = G.sp.a[2], b0 = G.sp.b[0], b1 = G.sp.b[1], b2 = G.sp.b[2];
+    // voxel index of the "1" octant along every axis
+    const float t1x = (float)(vx + G.olo[0] + 1), t1y = (float)(vy + G.olo[1] + 1), t1z = (float)(vz + G.olo[2] + 1);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int wd = 0; wd < G.words; ++wd) {
+        unsigned bits = G.cull[(size_t)blockIdx.x * G.words + wd];
+        while (bits) {
+            const int p = wd * 32 + __builtin_ctz(bits);
+            bits &= bits - 1;
+            const PoseLattice& P = G.poses[p];
+            const float s0 = P.s[0], s1 = P.s[1], s2 = P.s[2];
+            const float w0 = cx - s0, w1 = cy - s1, w2 = cz - s2;
+            const float av = P.nh[0] * w0 + P.nh[1] * w1 + P.nh[2] * w2;
+            const float da = 0.5f * P.dalpha;
+            const float amin = av - da, amax = av + da;
+            const float nj = P.gc[0] * w0 + P.gc[1] * w1 + P.gc[2] * w2, dnj = 0.5f * P.hwc;
+            const float ni = P.gr[0] * w0 + P.gr[1] * w1 + P.gr[2] * w2, dni = 0.5f * P.hwr;
+            int jlo = 0, jhi = -1, ilo = 0, ihi = -1;
+            if (inb && amin > 1e-6f && amax >= 0.f && amin <= 1.f) {
+                const float i0 = 1.f / amin, i1 = 1.f / amax;
+                const float ja = (nj - dnj) * i0, jb = (nj - dnj) * i1, jc = (nj + dnj) * i0, jd = (nj + dnj) * i1;
+                const float ia = (ni - dni) * i0, ib = (ni - dni) * i1, ic = (ni + dni) * i0, id = (ni + dni) * i1;
+                jlo = (int)ceilf(fmaxf(fminf(fminf(ja, jb), fminf(jc, jd)) + P.gc0 - GATHER_WIN_MARGIN, 0.f));
+                jhi = (int)floorf(fminf(fmaxf(fmaxf(ja, jb), fmaxf(jc, jd)) + P.gc0 + GATHER_WIN_MARGIN, (float)(G.W - 1)));
+                ilo = (int)ceilf(fmaxf(fminf(fminf(ia, ib), fminf(ic, id)) + P.gr0 - GATHER_WIN_MARGIN, 0.f));
+                ihi = (int)floorf(fminf(fmaxf(fmaxf(ia, ib), fmaxf(ic, id)) + P.gr0 + GATHER_WIN_MARGIN, (float)(G.H - 1)));
+            } else if (inb && amin <= 1e-6f && amax >= 0.f) {
+                jhi = G.W - 1;   // the cell reaches the source plane: no perspective bound -- visit every ray
+                ihi = G.H - 1;
+            }
+            const float lx = p0x - s0, ly = p0y - s1, lz = p0z - s2;
+            const float hx = p1x - s0, hy = p1y - s1, hz = p1z - s2;
+            const float4* __restrict__ q = G.q + (size_t)p * G.n;
+            const float4* __restrict__ qd = G.q + (size_t)G.B * G.n + (size_t)p * G.n;
+            const float2* __restrict__ q2 = G.q2 + (size_t)p * G.n;
+            for (int i = ilo; i <= ihi; ++i) {
+                for (int j = jlo; j <= jhi; ++j) {
+                    const size_t r = (size_t)i * G.W + j;
+                    const float4 t = q[r];
+                    const float2 ab = q2[r];
+                    const float x0 = lx * t.x, x1 = hx * t.x, y0 = ly * t.y, y1 = hy * t.y, z0 = lz * t.z, z1 = hz * t.z;
+                    float en = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+                    float ex = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+                    en = fmaxf(en, ab.x);
+                    ex = fminf(ex, ab.y);
+                    const float len = fmaxf(ex - en, 0.f) * t.w;
+                    if (len != 0.f) {
+                        // the forward's midpoint rule (k_siddon, EXACT = false), arithmetic and all
+                        const float4 dd = qd[r];
+                        const float mid = 0.5f * (en + ex);
+                        const bool ox = rintf(fmaf(a0, fmaf(mid, dd.x, s0), b0)) >= t1x;
+                        const bool oy = rintf(fmaf(a1, fmaf(mid, dd.y, s1), b1)) >= t1y;
+                        const bool oz = rintf(fmaf(a2, fmaf(mid, dd.z, s2), b2)) >= t1z;
+                        const float l1 = ox ? len : 0.f, l0 = len - l1;
+                        const float l01 = oy ? l0 : 0.f, l00 = l0 - l01, l11 = oy ? l1 : 0.f, l10 = l1 - l11;
+                        const float c001 = oz ? l00 : 0.f, c011 = oz ? l01 : 0.f, c101 = oz ? l10 : 0.f, c111 = oz ? l11 : 0.f;
+                        acc[0] += l00 - c001; acc[1] += c001;
+                        acc[2] += l01 - c011; acc[3] += c011;
+                        acc[4] += l10 - c101; acc[5] += c101;
+                        acc[6] += l11 - c111; acc[7] += c111;
+                    }
+                }
+            }
+        }
+    }
+    if (inb) {
+        float4* out = reinterpret_cast<float4*>(G.cells + (((size_t)vx * G.D1 + vy) * G.D2 + vz) * 8);
+        out[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        out[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+}
+
+// voxel v <- sum over the octants e = (ex, ey, ez) of cell (v - olo - e), entry e
+__global__ __launch_bounds__(WG) void k_siddon_cells_to_voxels(GatherArgs G) {
+    if (*G.flag > __float_as_uint(GATHER_DEV_TOL)) return;
+    const long long v = (long long)blockIdx.x * WG + threadIdx.x;
+    const long long nvox = (long long)G.D0 * G.D1 * G.D2;
+    if (v >= nvox) return;
+    const int z = (int)(v % G.D2), y = (int)((v / G.D2) % G.D1), x = (int)(v / ((long long)G.D1 * G.D2));
+    float tot = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int cxi = x - G.olo[0] - (e >> 2), cyi = y - G.olo[1] - ((e >> 1) & 1), czi = z - G.olo[2] - (e & 1);
+        if ((unsigned)cxi < (unsigned)G.D0 && (unsigned)cyi < (unsigned)G.D1 && (unsigned)czi < (unsigned)G.D2)
+            tot += G.cells[(((size_t)cxi * G.D1 + cyi) * G.D2 + czi) * 8 + e];
+    }
+    if (tot != 0.f) G.gvol[v] += tot;
+}
+
 // Same gather with a 2 x 2 x 2 voxel block per lane (one wavefront per 8^3 brick, as the trilinear gather):
 // the per-pose window and the candidate's loads are paid once for eight voxels, the three planes per axis give
 // nine crossing alphas per candidate (the forward's expression, plane by plane), from which every voxel's
@@ -1038,9 +1150,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 // (with skip_unless_flag_gt = the returned flag) right behind it.
 int xvr_detail::launch_gather(bool siddon, const float* source, const float* target, const float* raylen, const float* grad_out,
                   int B, int n, int gw, int D0, int D1, int D2, const xvr_drr_spec* sp, float* grad_volume,
-                  void* workspace, void* stream, unsigned** flag_out, const float* mask, int C) {
+                  void* workspace, void* stream, unsigned** flag_out, const float* mask, int C, const int* siddon_olo) {
     char* ws = static_cast<char*>(workspace);
     GatherArgs G = {};
+    if (siddon && siddon_olo) {   // non-exact index map: per-cell octant sums in the scratch behind the regular workspace
+        G.cells = reinterpret_cast<float*>(ws + align256(ws_bytes(B, n, D0, D1, D2)));
+        for (int k = 0; k < 3; ++k) G.olo[k] = siddon_olo[k];
+    }
     G.mask = siddon ? nullptr : mask;
     G.C = C;
     G.clip = (!siddon && sp->clip_to_volume) ? 1 : 0;
@@ -1065,7 +1181,7 @@ int xvr_detail::launch_gather(bool siddon, const float* source, const float* tar
     // both are exact and give identical sums)
     static const bool use_table = [] { const char* e = getenv("XVR_DRR_GATHER_TABLE"); return !(e && e[0] == '0'); }();
     static const bool siddon_v1 = [] { const char* e = getenv("XVR_DRR_SIDDON_GATHER_BLOCK"); return e && e[0] == '1'; }();
-    if (siddon && siddon_v1) { G.bd[0] = 4; G.bd[1] = 8; G.bd[2] = 8; }
+    if (siddon && (siddon_v1 || G.cells)) { G.bd[0] = 4; G.bd[1] = 8; G.bd[2] = 8; }
     else if (siddon) { G.bd[0] = G.bd[1] = G.bd[2] = 8; }
     else {
         if (G.clip || G.mask) G.V = 2;   // (the pixel-major kernel is written for 2x2x2 blocks)
@@ -1083,7 +1199,12 @@ int xvr_detail::launch_gather(bool siddon, const float* source, const float* tar
     if (bricks >= (1LL << 31)) return fail(XVR_DRR_E_UNSUPPORTED, "grid too large");
     hipLaunchKernelGGL(k_gather_cull, dim3((unsigned)((bricks + WG / 32 - 1) / (WG / 32))), dim3(WG), 0,
                        (hipStream_t)stream, G, (int)bricks);
-    if (siddon && siddon_v1) hipLaunchKernelGGL(k_siddon_gather_vol, dim3((unsigned)bricks), dim3(WG), 0, (hipStream_t)stream, G);
+    if (siddon && G.cells) {
+        hipLaunchKernelGGL(k_siddon_gather_cells, dim3((unsigned)bricks), dim3(WG), 0, (hipStream_t)stream, G);
+        const long long nvox = (long long)D0 * D1 * D2;
+        hipLaunchKernelGGL(k_siddon_cells_to_voxels, dim3((unsigned)((nvox + WG - 1) / WG)), dim3(WG), 0, (hipStream_t)stream, G);
+    }
+    else if (siddon && siddon_v1) hipLaunchKernelGGL(k_siddon_gather_vol, dim3((unsigned)bricks), dim3(WG), 0, (hipStream_t)stream, G);
     else if (siddon) hipLaunchKernelGGL(k_siddon_gather_vol2, dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
     else if (G.clip && G.mask) hipLaunchKernelGGL((k_trilinear_gather_px<true, true>), dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
     else if (G.clip) hipLaunchKernelGGL((k_trilinear_gather_px<true, false>), dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
@@ -1112,6 +1233,14 @@ int xvr_drr_debug_gather_stats(unsigned long long* out8, int reset) {
 size_t xvr_drr_backward_workspace_bytes(int B, int n, int D0, int D1, int D2) {
     if (B <= 0 || n <= 0 || D0 <= 0 || D1 <= 0 || D2 <= 0) return 0;
     return ws_bytes(B, n, D0, D1, D2);
+}
+
+size_t xvr_drr_siddon_backward_workspace_bytes(int B, int n, int D0, int D1, int D2, const xvr_drr_spec* sp) {
+    if (B <= 0 || n <= 0 || D0 <= 0 || D1 <= 0 || D2 <= 0 || !sp) return 0;
+    int olo[3];
+    const size_t base = ws_bytes(B, n, D0, D1, D2);
+    if (siddon_exact_geometry(sp) || !siddon_cell_offsets(sp, D0, D1, D2, olo)) return base;
+    return align256(base) + siddon_cells_bytes(D0, D1, D2);
 }
 
 }  // extern "C"

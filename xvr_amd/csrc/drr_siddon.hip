@@ -310,21 +310,26 @@ int xvr_drr_siddon_backward(const float* volume, const float* mask, int D0, int 
     const size_t lds = mask ? (size_t)C * WG * sizeof(float) : 0;
     // the gather needs the exact-geometry index map (voxel credited = voxel whose box holds the segment)
     const bool exact_geom = siddon_exact_geometry(sp);
-    if (gvol && !mask && exact_geom && gather_usable(sp, n, workspace, workspace_bytes, B, D0, D1, D2)) {
+    // (a non-exact index map gathers per plane cell into octant sums: needs the larger workspace of
+    //  xvr_drr_siddon_backward_workspace_bytes and a map that drifts by less than a voxel)
+    int olo[3] = {0, 0, 0};
+    const bool cells = !exact_geom && siddon_cell_offsets(sp, D0, D1, D2, olo) &&
+                       workspace_bytes >= align256(ws_bytes(B, n, D0, D1, D2)) + siddon_cells_bytes(D0, D1, D2);
+    if (gvol && !mask && (exact_geom || cells) && gather_usable(sp, n, workspace, workspace_bytes, B, D0, D1, D2)) {
         unsigned* flag = nullptr;
         rc = launch_gather(true, source, target, raylen, grad_out, B, n, sp->ray_grid_w, D0, D1, D2, sp, grad_volume,
-                           workspace, stream, &flag);
+                           workspace, stream, &flag, nullptr, 1, exact_geom ? nullptr : olo);
         if (rc) return rc;
-        if (gpose) {
-            RenderArgs Ap = A;
-            Ap.gvol = nullptr;
-            rc = launch(k_siddon<2, false, true, false, true>, Ap, 0, stream);
-            if (rc) return rc;
-        }
-        RenderArgs Av = A;
+        RenderArgs Ap = A, Av = A;
+        Ap.gvol = nullptr;
         Av.gsrc = nullptr; Av.gtgt = nullptr; Av.glen = nullptr;
         Av.skip_unless_flag_gt = flag;
-        return launch(k_siddon<2, false, false, true, true>, Av, 0, stream);
+        if (exact_geom) {
+            if (gpose) { rc = launch(k_siddon<2, false, true, false, true>, Ap, 0, stream); if (rc) return rc; }
+            return launch(k_siddon<2, false, false, true, true>, Av, 0, stream);
+        }
+        if (gpose) { rc = launch(k_siddon<2, false, true, false, false>, Ap, 0, stream); if (rc) return rc; }
+        return launch(k_siddon<2, false, false, true, false>, Av, 0, stream);
     }
 #define SID_BWD2(M, E)                                                                  \
     (gpose ? (gvol ? launch(k_siddon<2, M, true, true, E>, A, lds, stream)              \

@@ -87,10 +87,12 @@ VOXEL_GATHER = True
 _WORKSPACES = {}
 
 
-def _workspace(lib, B, n, shape, device):
+def _workspace(lib, B, n, shape, device, cspec=None):
     if not VOXEL_GATHER:
         return None, 0
-    nbytes = lib.xvr_drr_backward_workspace_bytes(B, n, *shape)
+    # (siddon under a non-exact index map: room for the per-cell octant sums as well)
+    nbytes = (lib.xvr_drr_siddon_backward_workspace_bytes(B, n, *shape, ctypes.byref(cspec)) if cspec is not None
+              else lib.xvr_drr_backward_workspace_bytes(B, n, *shape))
     key = (device, torch.cuda.current_stream(device).cuda_stream)   # one scratch per stream: concurrent backwards
     ws = _WORKSPACES.get(key)                                        # on two streams must not share it
     if ws is None or ws.numel() * 4 < nbytes:
@@ -220,7 +222,7 @@ class _Render(torch.autograd.Function):
             cs = make_cspec((D0, D1, D2), spec, ctx.ray_grid_w)
             fn = lib.xvr_drr_trilinear_backward if spec.renderer == "trilinear" else lib.xvr_drr_siddon_backward
             pose_here = need_pose and not from_jac
-            ws, ws_bytes = (_workspace(lib, B, n, (D0, D1, D2), dev) if need_vol else (None, 0))
+            ws, ws_bytes = (_workspace(lib, B, n, (D0, D1, D2), dev, cs if spec.renderer == "siddon" else None) if need_vol else (None, 0))
             tag = ("pose" if pose_here else "") + ("+vol" if need_vol else "")
             if msk_c is not None and uniform and not pose_here:
                 # every sample lands in exactly one channel, so a gradient that is the same for all channels (the backward
