@@ -1186,6 +1186,70 @@ def test_fuzz_random_configurations_against_the_oracle(seed):
         _close(h, r, tol, f"{name} [{what}]")
 
 
+@pytest.mark.parametrize("seed", list(range(80)))
+def test_fuzz_voxel_gather_equals_atomic_scatter(seed):
+    """Randomised: every voxel-gradient gather (table, pixel-major under clip / masks, Siddon blocks, Siddon cells for
+    non-exact index maps) against the ray-driven atomic scatter -- two HIP paths that share only the ray set-up -- over
+    random shapes, spacings, detectors, poses (incl. sources inside the volume) and RenderSpec knobs."""
+    import numpy as np
+
+    from xvr_amd import renderers
+    from xvr_amd.renderers import render
+    from xvr_amd.spec import RenderSpec
+
+    rng = np.random.default_rng(7000 + seed)
+    shape = tuple(int(x) for x in rng.integers(6, 30, size=3))
+    spacing = tuple(float(x) for x in rng.uniform(0.6, 2.5, size=3))
+    H, W = int(rng.integers(2, 40)), int(rng.integers(2, 40))
+    renderer = "trilinear" if rng.random() < 0.55 else "siddon"
+    kw = dict(renderer=renderer, voxel_shift=float(rng.choice([0.0, 0.5])), align_corners=bool(rng.random() < 0.25))
+    if renderer == "trilinear":
+        kw.update(n_points=int(rng.integers(1, 120)), norm_dims_offset=int(rng.choice([0, 0, -1])),
+                  step_mode="n_points", clip_to_volume=bool(rng.random() < 0.35))
+        if rng.random() < 0.3:
+            lo = float(rng.uniform(0.0, 0.4))
+            kw.update(near=lo, far=float(rng.uniform(lo + 0.2, 1.0)))
+    else:
+        kw.update(norm_dims_offset=int(rng.choice([0, 1, 1, -1])))
+    extent = max(s * p for s, p in zip(shape, spacing))
+    inside = rng.random() < 0.15
+    depth = float(rng.uniform(0.1, 0.4) * extent) if inside else float(rng.uniform(1.2, 4.0) * extent)
+    B = int(rng.integers(1, 40))       # up to two cull words
+    rot = tuple(tuple(float(a) for a in rng.uniform(-180, 180, size=3) * np.array([1.0, 0.4, 0.3])) for _ in range(B))
+    xyz = tuple((float(rng.uniform(-0.3, 0.3) * extent), depth, float(rng.uniform(-0.3, 0.3) * extent)) for _ in range(B))
+    case = make_case(shape=shape, height=H, width=W, sdd=float(rng.uniform(1.5, 3.0) * depth), delx=float(rng.uniform(0.5, 3.0)),
+                     n_labels=int(rng.integers(2, 6)), seed=seed, rot=rot, xyz=xyz, spacing=spacing)
+    spec = RenderSpec(**kw)
+    # (clip + mask is left out: the first / last sample then sits exactly on a volume face, where the label is a rounding tie)
+    masked = renderer == "trilinear" and bool(rng.random() < 0.35) and not kw.get("clip_to_volume")
+    mask = case["mask"].cuda() if masked else None
+    C = int(case["mask"].max().item()) + 1 if masked else 1
+    w = torch.rand(B, C, H * W, generator=torch.Generator().manual_seed(seed)).cuda()
+    grads = []
+    for flag in (True, False):
+        renderers.VOXEL_GATHER = flag
+        try:
+            vol, src, tgt, img = (case[k].cuda() for k in ("volume", "source", "target", "img"))
+            vol.requires_grad_(True)
+            (render(vol, src, tgt, img, spec, mask, ray_grid_w=W) * w).sum().backward()
+            grads.append(vol.grad)
+        finally:
+            renderers.VOXEL_GATHER = True
+    what = f"seed {seed}: {kw} shape {shape} det {H}x{W} B {B} masked {masked} inside {inside}"
+    assert torch.isfinite(grads[0]).all(), what
+    if renderer == "siddon" and kw["norm_dims_offset"]:
+        # (non-exact map: a segment whose midpoint sits within an ulp of a rounding boundary can go either way in the
+        #  two traversals and then moves its whole length between two neighbouring voxels.  Some of these maps are
+        #  degenerate in exactly that way -- align_corners with dims = shape - 1 and voxel_shift = 0 is index = rint(x)
+        #  over planes at the integers: the midpoint of every fully crossed cell sits ON the boundary -- so the bound is
+        #  on how many voxels differ and on the total, which no tie can change)
+        a, b = grads[0].double().cpu(), grads[1].double().cpu()
+        err = (a - b).abs() / b.abs().max().clamp_min(1e-12)
+        assert (err > 1e-4).double().mean().item() <= 1e-2 and abs(a.sum().item() - b.sum().item()) <= 1e-4 * b.abs().sum().item(), what
+    else:
+        _close(grads[0], grads[1], 1e-4, f"gather vs scatter [{what}]")
+
+
 @pytest.mark.parametrize("seed", list(range(30)))
 def test_fuzz_drr_module_end_to_end_against_the_oracle(seed):
     """Randomised DRR modules (orientation, x-axis reversal, principal-point offsets, non-square pixels and detectors,
