@@ -98,6 +98,7 @@ def main():
     hist_rows = np.zeros(16, int)
     hist_visit_rows = np.zeros(64, int)
     tile_sizes = []
+    zero_wave = zero_lane = 0
     lane_trips_by_pose, lane_rows_by_pose, keep_by_pose = [], [], []
     for p, L in enumerate(P):
         w = xv - L["s"]
@@ -211,6 +212,7 @@ def main():
         tot["lane_trip_max"] += int(lane_total_trips.max(axis=1).sum())   # everything flattened per lane
         hist_steps += np.bincount(np.minimum(nst[nst > 0], 7), minlength=8)
         lane_trips_by_pose.append(lane_total_trips)
+        zero_wave += int(((lane_cands.sum(axis=1) == 0) & visited).sum()); zero_lane += int(((lane_cands == 0) & (nst > 0)).sum())
         ok = bb[1] >= 0
         tile_sizes.extend(((bb[1] - bb[0] + 1) * (bb[3] - bb[2] + 1))[ok].tolist())
         lane_rows_by_pose.append(lane_nonempty_rows)
@@ -227,6 +229,7 @@ def main():
     print(f"per wave-pose: steps {tot['w_steps'] / wp:.2f}, row iterations {tot['w_rows'] / wp:.2f}, inner trips {tot['w_trips'] / wp:.2f} "
           f"(ideal, all lanes busy: {tot['cands'] / 2 / 64 / wp:.2f}; lanes' own trips, mean {tot['lane_trips'] / 64 / wp:.2f})")
     print(f"  flattened (k,row) per lane: row iterations {tot['flat_rows'] / wp:.2f}; everything flattened per lane: trips {tot['lane_trip_max'] / wp:.2f}")
+    print(f"wave-poses the cull lets through with no candidate at all: {zero_wave / wp:.3f}; (lane, pose) visits with no candidate: {zero_lane / tot['visits']:.3f}")
     ts = np.array(tile_sizes)
     print("pixel bounding box of a wavefront's candidates per pose (elements of 16 B): mean %.0f, median %.0f, 90 %% %.0f, 99 %% %.0f, max %d; fit in 256 / 320 / 384 / 448 / 512: %s" % (
         ts.mean(), np.median(ts), np.percentile(ts, 90), np.percentile(ts, 99), ts.max(), [round(float((ts <= c).mean()), 3) for c in (256, 320, 384, 448, 512)]))

@@ -184,8 +184,11 @@ __device__ __forceinline__ void tri_finish(const RenderArgs& A, const Ray& R, co
 // more resident wavefronts only thrash the L1/L2 -- the variant without the jacobian needs 64 VGPRs, ran at
 // 8 wavefronts per SIMD and took 8.2 ms where the (heavier) jacobian variant at 6 took 7.0; capped, both take
 // ~7.0 ms (measured flat from 3 to 6, worse at 2 and at 8).
+#ifndef XVR_FWD_WAVES   // (overridable for tuning builds)
+#define XVR_FWD_WAVES 4
+#endif
 template <bool JAC, int MASK, bool CLIP, bool YP = false>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, 4))) void k_trilinear_fwd(RenderArgs A) {
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, XVR_FWD_WAVES))) void k_trilinear_fwd(RenderArgs A) {
     extern __shared__ float lds[];  // MASK: per-lane channel accumulators [C][WG]
     int b, r;
     const bool valid = map_ray(A, b, r, threadIdx.x);
