@@ -142,10 +142,14 @@ def test_ypair_volume_layout_is_bit_identical(kw, shape, monkeypatch):
         for t in (src, tgt, img):
             t.requires_grad_(True)
         renderers.PROFILER = []
-        out = render(vol, src, tgt, img, spec, ray_grid_w=128)
+        with torch.no_grad():
+            first = render(vol, src, tgt, img, spec, ray_grid_w=128)     # first sight of this volume: natural layout
+        assert "pack_ypairs" not in [e[0] for e in renderers.PROFILER]
+        out = render(vol, src, tgt, img, spec, ray_grid_w=128)           # rendered again unchanged: the copy is built and used
         names = [e[0] for e in renderers.PROFILER]
         renderers.PROFILER = None
         assert ("pack_ypairs" in names) == flag                       # the layout really was (not) used
+        assert torch.equal(first, out.detach())
         (out * w).sum().backward()
         res.append((out.detach(), src.grad, tgt.grad, img.grad))
     for a, b, name in zip(res[0], res[1], ("out", "grad_source", "grad_target", "grad_img")):
@@ -154,6 +158,19 @@ def test_ypair_volume_layout_is_bit_identical(kw, shape, monkeypatch):
         else:
             assert torch.equal(a, b), name
     _close(res[0][0], _oracle_render(case, spec), FWD_TOL, "forward vs oracle")
+    if not kw.get("clip_to_volume"):
+        # mask -> channels with the labels packed into the taps: the y-pair copy is then made of the label-carrying volume
+        masked = []
+        for flag in (True, False):
+            monkeypatch.setattr(renderers, "YPAIR_LAYOUT", flag)
+            vol, src, tgt, img, msk = (case[k].cuda() for k in ("volume", "source", "target", "img", "mask"))
+            with torch.no_grad():
+                render(vol, src, tgt, img, spec, msk, ray_grid_w=128)
+                renderers.PROFILER = []
+                masked.append(render(vol, src, tgt, img, spec, msk, ray_grid_w=128))
+                assert ("pack_ypairs" in [e[0] for e in renderers.PROFILER]) == flag
+                renderers.PROFILER = None
+        assert masked[0].shape[1] == 3 and torch.equal(masked[0], masked[1])
 
 
 @pytest.mark.parametrize("packed", [True, False], ids=["packed-labels", "mask-lookup"])

@@ -598,7 +598,7 @@ static int trilinear_forward_impl(const float* volume, const float* mask, int D0
     const bool packed = !mask && C > 1;   // labels in the low mantissa bits of `volume` (xvr_drr_pack_labels)
     if (packed && C > (1 << LABEL_BITS)) return fail(XVR_DRR_E_ARG, "packed labels hold at most 16 channels");
     if (sp->volume_layout != 0 && sp->volume_layout != 1) return fail(XVR_DRR_E_ARG, "unknown volume_layout");
-    if (sp->volume_layout == 1 && (mask || C != 1)) return fail(XVR_DRR_E_UNSUPPORTED, "the y-pair layout serves one-channel renders");
+    if (sp->volume_layout == 1 && mask) return fail(XVR_DRR_E_UNSUPPORTED, "the y-pair layout takes labels packed into the volume, not a mask volume");
     if (sp->volume_layout == 1 && (long long)D0 * (D1 + 1) * D2 * 2 >= (1LL << 31))
         return fail(XVR_DRR_E_UNSUPPORTED, "y-pair copy has >= 2^31 elements");
     RenderArgs A;
@@ -606,6 +606,12 @@ static int trilinear_forward_impl(const float* volume, const float* mask, int D0
     A.out = out; A.jac = jac; A.work = work;
     const bool clip = sp->clip_to_volume != 0;
     const size_t lds = C > 1 || mask ? (size_t)C * WG * sizeof(float) : 0;
+    if (packed && sp->volume_layout == 1) {   // the y-pair copy of the label-carrying volume
+        if (jac) return clip ? launch(k_trilinear_fwd<true, 2, true, true>, A, lds, stream)
+                             : launch(k_trilinear_fwd<true, 2, false, true>, A, lds, stream);
+        return clip ? launch(k_trilinear_fwd<false, 2, true, true>, A, lds, stream)
+                    : launch(k_trilinear_fwd<false, 2, false, true>, A, lds, stream);
+    }
     if (packed && jac) return clip ? launch(k_trilinear_fwd<true, 2, true>, A, lds, stream)
                                    : launch(k_trilinear_fwd<true, 2, false>, A, lds, stream);
     if (packed) return clip ? launch(k_trilinear_fwd<false, 2, true>, A, lds, stream)

@@ -130,30 +130,39 @@ def _packed_volume(lib, volume, mask):
 # One-channel trilinear renders of LARGE launches march a y-pair interleaved copy of the volume (xvr_drr_pack_ypairs): two
 # 16-byte gathers per sample instead of four 8-byte ones -- the march is bound by the texture-address rate per gather
 # instruction -- with identical output bits.  Costs twice the volume's memory (cached ON the volume tensor object, keyed by
-# its version counter; rebuilt in one 0.3 ms pass when the voxels change).  False (or XVR_DRR_YPAIRS=0): natural layout.
+# its version counter, built the second time a version is rendered: see _ypair_volume).  False (or XVR_DRR_YPAIRS=0):
+# natural layout.
 YPAIR_LAYOUT = _os.environ.get("XVR_DRR_YPAIRS", "1") != "0"
 YPAIR_MIN_WAVEFRONTS = 2048     # smaller launches take the sample-split kernels on the natural layout
 
 
 def _ypair_volume(lib, volume):
+    """The y-pair copy of ``volume``, or None the FIRST time a version of it is seen: the copy costs 0.76 ms at 512^3 and
+    saves ~0.5 ms per render, so it only pays for a volume that is rendered again unchanged (registration, pose-regressor
+    training on a fixed CT, the benchmark); a volume that changes between renders -- voxels being optimised, a fresh
+    HU -> density map every training step -- stays on the natural layout."""
     D0, D1, D2 = volume.shape
     key = volume._version
     hit = getattr(volume, "_xvr_ypairs", None)
-    if hit is not None and hit[0] == key:
+    if hit is not None and hit[0] == key and hit[1] is not None:
         return hit[1]
-    pairs = hit[1] if hit is not None else torch.empty(lib.xvr_drr_ypairs_bytes(D0, D1, D2) // 4, device=volume.device, dtype=torch.float32)
+    if hit is None or hit[0] != key:      # first sight of this version: remember it, keep any old buffer for reuse
+        try:
+            volume._xvr_ypairs = (key, None, hit[2] if hit is not None else None)
+        except AttributeError:   # pragma: no cover
+            pass
+        return None
+    pairs = hit[2] if hit[2] is not None else torch.empty(lib.xvr_drr_ypairs_bytes(D0, D1, D2) // 4, device=volume.device, dtype=torch.float32)
     rc = _timed("pack_ypairs", lib.xvr_drr_pack_ypairs, _ptr(volume), D0, D1, D2, _ptr(pairs), _stream())
     _lib.check(rc, "xvr_drr_pack_ypairs")
-    try:
-        volume._xvr_ypairs = (key, pairs)
-    except AttributeError:   # pragma: no cover
-        pass
+    volume._xvr_ypairs = (key, pairs, pairs)
     return pairs
 
 
-def _use_ypairs(spec, volume, B, n, mask, C):
+def _use_ypairs(spec, volume, B, n):
+    """(one channel, or labels packed into the volume's mantissa bits -- never with a separate mask volume)"""
     D0, D1, D2 = volume.shape
-    return (YPAIR_LAYOUT and spec.renderer == "trilinear" and mask is None and C == 1 and B * ((n + 63) // 64) >= YPAIR_MIN_WAVEFRONTS
+    return (YPAIR_LAYOUT and spec.renderer == "trilinear" and B * ((n + 63) // 64) >= YPAIR_MIN_WAVEFRONTS
             and D0 * (D1 + 1) * D2 * 2 < 2 ** 31 and min(D0, D1, D2) >= 2)
 
 
@@ -171,16 +180,18 @@ class _Render(torch.autograd.Function):
         tgt_c = target.contiguous()
         len_c = img.reshape(B, n).contiguous()
         msk_c = mask.contiguous() if mask is not None else None
-        ypairs = _use_ypairs(spec, vol_c, B, n, msk_c, C)
-        cs = make_cspec((D0, D1, D2), spec, ray_grid_w, volume_layout=1 if ypairs else 0)
         need_pose = any(ctx.needs_input_grad[1:4])
         use_jac = need_pose  # with a mask: the jacobian of the channel sum (see backward)
         out = torch.empty(B, C, n, device=volume.device, dtype=torch.float32)
         jac = torch.empty(B, n, _lib.JAC_STRIDE, device=volume.device, dtype=torch.float32) if use_jac else None
         fn = lib.xvr_drr_trilinear_forward if spec.renderer == "trilinear" else lib.xvr_drr_siddon_forward
-        vol_f, msk_f = (_ypair_volume(lib, vol_c) if ypairs else vol_c), msk_c
+        vol_f, msk_f = vol_c, msk_c
         if msk_c is not None and PACK_LABELS and 2 <= C <= 16 and vol_c.data_ptr() % 16 == 0 and msk_c.data_ptr() % 16 == 0:
             vol_f, msk_f = _packed_volume(lib, vol_c, msk_c), None     # labels ride in the taps
+        pairs = _ypair_volume(lib, vol_f) if msk_f is None and _use_ypairs(spec, vol_c, B, n) else None
+        if pairs is not None:
+            vol_f = pairs                                              # (of the label-carrying copy when there is one)
+        cs = make_cspec((D0, D1, D2), spec, ray_grid_w, volume_layout=1 if pairs is not None else 0)
         rc = _timed(f"{spec.renderer}_forward" + ("+jac" if use_jac else ""), fn,
                     _ptr(vol_f), _ptr(msk_f), D0, D1, D2, C, _ptr(src_c), _ptr(tgt_c), _ptr(len_c), B, n,
                     ctypes.byref(cs), _ptr(out), _ptr(jac), _ptr(work), _stream())
@@ -250,13 +261,13 @@ class _RenderFromCamera(torch.autograd.Function):
         lib = _lib.load()
         cam_c, vol_c = cam.contiguous(), volume.contiguous()
         B, n = cam_c.shape[0], H * W
-        ypairs = _use_ypairs(spec, vol_c, B, n, None, 1)
-        cs = make_cspec(tuple(vol_c.shape), spec, W, volume_layout=1 if ypairs else 0)
+        pairs = _ypair_volume(lib, vol_c) if _use_ypairs(spec, vol_c, B, n) else None
+        cs = make_cspec(tuple(vol_c.shape), spec, W, volume_layout=1 if pairs is not None else 0)
         need = ctx.needs_input_grad[0]
         out = torch.empty(B, 1, n, device=cam.device, dtype=torch.float32)
         jac = torch.empty(B, n, _lib.JAC_STRIDE, device=cam.device, dtype=torch.float32) if need else None
         fn = lib.xvr_drr_trilinear_forward_camera if spec.renderer == "trilinear" else lib.xvr_drr_siddon_forward_camera
-        rc = _timed(f"{spec.renderer}_forward" + ("+jac" if need else ""), fn, _ptr(_ypair_volume(lib, vol_c) if ypairs else vol_c), None,
+        rc = _timed(f"{spec.renderer}_forward" + ("+jac" if need else ""), fn, _ptr(pairs if pairs is not None else vol_c), None,
                     *vol_c.shape, 1, _ptr(cam_c),
                     B, H, W, ctypes.byref(cs), _ptr(out), _ptr(jac), None, _stream())
         _lib.check(rc, f"xvr_drr_{spec.renderer}_forward_camera")
