@@ -68,6 +68,20 @@ int xvr_sim_ncc_forward_backward(const float* fixed, const float* fixed_sobel, c
  */
 int xvr_sim_gaussian_blur5(const float* in, float* out, float* scratch, int B, int H, int W, float sigma, int adjoint, void* stream);
 
+/*
+ * Equalize (/root/reference/src/xvr/utils/preprocess.py:34-66): the differentiable soft-histogram equalisation xvr's
+ * XrayTransforms applies between Standardize and Normalize when `equalize` is set -- forward and exact backward, per image,
+ * without the reference's [pixels x bins] weight matrix, sums in fixed order.
+ *   x, y, S, grad_y, grad_x  [B][n]   (x in [0, 1]: the standardised image; S = per-pixel weight sums the backward reuses)
+ *   n_bins in [2, 1024] (256), tau (0.01), eps (1e-10)
+ *   workspace  xvr_sim_equalize_workspace_bytes(B, n_bins); the backward needs it as the forward left it
+ */
+size_t xvr_sim_equalize_workspace_bytes(int B, int n_bins);
+int xvr_sim_equalize_forward(const float* x, int B, int n, int n_bins, float tau, float eps, float* y, float* S,
+                             void* workspace, size_t workspace_bytes, void* stream);
+int xvr_sim_equalize_backward(const float* x, const float* y, const float* S, const float* grad_y, int B, int n, int n_bins,
+                              float tau, float eps, float* grad_x, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

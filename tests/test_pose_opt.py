@@ -522,3 +522,33 @@ def test_device_loop_and_run_batch_take_every_similarity_configuration(kw):
         k = min(6, len(batch[n]["trajectory"]), len(single["trajectory"]))
         np.testing.assert_allclose(np.array(batch[n]["nccs"][:k]), np.array(single["nccs"][:k]), atol=3e-3)
         assert batch[n]["nccs"][-1] > batch[n]["nccs"][0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 40, 36), (3, 64, 64), (2, 17, 129)])
+def test_equalize_hip_matches_the_torch_formulation_value_and_gradient(shape, monkeypatch):
+    """xvr_sim_equalize_forward / _backward against the line-by-line torch restatement of the reference's Equalize
+    (/root/reference/src/xvr/utils/preprocess.py:34-66, [pixels x bins] weight matrix and autograd), incl. an image with
+    large flat regions (many pixels on the same value, as a standardised DRR has)."""
+    from xvr_amd import metrics, renderers
+
+    B, H, W = shape
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(B, 1, H, W, generator=g)
+    x[:, :, : H // 3] = 0.0                      # background at exactly 0
+    x[:, :, -2:] = 1.0                           # and a saturated border
+    w = torch.rand(B, 1, H, W, generator=g)
+    eq = metrics.Equalize().cuda()
+    xh = x.cuda().requires_grad_(True)
+    renderers.PROFILER = []
+    out = eq(xh)
+    assert "equalize_forward" in {e[0] for e in renderers.PROFILER}
+    renderers.PROFILER = None
+    (out * w.cuda()).sum().backward()
+    monkeypatch.setattr(metrics.Equalize, "FUSED", False)
+    xr = x.cuda().double().requires_grad_(True)      # the reference formulation in float64 on the same device
+    ref = eq(xr)
+    (ref * w.cuda().double()).sum().backward()
+    assert torch.allclose(out.double(), ref.detach(), atol=2e-5), (out.double() - ref).abs().max()
+    err = (xh.grad.double() - xr.grad).abs().max() / xr.grad.abs().max()
+    assert err <= 2e-3, err

@@ -61,6 +61,13 @@ for H, delx in ((256, 0.1360 * 8), (512, 0.1360 * 4)):
         n_it = len(out["nccs"]) - 1
         steady = sum(out["times"][-50:]) / 50 * 1e3
         print(f"  Registrar.run use_graph={use_graph}: {n_it} iterations, {steady:.2f} ms / iteration (last 50), ncc {out['nccs'][0]:.4f} -> {out['nccs'][-1]:.4f}")
+    for kw in (dict(sigma=1.0), dict(equalize=True), dict(sigma=1.0, equalize=True)):   # configurations beyond the single fused call
+        Rk = Registrar(drr, scales="1", n_itrs="120", max_n_plateaus=100, **kw)
+        torch.cuda.synchronize()
+        out = Rk.run(gt, init)
+        torch.cuda.synchronize()
+        steady = sum(out["times"][-50:]) / 50 * 1e3
+        print(f"  Registrar.run {kw}: {len(out['nccs']) - 1} iterations, {steady:.2f} ms / iteration (last 50), ncc {out['nccs'][0]:.4f} -> {out['nccs'][-1]:.4f}")
     g = torch.Generator().manual_seed(0)
     B = 8
     inits = convert(rot.cpu() + (torch.rand(B, 3, generator=g) - 0.5) * 0.06, xyz.cpu() + (torch.rand(B, 3, generator=g) - 0.5) * 10.0,

@@ -485,9 +485,183 @@ __global__ __launch_bounds__(TB) void k_blur5(const float* __restrict__ in, floa
     out[e] = acc;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Equalize: differentiable (soft-histogram) histogram equalisation of images in [0, 1]
+// (/root/reference/src/xvr/utils/preprocess.py:34-66), forward and backward, per image, deterministic (fixed-order sums).
+//   w_ib = exp(-(x_i - beta_b)^2 / (2 tau^2)), beta_b = b / (K - 1);   h_b = sum_i w_ib;   H = h / (sum h + eps);
+//   cdf = cumsum(H);   cn_b = (cdf_b - cdf_0) / (1 - cdf_0 + eps);   y_i = sum_b w_ib cn_b / (sum_b w_ib + eps)
+// The reference materialises the [pixels x bins] weight matrix (64 MB per 256^2 image, several times over under autograd);
+// here every weight is recomputed where it is needed.  Weights beyond |x - beta| > EQ_CUT tau underflow to less than 1e-19
+// of the row's largest and are skipped (they cannot change an fp32 sum).
+// ---------------------------------------------------------------------------------------------
+constexpr int EQ_MAX_BINS = 1024;
+constexpr float EQ_CUT = 9.5f;   // exp(-9.5^2 / 2) = 2.5e-20
+
+struct EqState {   // per image, in the workspace
+    float T, D, dh_scale_pad0, pad1;
+};
+
+// h[b] (or, GRAD, dcn[b] = sum_i g_i w_ib / S_i): one block per (bin, image), pixels in a fixed order
+template <bool GRAD>
+__global__ __launch_bounds__(TB) void k_eq_bins(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ S,
+                                                int n, int K, float inv2tau2, float cut, float* __restrict__ out) {
+    const int b = blockIdx.x, img = blockIdx.y;
+    const float beta = (float)b / (float)(K - 1);
+    const float* xi = x + (size_t)img * n;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += TB) {
+        const float d = xi[i] - beta;
+        if (fabsf(d) <= cut) {
+            const float w = __expf(-d * d * inv2tau2);
+            acc += GRAD ? g[(size_t)img * n + i] * w / S[(size_t)img * n + i] : w;
+        }
+    }
+    __shared__ float red[TB];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = TB / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[(size_t)img * K + b] = red[0];
+}
+
+// histogram -> normalised cdf (forward) ; d cn -> d h (backward).  One block per image, serial scans by thread 0 (K <= 1024)
+__global__ void k_eq_cdf(const float* __restrict__ h, int K, float eps, float* __restrict__ cn, float* __restrict__ cdf, EqState* st) {
+    const int img = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    const float* hb = h + (size_t)img * K;
+    float T = 0.f;
+    for (int b = 0; b < K; ++b) T += hb[b];
+    float run = 0.f, c0 = 0.f;
+    for (int b = 0; b < K; ++b) {
+        run += hb[b] / (T + eps);
+        if (b == 0) c0 = run;
+        cdf[(size_t)img * K + b] = run;
+    }
+    const float D = 1.f - c0 + eps;
+    for (int b = 0; b < K; ++b) cn[(size_t)img * K + b] = (cdf[(size_t)img * K + b] - c0) / D;
+    st[img].T = T;
+    st[img].D = D;
+}
+
+__global__ void k_eq_cdf_bwd(const float* __restrict__ h, const float* __restrict__ cdf, const float* __restrict__ dcn, int K, float eps,
+                             const EqState* st, float* __restrict__ dh) {
+    const int img = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    const float T = st[img].T, D = st[img].D;
+    const float* hb = h + (size_t)img * K;
+    const float* cb = cdf + (size_t)img * K;
+    const float* gb = dcn + (size_t)img * K;
+    float* out = dh + (size_t)img * K;
+    // d cdf_b = d cn_b / D, and through cdf_0's second role: d cdf_0 += sum_b d cn_b (cdf_b - 1 - eps) / D^2
+    float extra = 0.f;
+    for (int b = 0; b < K; ++b) extra += gb[b] * (cb[b] - 1.f - eps) / (D * D);
+    // d H_b = sum_{b' >= b} d cdf_b'   (reverse cumulative sum);  d h_b = d H_b / (T + eps) - (sum_b' d H_b' h_b') / (T + eps)^2
+    float run = 0.f, dot = 0.f;
+    for (int b = K - 1; b >= 0; --b) {
+        run += gb[b] / D + (b == 0 ? extra : 0.f);
+        out[b] = run;
+        dot += run * hb[b];
+    }
+    const float it = 1.f / (T + eps);
+    for (int b = 0; b < K; ++b) out[b] = out[b] * it - dot * it * it;
+}
+
+// per pixel: forward y_i (and S_i kept for the backward); backward g_x,i
+template <bool BWD>
+__global__ __launch_bounds__(TB) void k_eq_pixels(const float* __restrict__ x, int n, int K, float tau, float eps, float cut,
+                                                  const float* __restrict__ cn, float* __restrict__ y, float* __restrict__ S,
+                                                  const float* __restrict__ g, const float* __restrict__ dh, float* __restrict__ gx) {
+    __shared__ float c_s[EQ_MAX_BINS], d_s[EQ_MAX_BINS];
+    const int img = blockIdx.y;
+    for (int b = threadIdx.x; b < K; b += TB) {
+        c_s[b] = cn[(size_t)img * K + b];
+        if (BWD) d_s[b] = dh[(size_t)img * K + b];
+    }
+    __syncthreads();
+    const int i = blockIdx.x * TB + threadIdx.x;
+    if (i >= n) return;
+    const size_t e = (size_t)img * n + i;
+    const float xi = x[e];
+    const float inv2 = 1.f / (2.f * tau * tau), invt2 = 1.f / (tau * tau), fk = (float)(K - 1);
+    const int blo = max((int)ceilf((xi - cut) * fk), 0), bhi = min((int)floorf((xi + cut) * fk), K - 1);
+    if (!BWD) {
+        float Ssum = 0.f, N = 0.f;
+        for (int b = blo; b <= bhi; ++b) {
+            const float d = xi - (float)b / fk;
+            const float w = __expf(-d * d * inv2);
+            Ssum += w;
+            N = fmaf(w, c_s[b], N);
+        }
+        Ssum += eps;
+        y[e] = N / Ssum;
+        S[e] = Ssum;
+    } else {
+        const float Si = S[e], yi = y[e], gi = g[e];
+        float acc = 0.f;
+        for (int b = blo; b <= bhi; ++b) {
+            const float d = xi - (float)b / fk;
+            const float w = __expf(-d * d * inv2);
+            // d w / d x = -w d / tau^2;  direct term g_i (cn_b - y_i) / S_i, histogram term d h_b
+            acc = fmaf(-w * d * invt2, fmaf(gi, (c_s[b] - yi) / Si, d_s[b]), acc);
+        }
+        gx[e] = acc;
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+size_t xvr_sim_equalize_workspace_bytes(int B, int n_bins) {
+    if (B <= 0 || n_bins < 2 || n_bins > EQ_MAX_BINS) return 0;
+    return (size_t)B * ((size_t)n_bins * 5 * sizeof(float) + sizeof(EqState)) + 256;
+}
+
+// workspace layout: [h][cdf][cn][dcn][dh] (B x K floats each) [EqState x B]
+int xvr_sim_equalize_forward(const float* x, int B, int n, int n_bins, float tau, float eps, float* y, float* S, void* workspace,
+                             size_t workspace_bytes, void* stream_) {
+    if (!x || !y || !S || !workspace) return sim_fail(XVR_DRR_E_ARG, "null pointer argument");
+    if (B <= 0 || n <= 0 || n_bins < 2 || n_bins > EQ_MAX_BINS || !(tau > 0.f)) return sim_fail(XVR_DRR_E_ARG, "bad size / bins / tau");
+    if (workspace_bytes < xvr_sim_equalize_workspace_bytes(B, n_bins)) return sim_fail(XVR_DRR_E_ARG, "workspace too small");
+    hipStream_t stream = (hipStream_t)stream_;
+    float* h = static_cast<float*>(workspace);
+    float* cdf = h + (size_t)B * n_bins;
+    float* cn = cdf + (size_t)B * n_bins;
+    EqState* st = reinterpret_cast<EqState*>(h + (size_t)B * n_bins * 5);
+    const float cut = EQ_CUT * tau;
+    hipLaunchKernelGGL(k_eq_bins<false>, dim3(n_bins, B), dim3(TB), 0, stream, x, (const float*)nullptr, (const float*)nullptr, n, n_bins,
+                       1.f / (2.f * tau * tau), cut, h);
+    hipLaunchKernelGGL(k_eq_cdf, dim3(B), dim3(64), 0, stream, (const float*)h, n_bins, eps, cn, cdf, st);
+    hipLaunchKernelGGL(k_eq_pixels<false>, dim3((n + TB - 1) / TB, B), dim3(TB), 0, stream, x, n, n_bins, tau, eps, cut, (const float*)cn, y, S,
+                       (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? XVR_DRR_OK : sim_fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
+}
+
+// needs the workspace exactly as the forward left it (h, cdf, cn, state), and the forward's y and S
+int xvr_sim_equalize_backward(const float* x, const float* y, const float* S, const float* grad_y, int B, int n, int n_bins, float tau,
+                              float eps, float* grad_x, void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!x || !y || !S || !grad_y || !grad_x || !workspace) return sim_fail(XVR_DRR_E_ARG, "null pointer argument");
+    if (B <= 0 || n <= 0 || n_bins < 2 || n_bins > EQ_MAX_BINS || !(tau > 0.f)) return sim_fail(XVR_DRR_E_ARG, "bad size / bins / tau");
+    if (workspace_bytes < xvr_sim_equalize_workspace_bytes(B, n_bins)) return sim_fail(XVR_DRR_E_ARG, "workspace too small");
+    hipStream_t stream = (hipStream_t)stream_;
+    float* h = static_cast<float*>(workspace);
+    float* cdf = h + (size_t)B * n_bins;
+    float* cn = cdf + (size_t)B * n_bins;
+    float* dcn = cn + (size_t)B * n_bins;
+    float* dh = dcn + (size_t)B * n_bins;
+    EqState* st = reinterpret_cast<EqState*>(h + (size_t)B * n_bins * 5);
+    const float cut = EQ_CUT * tau;
+    hipLaunchKernelGGL(k_eq_bins<true>, dim3(n_bins, B), dim3(TB), 0, stream, x, grad_y, S, n, n_bins, 1.f / (2.f * tau * tau), cut, dcn);
+    hipLaunchKernelGGL(k_eq_cdf_bwd, dim3(B), dim3(64), 0, stream, (const float*)h, (const float*)cdf, (const float*)dcn, n_bins, eps,
+                       (const EqState*)st, dh);
+    hipLaunchKernelGGL(k_eq_pixels<true>, dim3((n + TB - 1) / TB, B), dim3(TB), 0, stream, x, n, n_bins, tau, eps, cut, (const float*)cn,
+                       const_cast<float*>(y), const_cast<float*>(S), grad_y, (const float*)dh, grad_x);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? XVR_DRR_OK : sim_fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
+}
 
 int xvr_sim_gaussian_blur5(const float* in, float* out, float* scratch, int B, int H, int W, float sigma, int adjoint, void* stream_) {
     if (!in || !out || !scratch) return sim_fail(XVR_DRR_E_ARG, "null pointer argument");

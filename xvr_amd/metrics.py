@@ -169,7 +169,14 @@ class Equalize(torch.nn.Module):
         super().__init__()
         self.n_bins, self.tau, self.eps = n_bins, tau, eps
 
+    FUSED = True   # float32 CUDA images of one channel: HIP kernels (xvr_sim_equalize_*), no [pixels x bins] matrix
+
     def forward(self, x):
+        if self.FUSED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 1 and 2 <= self.n_bins <= 1024 \
+                and x.shape[0] > 0:
+            from .similarity import equalize_hip
+
+            return equalize_hip(x, self.n_bins, self.tau, self.eps)
         B, _, H, W = x.shape
         bins = torch.linspace(0, 1, self.n_bins, device=x.device, dtype=x.dtype)[None, None]
         out = []

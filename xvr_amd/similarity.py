@@ -161,6 +161,44 @@ class _Blur5(torch.autograd.Function):
         return out
 
 
+class _EqualizeHIP(torch.autograd.Function):
+    """xvr_sim_equalize_forward / _backward: the soft-histogram equalisation without the [pixels x bins] matrix."""
+
+    @staticmethod
+    def forward(ctx, x, n_bins, tau, eps):
+        lib = _lib.load()
+        xc = x.contiguous()
+        B = xc.shape[0]
+        n = xc.numel() // B
+        y, S = torch.empty_like(xc), torch.empty_like(xc)
+        nbytes = lib.xvr_sim_equalize_workspace_bytes(B, int(n_bins))
+        if nbytes == 0:
+            raise ValueError("Equalize (HIP): n_bins must be in [2, 1024]")
+        ws = torch.empty((nbytes + 3) // 4, device=x.device, dtype=torch.float32)
+        rc = _timed("equalize_forward", lib.xvr_sim_equalize_forward, _ptr(xc), B, n, int(n_bins), ctypes.c_float(tau), ctypes.c_float(eps),
+                    _ptr(y), _ptr(S), _ptr(ws), ws.numel() * 4, _stream())
+        _lib.check(rc, "xvr_sim_equalize_forward")
+        ctx.save_for_backward(xc, y, S, ws)
+        ctx.args = (B, n, int(n_bins), float(tau), float(eps))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        xc, y, S, ws = ctx.saved_tensors
+        B, n, K, tau, eps = ctx.args
+        gx = torch.empty_like(xc)
+        rc = _timed("equalize_backward", lib.xvr_sim_equalize_backward, _ptr(xc), _ptr(y), _ptr(S), _ptr(g.contiguous()), B, n, K,
+                    ctypes.c_float(tau), ctypes.c_float(eps), _ptr(gx), _ptr(ws), ws.numel() * 4, _stream())
+        _lib.check(rc, "xvr_sim_equalize_backward")
+        return gx, None, None, None
+
+
+def equalize_hip(x, n_bins: int = 256, tau: float = 0.01, eps: float = 1e-10):
+    """``Equalize`` of /root/reference/src/xvr/utils/preprocess.py:34-66 as HIP kernels (float32 CUDA [B,1,H,W] in [0, 1])."""
+    return _EqualizeHIP.apply(x, int(n_bins), float(tau), float(eps))
+
+
 def gaussian_blur5(x, sigma: float):
     """The pre-blur of ``GradientNormalizedCrossCorrelation2d(p, sigma > 0)`` as a HIP kernel pair (float32 CUDA, H, W >= 3)."""
     if not x.is_cuda or x.dtype != torch.float32:
