@@ -1,0 +1,40 @@
+"""A/B builds of the brick-local splat kernels: builds one diagnostic library per variant HERE (hipcc cross-compiles)
+and times the trilinear backward with each through bench.py ON the GPU box.
+    python tools/tune_splat.py build      # in the build container
+    python tools/tune_splat.py run        # on the GPU box (gpurun)"""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+
+# (name, defines, XVR_DRR_GATHER_SPLAT)
+VARIANTS = [
+    ("b16", ["XVR_S16_DEPTH=2"], "16"),
+    ("b16_noadds", ["XVR_SP_ABLATE_ADDS=1"], "16"),
+    ("b16_noloads", ["XVR_S16_ABLATE_LOADS=1"], "16"),
+    ("b16_neither", ["XVR_S16_ABLATE_LOADS=1", "XVR_SP_ABLATE_ADDS=1"], "16"),
+]
+
+
+def lib(name):
+    return ROOT / "xvr_amd" / "lib" / f"libxvr_drr_tune_{name}.so"
+
+
+if sys.argv[1:] == ["build"]:
+    from xvr_amd.build import build_diagnostic_library
+    for name, defs, _ in VARIANTS:
+        print(build_diagnostic_library(defs or ["XVR_TUNE_DEFAULT=1"], lib(name)))
+else:
+    for name, defs, mode in VARIANTS:
+        env = dict(os.environ, XVR_DRR_LIBRARY=str(lib(name)), XVR_DRR_GATHER_SPLAT=mode)
+        out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "6", "--warmup", "2", "--no-cpu-baseline"],
+                             env=env, capture_output=True, text=True)
+        try:
+            d = json.loads(out.stdout.strip().splitlines()[-1])
+            print(f"{name} {defs}: step {d['ms_per_step']:.2f} ms, voxel gradient {d['kernels']['trilinear_backward[vol]']['avg_ms']:.3f} ms", flush=True)
+        except Exception as e:  # noqa: BLE001
+            print(f"{name}: failed ({e}) {out.stderr[-300:]}", flush=True)

@@ -13,6 +13,11 @@ __device__ unsigned long long g_gather_stats[8];
 #define XVR_STAT(i, n) ((void)0)
 #define XVR_STAT_WAVE(i) ((void)0)
 #endif
+#ifdef XVR_S16_TRACE
+// Diagnostic build only (tools/splat_trace.py): per workgroup of k_trilinear_splat_b16 -- wall clock at start and end
+// (100 MHz constant clock), visits, samples.
+__device__ unsigned long long g_s16_trace[12 * 65536];
+#endif
 namespace {
 
 // =============================================================================================
@@ -52,7 +57,7 @@ __global__ __launch_bounds__(WG) void k_gather_prep(GatherArgs G) {
         er[i] = (T[(size_t)(G.H - 1) * G.W * 3 + i] - t00[i]) / (float)(G.H - 1);
     }
     const float pitch = fminf(sqrtf(dot3(ec, ec)), sqrtf(dot3(er, er)));
-    float dev = 0.f;
+    float dev = 0.f, cabs = 0.f;
     if (r < G.n) {
         const int i = r / G.W, j = r - i * G.W;
         const float tx = T[(size_t)r * 3], ty = T[(size_t)r * 3 + 1], tz = T[(size_t)r * 3 + 2];
@@ -70,6 +75,7 @@ __global__ __launch_bounds__(WG) void k_gather_prep(GatherArgs G) {
             // a * d: the gather forms a (s + alpha d) + b - v as fma(alpha, a d, a s + b - v) (a = 1 for the default index map)
             float4* row = G.q + (size_t)b * G.qn + (size_t)i * G.qs;
             row[j] = make_float4(G.sp.a[0] * ddx, G.sp.a[1] * ddy, G.sp.a[2] * ddz, c);
+            cabs = (c == c && fabsf(c) < INFINITY) ? fabsf(c) : 0.f;
             if (j == G.W - 1) row[G.W] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (G.clip) {
                 // the ray's own [alpha_min, alpha_max], computed exactly as ray_setup() does for the forward; the image is
@@ -104,6 +110,11 @@ __global__ __launch_bounds__(WG) void k_gather_prep(GatherArgs G) {
             G.q2[(size_t)b * G.n + r] = make_float2(lo, hi);
             if (G.cells) G.q[(size_t)G.B * G.n + (size_t)b * G.n + r] = make_float4(ddx, ddy, ddz, 0.f);   // d itself, for the midpoints
         }
+    }
+    if (G.cmax) {   // max |c| of the pose: the fixed-point scale of the brick-local splat
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cabs = fmaxf(cabs, __shfl_xor(cabs, o));
+        if ((threadIdx.x & 63) == 0 && cabs > 0.f) atomicMax(G.cmax + b, __float_as_uint(cabs));
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) dev = fmaxf(dev, __shfl_xor(dev, o));
@@ -164,6 +175,14 @@ __global__ __launch_bounds__(WG) void k_gather_prep(GatherArgs G) {
             const float eca = G.sp.a[i] * ec[i];
             P.rec[i] = fabsf(eca) < 1e-9f ? 1e9f : 1.f / eca;
             P.hsr[i] = HSv * fabsf(P.rec[i]);
+        }
+        {   // the sample lattice's three spacings in index space (the splat's bound on the samples that can touch one voxel)
+            float eca[3], cr[3], nha[3];
+            for (int i = 0; i < 3; ++i) { eca[i] = G.sp.a[i] * ec[i]; nha[i] = P.nh[i] / G.sp.a[i]; }
+            cross3(P.era, eca, cr);
+            P.ecl = sqrtf(dot3(eca, eca));
+            P.rperp = P.ecl > 0.f ? sqrtf(dot3(cr, cr)) / P.ecl : 0.f;
+            P.gn = sqrtf(dot3(nha, nha));
         }
         P.nh_norm = sqrtf(dot3(P.nh, P.nh));
         P.gc_norm = sqrtf(dot3(gc, gc));
@@ -706,6 +725,641 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(XVR_TAB_WAVE
 }
 
 // ---------------------------------------------------------------------------------------------
+// Brick-local splat (round 2): the same voxel gradient, SAMPLE-driven, with the sums of an 8^3-voxel brick held in LDS as
+// 32-bit fixed point.
+//
+// Why: the counters say the table gather above is limited twice over -- the vector ALUs are 64 % busy on work of which
+// 70 % is multiplications by a zero weight (a candidate of a 2x2x2 block has 2.4 non-zero weights of 8, and 41 of 64
+// lanes are live), and the L1 is 85-89 % busy because every lane's 16-byte candidate load is its own cache access (39
+// accesses per load instruction; tools/profile_mempipe.sh).  A sample-driven pass has neither problem: every sample is
+// evaluated once per brick whose support holds it (1.42 x the samples instead of 3.4 x), with all eight weights useful,
+// and four neighbouring lanes read four neighbouring pixels.  What it needs is an accumulate into shared memory, and
+// tools/microbench/lds_atomics.hip measured the one that works: ds_add_f32 retires 0.33 lanes per clock and CU (it is
+// serialised), ds_add_u32 11.8 (random words), 4.5 (four lanes per word).  So the sums are integers:
+//   * per (brick, pose) visit the wavefront enumerates, with the lattice arithmetic of the table kernel applied to the
+//     brick's whole support box, the runs (row, first pixel, count) of samples inside the box -- one row per lane, packed
+//     into an LDS list by ballot;
+//   * the scale is 2^30 / (T * max|c|), T = the number of samples in the list and max|c| the pose's largest weight
+//     (k_gather_prep), so no sum can overflow; a sample's eight products w * c * scale are rounded to nearest
+//     (v_cvt_rpi_i32_f32) and added with ds_add_u32 to a 10^3 array of cells, the brick and one cell around it (the
+//     outer cells are never read);
+//   * after the pose's samples the lanes read their eight voxels, convert, add them to fp32 registers and clear the cells.
+// Integer sums are exact and order-free: the result is deterministic, and differs from the table kernel's by the
+// rounding of the products, ~0.3 LSB per add with LSB = T max|c| / 2^30 (5e-7 max|c| at the benchmark geometry).
+// A pose whose upstream gradient holds a non-finite value poisons the voxels of the bricks it visits (NaN).
+// ---------------------------------------------------------------------------------------------
+#ifndef XVR_SP_BLOCKED     // (tuning switches of tools/tune_splat.py)
+#define XVR_SP_BLOCKED 0
+#endif
+#ifndef XVR_SP_QUARTERS
+#define XVR_SP_QUARTERS 1
+#endif
+#ifndef XVR_SP_ABLATE_ADDS
+#define XVR_SP_ABLATE_ADDS 0
+#endif
+constexpr int SP_DIM = 10, SP_CELLS = SP_DIM * SP_DIM * SP_DIM, SP_TAB = 256, SP_RUN_MAX = 252;
+
+// a value every lane holds alike, moved to a scalar register (gfx950 has no scalar float ALU: uniform float arithmetic is
+// done by the vector ALU and would otherwise sit in a vector register for as long as it lives)
+__device__ __forceinline__ float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
+__device__ __forceinline__ int cvt_nearest(float v) {
+    int r;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(v));   // floor(v + 0.5)
+    return r;
+}
+
+__global__ __launch_bounds__(64) void k_trilinear_splat_brick(GatherArgs G) {
+    if (*G.flag > __float_as_uint(GATHER_DEV_TOL)) return;  // not a lattice: the scatter kernel runs instead
+    __shared__ __attribute__((aligned(16))) int cell[SP_CELLS];
+    __shared__ uint2 tab[SP_TAB];
+    __shared__ int tsum;
+    constexpr float HS = 4.5f, CO = 3.5f;   // samples that touch voxels 0..7 of the brick sit in [-1, 8): centre 3.5, half 4.5
+    constexpr float HSR = HS / 1.5f;        // PoseLattice.hsr is made for the 2x2x2 block's half-size 1.5
+    int bx, by, bz;
+    brick_coords(blockIdx.x, G.D1, G.D2, G.bd, bx, by, bz);
+    const int tid = threadIdx.x;
+    const int ox = bx * 8, oy = by * 8, oz = bz * 8;            // first voxel of the brick
+    const int lx = tid >> 3, ly = tid & 7;                      // this lane's column of 8 voxels along z
+    const float fv[3] = {(float)ox, (float)oy, (float)oz};
+    float xv[3];  // centre of the support box in x coordinates
+#pragma unroll
+    for (int i = 0; i < 3; ++i) xv[i] = (fv[i] + CO - G.sp.b[i]) / G.sp.a[i];
+    const int N = G.sp.n_points;
+    const float near_ = G.sp.near_, far_ = G.sp.far_;
+    const float step = N > 1 ? (far_ - near_) / (float)(N - 1) : 0.f;
+    const float inv_step = step > 0.f ? 1.f / step : 0.f;
+    const float a0 = G.sp.a[0], a1 = G.sp.a[1], a2 = G.sp.a[2];
+    const float b0 = G.sp.b[0], b1 = G.sp.b[1], b2 = G.sp.b[2];
+    const float jmargin = GATHER_DEV_TOL + 0.01f;
+    const float Hm1 = (float)(G.H - 1), Wm1 = (float)(G.W - 1);
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    for (int i = tid; i < SP_CELLS / 4; i += 64) reinterpret_cast<int4*>(cell)[i] = make_int4(0, 0, 0, 0);
+    if (tid == 0) tsum = 0;
+
+    for (int wd = 0; wd < G.words; ++wd) {
+        unsigned bits = G.cull[(size_t)blockIdx.x * G.words + wd];  // uniform: scalar load
+        while (bits) {
+            const int p = wd * 32 + __builtin_ctz(bits);
+            bits &= bits - 1;
+            const float cmax = __uint_as_float(G.cmax[p]);
+            if (cmax == 0.f) continue;   // the pose's upstream gradient is all zeros
+            const PoseLattice& P = G.poses[p];
+            const float s0 = P.s[0], s1 = P.s[1], s2 = P.s[2];
+            const float w0 = xv[0] - s0, w1 = xv[1] - s1, w2 = xv[2] - s2;
+            const float av = P.nh[0] * w0 + P.nh[1] * w1 + P.nh[2] * w2;
+            const float da = HS * P.dalpha;
+            int klo, khi;
+            if (step > 0.f) {
+                const float k0 = (av - da - near_) * inv_step, k1 = (av + da - near_) * inv_step;
+                klo = (int)ceilf(fmaxf(k0 - GATHER_K_SLACK, 0.f));
+                khi = (int)floorf(fminf(k1 + GATHER_K_SLACK, (float)(N - 1)));
+            } else {
+                klo = 0;
+                khi = (fabsf(av - near_) <= da) ? 0 : -1;
+            }
+            if (!(av == av)) khi = -1;
+            const float grw = P.gr[0] * w0 + P.gr[1] * w1 + P.gr[2] * w2;
+            const float4* __restrict__ q = G.q + (size_t)p * G.qn;
+            // a s + b - (first cell of the array): array index of a sample = floor of this + alpha (a d); the brick's voxel v
+            // is cell v + 1 (a sample in [-1, 8) has its lower tap in cells 0..8)
+            const float Bx = fmaf(a0, s0, b0 - (fv[0] - 1.f)), By = fmaf(a1, s1, b1 - (fv[1] - 1.f)), Bz = fmaf(a2, s2, b2 - (fv[2] - 1.f));
+            // ... and relative to the centre of the support box, for the windows
+            const float Cx = fmaf(a0, s0, b0 - fv[0]) - CO, Cy = fmaf(a1, s1, b1 - fv[1]) - CO, Cz = fmaf(a2, s2, b2 - fv[2]) - CO;
+            const float rcx = HS * P.rc[0], rcy = HS * P.rc[1], rcz = HS * P.rc[2], rcw = HS * P.hwr;
+
+            int cnt = 0;        // entries in the list (uniform)
+            // ---- the list's samples into the cells, the cells into the lanes' registers
+            auto drain = [&]() {
+                const int T = tsum;   // (all lanes read the one word)
+                if (T > 0) {
+                    if (!(cmax < INFINITY)) {
+#pragma unroll
+                        for (int z = 0; z < 8; ++z) acc[z] = NAN;
+                    } else {
+                        // scale = the power of two that puts T max|c| into [2^29, 2^30): exact to apply and to undo
+                        const int ex = (int)(__float_as_uint((float)T * cmax) >> 23) - 126;   // T max|c| < 2^ex
+                        const float cs = __uint_as_float((unsigned)(127 + 30 - ex) << 23), ics = __uint_as_float((unsigned)(127 - 30 + ex) << 23);
+                        // One flat loop per lane.  The 16 groups of four lanes take contiguous sixteenths of the list (rows far
+                        // apart: their samples fall into different cells) and the four lanes of a group take the four quarters
+                        // of a run -- so the lanes of one ds_add hit different words (the microbenchmark's 11.8 lanes per clock
+                        // rather than the 4.5 of four lanes per word), and a lane's consecutive samples are neighbours in memory.
+                        // The next sample's load is issued before this sample is evaluated.
+                        const int c4 = tid & 3;
+#if XVR_SP_BLOCKED
+                        const int per = (cnt + 15) >> 4, stride = 1;
+                        int idx = (tid >> 2) * per, rem = 0;
+                        const int end = idx + per < cnt ? idx + per : cnt;
+#else
+                        constexpr int stride = 16;
+                        int idx = tid >> 2, rem = 0;
+                        const int end = cnt;
+#endif
+                        const float4* __restrict__ ptr = q;
+                        float al = 0.f;
+                        // on to the lane's next sample: 1 = there is one at (ptr, al), 0 = an idle trip (the run is shorter than
+                        // this lane's quarter starts), -1 = the lane is done
+                        auto advance = [&]() -> int {
+                            --rem;
+                            ptr += XVR_SP_QUARTERS ? 1 : 4;
+                            if (rem > 0) return 1;
+                            if (idx >= end) return -1;
+                            const uint2 e = tab[idx];
+                            idx += stride;
+#if XVR_SP_QUARTERS
+                            const int n = (int)(e.x >> 24), m = (n + 3) >> 2, first = c4 * m;
+                            rem = n - first < m ? n - first : m;
+                            ptr = q + (e.x & 0xffffffu) + first;
+#else
+                            rem = ((int)(e.x >> 24) - c4 + 3) >> 2;
+                            ptr = q + (e.x & 0xffffffu) + c4;
+#endif
+                            al = __uint_as_float(e.y);
+                            return rem > 0 ? 1 : 0;
+                        };
+                        auto splat = [&](const float4 t, const float alc) {
+                            const float px = fmaf(alc, t.x, Bx), py = fmaf(alc, t.y, By), pz = fmaf(alc, t.z, Bz);
+                            const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+                            const float rx = px - fx, ry = py - fy, rz = pz - fz;
+                            const int ix = (int)fx, iy = (int)fy, iz = (int)fz;
+                            // a sample outside [-1, 8) on some axis (the windows are conservative by a fraction of a pixel) touches
+                            // no voxel of the brick
+                            const bool ok = (unsigned)ix < (unsigned)(SP_DIM - 1) && (unsigned)iy < (unsigned)(SP_DIM - 1) && (unsigned)iz < (unsigned)(SP_DIM - 1);
+                            const float cz = ok ? t.w * cs : 0.f;
+                            const int base = ok ? (ix * SP_DIM + iy) * SP_DIM + iz : 0;
+                            const float z1 = rz * cz, z0 = cz - z1;   // (1 - rz) cz
+                            const float x1 = rx, x0 = 1.f - rx, y1 = ry, y0 = 1.f - ry;
+                            const float p00 = x0 * y0, p01 = x0 * y1, p10 = x1 * y0, p11 = x1 * y1;
+                            int* c = cell + base;
+#if XVR_SP_ABLATE_ADDS   // diagnostic build only (tools/tune_splat.py): one add instead of eight -- WRONG sums, the price of seven adds
+                            __hip_atomic_fetch_add(c, cvt_nearest(p00 * z0) + cvt_nearest(p00 * z1) + cvt_nearest(p01 * z0) + cvt_nearest(p01 * z1) +
+                                                   cvt_nearest(p10 * z0) + cvt_nearest(p10 * z1) + cvt_nearest(p11 * z0) + cvt_nearest(p11 * z1),
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            return;
+#endif
+                            __hip_atomic_fetch_add(c, cvt_nearest(p00 * z0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_add(c + 1, cvt_nearest(p00 * z1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_add(c + SP_DIM, cvt_nearest(p01 * z0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_add(c + SP_DIM + 1, cvt_nearest(p01 * z1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_add(c + SP_DIM * SP_DIM, cvt_nearest(p10 * z0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_add(c + SP_DIM * SP_DIM + 1, cvt_nearest(p10 * z1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_add(c + SP_DIM * SP_DIM + SP_DIM, cvt_nearest(p11 * z0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_add(c + SP_DIM * SP_DIM + SP_DIM + 1, cvt_nearest(p11 * z1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        };
+                        // two samples in flight, in two register sets (no copies between trips)
+                        // (the loads are unconditional -- ptr always points into q, at worst one element past a run -- so that
+                        //  no exec-masked join sits between a load and its use: the compiler would drain vmcnt there)
+                        int sa = advance(), sb;
+                        float4 ta = *ptr, tb;
+                        float ala = al, alb;
+                        while (sa >= 0) {
+                            sb = advance();
+                            tb = *ptr;
+                            alb = al;
+                            if (sa > 0) splat(ta, ala);
+                            if (sb < 0) break;
+                            sa = advance();
+                            ta = *ptr;
+                            ala = al;
+                            if (sb > 0) splat(tb, alb);
+                        }
+                        // the brick's voxels: cells 1..8 on every axis
+                        const int* col = cell + ((lx + 1) * SP_DIM + (ly + 1)) * SP_DIM + 1;
+#pragma unroll
+                        for (int z = 0; z < 8; ++z) acc[z] = fmaf((float)col[z], ics, acc[z]);
+                        for (int i = tid; i < SP_CELLS / 4; i += 64) reinterpret_cast<int4*>(cell)[i] = make_int4(0, 0, 0, 0);
+                    }
+                }
+                cnt = 0;
+                if (tid == 0) tsum = 0;
+            };
+            // append one run per lane (n <= 0: none); runs longer than an entry can say are split
+            auto append = [&](int off, int n, const float al) {
+                do {
+                    const int m = n < SP_RUN_MAX ? n : SP_RUN_MAX;
+                    const unsigned long long has = __ballot(m > 0);
+                    const int np = __popcll(has);
+                    if (cnt + np > SP_TAB) drain();
+                    const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(has >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)has, 0u));
+                    if (m > 0) {
+                        tab[pos] = make_uint2((unsigned)off | ((unsigned)m << 24), __float_as_uint(al));
+                        __hip_atomic_fetch_add(&tsum, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // samples in the list
+                        off += m;
+                        n -= m;
+                    }
+                    cnt += np;
+                } while (__any(n > 0));
+            };
+
+            for (int k = klo; k <= khi; ++k) {
+                const float al = linspace_sel(k, N, near_, far_, step);
+                if (al > 1e-12f) {
+                    // the table kernel's window arithmetic (step_setup / row_setup there) on the brick's support box
+                    const float inv = __builtin_amdgcn_rcpf(al);
+                    const float ic = fmaf(grw, inv, P.gr0);
+                    const float dlt = al - av;
+                    const float up = fminf(fminf(fmaf(P.rl[0], dlt, rcx), fmaf(P.rl[1], dlt, rcy)), fminf(fmaf(P.rl[2], dlt, rcz), rcw));
+                    const float dn = fminf(fminf(fmaf(-P.rl[0], dlt, rcx), fmaf(-P.rl[1], dlt, rcy)), fminf(fmaf(-P.rl[2], dlt, rcz), rcw));
+                    const int ilo = (int)ceilf(fmaxf(ic - fmaf(fmaxf(dn, 0.f), inv, GATHER_WIN_MARGIN), 0.f));
+                    const int ihi = (int)floorf(fminf(ic + fmaf(fmaxf(up, 0.f), inv, GATHER_WIN_MARGIN), Hm1));
+                    const float q0x = fmaf(al, P.e0[0], Cx), q0y = fmaf(al, P.e0[1], Cy), q0z = fmaf(al, P.e0[2], Cz);
+                    const float urx = al * P.era[0], ury = al * P.era[1], urz = al * P.era[2];
+                    const float rx = inv * P.rec[0], ry = inv * P.rec[1], rz = inv * P.rec[2];
+                    const float hx = fmaf(inv, HSR * P.hsr[0], jmargin), hy = fmaf(inv, HSR * P.hsr[1], jmargin), hz = fmaf(inv, HSR * P.hsr[2], jmargin);
+                    for (int i0 = ilo; i0 <= ihi; i0 += 64) {
+                        const int i = i0 + tid;
+                        const float fi = (float)i;
+                        const float qx = fmaf(fi, urx, q0x), qy = fmaf(fi, ury, q0y), qz = fmaf(fi, urz, q0z);
+                        const float mx = -qx * rx, my = -qy * ry, mz = -qz * rz;
+                        const float lo = fmaxf(fmaxf(mx - hx, my - hy), mz - hz);
+                        const float hiJ = fminf(fminf(mx + hx, my + hy), mz + hz);
+                        const int jlo = (int)ceilf(fmaxf(lo, 0.f));
+                        const int jhi = (int)floorf(fminf(hiJ, Wm1));
+                        append(i * G.qs + jlo, i <= ihi ? jhi - jlo + 1 : 0, al);
+                    }
+                } else {
+                    // alpha_k = 0: every ray's sample sits on the source; all pixels, if the source is inside the support box
+                    const bool hit = fabsf(Cx) < HS && fabsf(Cy) < HS && fabsf(Cz) < HS;
+                    if (hit)
+                        for (int i0 = 0; i0 < G.H; i0 += 64) append((i0 + tid) * G.qs, i0 + tid < G.H ? G.W : 0, al);
+                }
+            }
+            drain();
+        }
+    }
+    float* out = G.gvol + ((size_t)(ox + lx) * G.D1 + (oy + ly)) * G.D2 + oz;
+    if (ox + lx < G.D0 && oy + ly < G.D1) {
+#pragma unroll
+        for (int z = 0; z < 8; ++z)
+            if (oz + z < G.D2 && acc[z] != 0.f) out[z] += acc[z];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same splat on 16^3-voxel bricks, four wavefronts per brick: the per-visit work that does not depend on the number of
+// samples (pose constants, one window set-up per step, the flush) is paid once for 8 x the voxels, and the support box
+// holds 1.20 x the brick's samples instead of 1.42 x.
+//   enumeration  wavefront w takes steps klo + w, klo + w + 4, ...; lane = detector row; the runs are packed into ONE list by
+//                an LDS counter (one ds_add_rtn per wavefront and 64 rows);
+//   splat        64 groups of four lanes; group g takes runs g, g + 64, ..., lane c of the group the c-th quarter of a run;
+//   flush        thread t owns the 16 voxels (t / 16, t % 16, 0..15).
+// A visit whose list would overflow, that has more steps than the alpha table holds, or that meets a step at alpha = 0 is
+// redone in "safe mode": one step at a time over all four wavefronts, drained after every step.
+// ---------------------------------------------------------------------------------------------
+#if defined(XVR_S16_ABLATE_LOADS)   // diagnostic build only: no memory traffic for the samples -- WRONG sums
+#define XVR_S16_LOAD(p) make_float4(0.25f, 0.5f, 0.125f, (float)((size_t)(p) & 255u))
+#else
+#define XVR_S16_LOAD(p) (*(p))
+#endif
+#ifndef XVR_S16_DEPTH
+#define XVR_S16_DEPTH 2
+#endif
+#ifndef XVR_S16_TAB
+#define XVR_S16_TAB 896
+#endif
+constexpr int S16_DIM = 18, S16_CELLS = S16_DIM * S16_DIM * S16_DIM, S16_TAB = XVR_S16_TAB, S16_STEPS = 128;
+
+#ifndef XVR_S16_CENTRE_OUT
+#define XVR_S16_CENTRE_OUT 1
+#endif
+#ifndef XVR_S16_WAVES   // wavefronts per SIMD the register budget is set for (tools/tune_splat.py)
+#define XVR_S16_WAVES 4
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XVR_S16_WAVES, XVR_S16_WAVES))) void k_trilinear_splat_b16(GatherArgs G) {
+    if (*G.flag > __float_as_uint(GATHER_DEV_TOL)) return;  // not a lattice: the scatter kernel runs instead
+    __shared__ __attribute__((aligned(16))) int cell[S16_CELLS];
+    __shared__ uint2 tab[S16_TAB];          // x = first element of the run in q;  y = count << 8 | step - kbase
+    // list length, samples in the list, "redo in safe mode": two sets, alternating between visits, so that the set of visit
+    // v is cleared (by thread 0, after v's second barrier) while nobody reads or writes it -- two barriers per visit suffice
+    __shared__ int s_ctl[2][4];
+    __shared__ int s_next[2];   // the brick this workgroup takes next (two slots: written for turn t + 1 while t may still be read)
+    int par = 0;
+    constexpr float HS = 8.5f, CO = 7.5f;   // samples that touch voxels 0..15 sit in [-1, 16): centre 7.5, half 8.5
+    constexpr float HSR = HS / 1.5f;        // PoseLattice.hsr is made for the 2x2x2 block's half-size 1.5
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int lx = tid >> 4, ly = tid & 15;                     // this thread's column of 16 voxels along z
+    const int N = G.sp.n_points;
+    const float near_ = G.sp.near_, far_ = G.sp.far_;
+    const float step = N > 1 ? (far_ - near_) / (float)(N - 1) : 0.f;
+    const float inv_step = step > 0.f ? 1.f / step : 0.f;
+    const float a0 = G.sp.a[0], a1 = G.sp.a[1], a2 = G.sp.a[2];
+    const float b0 = G.sp.b[0], b1 = G.sp.b[1], b2 = G.sp.b[2];
+    const float jmargin = GATHER_DEV_TOL + 0.01f;
+    const float Hm1 = (float)(G.H - 1), Wm1 = (float)(G.W - 1);
+    const int n0 = (G.D0 + 15) / 16, n1 = (G.D1 + 15) / 16, n2 = (G.D2 + 15) / 16;
+    for (int i = tid; i < S16_CELLS / 4; i += 256) reinterpret_cast<int4*>(cell)[i] = make_int4(0, 0, 0, 0);
+    if (tid < 8) s_ctl[tid >> 2][tid & 3] = 0;
+#ifdef XVR_S16_TRACE
+#define XVR_TICK(i) do { const unsigned long long now_ = clock64(); tk[i] += now_ - tl; tl = now_; } while (0)
+#else
+#define XVR_TICK(i) ((void)0)
+#endif
+
+    // Persistent workgroups: the launch holds as many as the chip runs at once and every one takes bricks off a queue (a
+    // counter next to the lattice flag) until it is empty.  One workgroup per brick left 42 % of the workgroup slots idle
+    // for the whole launch (tools/splat_trace.py) -- the dispatcher does not keep up with 31 KiB / 4-wavefront workgroups
+    // of very unequal length.
+    for (int turn = 0;; turn ^= 1) {
+    if (tid == 0) s_next[turn] = (int)atomicAdd(G.flag + 1, 1u);
+    __syncthreads();   // (also: the cells are clear, the previous brick's flush is done)
+    const int blk = s_next[turn];
+    if (blk >= n0 * n1 * n2) break;
+    int bx = blk / (n1 * n2), by = (blk / n2) % n1, bz = blk % n2;
+#if XVR_S16_CENTRE_OUT
+    // bricks from the middle of the volume outwards: the ones most poses cross first, the empty corners last
+    bx = (bx & 1) ? (n0 >> 1) - ((bx + 1) >> 1) : (n0 >> 1) + (bx >> 1);
+    by = (by & 1) ? (n1 >> 1) - ((by + 1) >> 1) : (n1 >> 1) + (by >> 1);
+    bz = (bz & 1) ? (n2 >> 1) - ((bz + 1) >> 1) : (n2 >> 1) + (bz >> 1);
+#endif
+    const int brick_id = (bx * n1 + by) * n2 + bz;
+#ifdef XVR_S16_TRACE
+    const unsigned long long t_start = wall_clock64();
+    unsigned long long n_visits = 0, n_samples = 0, tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = clock64();
+#endif
+    const int ox = bx * 16, oy = by * 16, oz = bz * 16;         // first voxel of the brick
+    const float fv[3] = {(float)ox, (float)oy, (float)oz};
+    float xv[3];  // centre of the support box in x coordinates
+#pragma unroll
+    for (int i = 0; i < 3; ++i) xv[i] = uni((fv[i] + CO - G.sp.b[i]) / G.sp.a[i]);
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    for (int wd = 0; wd < G.words; ++wd) {
+        unsigned bits = G.cull[(size_t)brick_id * G.words + wd];  // uniform: scalar load
+        while (bits) {
+            const int p = wd * 32 + __builtin_ctz(bits);
+            bits &= bits - 1;
+            const float cmax = __uint_as_float(G.cmax[p]);
+            if (cmax == 0.f) continue;   // the pose's upstream gradient is all zeros
+            const PoseLattice P = G.poses[p];   // by value: uniform, lives in scalar registers across the barriers
+            const float s0 = P.s[0], s1 = P.s[1], s2 = P.s[2];
+            const float w0 = xv[0] - s0, w1 = xv[1] - s1, w2 = xv[2] - s2;
+            const float av = uni(P.nh[0] * w0 + P.nh[1] * w1 + P.nh[2] * w2);
+            const float da = HS * P.dalpha;
+            int klo, khi;
+            if (step > 0.f) {
+                const float k0 = (av - da - near_) * inv_step, k1 = (av + da - near_) * inv_step;
+                klo = (int)ceilf(fmaxf(k0 - GATHER_K_SLACK, 0.f));
+                khi = (int)floorf(fminf(k1 + GATHER_K_SLACK, (float)(N - 1)));
+            } else {
+                klo = 0;
+                khi = (fabsf(av - near_) <= da) ? 0 : -1;
+            }
+            if (!(av == av)) khi = -1;
+            if (khi < klo) continue;
+            const float grw = uni(P.gr[0] * w0 + P.gr[1] * w1 + P.gr[2] * w2);
+            const float4* __restrict__ q = G.q + (size_t)p * G.qn;
+            // a s + b - (first cell of the array): array index of a sample = floor of this + alpha (a d); the brick's voxel v
+            // is cell v + 1 (a sample in [-1, 16) has its lower tap in cells 0..16)
+            const float Bx = uni(fmaf(a0, s0, b0 - (fv[0] - 1.f))), By = uni(fmaf(a1, s1, b1 - (fv[1] - 1.f))), Bz = uni(fmaf(a2, s2, b2 - (fv[2] - 1.f)));
+            // ... and relative to the centre of the support box, for the windows
+            const float Cx = uni(fmaf(a0, s0, b0 - fv[0]) - CO), Cy = uni(fmaf(a1, s1, b1 - fv[1]) - CO), Cz = uni(fmaf(a2, s2, b2 - fv[2]) - CO);
+            const float rcx = HS * P.rc[0], rcy = HS * P.rc[1], rcz = HS * P.rc[2], rcw = HS * P.hwr;
+            // no more than this many samples of the pose can touch one voxel: lattice points inside a ball of radius sqrt 3
+            // (a voxel's 2-cube), from the three spacings of the sample lattice at the box's smallest alpha
+            float tcell = INFINITY;
+            {
+                const float amin = av - da;
+                if (amin > 1e-6f && step > 0.f) {
+                    const float two_r = 3.4641016f;
+                    const float mc = two_r / (amin * P.ecl) + 1.f, mr = two_r / (amin * P.rperp) + 1.f, mp = two_r * P.gn / step + 1.f;
+                    tcell = mc * mr * mp;
+                    if (!(tcell == tcell)) tcell = INFINITY;
+                }
+                tcell = uni(tcell);
+            }
+
+            int kbase = klo;    // step of slot 0 of the list
+            // ---- the list's samples into the cells, the cells into the threads' registers.  Called by ALL threads, after the
+            // barrier that completes the list; ends with the barrier after which the cells may be added to again.
+            auto drain = [&]() {
+                int* ctl = s_ctl[par];
+                const int cnt = ctl[0], T = ctl[1];
+#ifdef XVR_S16_TRACE
+                n_visits += 1; n_samples += (unsigned long long)T;
+#endif
+                if (T > 0 && cmax < INFINITY) {
+                    // scale = the power of two that puts (bound on a voxel's sum) into [2^29, 2^30): exact to apply and undo
+                    const float bound = fminf((float)T, tcell) * cmax;
+                    const int ex = (int)(__float_as_uint(bound) >> 23) - 126;   // bound < 2^ex
+                    const float cs = uni(__uint_as_float((unsigned)(127 + 30 - ex) << 23)), ics = uni(__uint_as_float((unsigned)(127 - 30 + ex) << 23));
+                    const int c4 = tid & 3;
+                    int idx = tid >> 2, rem = 0;
+                    const float4* __restrict__ ptr = q;
+                    float al = 0.f;
+                    // on to the thread's next sample: 1 = there is one at (ptr, al), 0 = an idle trip (the run is shorter than
+                    // this lane's quarter starts), -1 = the thread is done
+                    auto advance = [&]() -> int {
+                        --rem;
+                        ++ptr;
+                        if (rem > 0) return 1;
+                        if (idx >= cnt) return -1;
+                        const uint2 e = tab[idx];
+                        idx += 64;
+                        const int n = (int)(e.y >> 8), m = (n + 3) >> 2, first = c4 * m;
+                        rem = n - first < m ? n - first : m;
+                        ptr = q + e.x + first;
+                        al = linspace_sel(kbase + (int)(e.y & 255u), N, near_, far_, step);   // (recomputed: no second LDS read)
+                        return rem > 0 ? 1 : 0;
+                    };
+                    auto splat = [&](const float4 t, const float alc) {
+                        const float px = fmaf(alc, t.x, Bx), py = fmaf(alc, t.y, By), pz = fmaf(alc, t.z, Bz);
+                        const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+                        const float rx = px - fx, ry = py - fy, rz = pz - fz;
+                        const int ix = (int)fx, iy = (int)fy, iz = (int)fz;
+                        // a sample outside [-1, 16) on some axis (the windows are conservative by a fraction of a pixel) touches
+                        // no voxel of the brick
+                        const bool ok = (unsigned)ix < (unsigned)(S16_DIM - 1) && (unsigned)iy < (unsigned)(S16_DIM - 1) && (unsigned)iz < (unsigned)(S16_DIM - 1);
+                        const float cz = ok ? t.w * cs : 0.f;
+                        const int base = ok ? (ix * S16_DIM + iy) * S16_DIM + iz : 0;
+                        const float z1 = rz * cz, z0 = cz - z1;   // (1 - rz) cz
+                        const float x1 = rx, x0 = 1.f - rx, y1 = ry, y0 = 1.f - ry;
+                        const float p00 = x0 * y0, p01 = x0 * y1, p10 = x1 * y0, p11 = x1 * y1;
+                        int* c = cell + base;
+#if XVR_SP_ABLATE_ADDS   // diagnostic build only (tools/tune_splat.py): one add instead of eight -- WRONG sums, the price of seven adds
+                        __hip_atomic_fetch_add(c, cvt_nearest(p00 * z0) + cvt_nearest(p00 * z1) + cvt_nearest(p01 * z0) + cvt_nearest(p01 * z1) +
+                                               cvt_nearest(p10 * z0) + cvt_nearest(p10 * z1) + cvt_nearest(p11 * z0) + cvt_nearest(p11 * z1),
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        return;
+#endif
+                        __hip_atomic_fetch_add(c, cvt_nearest(p00 * z0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(c + 1, cvt_nearest(p00 * z1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(c + S16_DIM, cvt_nearest(p01 * z0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(c + S16_DIM + 1, cvt_nearest(p01 * z1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(c + S16_DIM * S16_DIM, cvt_nearest(p10 * z0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(c + S16_DIM * S16_DIM + 1, cvt_nearest(p10 * z1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(c + S16_DIM * S16_DIM + S16_DIM, cvt_nearest(p11 * z0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(c + S16_DIM * S16_DIM + S16_DIM + 1, cvt_nearest(p11 * z1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    };
+                    // two samples in flight per thread, in two register sets (deeper rings measured no faster).  Unconditional
+                    // loads (ptr always points into q, at worst one element past a run) so that no exec-masked join sits
+                    // between a load and its use; the only LDS read of the loop is the run's entry, consumed where it is
+                    // read -- a pending LDS result anywhere else makes the compiler drain the eight adds on every trip.
+                    int sa = advance(), sb;
+                    float4 ta = XVR_S16_LOAD(ptr), tb;
+                    float ala = al, alb;
+                    while (sa >= 0) {
+                        sb = advance();
+                        tb = XVR_S16_LOAD(ptr);
+                        alb = al;
+                        if (sa > 0) splat(ta, ala);
+                        if (sb < 0) break;
+                        sa = advance();
+                        ta = XVR_S16_LOAD(ptr);
+                        ala = al;
+                        if (sb > 0) splat(tb, alb);
+                    }
+                    XVR_TICK(3);
+                    __syncthreads();   // every sample is in the cells
+                    XVR_TICK(4);
+                    if (tid == 0) { ctl[0] = 0; ctl[1] = 0; ctl[2] = 0; }
+                    // the brick's voxels are cells 1..16 on every axis; a thread reads its 16 and clears them (the outer cells
+                    // are never read: they may hold anything, and wrap around)
+                    int* col = cell + ((lx + 1) * S16_DIM + (ly + 1)) * S16_DIM + 1;
+#pragma unroll
+                    for (int z = 0; z < 16; ++z) {
+                        acc[z] = fmaf((float)col[z], ics, acc[z]);
+                        col[z] = 0;
+                    }
+                    XVR_TICK(5);
+                } else {
+                    if (T > 0) {   // a non-finite upstream gradient poisons the brick
+#pragma unroll
+                        for (int z = 0; z < 16; ++z) acc[z] = NAN;
+                    }
+                    __syncthreads();
+                    if (tid == 0) { ctl[0] = 0; ctl[1] = 0; ctl[2] = 0; }
+                }
+                par ^= 1;
+            };
+            // one run per lane of the calling wavefront (n <= 0: none) into the shared list; false = it does not fit
+            auto append = [&](const int off, int n, const int slot) -> bool {
+                n = n > 0 ? (n < 0xffffff ? n : 0xffffff) : 0;
+                const unsigned long long has = __ballot(n > 0);
+                const int np = __popcll(has);
+                if (np == 0) return true;
+                int base = 0;
+                if (lane == 0) base = __hip_atomic_fetch_add(&s_ctl[par][0], np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base + np > S16_TAB) return false;
+                if (n > 0) {
+                    const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(has >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)has, 0u));
+                    tab[pos] = make_uint2((unsigned)off, ((unsigned)n << 8) | (unsigned)slot);
+                    __hip_atomic_fetch_add(&s_ctl[par][1], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // samples in the list
+                }
+                return true;
+            };
+            // the rows i0 + lane of step alpha = al (the table kernel's window arithmetic on the brick's support box)
+            struct StepC { float q0x, q0y, q0z, urx, ury, urz, rx, ry, rz, hx, hy, hz; int ilo, ihi; };
+            auto step_setup = [&](const float al, StepC& S) {
+                const float inv = __builtin_amdgcn_rcpf(al);
+                const float ic = fmaf(grw, inv, P.gr0);
+                const float dlt = al - av;
+                const float up = fminf(fminf(fmaf(P.rl[0], dlt, rcx), fmaf(P.rl[1], dlt, rcy)), fminf(fmaf(P.rl[2], dlt, rcz), rcw));
+                const float dn = fminf(fminf(fmaf(-P.rl[0], dlt, rcx), fmaf(-P.rl[1], dlt, rcy)), fminf(fmaf(-P.rl[2], dlt, rcz), rcw));
+                S.ilo = (int)ceilf(fmaxf(ic - fmaf(fmaxf(dn, 0.f), inv, GATHER_WIN_MARGIN), 0.f));
+                S.ihi = (int)floorf(fminf(ic + fmaf(fmaxf(up, 0.f), inv, GATHER_WIN_MARGIN), Hm1));
+                S.q0x = fmaf(al, P.e0[0], Cx); S.q0y = fmaf(al, P.e0[1], Cy); S.q0z = fmaf(al, P.e0[2], Cz);
+                S.urx = al * P.era[0]; S.ury = al * P.era[1]; S.urz = al * P.era[2];
+                S.rx = inv * P.rec[0]; S.ry = inv * P.rec[1]; S.rz = inv * P.rec[2];
+                S.hx = fmaf(inv, HSR * P.hsr[0], jmargin); S.hy = fmaf(inv, HSR * P.hsr[1], jmargin); S.hz = fmaf(inv, HSR * P.hsr[2], jmargin);
+            };
+            auto rows = [&](const StepC& S, const int i, int& off, int& n) {
+                const float fi = (float)i;
+                const float qx = fmaf(fi, S.urx, S.q0x), qy = fmaf(fi, S.ury, S.q0y), qz = fmaf(fi, S.urz, S.q0z);
+                const float mx = -qx * S.rx, my = -qy * S.ry, mz = -qz * S.rz;
+                const float lo = fmaxf(fmaxf(mx - S.hx, my - S.hy), mz - S.hz);
+                const float hiJ = fminf(fminf(mx + S.hx, my + S.hy), mz + S.hz);
+                const int jlo = (int)ceilf(fmaxf(lo, 0.f));
+                const int jhi = (int)floorf(fminf(hiJ, Wm1));
+                off = i * G.qs + jlo;
+                n = i <= S.ihi ? jhi - jlo + 1 : 0;
+            };
+
+            // ---- fast mode: every wavefront its own steps, one list for the whole visit
+            XVR_TICK(0);
+            bool redo = khi - klo >= S16_STEPS;
+            if (!redo) {
+                for (int k = klo + wave; k <= khi; k += 4) {
+                    const float al = linspace_sel(k, N, near_, far_, step);
+                    if (!(al > 1e-12f)) { redo = true; break; }
+                    StepC S;
+                    step_setup(al, S);
+                    for (int i0 = S.ilo; i0 <= S.ihi && !redo; i0 += 64) {
+                        int off, n;
+                        rows(S, i0 + lane, off, n);
+                        if (!append(off, n, k - klo)) redo = true;
+                    }
+                    if (redo) break;
+                }
+                if (redo && lane == 0) s_ctl[par][2] = 1;
+            }
+            XVR_TICK(1);
+            __syncthreads();   // the list is complete
+            XVR_TICK(2);
+            redo = redo || s_ctl[par][2] != 0;   // (uniform: the first operand is, where it is set before the barrier)
+            if (!redo) {
+                drain();
+            } else {
+                // ---- safe mode (rare): the list is thrown away; one step at a time, all four wavefronts on its rows, drained
+                // whenever another 256 runs might not fit and after every step
+                __syncthreads();
+                if (tid == 0) { s_ctl[par][0] = 0; s_ctl[par][1] = 0; s_ctl[par][2] = 0; }
+                __syncthreads();
+                for (int k = klo; k <= khi; ++k) {
+                    kbase = k;
+                    const float al = linspace_sel(k, N, near_, far_, step);
+                    if (al > 1e-12f) {
+                        StepC S;
+                        step_setup(al, S);
+                        for (int i0 = S.ilo; i0 <= S.ihi; i0 += 256) {
+                            int off, n;
+                            rows(S, i0 + tid, off, n);
+                            append(off, n, 0);
+                            if (i0 + 256 <= S.ihi) {   // (uniform) more rows to come: make room
+                                __syncthreads();
+                                if (s_ctl[par][0] > S16_TAB - 256) drain(); else __syncthreads();
+                            }
+                        }
+                    } else {
+                        // alpha_k = 0: every ray's sample sits on the source; all pixels, if the source is inside the support box
+                        const bool hit = fabsf(Cx) < HS && fabsf(Cy) < HS && fabsf(Cz) < HS;
+                        if (hit)
+                            for (int i0 = 0; i0 < G.H; i0 += 256) {
+                                append((i0 + tid) * G.qs, i0 + tid < G.H ? G.W : 0, 0);
+                                if (i0 + 256 < G.H) {
+                                    __syncthreads();
+                                    if (s_ctl[par][0] > S16_TAB - 256) drain(); else __syncthreads();
+                                }
+                            }
+                    }
+                    __syncthreads();
+                    drain();
+                    __syncthreads();   // (the flush's clears before the next step's adds; fast mode has the list barrier there)
+                }
+            }
+        }
+    }
+#ifdef XVR_S16_TRACE
+    if (tid == 0 && blk < 65536) {
+        unsigned long long* o = g_s16_trace + 12 * blk;
+        o[0] = t_start; o[1] = wall_clock64(); o[2] = n_visits; o[3] = n_samples;
+        for (int i = 0; i < 8; ++i) o[4 + i] = tk[i];
+    }
+#endif
+    float* out = G.gvol + ((size_t)(ox + lx) * G.D1 + (oy + ly)) * G.D2 + oz;
+    if (ox + lx < G.D0 && oy + ly < G.D1) {
+#pragma unroll
+        for (int z = 0; z < 16; ++z)
+            if (oz + z < G.D2 && acc[z] != 0.f) out[z] += acc[z];
+    }
+    }   // next brick
+}
+
+// ---------------------------------------------------------------------------------------------
 // Pixel-major voxel gather for the renders the lattice-of-planes kernels above cannot take (round 2):
 //   CLIP  spec.clip_to_volume: alpha_k = alpha_min(ray) + u_k (alpha_max - alpha_min)(ray) -- the samples of a step no longer
 //         lie on one plane, so there is no per-step row table; the image is scaled by the ray's span.
@@ -1181,17 +1835,25 @@ int xvr_detail::launch_gather(bool siddon, const float* source, const float* tar
     // both are exact and give identical sums)
     static const bool use_table = [] { const char* e = getenv("XVR_DRR_GATHER_TABLE"); return !(e && e[0] == '0'); }();
     static const bool siddon_v1 = [] { const char* e = getenv("XVR_DRR_SIDDON_GATHER_BLOCK"); return e && e[0] == '1'; }();
+    // trilinear without clip / per-channel masks: the brick-local fixed-point splat on 16^3 bricks (k_trilinear_splat_b16);
+    // XVR_DRR_GATHER_SPLAT=8 selects its 8^3 single-wavefront form, =0 the voxel-driven table gather (A/B switches)
+    static const int splat_mode = [] { const char* e = getenv("XVR_DRR_GATHER_SPLAT"); return !e ? 16 : (e[0] == '0' ? 0 : (e[0] == '8' ? 8 : 16)); }();
+    const bool use_splat = splat_mode != 0, splat16 = splat_mode == 16;
+    const bool splat = !siddon && use_splat && !sp->clip_to_volume && !mask && (splat16 || (unsigned)((n / gw) * (gw + 1)) <= TAB_MAX_RAYS);
     if (siddon && (siddon_v1 || G.cells)) { G.bd[0] = 4; G.bd[1] = 8; G.bd[2] = 8; }
     else if (siddon) { G.bd[0] = G.bd[1] = G.bd[2] = 8; }
     else {
-        if (G.clip || G.mask) G.V = 2;   // (the pixel-major kernel is written for 2x2x2 blocks)
+        if (G.clip || G.mask || splat) G.V = 2;   // (the pixel-major kernel is written for 2x2x2 blocks; the splat's brick is 8^3 too)
         G.bd[0] = G.bd[1] = G.bd[2] = 4 * G.V;
     }
+    if (splat) G.cmax = reinterpret_cast<unsigned*>(G.q2);   // (q2 is the clip / siddon kernels')
+    if (splat && splat16) G.bd[0] = G.bd[1] = G.bd[2] = 16;
     G.cull = reinterpret_cast<unsigned*>(ws + ws_cull_off(B, n));
     G.words = (B + 31) / 32;
     G.gvol = grad_volume;
     *flag_out = G.flag;
     hipError_t e = hipMemsetAsync(G.flag, 0, 16, (hipStream_t)stream);
+    if (e == hipSuccess && G.cmax) e = hipMemsetAsync(G.cmax, 0, (size_t)B * sizeof(unsigned), (hipStream_t)stream);
     if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
     hipLaunchKernelGGL(k_gather_prep, dim3((unsigned)((n + WG - 1) / WG), (unsigned)B), dim3(WG), 0,
                        (hipStream_t)stream, G);
@@ -1209,6 +1871,17 @@ int xvr_detail::launch_gather(bool siddon, const float* source, const float* tar
     else if (G.clip && G.mask) hipLaunchKernelGGL((k_trilinear_gather_px<true, true>), dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
     else if (G.clip) hipLaunchKernelGGL((k_trilinear_gather_px<true, false>), dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
     else if (G.mask) hipLaunchKernelGGL((k_trilinear_gather_px<false, true>), dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
+    else if (splat && splat16) {
+        // persistent workgroups: as many as run at once (the occupancy the runtime reports x the CUs), never more than bricks
+        static const int resident = [] {
+            int per_cu = 0, dev = 0, cus = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trilinear_splat_b16, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+            return per_cu * cus;
+        }();
+        hipLaunchKernelGGL(k_trilinear_splat_b16, dim3((unsigned)(bricks < resident ? bricks : resident)), dim3(256), 0, (hipStream_t)stream, G);
+    }
+    else if (splat) hipLaunchKernelGGL(k_trilinear_splat_brick, dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
     else if (G.V == 2 && use_table && (unsigned)G.qn <= TAB_MAX_RAYS) hipLaunchKernelGGL(k_trilinear_gather_tab, dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
     else if (G.V == 2) hipLaunchKernelGGL(k_trilinear_gather_vol<2>, dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
     else hipLaunchKernelGGL(k_trilinear_gather_vol<1>, dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
@@ -1226,6 +1899,18 @@ int xvr_drr_debug_gather_stats(unsigned long long* out8, int reset) {
         const unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_gather_stats), zero, 64) != hipSuccess) return XVR_DRR_E_LAUNCH;
     }
+    return XVR_DRR_OK;
+}
+#endif
+
+#ifdef XVR_S16_TRACE
+int xvr_drr_debug_s16_occupancy() {   // workgroups of the 16^3 splat the runtime says fit one CU
+    int n = -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trilinear_splat_b16, 256, 0) != hipSuccess) return -1;
+    return n;
+}
+int xvr_drr_debug_s16_trace(unsigned long long* out, int n_groups) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_s16_trace), (size_t)n_groups * 96) != hipSuccess) return XVR_DRR_E_LAUNCH;
     return XVR_DRR_OK;
 }
 #endif
