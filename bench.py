@@ -36,7 +36,7 @@ TAP_BYTES_PER_SAMPLE = 32   # 8 taps x 4 B; the voxel backward ac
 # which profiled kernels make up each timed C-ABI call (one call may launch several kernels)
 TRAFFIC_KERNELS = {
     "trilinear_forward": ["k_trilinear_fwd"],
-    "trilinear_backward": ["k_trilinear_gather_tab", "k_trilinear_gather_vol", "k_gather_prep", "k_gather_cull", "k_trilinear_bwd"],
+    "trilinear_backward": ["k_trilinear_splat_b16", "k_trilinear_gather_tab", "k_trilinear_gather_vol", "k_gather_prep", "k_gather_cull", "k_trilinear_bwd"],
     "siddon_forward": ["k_siddon<"],
     "siddon_backward": ["k_siddon_gather_vol", "k_gather_prep", "k_gather_cull", "k_siddon<"],
     "backward_from_jac": ["k_backward_from_jac"],

@@ -1,0 +1,96 @@
+"""The default voxel gradient of the trilinear renderer: the brick-local fixed-point splat (k_trilinear_splat_b16,
+DESIGN.md section 4.1) against the fp32 table gather (XVR_DRR_GATHER_SPLAT=0), the atomic scatter and the oracle -- on
+the paths the small parity cases do not reach (list overflow and more steps than a list holds -> "safe mode", a pose with
+an all-zero or a non-finite upstream gradient, volumes smaller than a brick) and bit-for-bit repeatability."""
+import pytest
+import torch
+
+from conftest import make_case, to_oracle_spec
+from test_hip_parity import GRAD_TOL, _close, _hip_render, _oracle_render
+
+pytestmark = pytest.mark.gpu
+
+
+def _grad(case, spec, w, grid_w, monkeypatch, splat=True, gather=True):
+    from xvr_amd import renderers
+
+    monkeypatch.setenv("XVR_DRR_GATHER_SPLAT", "1" if splat else "0")
+    renderers.VOXEL_GATHER = gather
+    try:
+        return _hip_render(case, spec, grid_w=grid_w, grads=True, w=w)[1]
+    finally:
+        renderers.VOXEL_GATHER = True
+
+
+@pytest.mark.parametrize("shape,hw,n_points,why", [
+    ((40, 36, 44), (96, 80), 90, "several bricks, ordinary visits"),
+    ((20, 18, 22), (300, 280), 160, "a fine detector on a small volume: more runs per visit than the list holds"),
+    ((18, 20, 16), (40, 36), 6000, "more steps across a brick than the list has slots"),
+    ((9, 7, 11), (24, 20), 50, "a volume smaller than one brick"),
+    ((33, 17, 49), (31, 57), 70, "ragged: one voxel / one row past a brick / a wavefront"),
+])
+def test_splat_equals_table_gather_scatter_and_oracle(shape, hw, n_points, why, monkeypatch):
+    from xvr_amd.spec import RenderSpec
+
+    spec = RenderSpec(renderer="trilinear", n_points=n_points)
+    case = make_case(seed=23, shape=shape, height=hw[0], width=hw[1], delx=0.9 * max(shape) / max(hw),
+                     xyz=((2.0, 300.0, -1.0), (-1.5, 200.0, 3.0)))
+    w = torch.randn(2, 1, hw[0] * hw[1], generator=torch.Generator().manual_seed(3))
+    splat = _grad(case, spec, w, hw[1], monkeypatch)
+    table = _grad(case, spec, w, hw[1], monkeypatch, splat=False)
+    scatter = _grad(case, spec, w, hw[1], monkeypatch, gather=False)
+    assert splat.abs().max() > 0, why
+    # the table gather adds the same weights in fp32; the splat rounds every product to 2^-30 of the bound on a voxel's sum
+    # (the fine detector puts ~1500 samples of a pose on every voxel: the bound, hence the LSB, is 30 x the benchmark's)
+    _close(splat, table, 4e-5 if hw[0] >= 300 else 1e-5, f"splat vs table gather ({why})")
+    _close(splat, scatter, 4e-5, f"splat vs scatter ({why})")
+    if n_points <= 200 and hw[0] * hw[1] <= 10000:
+        _close(splat, _oracle_render(case, spec, grads=True, w=w)[1], GRAD_TOL, f"splat vs oracle ({why})")
+
+
+def test_splat_is_bit_reproducible(monkeypatch):
+    from xvr_amd.spec import RenderSpec
+
+    spec = RenderSpec(renderer="trilinear", n_points=120)
+    case = make_case(seed=29, shape=(48, 40, 36), height=64, width=72, delx=0.7)
+    w = torch.randn(2, 1, 64 * 72, generator=torch.Generator().manual_seed(4))
+    a = _grad(case, spec, w, 72, monkeypatch)
+    for _ in range(3):
+        assert torch.equal(a, _grad(case, spec, w, 72, monkeypatch))
+
+
+def test_splat_is_as_close_to_the_f64_sum_as_the_fp32_gather(monkeypatch):
+    """Fixed point costs nothing visible: against the oracle run in float64, the splat's error is of the size of the fp32
+    table gather's (both dominated by the fp32 sample positions)."""
+    from oracle.diffdrr_restated import render
+    from xvr_amd.spec import RenderSpec
+
+    spec = RenderSpec(renderer="trilinear", n_points=150)
+    case = make_case(seed=31, shape=(40, 44, 36), height=48, width=52, delx=0.9)
+    w = torch.randn(2, 1, 48 * 52, generator=torch.Generator().manual_seed(5))
+    vol = case["volume"].double().requires_grad_(True)
+    out = render(vol, case["source"].double(), case["target"].double(), case["img"].double(), to_oracle_spec(spec), None)
+    (out * w.double()).sum().backward()
+    ref = vol.grad
+    err = [((_grad(case, spec, w, 52, monkeypatch, splat=s).cpu().double() - ref).abs().max() / ref.abs().max()).item() for s in (True, False)]
+    assert err[0] < 2e-5 and err[0] < 2.0 * err[1] + 1e-6, err
+
+
+def test_splat_skips_a_pose_whose_upstream_gradient_is_zero_and_flags_a_non_finite_one(monkeypatch):
+    from xvr_amd.spec import RenderSpec
+
+    spec = RenderSpec(renderer="trilinear", n_points=80)
+    case = make_case(seed=37, shape=(36, 40, 34), height=40, width=44, delx=0.9)
+    w = torch.randn(2, 1, 40 * 44, generator=torch.Generator().manual_seed(6))
+    w0 = w.clone()
+    w0[1] = 0.0
+    both = _grad(case, spec, w0, 44, monkeypatch)
+    table = _grad(case, spec, w0, 44, monkeypatch, splat=False)
+    _close(both, table, 2e-5, "second pose has no upstream gradient")
+    wn = w.clone()
+    wn[1, 0, 17] = float("nan")
+    bad = _grad(case, spec, wn, 44, monkeypatch)
+    assert not torch.isfinite(bad).all(), "a NaN upstream gradient must not disappear"
+    # voxels only the first pose touches keep their finite value
+    only_first = (_grad(case, spec, torch.cat([w[:1], torch.zeros_like(w[1:])]), 44, monkeypatch) != 0) & torch.isfinite(bad)
+    assert only_first.any()

@@ -15,9 +15,10 @@ constexpr int BRICK = 4096;   // floats per workgroup (16 KiB)
 // PAT 2: groups of 4 neighbouring lanes share a word, groups consecutive (the duplicate pattern of dense samples)
 // PAT 3: all 64 lanes one word
 // OP 0: ds_add_f32   1: ds_add_u32   2: ds_read + v_add + ds_write (non-atomic)   3: ds_add_rtn_f32 (value used)
+// OP 4: ds_add_u64 (two neighbouring words per lane)   5: ds_add_u32 with every other lane masked off
 template <int OP, int PAT>
 __global__ __launch_bounds__(256) void k_lds(float* out, int iters) {
-    __shared__ float brick[BRICK];
+    __shared__ __attribute__((aligned(16))) float brick[BRICK];
     for (int i = threadIdx.x; i < BRICK; i += blockDim.x) brick[i] = 0.f;
     __syncthreads();
     const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -31,7 +32,9 @@ __global__ __launch_bounds__(256) void k_lds(float* out, int iters) {
         if (OP == 0) __hip_atomic_fetch_add(&brick[idx], 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         else if (OP == 1) __hip_atomic_fetch_add((unsigned*)&brick[idx], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         else if (OP == 2) { volatile float* p = &brick[idx]; *p = *p + 1.0f; }
-        else keep += __hip_atomic_fetch_add(&brick[idx], 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else if (OP == 3) keep += __hip_atomic_fetch_add(&brick[idx], 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else if (OP == 4) __hip_atomic_fetch_add((unsigned long long*)__builtin_assume_aligned(&brick[idx & ~1u], 8), 0x100000001ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else { if (lane & 1) __hip_atomic_fetch_add((unsigned*)&brick[idx], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }   // half the lanes
         a += stride;
     }
     __syncthreads();
@@ -56,7 +59,7 @@ int main() {
     float* out; CK(hipMalloc(&out, 1 << 20));
     const int blocks = 256 * 32, threads = 256, iters = 4096;
     const double total = (double)blocks * threads * iters;
-    const char* on[] = {"ds_add_f32", "ds_add_u32", "read+add+write", "ds_add_rtn_f32"};
+    const char* on[] = {"ds_add_f32", "ds_add_u32", "read+add+write", "ds_add_rtn_f32", "ds_add_u64", "ds_add_u32 (32 lanes)"};
     const char* pn[] = {"conflict-free", "random", "4-lane-dup", "all-one-word"};
 #define RUN(O, P) { double t = time_kernel(k_lds<O, P>, dim3(blocks), dim3(threads), out, iters); \
     printf("LDS %-15s pattern=%-14s %9.1f Gop/s  = %6.2f lane-ops / clk / CU (2.4 GHz, 256 CUs)\n", on[O], pn[P], total / t * 1e-9, total / t / 2.4e9 / 256); }
@@ -64,5 +67,7 @@ int main() {
     RUN(1, 0) RUN(1, 1) RUN(1, 2) RUN(1, 3)
     RUN(2, 0) RUN(2, 1)
     RUN(3, 0) RUN(3, 1)
+    RUN(4, 0) RUN(4, 1) RUN(4, 2)
+    RUN(5, 0) RUN(5, 1) RUN(5, 2)
     return 0;
 }

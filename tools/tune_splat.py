@@ -11,12 +11,12 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 
-# (name, defines, XVR_DRR_GATHER_SPLAT)
+# (name, defines, XVR_DRR_GATHER_SPLAT: 0 = the table gather)
 VARIANTS = [
-    ("b16", ["XVR_S16_DEPTH=2"], "16"),
-    ("b16_noadds", ["XVR_SP_ABLATE_ADDS=1"], "16"),
-    ("b16_noloads", ["XVR_S16_ABLATE_LOADS=1"], "16"),
-    ("b16_neither", ["XVR_S16_ABLATE_LOADS=1", "XVR_SP_ABLATE_ADDS=1"], "16"),
+    ("b16", [], "1"),
+    ("b16_noadds", ["XVR_SP_ABLATE_ADDS=1"], "1"),
+    ("b16_gs1", ["XVR_S16_GROUP_STRIDE=1"], "1"),
+    ("table", [], "0"),
 ]
 
 

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(WG) void k_gather_prep(GatherArgs G) {
             // a * d: the gather forms a (s + alpha d) + b - v as fma(alpha, a d, a s + b - v) (a = 1 for the default index map)
             float4* row = G.q + (size_t)b * G.qn + (size_t)i * G.qs;
             row[j] = make_float4(G.sp.a[0] * ddx, G.sp.a[1] * ddy, G.sp.a[2] * ddz, c);
-            cabs = (c == c && fabsf(c) < INFINITY) ? fabsf(c) : 0.f;
+            cabs = (c == c) ? fabsf(c) : INFINITY;   // (a NaN counts as infinite: the splat poisons what the pose touches)
             if (j == G.W - 1) row[G.W] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (G.clip) {
                 // the ray's own [alpha_min, alpha_max], computed exactly as ray_setup() does for the forward; the image is
@@ -725,40 +725,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(XVR_TAB_WAVE
 }
 
 // ---------------------------------------------------------------------------------------------
-// Brick-local splat (round 2): the same voxel gradient, SAMPLE-driven, with the sums of an 8^3-voxel brick held in LDS as
+// Brick-local splat (round 2): the same voxel gradient, SAMPLE-driven, with the sums of a brick of voxels held in LDS as
 // 32-bit fixed point.
 //
 // Why: the counters say the table gather above is limited twice over -- the vector ALUs are 64 % busy on work of which
 // 70 % is multiplications by a zero weight (a candidate of a 2x2x2 block has 2.4 non-zero weights of 8, and 41 of 64
 // lanes are live), and the L1 is 85-89 % busy because every lane's 16-byte candidate load is its own cache access (39
 // accesses per load instruction; tools/profile_mempipe.sh).  A sample-driven pass has neither problem: every sample is
-// evaluated once per brick whose support holds it (1.42 x the samples instead of 3.4 x), with all eight weights useful,
-// and four neighbouring lanes read four neighbouring pixels.  What it needs is an accumulate into shared memory, and
-// tools/microbench/lds_atomics.hip measured the one that works: ds_add_f32 retires 0.33 lanes per clock and CU (it is
-// serialised), ds_add_u32 11.8 (random words), 4.5 (four lanes per word).  So the sums are integers:
-//   * per (brick, pose) visit the wavefront enumerates, with the lattice arithmetic of the table kernel applied to the
+// evaluated once per brick whose support holds it, with all eight weights useful, and neighbouring lanes read
+// neighbouring pixels.  What it needs is an accumulate into shared memory, and tools/microbench/lds_atomics.hip measured
+// the one that works: ds_add_f32 retires 0.33 lanes per clock and CU (it is serialised), ds_add_u32 11.5 (random words;
+// 4.4 clocks per wavefront instruction when no two lanes share a word), ds_add_u64 half that.  So the sums are integers:
+//   * per (brick, pose) visit the workgroup enumerates, with the lattice arithmetic of the table kernel applied to the
 //     brick's whole support box, the runs (row, first pixel, count) of samples inside the box -- one row per lane, packed
-//     into an LDS list by ballot;
-//   * the scale is 2^30 / (T * max|c|), T = the number of samples in the list and max|c| the pose's largest weight
-//     (k_gather_prep), so no sum can overflow; a sample's eight products w * c * scale are rounded to nearest
-//     (v_cvt_rpi_i32_f32) and added with ds_add_u32 to a 10^3 array of cells, the brick and one cell around it (the
-//     outer cells are never read);
-//   * after the pose's samples the lanes read their eight voxels, convert, add them to fp32 registers and clear the cells.
+//     into an LDS list;
+//   * the scale is a power of two that keeps (most samples that can touch one voxel) x (the pose's max |c|, from
+//     k_gather_prep) below 2^30, so no sum can overflow; a sample's eight products w * c * scale are rounded to nearest
+//     (v_cvt_rpi_i32_f32) and added with ds_add_u32 to an array of cells, the brick and one cell around it (the outer
+//     cells are never read);
+//   * after the pose's samples the threads read their voxels, convert, add them to fp32 registers and clear the cells.
 // Integer sums are exact and order-free: the result is deterministic, and differs from the table kernel's by the
-// rounding of the products, ~0.3 LSB per add with LSB = T max|c| / 2^30 (5e-7 max|c| at the benchmark geometry).
+// rounding of the products, ~0.3 LSB per add with LSB = bound / 2^30.
 // A pose whose upstream gradient holds a non-finite value poisons the voxels of the bricks it visits (NaN).
 // ---------------------------------------------------------------------------------------------
-#ifndef XVR_SP_BLOCKED     // (tuning switches of tools/tune_splat.py)
-#define XVR_SP_BLOCKED 0
-#endif
-#ifndef XVR_SP_QUARTERS
-#define XVR_SP_QUARTERS 1
-#endif
 #ifndef XVR_SP_ABLATE_ADDS
 #define XVR_SP_ABLATE_ADDS 0
 #endif
-constexpr int SP_DIM = 10, SP_CELLS = SP_DIM * SP_DIM * SP_DIM, SP_TAB = 256, SP_RUN_MAX = 252;
-
 // a value every lane holds alike, moved to a scalar register (gfx950 has no scalar float ALU: uniform float arithmetic is
 // done by the vector ALU and would otherwise sit in a vector register for as long as it lives)
 __device__ __forceinline__ float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
@@ -767,234 +759,6 @@ __device__ __forceinline__ int cvt_nearest(float v) {
     int r;
     asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(v));   // floor(v + 0.5)
     return r;
-}
-
-__global__ __launch_bounds__(64) void k_trilinear_splat_brick(GatherArgs G) {
-    if (*G.flag > __float_as_uint(GATHER_DEV_TOL)) return;  // not a lattice: the scatter kernel runs instead
-    __shared__ __attribute__((aligned(16))) int cell[SP_CELLS];
-    __shared__ uint2 tab[SP_TAB];
-    __shared__ int tsum;
-    constexpr float HS = 4.5f, CO = 3.5f;   // samples that touch voxels 0..7 of the brick sit in [-1, 8): centre 3.5, half 4.5
-    constexpr float HSR = HS / 1.5f;        // PoseLattice.hsr is made for the 2x2x2 block's half-size 1.5
-    int bx, by, bz;
-    brick_coords(blockIdx.x, G.D1, G.D2, G.bd, bx, by, bz);
-    const int tid = threadIdx.x;
-    const int ox = bx * 8, oy = by * 8, oz = bz * 8;            // first voxel of the brick
-    const int lx = tid >> 3, ly = tid & 7;                      // this lane's column of 8 voxels along z
-    const float fv[3] = {(float)ox, (float)oy, (float)oz};
-    float xv[3];  // centre of the support box in x coordinates
-#pragma unroll
-    for (int i = 0; i < 3; ++i) xv[i] = (fv[i] + CO - G.sp.b[i]) / G.sp.a[i];
-    const int N = G.sp.n_points;
-    const float near_ = G.sp.near_, far_ = G.sp.far_;
-    const float step = N > 1 ? (far_ - near_) / (float)(N - 1) : 0.f;
-    const float inv_step = step > 0.f ? 1.f / step : 0.f;
-    const float a0 = G.sp.a[0], a1 = G.sp.a[1], a2 = G.sp.a[2];
-    const float b0 = G.sp.b[0], b1 = G.sp.b[1], b2 = G.sp.b[2];
-    const float jmargin = GATHER_DEV_TOL + 0.01f;
-    const float Hm1 = (float)(G.H - 1), Wm1 = (float)(G.W - 1);
-    float acc[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-    for (int i = tid; i < SP_CELLS / 4; i += 64) reinterpret_cast<int4*>(cell)[i] = make_int4(0, 0, 0, 0);
-    if (tid == 0) tsum = 0;
-
-    for (int wd = 0; wd < G.words; ++wd) {
-        unsigned bits = G.cull[(size_t)blockIdx.x * G.words + wd];  // uniform: scalar load
-        while (bits) {
-            const int p = wd * 32 + __builtin_ctz(bits);
-            bits &= bits - 1;
-            const float cmax = __uint_as_float(G.cmax[p]);
-            if (cmax == 0.f) continue;   // the pose's upstream gradient is all zeros
-            const PoseLattice& P = G.poses[p];
-            const float s0 = P.s[0], s1 = P.s[1], s2 = P.s[2];
-            const float w0 = xv[0] - s0, w1 = xv[1] - s1, w2 = xv[2] - s2;
-            const float av = P.nh[0] * w0 + P.nh[1] * w1 + P.nh[2] * w2;
-            const float da = HS * P.dalpha;
-            int klo, khi;
-            if (step > 0.f) {
-                const float k0 = (av - da - near_) * inv_step, k1 = (av + da - near_) * inv_step;
-                klo = (int)ceilf(fmaxf(k0 - GATHER_K_SLACK, 0.f));
-                khi = (int)floorf(fminf(k1 + GATHER_K_SLACK, (float)(N - 1)));
-            } else {
-                klo = 0;
-                khi = (fabsf(av - near_) <= da) ? 0 : -1;
-            }
-            if (!(av == av)) khi = -1;
-            const float grw = P.gr[0] * w0 + P.gr[1] * w1 + P.gr[2] * w2;
-            const float4* __restrict__ q = G.q + (size_t)p * G.qn;
-            // a s + b - (first cell of the array): array index of a sample = floor of this + alpha (a d); the brick's voxel v
-            // is cell v + 1 (a sample in [-1, 8) has its lower tap in cells 0..8)
-            const float Bx = fmaf(a0, s0, b0 - (fv[0] - 1.f)), By = fmaf(a1, s1, b1 - (fv[1] - 1.f)), Bz = fmaf(a2, s2, b2 - (fv[2] - 1.f));
-            // ... and relative to the centre of the support box, for the windows
-            const float Cx = fmaf(a0, s0, b0 - fv[0]) - CO, Cy = fmaf(a1, s1, b1 - fv[1]) - CO, Cz = fmaf(a2, s2, b2 - fv[2]) - CO;
-            const float rcx = HS * P.rc[0], rcy = HS * P.rc[1], rcz = HS * P.rc[2], rcw = HS * P.hwr;
-
-            int cnt = 0;        // entries in the list (uniform)
-            // ---- the list's samples into the cells, the cells into the lanes' registers
-            auto drain = [&]() {
-                const int T = tsum;   // (all lanes read the one word)
-                if (T > 0) {
-                    if (!(cmax < INFINITY)) {
-#pragma unroll
-                        for (int z = 0; z < 8; ++z) acc[z] = NAN;
-                    } else {
-                        // scale = the power of two that puts T max|c| into [2^29, 2^30): exact to apply and to undo
-                        const int ex = (int)(__float_as_uint((float)T * cmax) >> 23) - 126;   // T max|c| < 2^ex
-                        const float cs = __uint_as_float((unsigned)(127 + 30 - ex) << 23), ics = __uint_as_float((unsigned)(127 - 30 + ex) << 23);
-                        // One flat loop per lane.  The 16 groups of four lanes take contiguous sixteenths of the list (rows far
-                        // apart: their samples fall into different cells) and the four lanes of a group take the four quarters
-                        // of a run -- so the lanes of one ds_add hit different words (the microbenchmark's 11.8 lanes per clock
-                        // rather than the 4.5 of four lanes per word), and a lane's consecutive samples are neighbours in memory.
-                        // The next sample's load is issued before this sample is evaluated.
-                        const int c4 = tid & 3;
-#if XVR_SP_BLOCKED
-                        const int per = (cnt + 15) >> 4, stride = 1;
-                        int idx = (tid >> 2) * per, rem = 0;
-                        const int end = idx + per < cnt ? idx + per : cnt;
-#else
-                        constexpr int stride = 16;
-                        int idx = tid >> 2, rem = 0;
-                        const int end = cnt;
-#endif
-                        const float4* __restrict__ ptr = q;
-                        float al = 0.f;
-                        // on to the lane's next sample: 1 = there is one at (ptr, al), 0 = an idle trip (the run is shorter than
-                        // this lane's quarter starts), -1 = the lane is done
-                        auto advance = [&]() -> int {
-                            --rem;
-                            ptr += XVR_SP_QUARTERS ? 1 : 4;
-                            if (rem > 0) return 1;
-                            if (idx >= end) return -1;
-                            const uint2 e = tab[idx];
-                            idx += stride;
-#if XVR_SP_QUARTERS
-                            const int n = (int)(e.x >> 24), m = (n + 3) >> 2, first = c4 * m;
-                            rem = n - first < m ? n - first : m;
-                            ptr = q + (e.x & 0xffffffu) + first;
-#else
-                            rem = ((int)(e.x >> 24) - c4 + 3) >> 2;
-                            ptr = q + (e.x & 0xffffffu) + c4;
-#endif
-                            al = __uint_as_float(e.y);
-                            return rem > 0 ? 1 : 0;
-                        };
-                        auto splat = [&](const float4 t, const float alc) {
-                            const float px = fmaf(alc, t.x, Bx), py = fmaf(alc, t.y, By), pz = fmaf(alc, t.z, Bz);
-                            const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
-                            const float rx = px - fx, ry = py - fy, rz = pz - fz;
-                            const int ix = (int)fx, iy = (int)fy, iz = (int)fz;
-                            // a sample outside [-1, 8) on some axis (the windows are conservative by a fraction of a pixel) touches
-                            // no voxel of the brick
-                            const bool ok = (unsigned)ix < (unsigned)(SP_DIM - 1) && (unsigned)iy < (unsigned)(SP_DIM - 1) && (unsigned)iz < (unsigned)(SP_DIM - 1);
-                            const float cz = ok ? t.w * cs : 0.f;
-                            const int base = ok ? (ix * SP_DIM + iy) * SP_DIM + iz : 0;
-                            const float z1 = rz * cz, z0 = cz - z1;   // (1 - rz) cz
-                            const float x1 = rx, x0 = 1.f - rx, y1 = ry, y0 = 1.f - ry;
-                            const float p00 = x0 * y0, p01 = x0 * y1, p10 = x1 * y0, p11 = x1 * y1;
-                            int* c = cell + base;
-#if XVR_SP_ABLATE_ADDS   // diagnostic build only (tools/tune_splat.py): one add instead of eight -- WRONG sums, the price of seven adds
-                            __hip_atomic_fetch_add(c, cvt_nearest(p00 * z0) + cvt_nearest(p00 * z1) + cvt_nearest(p01 * z0) + cvt_nearest(p01 * z1) +
-                                                   cvt_nearest(p10 * z0) + cvt_nearest(p10 * z1) + cvt_nearest(p11 * z0) + cvt_nearest(p11 * z1),
-                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            return;
-#endif
-                            __hip_atomic_fetch_add(c, cvt_nearest(p00 * z0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            __hip_atomic_fetch_add(c + 1, cvt_nearest(p00 * z1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            __hip_atomic_fetch_add(c + SP_DIM, cvt_nearest(p01 * z0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            __hip_atomic_fetch_add(c + SP_DIM + 1, cvt_nearest(p01 * z1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            __hip_atomic_fetch_add(c + SP_DIM * SP_DIM, cvt_nearest(p10 * z0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            __hip_atomic_fetch_add(c + SP_DIM * SP_DIM + 1, cvt_nearest(p10 * z1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            __hip_atomic_fetch_add(c + SP_DIM * SP_DIM + SP_DIM, cvt_nearest(p11 * z0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            __hip_atomic_fetch_add(c + SP_DIM * SP_DIM + SP_DIM + 1, cvt_nearest(p11 * z1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        };
-                        // two samples in flight, in two register sets (no copies between trips)
-                        // (the loads are unconditional -- ptr always points into q, at worst one element past a run -- so that
-                        //  no exec-masked join sits between a load and its use: the compiler would drain vmcnt there)
-                        int sa = advance(), sb;
-                        float4 ta = *ptr, tb;
-                        float ala = al, alb;
-                        while (sa >= 0) {
-                            sb = advance();
-                            tb = *ptr;
-                            alb = al;
-                            if (sa > 0) splat(ta, ala);
-                            if (sb < 0) break;
-                            sa = advance();
-                            ta = *ptr;
-                            ala = al;
-                            if (sb > 0) splat(tb, alb);
-                        }
-                        // the brick's voxels: cells 1..8 on every axis
-                        const int* col = cell + ((lx + 1) * SP_DIM + (ly + 1)) * SP_DIM + 1;
-#pragma unroll
-                        for (int z = 0; z < 8; ++z) acc[z] = fmaf((float)col[z], ics, acc[z]);
-                        for (int i = tid; i < SP_CELLS / 4; i += 64) reinterpret_cast<int4*>(cell)[i] = make_int4(0, 0, 0, 0);
-                    }
-                }
-                cnt = 0;
-                if (tid == 0) tsum = 0;
-            };
-            // append one run per lane (n <= 0: none); runs longer than an entry can say are split
-            auto append = [&](int off, int n, const float al) {
-                do {
-                    const int m = n < SP_RUN_MAX ? n : SP_RUN_MAX;
-                    const unsigned long long has = __ballot(m > 0);
-                    const int np = __popcll(has);
-                    if (cnt + np > SP_TAB) drain();
-                    const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(has >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)has, 0u));
-                    if (m > 0) {
-                        tab[pos] = make_uint2((unsigned)off | ((unsigned)m << 24), __float_as_uint(al));
-                        __hip_atomic_fetch_add(&tsum, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // samples in the list
-                        off += m;
-                        n -= m;
-                    }
-                    cnt += np;
-                } while (__any(n > 0));
-            };
-
-            for (int k = klo; k <= khi; ++k) {
-                const float al = linspace_sel(k, N, near_, far_, step);
-                if (al > 1e-12f) {
-                    // the table kernel's window arithmetic (step_setup / row_setup there) on the brick's support box
-                    const float inv = __builtin_amdgcn_rcpf(al);
-                    const float ic = fmaf(grw, inv, P.gr0);
-                    const float dlt = al - av;
-                    const float up = fminf(fminf(fmaf(P.rl[0], dlt, rcx), fmaf(P.rl[1], dlt, rcy)), fminf(fmaf(P.rl[2], dlt, rcz), rcw));
-                    const float dn = fminf(fminf(fmaf(-P.rl[0], dlt, rcx), fmaf(-P.rl[1], dlt, rcy)), fminf(fmaf(-P.rl[2], dlt, rcz), rcw));
-                    const int ilo = (int)ceilf(fmaxf(ic - fmaf(fmaxf(dn, 0.f), inv, GATHER_WIN_MARGIN), 0.f));
-                    const int ihi = (int)floorf(fminf(ic + fmaf(fmaxf(up, 0.f), inv, GATHER_WIN_MARGIN), Hm1));
-                    const float q0x = fmaf(al, P.e0[0], Cx), q0y = fmaf(al, P.e0[1], Cy), q0z = fmaf(al, P.e0[2], Cz);
-                    const float urx = al * P.era[0], ury = al * P.era[1], urz = al * P.era[2];
-                    const float rx = inv * P.rec[0], ry = inv * P.rec[1], rz = inv * P.rec[2];
-                    const float hx = fmaf(inv, HSR * P.hsr[0], jmargin), hy = fmaf(inv, HSR * P.hsr[1], jmargin), hz = fmaf(inv, HSR * P.hsr[2], jmargin);
-                    for (int i0 = ilo; i0 <= ihi; i0 += 64) {
-                        const int i = i0 + tid;
-                        const float fi = (float)i;
-                        const float qx = fmaf(fi, urx, q0x), qy = fmaf(fi, ury, q0y), qz = fmaf(fi, urz, q0z);
-                        const float mx = -qx * rx, my = -qy * ry, mz = -qz * rz;
-                        const float lo = fmaxf(fmaxf(mx - hx, my - hy), mz - hz);
-                        const float hiJ = fminf(fminf(mx + hx, my + hy), mz + hz);
-                        const int jlo = (int)ceilf(fmaxf(lo, 0.f));
-                        const int jhi = (int)floorf(fminf(hiJ, Wm1));
-                        append(i * G.qs + jlo, i <= ihi ? jhi - jlo + 1 : 0, al);
-                    }
-                } else {
-                    // alpha_k = 0: every ray's sample sits on the source; all pixels, if the source is inside the support box
-                    const bool hit = fabsf(Cx) < HS && fabsf(Cy) < HS && fabsf(Cz) < HS;
-                    if (hit)
-                        for (int i0 = 0; i0 < G.H; i0 += 64) append((i0 + tid) * G.qs, i0 + tid < G.H ? G.W : 0, al);
-                }
-            }
-            drain();
-        }
-    }
-    float* out = G.gvol + ((size_t)(ox + lx) * G.D1 + (oy + ly)) * G.D2 + oz;
-    if (ox + lx < G.D0 && oy + ly < G.D1) {
-#pragma unroll
-        for (int z = 0; z < 8; ++z)
-            if (oz + z < G.D2 && acc[z] != 0.f) out[z] += acc[z];
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1016,6 +780,9 @@ __global__ __launch_bounds__(64) void k_trilinear_splat_brick(GatherArgs G) {
 #ifndef XVR_S16_DEPTH
 #define XVR_S16_DEPTH 2
 #endif
+#ifndef XVR_S16_GROUP_STRIDE
+#define XVR_S16_GROUP_STRIDE 19
+#endif
 #ifndef XVR_S16_TAB
 #define XVR_S16_TAB 896
 #endif
@@ -1034,6 +801,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XVR_S16_WAV
     // list length, samples in the list, "redo in safe mode": two sets, alternating between visits, so that the set of visit
     // v is cleared (by thread 0, after v's second barrier) while nobody reads or writes it -- two barriers per visit suffice
     __shared__ int s_ctl[2][4];
+    // the pose constants of this visit and of the next one (PoseLattice's floats + max|c|): the next pose's are fetched
+    // while this pose's samples are splatted -- a visit's first use of them was 7000 clocks of exposed memory latency
+    constexpr int PW = (int)(sizeof(PoseLattice) / sizeof(float));
+    __shared__ float s_P[2][PW + 4];
     __shared__ int s_next[2];   // the brick this workgroup takes next (two slots: written for turn t + 1 while t may still be read)
     int par = 0;
     constexpr float HS = 8.5f, CO = 7.5f;   // samples that touch voxels 0..15 sit in [-1, 16): centre 7.5, half 8.5
@@ -1064,7 +835,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XVR_S16_WAV
     for (int turn = 0;; turn ^= 1) {
     if (tid == 0) s_next[turn] = (int)atomicAdd(G.flag + 1, 1u);
     __syncthreads();   // (also: the cells are clear, the previous brick's flush is done)
-    const int blk = s_next[turn];
+    const int blk = __builtin_amdgcn_readfirstlane(s_next[turn]);   // (scalar: everything per brick and per pose below is uniform)
     if (blk >= n0 * n1 * n2) break;
     int bx = blk / (n1 * n2), by = (blk / n2) % n1, bz = blk % n2;
 #if XVR_S16_CENTRE_OUT
@@ -1087,14 +858,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XVR_S16_WAV
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
-    for (int wd = 0; wd < G.words; ++wd) {
-        unsigned bits = G.cull[(size_t)brick_id * G.words + wd];  // uniform: scalar load
-        while (bits) {
-            const int p = wd * 32 + __builtin_ctz(bits);
-            bits &= bits - 1;
-            const float cmax = __uint_as_float(G.cmax[p]);
-            if (cmax == 0.f) continue;   // the pose's upstream gradient is all zeros
-            const PoseLattice P = G.poses[p];   // by value: uniform, lives in scalar registers across the barriers
+    // the brick's poses, one ahead: pc is this visit's pose, pn the next one's
+    int wd = 0;
+    unsigned bits = G.cull[(size_t)brick_id * G.words];  // uniform: scalar load
+    auto next_pose = [&]() -> int {
+        while (!bits) {
+            if (++wd >= G.words) return -1;
+            bits = G.cull[(size_t)brick_id * G.words + wd];
+        }
+        const int p = wd * 32 + __builtin_ctz(bits);
+        bits &= bits - 1;
+        return p;
+    };
+    auto fetch = [&](const int p) -> float {   // thread t <= PW: word t of the pose's constants
+        return tid < PW ? reinterpret_cast<const float*>(G.poses + p)[tid] : __uint_as_float(G.cmax[p]);
+    };
+    int pc = next_pose(), visit = 0;
+    if (pc >= 0 && tid <= PW) s_P[0][tid] = fetch(pc);
+    __syncthreads();
+    while (pc >= 0) {
+        {
+            const int p = pc, pn = next_pose();
+            float pre = 0.f;
+            if (pn >= 0 && tid <= PW) pre = fetch(pn);    // in flight during the visit; parked in s_P before the visit's last barrier
+            const int cur = visit & 1;
+            ++visit;
+            auto park = [&]() { if (pn >= 0 && tid <= PW) s_P[cur ^ 1][tid] = pre; };
+            pc = pn;
+            const float* Pf = s_P[cur];
+            const PoseLattice& P = *reinterpret_cast<const PoseLattice*>(Pf);
+            const float cmax = Pf[PW];
+            if (cmax == 0.f) { park(); __syncthreads(); continue; }   // the pose's upstream gradient is all zeros
             const float s0 = P.s[0], s1 = P.s[1], s2 = P.s[2];
             const float w0 = xv[0] - s0, w1 = xv[1] - s1, w2 = xv[2] - s2;
             const float av = uni(P.nh[0] * w0 + P.nh[1] * w1 + P.nh[2] * w2);
@@ -1109,7 +903,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XVR_S16_WAV
                 khi = (fabsf(av - near_) <= da) ? 0 : -1;
             }
             if (!(av == av)) khi = -1;
-            if (khi < klo) continue;
+            if (khi < klo) { park(); __syncthreads(); continue; }
             const float grw = uni(P.gr[0] * w0 + P.gr[1] * w1 + P.gr[2] * w2);
             const float4* __restrict__ q = G.q + (size_t)p * G.qn;
             // a s + b - (first cell of the array): array index of a sample = floor of this + alpha (a d); the brick's voxel v
@@ -1118,15 +912,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XVR_S16_WAV
             // ... and relative to the centre of the support box, for the windows
             const float Cx = uni(fmaf(a0, s0, b0 - fv[0]) - CO), Cy = uni(fmaf(a1, s1, b1 - fv[1]) - CO), Cz = uni(fmaf(a2, s2, b2 - fv[2]) - CO);
             const float rcx = HS * P.rc[0], rcy = HS * P.rc[1], rcz = HS * P.rc[2], rcw = HS * P.hwr;
-            // no more than this many samples of the pose can touch one voxel: lattice points inside a ball of radius sqrt 3
-            // (a voxel's 2-cube), from the three spacings of the sample lattice at the box's smallest alpha
+            // A voxel's sum of weights over the pose's samples is at most `tcell`: the samples are a lattice (pixel spacing dc
+            // along a row, rows dr apart, planes dn apart, all in voxels at the box's smallest alpha) and the weight w =
+            // hat x hat x hat is log-concave, so along a row sum <= integral / dc + max (<= 1), the row integrals are
+            // unimodal in the row index (sum <= plane integral / dr + max line integral <= sqrt 3), the plane integrals in the
+            // plane index (sum <= 1 / dn + max plane integral <= sqrt 3), and at most mr rows per plane and mp planes touch the
+            // voxel's 2-cube:   sum w <= (1 / (dc dr)) (1 / dn + sqrt 3) + mp (sqrt 3 / dc + mr).
+            // (The plain count of lattice points in the 2-cube is 4-11 x larger; the fixed-point LSB scales with this bound.)
             float tcell = INFINITY;
             {
                 const float amin = av - da;
                 if (amin > 1e-6f && step > 0.f) {
-                    const float two_r = 3.4641016f;
-                    const float mc = two_r / (amin * P.ecl) + 1.f, mr = two_r / (amin * P.rperp) + 1.f, mp = two_r * P.gn / step + 1.f;
-                    tcell = mc * mr * mp;
+                    const float r3 = 1.7320508f;
+                    const float idc = __builtin_amdgcn_rcpf(amin * P.ecl), idr = __builtin_amdgcn_rcpf(amin * P.rperp), idn = P.gn * inv_step;
+                    const float mp = 2.f * r3 * idn + 1.f, mr = 2.f * r3 * idr + 1.f;
+                    tcell = 1.02f * (idc * idr * (idn + r3) + mp * (r3 * idc + mr));
                     if (!(tcell == tcell)) tcell = INFINITY;
                 }
                 tcell = uni(tcell);
@@ -1147,7 +947,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XVR_S16_WAV
                     const int ex = (int)(__float_as_uint(bound) >> 23) - 126;   // bound < 2^ex
                     const float cs = uni(__uint_as_float((unsigned)(127 + 30 - ex) << 23)), ics = uni(__uint_as_float((unsigned)(127 - 30 + ex) << 23));
                     const int c4 = tid & 3;
-                    int idx = tid >> 2, rem = 0;
+                    // group g starts at run (19 g) mod 64: the 16 groups of a wavefront then work on runs at least two detector
+                    // rows apart (neighbouring rows' samples fall into the same cells: same-word adds serialise)
+                    int idx = (XVR_S16_GROUP_STRIDE * (tid >> 2)) & 63, rem = 0;
                     const float4* __restrict__ ptr = q;
                     float al = 0.f;
                     // on to the thread's next sample: 1 = there is one at (ptr, al), 0 = an idle trip (the run is shorter than
@@ -1213,6 +1015,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XVR_S16_WAV
                         if (sb > 0) splat(tb, alb);
                     }
                     XVR_TICK(3);
+                    park();
                     __syncthreads();   // every sample is in the cells
                     XVR_TICK(4);
                     if (tid == 0) { ctl[0] = 0; ctl[1] = 0; ctl[2] = 0; }
@@ -1230,6 +1033,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XVR_S16_WAV
 #pragma unroll
                         for (int z = 0; z < 16; ++z) acc[z] = NAN;
                     }
+                    park();
                     __syncthreads();
                     if (tid == 0) { ctl[0] = 0; ctl[1] = 0; ctl[2] = 0; }
                 }
@@ -1835,19 +1639,19 @@ int xvr_detail::launch_gather(bool siddon, const float* source, const float* tar
     // both are exact and give identical sums)
     static const bool use_table = [] { const char* e = getenv("XVR_DRR_GATHER_TABLE"); return !(e && e[0] == '0'); }();
     static const bool siddon_v1 = [] { const char* e = getenv("XVR_DRR_SIDDON_GATHER_BLOCK"); return e && e[0] == '1'; }();
-    // trilinear without clip / per-channel masks: the brick-local fixed-point splat on 16^3 bricks (k_trilinear_splat_b16);
-    // XVR_DRR_GATHER_SPLAT=8 selects its 8^3 single-wavefront form, =0 the voxel-driven table gather (A/B switches)
-    static const int splat_mode = [] { const char* e = getenv("XVR_DRR_GATHER_SPLAT"); return !e ? 16 : (e[0] == '0' ? 0 : (e[0] == '8' ? 8 : 16)); }();
-    const bool use_splat = splat_mode != 0, splat16 = splat_mode == 16;
-    const bool splat = !siddon && use_splat && !sp->clip_to_volume && !mask && (splat16 || (unsigned)((n / gw) * (gw + 1)) <= TAB_MAX_RAYS);
+    // trilinear without clip / per-channel masks: the brick-local fixed-point splat on 16^3 bricks (k_trilinear_splat_b16)
+    // unless XVR_DRR_GATHER_SPLAT=0 (A/B switch: the voxel-driven table gather)
+    // (read at every launch -- a getenv -- so that the tests can compare the two in one process)
+    const bool use_splat = [] { const char* e = getenv("XVR_DRR_GATHER_SPLAT"); return !(e && e[0] == '0'); }();
+    const bool splat = !siddon && use_splat && !sp->clip_to_volume && !mask;
     if (siddon && (siddon_v1 || G.cells)) { G.bd[0] = 4; G.bd[1] = 8; G.bd[2] = 8; }
     else if (siddon) { G.bd[0] = G.bd[1] = G.bd[2] = 8; }
     else {
-        if (G.clip || G.mask || splat) G.V = 2;   // (the pixel-major kernel is written for 2x2x2 blocks; the splat's brick is 8^3 too)
+        if (G.clip || G.mask) G.V = 2;   // (the pixel-major kernel is written for 2x2x2 blocks)
         G.bd[0] = G.bd[1] = G.bd[2] = 4 * G.V;
     }
     if (splat) G.cmax = reinterpret_cast<unsigned*>(G.q2);   // (q2 is the clip / siddon kernels')
-    if (splat && splat16) G.bd[0] = G.bd[1] = G.bd[2] = 16;
+    if (splat) G.bd[0] = G.bd[1] = G.bd[2] = 16;
     G.cull = reinterpret_cast<unsigned*>(ws + ws_cull_off(B, n));
     G.words = (B + 31) / 32;
     G.gvol = grad_volume;
@@ -1871,7 +1675,7 @@ int xvr_detail::launch_gather(bool siddon, const float* source, const float* tar
     else if (G.clip && G.mask) hipLaunchKernelGGL((k_trilinear_gather_px<true, true>), dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
     else if (G.clip) hipLaunchKernelGGL((k_trilinear_gather_px<true, false>), dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
     else if (G.mask) hipLaunchKernelGGL((k_trilinear_gather_px<false, true>), dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
-    else if (splat && splat16) {
+    else if (splat) {
         // persistent workgroups: as many as run at once (the occupancy the runtime reports x the CUs), never more than bricks
         static const int resident = [] {
             int per_cu = 0, dev = 0, cus = 0;
@@ -1881,7 +1685,6 @@ int xvr_detail::launch_gather(bool siddon, const float* source, const float* tar
         }();
         hipLaunchKernelGGL(k_trilinear_splat_b16, dim3((unsigned)(bricks < resident ? bricks : resident)), dim3(256), 0, (hipStream_t)stream, G);
     }
-    else if (splat) hipLaunchKernelGGL(k_trilinear_splat_brick, dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
     else if (G.V == 2 && use_table && (unsigned)G.qn <= TAB_MAX_RAYS) hipLaunchKernelGGL(k_trilinear_gather_tab, dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
     else if (G.V == 2) hipLaunchKernelGGL(k_trilinear_gather_vol<2>, dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
     else hipLaunchKernelGGL(k_trilinear_gather_vol<1>, dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
