@@ -18,6 +18,7 @@ VARIANTS = [
     ("b16_gs1", ["XVR_S16_GROUP_STRIDE=1"], "1"),
     ("table", [], "0"),
 ]
+RENDERER = "trilinear"
 
 
 def lib(name):
@@ -31,10 +32,10 @@ if sys.argv[1:] == ["build"]:
 else:
     for name, defs, mode in VARIANTS:
         env = dict(os.environ, XVR_DRR_LIBRARY=str(lib(name)), XVR_DRR_GATHER_SPLAT=mode)
-        out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "6", "--warmup", "2", "--no-cpu-baseline"],
+        out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--renderer", RENDERER],
                              env=env, capture_output=True, text=True)
         try:
             d = json.loads(out.stdout.strip().splitlines()[-1])
-            print(f"{name} {defs}: step {d['ms_per_step']:.2f} ms, voxel gradient {d['kernels']['trilinear_backward[vol]']['avg_ms']:.3f} ms", flush=True)
+            print(f"{name} {defs}: step {d['ms_per_step']:.2f} ms, voxel gradient {d['kernels'][RENDERER + '_backward[vol]']['avg_ms']:.3f} ms", flush=True)
         except Exception as e:  # noqa: BLE001
             print(f"{name}: failed ({e}) {out.stderr[-300:]}", flush=True)

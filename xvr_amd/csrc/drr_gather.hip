@@ -1602,6 +1602,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 }
 
 
+
+// (Round 2 also built the RAY-driven counterpart of the trilinear splat for Siddon -- per (16^3 brick, pose) visit the rays
+//  of the brick's pixel footprint walk its voxels with the forward's plane arithmetic and add segment * g * L to fixed-point
+//  LDS cells, one ds_add_u32 per segment -- and dropped it: parity-green, 17.5-21 ms at C3 against the 12.2 ms of
+//  k_siddon_gather_vol2.  A ray crosses only ~20 voxels of a brick, so the per-(ray, brick) set-up (three times a step) and
+//  the divergence between rays of 0..45 steps leave 48 % of the lanes live in the walk and 25 % in the set-up: 1.16e10
+//  vector instructions against the gather's 7.3e9.  One lesson kept: where a walk is (re)started mid-ray, the start voxel
+//  must come from the forward's own plane alphas, alpha(previous plane) <= start < alpha(next plane), not from the
+//  position -- for a ray grazing a plane family the two disagree over a visible stretch, an ulp of the plane's position
+//  divided by the direction cosine.)
+
 }  // namespace
 
 // Set up the workspace and launch prep -> cull -> gather.  The caller launches the scatter fallback
