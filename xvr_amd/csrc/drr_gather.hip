@@ -114,7 +114,11 @@ __global__ __launch_bounds__(WG) void k_gather_prep(GatherArgs G) {
     if (G.cmax) {   // max |c| of the pose: the fixed-point scale of the brick-local splat
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) cabs = fmaxf(cabs, __shfl_xor(cabs, o));
-        if ((threadIdx.x & 63) == 0 && cabs > 0.f) atomicMax(G.cmax + b, __float_as_uint(cabs));
+        // (one word per pose and a thousand wavefronts: only a wavefront that would RAISE the maximum touches it -- a handful
+        //  do; unconditional atomics serialised into 0.56 ms.  A stale read only costs a redundant atomic.)
+        if ((threadIdx.x & 63) == 0 && cabs > 0.f &&
+            __float_as_uint(cabs) > __hip_atomic_load(G.cmax + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(G.cmax + b, __float_as_uint(cabs));
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) dev = fmaxf(dev, __shfl_xor(dev, o));
@@ -948,7 +952,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XVR_S16_WAV
                     const float cs = uni(__uint_as_float((unsigned)(127 + 30 - ex) << 23)), ics = uni(__uint_as_float((unsigned)(127 - 30 + ex) << 23));
                     const int c4 = tid & 3;
                     // group g starts at run (19 g) mod 64: the 16 groups of a wavefront then work on runs at least two detector
-                    // rows apart (neighbouring rows' samples fall into the same cells: same-word adds serialise)
+                    // rows apart (neighbouring rows' samples fall into the same cells: same-word adds serialise).  Static shares
+                    // leave the slowest thread 18-20 trips for a mean of 13; handing quarters out by a counter instead was
+                    // measured SLOWER (10.7 against 8.9 ms: a ds_add_rtn and a dependent read on every pull).
                     int idx = (XVR_S16_GROUP_STRIDE * (tid >> 2)) & 63, rem = 0;
                     const float4* __restrict__ ptr = q;
                     float al = 0.f;
