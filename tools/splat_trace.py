@@ -44,10 +44,10 @@ tick = 1e-8   # wall_clock64: 100 MHz
 t0 = (t0 - t0.min()) * tick * 1e3
 t1 = (t1 - t[:, 0].min()) * tick * 1e3
 dur = t1 - t0
-print(f"launch {t1.max():.2f} ms; workgroups {n}, with work {(visits > 0).sum()}; visits {visits.sum():.4g}, samples {samples.sum():.4g}")
+print(f"launch {t1.max():.2f} ms; workgroups {n}, with work {(visits > 0).sum()}; visits {visits.sum():.4g}, runs {samples.sum():.4g}")
 print(f"workgroup-time {dur.sum():.1f} ms = {dur.sum() / t1.max():.0f} workgroups resident on average (1024 = 4 per CU)")
 w = visits > 0
-print(f"per visit: {1e3 * dur[w].sum() / visits.sum():.2f} us, {samples.sum() / visits.sum():.0f} samples")
+print(f"per visit: {1e3 * dur[w].sum() / visits.sum():.2f} us, {samples.sum() / visits.sum():.0f} runs")
 print("duration of a workgroup with work: median %.3f ms, 90 %% %.3f, 99 %% %.3f, max %.3f" % tuple(np.percentile(dur[w], [50, 90, 99, 100])))
 tk = t[:, 4:10].sum(axis=0)
 names = ["pose set-up", "enumeration", "wait: list barrier", "splat loop", "wait: cells barrier", "flush"]
