@@ -14,8 +14,8 @@ sys.path.insert(0, str(ROOT))
 # (name, defines, XVR_DRR_GATHER_SPLAT: 0 = the table gather)
 VARIANTS = [
     ("b16", [], "1"),
+    ("b16_quarters", ["XVR_S16_SHARES=0"], "1"),
     ("b16_noadds", ["XVR_SP_ABLATE_ADDS=1"], "1"),
-    ("b16_gs1", ["XVR_S16_GROUP_STRIDE=1"], "1"),
     ("table", [], "0"),
 ]
 RENDERER = "trilinear"

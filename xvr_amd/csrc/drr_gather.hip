@@ -784,6 +784,9 @@ __device__ __forceinline__ int cvt_nearest(float v) {
 #ifndef XVR_S16_DEPTH
 #define XVR_S16_DEPTH 2
 #endif
+#ifndef XVR_S16_SHARES   // 1: every thread the same number of samples (prefix over the list); 0: quarters of runs, round robin
+#define XVR_S16_SHARES 1
+#endif
 #ifndef XVR_S16_GROUP_STRIDE
 #define XVR_S16_GROUP_STRIDE 19
 #endif
@@ -804,7 +807,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XVR_S16_WAV
     __shared__ uint2 tab[S16_TAB];          // x = first element of the run in q;  y = count << 8 | step - kbase
     // list length, samples in the list, "redo in safe mode": two sets, alternating between visits, so that the set of visit
     // v is cleared (by thread 0, after v's second barrier) while nobody reads or writes it -- two barriers per visit suffice
-    __shared__ int s_ctl[2][4];
+    __shared__ __attribute__((aligned(16))) int s_ctl[2][4];   // [0] runs in the list, [1] samples in the list, [2] redo
+#if XVR_S16_SHARES
+    __shared__ unsigned run_start[S16_TAB]; // samples in the runs before this one (list order)
+#endif
     // the pose constants of this visit and of the next one (PoseLattice's floats + max|c|): the next pose's are fetched
     // while this pose's samples are splatted -- a visit's first use of them was 7000 clocks of exposed memory latency
     constexpr int PW = (int)(sizeof(PoseLattice) / sizeof(float));
@@ -953,6 +959,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XVR_S16_WAV
                     const float bound = fminf((float)cnt * (float)G.W, tcell) * cmax;
                     const int ex = (int)(__float_as_uint(bound) >> 23) - 126;   // bound < 2^ex
                     const float cs = uni(__uint_as_float((unsigned)(127 + 30 - ex) << 23)), ics = uni(__uint_as_float((unsigned)(127 - 30 + ex) << 23));
+#if XVR_S16_SHARES
+                    // every thread the same number of samples (+-1): thread t takes samples [t T / 256, (t + 1) T / 256) of the
+                    // list, found by bisection on the runs' offsets; neighbouring threads are a share (~13 pixels, 7 voxels)
+                    // apart.  (Static quarters of runs left the slowest thread 18-20 trips for a mean of 13.)
+                    const unsigned T = (unsigned)ctl[1];
+                    const unsigned lo = (unsigned)(((unsigned long long)tid * T) >> 8), hi = (unsigned)(((unsigned long long)(tid + 1) * T) >> 8);
+                    int e = 0;
+#pragma unroll
+                    for (int stp = 512; stp > 0; stp >>= 1) {
+                        const int c = e + stp;
+                        if (c < cnt && run_start[c] <= lo) e = c;
+                    }
+                    int left = (int)(hi - lo), rem = 0;   // samples of the share / of the current run still to come (incl. this one)
+                    const float4* __restrict__ ptr = q;
+                    float al = 0.f;
+                    int first = (int)(lo - run_start[e]);       // (only the first run of a share is entered in its middle)
+                    --e;
+                    // on to the thread's next sample: 1 = there is one at (ptr, al), -1 = the thread is done
+                    auto advance = [&]() -> int {
+                        if (left <= 0) return -1;
+                        --left;
+                        --rem;
+                        ++ptr;
+                        if (rem > 0) return 1;
+                        ++e;
+                        const uint2 en = tab[e < cnt ? e : cnt - 1];
+                        rem = (int)(en.y >> 8) - first;
+                        ptr = q + en.x + first;
+                        first = 0;
+                        al = linspace_sel(kbase + (int)(en.y & 255u), N, near_, far_, step);   // (recomputed: no second LDS read)
+                        return 1;
+                    };
+#else
                     const int c4 = tid & 3;
                     // group g starts at run (19 g) mod 64: the 16 groups of a wavefront then work on runs at least two detector
                     // rows apart (neighbouring rows' samples fall into the same cells: same-word adds serialise).  Static shares
@@ -976,6 +1015,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XVR_S16_WAV
                         al = linspace_sel(kbase + (int)(e.y & 255u), N, near_, far_, step);   // (recomputed: no second LDS read)
                         return rem > 0 ? 1 : 0;
                     };
+#endif
                     auto splat = [&](const float4 t, const float alc) {
                         const float px = fmaf(alc, t.x, Bx), py = fmaf(alc, t.y, By), pz = fmaf(alc, t.z, Bz);
                         const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
@@ -1056,6 +1096,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XVR_S16_WAV
                 const unsigned long long has = __ballot(n > 0);
                 const int np = __popcll(has);
                 if (np == 0) return true;
+#if XVR_S16_SHARES
+                // samples of the lanes before this one (wavefront scan by DPP: four shifts within the rows of 16 lanes, two
+                // row broadcasts) and of the whole wavefront; runs and samples are reserved by ONE 64-bit add, so that the
+                // list's order is the order of the sample offsets
+                int x = n;
+                x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);   // row_shr:1
+                x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);   // row_shr:2
+                x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);   // row_shr:4
+                x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);   // row_shr:8
+                x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+                x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+                const int wsum = __builtin_amdgcn_readlane(x, 63);
+                unsigned long long got = 0ull;
+                if (lane == 0)
+                    got = __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(&s_ctl[par][0]),
+                                                 (unsigned long long)(unsigned)np | ((unsigned long long)(unsigned)wsum << 32),
+                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int base = __builtin_amdgcn_readfirstlane((int)(unsigned)got);
+                const int sbase = __builtin_amdgcn_readfirstlane((int)(unsigned)(got >> 32));
+                if (base + np > S16_TAB) return false;
+                if (n > 0) {
+                    const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(has >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)has, 0u));
+                    tab[pos] = make_uint2((unsigned)off, ((unsigned)n << 8) | (unsigned)slot);
+                    run_start[pos] = (unsigned)(sbase + x - n);
+                }
+                return true;
+#else
                 int base = 0;
                 if (lane == 0) base = __hip_atomic_fetch_add(&s_ctl[par][0], np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 base = __builtin_amdgcn_readfirstlane(base);
@@ -1065,6 +1132,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XVR_S16_WAV
                     tab[pos] = make_uint2((unsigned)off, ((unsigned)n << 8) | (unsigned)slot);
                 }
                 return true;
+#endif
             };
             // the rows i0 + lane of step alpha = al (the table kernel's window arithmetic on the brick's support box)
             struct StepC { float q0x, q0y, q0z, urx, ury, urz, rx, ry, rz, hx, hy, hz; int ilo, ihi; };
