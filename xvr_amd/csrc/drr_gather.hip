@@ -36,6 +36,8 @@ namespace {
 // transpose of the forward gather, up to summation order -- and it is deterministic.
 // =============================================================================================
 
+constexpr int CMAX_STRIDE = 32;   // words between two poses' max |c| (GatherArgs.cmax): one 128-byte line each
+
 __device__ __forceinline__ void cross3(const float* a, const float* b, float* o) {
     o[0] = a[1] * b[2] - a[2] * b[1];
     o[1] = a[2] * b[0] - a[0] * b[2];
@@ -114,11 +116,12 @@ __global__ __launch_bounds__(WG) void k_gather_prep(GatherArgs G) {
     if (G.cmax) {   // max |c| of the pose: the fixed-point scale of the brick-local splat
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) cabs = fmaxf(cabs, __shfl_xor(cabs, o));
-        // (one word per pose and a thousand wavefronts: only a wavefront that would RAISE the maximum touches it -- a handful
-        //  do; unconditional atomics serialised into 0.56 ms.  A stale read only costs a redundant atomic.)
+        // (a thousand wavefronts per pose meet in its word: the poses' words sit in different cache lines -- packed, the 116
+        //  of the benchmark shared four lines and 1.2e5 L2 atomics queued up behind each other for 0.6 ms -- and only a
+        //  wavefront that would RAISE the maximum writes.  A stale read only costs a redundant atomic.)
         if ((threadIdx.x & 63) == 0 && cabs > 0.f &&
-            __float_as_uint(cabs) > __hip_atomic_load(G.cmax + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            atomicMax(G.cmax + b, __float_as_uint(cabs));
+            __float_as_uint(cabs) > __hip_atomic_load(G.cmax + (size_t)b * G.cmax_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(G.cmax + (size_t)b * G.cmax_stride, __float_as_uint(cabs));
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) dev = fmaxf(dev, __shfl_xor(dev, o));
@@ -881,7 +884,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XVR_S16_WAV
         return p;
     };
     auto fetch = [&](const int p) -> float {   // thread t <= PW: word t of the pose's constants
-        return tid < PW ? reinterpret_cast<const float*>(G.poses + p)[tid] : __uint_as_float(G.cmax[p]);
+        return tid < PW ? reinterpret_cast<const float*>(G.poses + p)[tid] : __uint_as_float(G.cmax[(size_t)p * G.cmax_stride]);
     };
     int pc = next_pose(), visit = 0;
     if (pc >= 0 && tid <= PW) s_P[0][tid] = fetch(pc);
@@ -1739,14 +1742,17 @@ int xvr_detail::launch_gather(bool siddon, const float* source, const float* tar
         if (G.clip || G.mask) G.V = 2;   // (the pixel-major kernel is written for 2x2x2 blocks)
         G.bd[0] = G.bd[1] = G.bd[2] = 4 * G.V;
     }
-    if (splat) G.cmax = reinterpret_cast<unsigned*>(G.q2);   // (q2 is the clip / siddon kernels')
+    if (splat) {   // (q2, [B][n] float2, is the clip / siddon kernels': a line per pose where n >= 16, what fits otherwise)
+        G.cmax = reinterpret_cast<unsigned*>(G.q2);
+        G.cmax_stride = 2 * n < CMAX_STRIDE ? 2 * n : CMAX_STRIDE;
+    }
     if (splat) G.bd[0] = G.bd[1] = G.bd[2] = 16;
     G.cull = reinterpret_cast<unsigned*>(ws + ws_cull_off(B, n));
     G.words = (B + 31) / 32;
     G.gvol = grad_volume;
     *flag_out = G.flag;
     hipError_t e = hipMemsetAsync(G.flag, 0, 16, (hipStream_t)stream);
-    if (e == hipSuccess && G.cmax) e = hipMemsetAsync(G.cmax, 0, (size_t)B * sizeof(unsigned), (hipStream_t)stream);
+    if (e == hipSuccess && G.cmax) e = hipMemsetAsync(G.cmax, 0, (size_t)B * G.cmax_stride * sizeof(unsigned), (hipStream_t)stream);
     if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
     hipLaunchKernelGGL(k_gather_prep, dim3((unsigned)((n + WG - 1) / WG), (unsigned)B), dim3(WG), 0,
                        (hipStream_t)stream, G);
