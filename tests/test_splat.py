@@ -94,3 +94,36 @@ def test_splat_skips_a_pose_whose_upstream_gradient_is_zero_and_flags_a_non_fini
     # voxels only the first pose touches keep their finite value
     only_first = (_grad(case, spec, torch.cat([w[:1], torch.zeros_like(w[1:])]), 44, monkeypatch) != 0) & torch.isfinite(bad)
     assert only_first.any()
+
+
+@pytest.mark.parametrize("kw,masked", [
+    (dict(n_points=70, clip_to_volume=True), False),
+    (dict(n_points=45, clip_to_volume=True, near=0.1, far=0.95), False),
+    (dict(n_points=60), True),
+    (dict(n_points=50, norm_dims_offset=-1), True),
+], ids=["clip", "clip-near-far", "mask-per-channel", "mask-per-channel-dims-1"])
+@pytest.mark.parametrize("shape,hw", [((40, 36, 44), (48, 40)), ((9, 7, 11), (24, 20)), ((33, 17, 49), (31, 57))])
+def test_ray_major_splat_equals_the_voxel_driven_gather_and_the_scatter(kw, masked, shape, hw, monkeypatch):
+    """k_trilinear_splat_px (clip_to_volume, masks with a per-channel gradient) against k_trilinear_gather_px
+    (XVR_DRR_GATHER_SPLAT=0) and the atomic scatter."""
+    from xvr_amd import renderers
+    from xvr_amd.spec import RenderSpec
+
+    spec = RenderSpec(renderer="trilinear", **kw)
+    case = make_case(seed=41, shape=shape, height=hw[0], width=hw[1], delx=0.9 * max(shape) / max(hw), n_labels=4,
+                     xyz=((2.0, 300.0, -1.0), (-1.5, 200.0, 3.0)))
+    C = 4 if masked else 1
+    w = torch.randn(2, C, hw[0] * hw[1], generator=torch.Generator().manual_seed(8))
+    mask = case["mask"] if masked else None
+    out = []
+    for splat, gather in ((True, True), (False, True), (False, False)):
+        monkeypatch.setenv("XVR_DRR_GATHER_SPLAT", "1" if splat else "0")
+        renderers.VOXEL_GATHER = gather
+        try:
+            out.append(_hip_render(case, spec, mask=mask, grid_w=hw[1], grads=True, w=w)[1])
+        finally:
+            renderers.VOXEL_GATHER = True
+    assert out[0].abs().max() > 0
+    # (under clip the fixed-point bound is a count of rays x samples, 4-10 x looser than the lattice bound of the plain splat)
+    _close(out[0], out[1], 4e-5 if kw.get("clip_to_volume") else 2e-5, "ray-major splat vs voxel-driven pixel-major gather")
+    _close(out[0], out[2], 4e-5, "ray-major splat vs scatter")

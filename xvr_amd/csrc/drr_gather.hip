@@ -77,7 +77,17 @@ __global__ __launch_bounds__(WG) void k_gather_prep(GatherArgs G) {
             // a * d: the gather forms a (s + alpha d) + b - v as fma(alpha, a d, a s + b - v) (a = 1 for the default index map)
             float4* row = G.q + (size_t)b * G.qn + (size_t)i * G.qs;
             row[j] = make_float4(G.sp.a[0] * ddx, G.sp.a[1] * ddy, G.sp.a[2] * ddz, c);
-            cabs = (c == c) ? fabsf(c) : INFINITY;   // (a NaN counts as infinite: the splat poisons what the pose touches)
+            if (G.mask && G.cmax) {   // the splat's bound needs the largest upstream value over the channels
+                float gm = 0.f;
+                for (int ch = 0; ch < G.C; ++ch) {
+                    const float g = G.gout[((size_t)b * G.C + ch) * G.n + r];
+                    gm = (g == g) ? fmaxf(gm, fabsf(g)) : INFINITY;
+                }
+                cabs = c * gm;
+                cabs = (cabs == cabs) ? fabsf(cabs) : INFINITY;
+            } else {
+                cabs = (c == c) ? fabsf(c) : INFINITY;   // (a NaN counts as infinite: the splat poisons what the pose touches)
+            }
             if (j == G.W - 1) row[G.W] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (G.clip) {
                 // the ray's own [alpha_min, alpha_max], computed exactly as ray_setup() does for the forward; the image is
@@ -94,6 +104,16 @@ __global__ __launch_bounds__(WG) void k_gather_prep(GatherArgs G) {
                 if (!(hi < 1.f)) hi = 1.f;
                 row[j].w = c * fmaxf(hi - lo, 0.f);
                 G.q2[(size_t)b * G.n + r] = make_float2(lo, hi);
+                if (G.cmax) {
+                    // a ray's samples sit span * L_x / (N - 1) apart (L_x = |a d|, its length in index space): at most m of them
+                    // inside one voxel's 2-cube, each worth |c| span at most
+                    const float span = fmaxf(hi - lo, 0.f), N1 = (float)(G.sp.n_points > 1 ? G.sp.n_points - 1 : 1);
+                    const float lx = sqrtf(G.sp.a[0] * ddx * G.sp.a[0] * ddx + G.sp.a[1] * ddy * G.sp.a[1] * ddy + G.sp.a[2] * ddz * G.sp.a[2] * ddz);
+                    const float gap = span * lx * (G.sp.far_ - G.sp.near_) / N1;
+                    const float m = gap > 0.f ? fminf(3.4641016f / gap + 1.f, (float)G.sp.n_points) : (float)G.sp.n_points;
+                    cabs = cabs * span * m;
+                    if (!(cabs == cabs)) cabs = INFINITY;
+                }
             }
         } else {
             // the ray's own integration interval, computed exactly as ray_setup() does for the forward
@@ -1245,6 +1265,259 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XVR_S16_WAV
 }
 
 // ---------------------------------------------------------------------------------------------
+// The brick-local splat, RAY-major: for the renders whose samples cannot be enumerated as runs on shared planes.
+//   CLIP  spec.clip_to_volume: alpha_k = alpha_min(ray) + u_k (alpha_max - alpha_min)(ray) (k_trilinear_gather_px below);
+//   MASK  mask -> channels with a gradient that differs between channels: a sample's upstream value is
+//         gout[b][label(sample)][ray].
+// Same bricks, cells, fixed point, flush, persistent workgroups and pose prefetch as k_trilinear_splat_b16; per (brick, pose)
+// visit the threads take the rays f = thread, thread + 256, ... of the brick's pixel footprint (bounding box of the 8
+// projected corners of its support box), clip each against the support box (slab test) and evaluate its samples inside with
+// the forward's own alpha arithmetic.  A ray has ~5-25 samples in a brick and many rays of the footprint miss it: a lane
+// whose ray is done waits until a quarter of the wavefront is idle, then those lanes set up their next rays together.
+// The scale's bound on a voxel's sum: MASK alone -- the samples are the lattice of k_trilinear_splat_b16, same bound, with
+// max |c g| over rays and channels; CLIP -- (rays that can cross a voxel's 2-cube) x max over the rays of (samples of the ray
+// inside the 2-cube x |c| span), both from k_gather_prep.
+// ---------------------------------------------------------------------------------------------
+template <bool CLIP, bool MASK>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 6))) void k_trilinear_splat_px(GatherArgs G) {
+    if (*G.flag > __float_as_uint(GATHER_DEV_TOL)) return;  // not a lattice: the scatter kernel runs instead
+    __shared__ __attribute__((aligned(16))) int cell[S16_CELLS];
+    constexpr int PW = (int)(sizeof(PoseLattice) / sizeof(float));
+    __shared__ float s_P[2][PW + 4];
+    __shared__ int s_next[2];
+    constexpr float HS = 8.5f, CO = 7.5f;
+    const int tid = threadIdx.x;
+    const int lx = tid >> 4, ly = tid & 15;
+    const int N = G.sp.n_points;
+    const float near_ = G.sp.near_, far_ = G.sp.far_;
+    const float step = N > 1 ? (far_ - near_) / (float)(N - 1) : 0.f;
+    const float inv_step = step > 0.f ? 1.f / step : 0.f;
+    const float a0 = G.sp.a[0], a1 = G.sp.a[1], a2 = G.sp.a[2];
+    const float b0 = G.sp.b[0], b1 = G.sp.b[1], b2 = G.sp.b[2];
+    const float ea0 = HS / a0, ea1 = HS / a1, ea2 = HS / a2;   // half-size of the support box, in x coordinates
+    const int n0 = (G.D0 + 15) / 16, n1 = (G.D1 + 15) / 16, n2 = (G.D2 + 15) / 16;
+    for (int i = tid; i < S16_CELLS / 4; i += 256) reinterpret_cast<int4*>(cell)[i] = make_int4(0, 0, 0, 0);
+
+    for (int turn = 0;; turn ^= 1) {
+    if (tid == 0) s_next[turn] = (int)atomicAdd(G.flag + 1, 1u);
+    __syncthreads();   // (also: the cells are clear, the previous brick's flush is done)
+    const int blk = __builtin_amdgcn_readfirstlane(s_next[turn]);
+    if (blk >= n0 * n1 * n2) break;
+    int bx = blk / (n1 * n2), by = (blk / n2) % n1, bz = blk % n2;
+    bx = (bx & 1) ? (n0 >> 1) - ((bx + 1) >> 1) : (n0 >> 1) + (bx >> 1);
+    by = (by & 1) ? (n1 >> 1) - ((by + 1) >> 1) : (n1 >> 1) + (by >> 1);
+    bz = (bz & 1) ? (n2 >> 1) - ((bz + 1) >> 1) : (n2 >> 1) + (bz >> 1);
+    const int brick_id = (bx * n1 + by) * n2 + bz;
+    const int ox = bx * 16, oy = by * 16, oz = bz * 16;
+    const float fv[3] = {(float)ox, (float)oy, (float)oz};
+    float xv[3];  // centre of the support box in x coordinates
+#pragma unroll
+    for (int i = 0; i < 3; ++i) xv[i] = uni((fv[i] + CO - G.sp.b[i]) / G.sp.a[i]);
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    int wd = 0;
+    unsigned bits = G.cull[(size_t)brick_id * G.words];
+    auto next_pose = [&]() -> int {
+        while (!bits) {
+            if (++wd >= G.words) return -1;
+            bits = G.cull[(size_t)brick_id * G.words + wd];
+        }
+        const int p = wd * 32 + __builtin_ctz(bits);
+        bits &= bits - 1;
+        return p;
+    };
+    auto fetch = [&](const int p) -> float {
+        return tid < PW ? reinterpret_cast<const float*>(G.poses + p)[tid] : __uint_as_float(G.cmax[(size_t)p * G.cmax_stride]);
+    };
+    int pc = next_pose(), visit = 0;
+    if (pc >= 0 && tid <= PW) s_P[0][tid] = fetch(pc);
+    __syncthreads();
+    while (pc >= 0) {
+        const int p = pc, pn = next_pose();
+        float pre = 0.f;
+        if (pn >= 0 && tid <= PW) pre = fetch(pn);
+        const int cur = visit & 1;
+        ++visit;
+        pc = pn;
+        const float* Pf = s_P[cur];
+        const PoseLattice& P = *reinterpret_cast<const PoseLattice*>(Pf);
+        const float cmax = Pf[PW];
+        const float s0 = P.s[0], s1 = P.s[1], s2 = P.s[2];
+        const float w0 = xv[0] - s0, w1 = xv[1] - s1, w2 = xv[2] - s2;
+        const float av = uni(P.nh[0] * w0 + P.nh[1] * w1 + P.nh[2] * w2);
+        const float en0 = P.nh[0] * ea0, en1 = P.nh[1] * ea1, en2 = P.nh[2] * ea2;
+        const float da = fabsf(en0) + fabsf(en1) + fabsf(en2);
+        const float amin = av - da, amax = av + da;   // alpha range of the support box on this pose's rays
+        // pixel footprint: bounding box of the box's 8 projected corners; every ray when the box reaches the source plane
+        int jlo = 0, jhi = -1, ilo = 0, ihi = -1;
+        if (cmax != 0.f && amin > 1e-6f && amax >= G.cull_lo && amin <= G.cull_hi) {
+            const float nj = P.gc[0] * w0 + P.gc[1] * w1 + P.gc[2] * w2;
+            const float ni = P.gr[0] * w0 + P.gr[1] * w1 + P.gr[2] * w2;
+            const float ec0 = P.gc[0] * ea0, ec1 = P.gc[1] * ea1, ec2 = P.gc[2] * ea2;
+            const float er0 = P.gr[0] * ea0, er1 = P.gr[1] * ea1, er2 = P.gr[2] * ea2;
+            float jmn = INFINITY, jmx = -INFINITY, imn = INFINITY, imx = -INFINITY;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float sx = (c & 4) ? 1.f : -1.f, sy = (c & 2) ? 1.f : -1.f, sz = (c & 1) ? 1.f : -1.f;
+                const float inv = 1.f / (av + sx * en0 + sy * en1 + sz * en2);
+                const float jv = (nj + sx * ec0 + sy * ec1 + sz * ec2) * inv, iv = (ni + sx * er0 + sy * er1 + sz * er2) * inv;
+                jmn = fminf(jmn, jv); jmx = fmaxf(jmx, jv);
+                imn = fminf(imn, iv); imx = fmaxf(imx, iv);
+            }
+            jlo = (int)ceilf(fmaxf(jmn + P.gc0 - GATHER_WIN_MARGIN, 0.f));
+            jhi = (int)floorf(fminf(jmx + P.gc0 + GATHER_WIN_MARGIN, (float)(G.W - 1)));
+            ilo = (int)ceilf(fmaxf(imn + P.gr0 - GATHER_WIN_MARGIN, 0.f));
+            ihi = (int)floorf(fminf(imx + P.gr0 + GATHER_WIN_MARGIN, (float)(G.H - 1)));
+        } else if (cmax != 0.f && amin <= 1e-6f && amax >= G.cull_lo) {
+            jhi = G.W - 1;
+            ihi = G.H - 1;
+        }
+        const int nc = __builtin_amdgcn_readfirstlane(jhi - jlo + 1), nr = __builtin_amdgcn_readfirstlane(ihi - ilo + 1);
+        const int total = (nc > 0 && nr > 0) ? nc * nr : 0;
+        if (total > 0 && cmax < INFINITY) {
+            // bound on one voxel's sum over this pose (see the header)
+            float tsum = (float)total * (CLIP ? 1.f : (float)N);
+            if (amin > 1e-6f) {
+                const float r3 = 1.7320508f;
+                const float idc = __builtin_amdgcn_rcpf(amin * P.ecl), idr = __builtin_amdgcn_rcpf(amin * P.rperp);
+                if (CLIP) {
+                    tsum = fminf(tsum, 1.02f * (2.f * r3 * idc + 1.f) * (2.f * r3 * idr + 1.f));
+                } else if (step > 0.f) {
+                    const float idn = P.gn * inv_step;
+                    const float mp = 2.f * r3 * idn + 1.f, mr = 2.f * r3 * idr + 1.f;
+                    tsum = fminf(tsum, 1.02f * (idc * idr * (idn + r3) + mp * (r3 * idc + mr)));
+                }
+            }
+            if (!(tsum == tsum)) tsum = (float)total * (float)N;
+            const float bound = uni(tsum * cmax);
+            const int ex = (int)(__float_as_uint(bound) >> 23) - 126;   // bound < 2^ex
+            const float cs = uni(__uint_as_float((unsigned)(127 + 30 - ex) << 23)), ics = uni(__uint_as_float((unsigned)(127 - 30 + ex) << 23));
+            const float4* __restrict__ q = G.q + (size_t)p * G.qn;
+            const float2* __restrict__ q2 = G.q2 + (size_t)p * G.n;
+            // a s + b - (first cell of the array) for the cells, relative to the centre of the support box for the slab test
+            const float Bx = uni(fmaf(a0, s0, b0 - (fv[0] - 1.f))), By = uni(fmaf(a1, s1, b1 - (fv[1] - 1.f))), Bz = uni(fmaf(a2, s2, b2 - (fv[2] - 1.f)));
+            const float Cx = uni(fmaf(a0, s0, b0 - fv[0]) - CO), Cy = uni(fmaf(a1, s1, b1 - fv[1]) - CO), Cz = uni(fmaf(a2, s2, b2 - fv[2]) - CO);
+            const float inc = 1.f / (float)nc;
+
+            int f = tid;             // the lane's next ray of the footprint
+            bool active = false;
+            float tx = 0.f, ty = 0.f, tz = 0.f, tw = 0.f, lo = 0.f, span = 1.f;
+            float ddx = 0.f, ddy = 0.f, ddz = 0.f;   // MASK: the forward's own d, for the label
+            int k = 0, khi = -1, ray = 0;
+            while (true) {
+                const unsigned long long idle = __ballot(!active && f < total);
+                if (idle != 0ull && (__popcll(idle) >= 16 || __ballot(active) == 0ull)) {
+                    if (!active && f < total) {
+                        // ---- set up ray f: the alphas where it is inside the support box -> its sample indices
+                        const int ri = (int)(((float)f + 0.5f) * inc), rj = f - ri * nc;
+                        const int i = ilo + ri, j = jlo + rj;
+                        f += 256;
+                        const float4 t = q[(size_t)i * G.qs + j];   // a * d, (g *) L / N (* span)
+                        ray = i * G.W + j;
+                        if (CLIP) {
+                            const float2 ab = q2[ray];
+                            lo = ab.x;
+                            span = ab.y - ab.x;      // exactly the forward's (amax - amin)
+                        }
+                        tx = t.x; ty = t.y; tz = t.z; tw = t.w * cs;
+                        if (MASK) {   // d exactly as the forward forms it, (target - source) + eps
+                            const float* T = G.target + ((size_t)p * G.n + ray) * 3;
+                            ddx = (T[0] - s0) + G.sp.eps; ddy = (T[1] - s1) + G.sp.eps; ddz = (T[2] - s2) + G.sp.eps;
+                        }
+                        const float ix = fabsf(tx) < 1e-12f ? copysignf(1e12f, tx) : 1.f / tx;
+                        const float iy = fabsf(ty) < 1e-12f ? copysignf(1e12f, ty) : 1.f / ty;
+                        const float iz = fabsf(tz) < 1e-12f ? copysignf(1e12f, tz) : 1.f / tz;
+                        const float x0 = (-HS - Cx) * ix, x1 = (HS - Cx) * ix, y0 = (-HS - Cy) * iy, y1 = (HS - Cy) * iy;
+                        const float z0 = (-HS - Cz) * iz, z1 = (HS - Cz) * iz;
+                        const float e0 = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+                        const float e1 = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+                        k = 0;
+                        khi = -1;
+                        if (e1 >= e0 && (!CLIP || span > 0.f) && tw != 0.f) {
+                            const float u0 = CLIP ? (e0 - lo) / span : e0, u1 = CLIP ? (e1 - lo) / span : e1;
+                            if (step > 0.f) {   // one step of slack each side: the cell test decides, not the window
+                                k = (int)ceilf(fmaxf((u0 - near_) * inv_step - 1.f, 0.f));
+                                khi = (int)floorf(fminf((u1 - near_) * inv_step + 1.f, (float)(N - 1)));
+                            } else {
+                                khi = 0;
+                            }
+                        }
+                        active = k <= khi;
+                    }
+                }
+                if (__ballot(active) == 0ull) {
+                    if (__ballot(f < total) == 0ull) break;
+                    continue;
+                }
+                if (active) {
+                    // ---- one sample, with the forward's alpha and position arithmetic
+                    const float u = linspace_at(k, N, near_, far_, step);
+                    const float al = CLIP ? fmaf(u, span, lo) : u;
+                    const float px = fmaf(al, tx, Bx), py = fmaf(al, ty, By), pz = fmaf(al, tz, Bz);
+                    const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+                    const float rx = px - fx, ry = py - fy, rz = pz - fz;
+                    const int ix = (int)fx, iy = (int)fy, iz = (int)fz;
+                    const bool ok = (unsigned)ix < (unsigned)(S16_DIM - 1) && (unsigned)iy < (unsigned)(S16_DIM - 1) && (unsigned)iz < (unsigned)(S16_DIM - 1);
+                    float cw = tw;
+                    if (MASK) {
+                        // the channel of the sample = the label of its nearest voxel (0 outside the volume), from the forward's own
+                        // position arithmetic, a (s + alpha d) + b as two fmas, bit for bit: a sample within an ulp of the middle
+                        // between two voxels must get the label the forward gave it
+                        const int mx = (int)rintf(fmaf(a0, fmaf(al, ddx, s0), b0)), my = (int)rintf(fmaf(a1, fmaf(al, ddy, s1), b1)),
+                                  mz = (int)rintf(fmaf(a2, fmaf(al, ddz, s2), b2));
+                        const bool in = (unsigned)mx < (unsigned)G.D0 && (unsigned)my < (unsigned)G.D1 && (unsigned)mz < (unsigned)G.D2;
+                        int lab = 0;
+                        if (ok && in) lab = min(max((int)G.mask[((size_t)mx * G.D1 + my) * G.D2 + mz], 0), G.C - 1);
+                        cw *= ok ? G.gout[((size_t)p * G.C + lab) * G.n + ray] : 0.f;
+                    }
+                    const float cz = ok ? cw : 0.f;
+                    const int base = ok ? (ix * S16_DIM + iy) * S16_DIM + iz : 0;
+                    const float z1 = rz * cz, z0 = cz - z1;
+                    const float x1 = rx, x0 = 1.f - rx, y1 = ry, y0 = 1.f - ry;
+                    const float p00 = x0 * y0, p01 = x0 * y1, p10 = x1 * y0, p11 = x1 * y1;
+                    int* c = cell + base;
+                    __hip_atomic_fetch_add(c, cvt_nearest(p00 * z0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(c + 1, cvt_nearest(p00 * z1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(c + S16_DIM, cvt_nearest(p01 * z0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(c + S16_DIM + 1, cvt_nearest(p01 * z1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(c + S16_DIM * S16_DIM, cvt_nearest(p10 * z0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(c + S16_DIM * S16_DIM + 1, cvt_nearest(p10 * z1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(c + S16_DIM * S16_DIM + S16_DIM, cvt_nearest(p11 * z0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(c + S16_DIM * S16_DIM + S16_DIM + 1, cvt_nearest(p11 * z1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    ++k;
+                    active = k <= khi;
+                }
+            }
+            if (pn >= 0 && tid <= PW) s_P[cur ^ 1][tid] = pre;
+            __syncthreads();   // every sample is in the cells
+            int* col = cell + ((lx + 1) * S16_DIM + (ly + 1)) * S16_DIM + 1;
+#pragma unroll
+            for (int z = 0; z < 16; ++z) {
+                acc[z] = fmaf((float)col[z], ics, acc[z]);
+                col[z] = 0;
+            }
+            __syncthreads();   // the cells are clear
+        } else {
+            if (total > 0) {   // a non-finite upstream gradient poisons the brick
+#pragma unroll
+                for (int z = 0; z < 16; ++z) acc[z] = NAN;
+            }
+            if (pn >= 0 && tid <= PW) s_P[cur ^ 1][tid] = pre;
+            __syncthreads();
+        }
+    }
+    float* out = G.gvol + ((size_t)(ox + lx) * G.D1 + (oy + ly)) * G.D2 + oz;
+    if (ox + lx < G.D0 && oy + ly < G.D1) {
+#pragma unroll
+        for (int z = 0; z < 16; ++z)
+            if (oz + z < G.D2 && acc[z] != 0.f) out[z] += acc[z];
+    }
+    }   // next brick
+}
+
+// ---------------------------------------------------------------------------------------------
 // Pixel-major voxel gather for the renders the lattice-of-planes kernels above cannot take (round 2):
 //   CLIP  spec.clip_to_volume: alpha_k = alpha_min(ray) + u_k (alpha_max - alpha_min)(ray) -- the samples of a step no longer
 //         lie on one plane, so there is no per-step row table; the image is scaled by the ray's span.
@@ -1742,10 +2015,14 @@ int xvr_detail::launch_gather(bool siddon, const float* source, const float* tar
         if (G.clip || G.mask) G.V = 2;   // (the pixel-major kernel is written for 2x2x2 blocks)
         G.bd[0] = G.bd[1] = G.bd[2] = 4 * G.V;
     }
-    if (splat) {   // (q2, [B][n] float2, is the clip / siddon kernels': a line per pose where n >= 16, what fits otherwise)
-        G.cmax = reinterpret_cast<unsigned*>(G.q2);
-        G.cmax_stride = 2 * n < CMAX_STRIDE ? 2 * n : CMAX_STRIDE;
+    // clip_to_volume / per-channel mask: the ray-major splat unless XVR_DRR_GATHER_SPLAT=0 (A/B: the voxel-driven pixel-major gather)
+    const bool psplat = !siddon && use_splat && !splat;
+    if (splat || psplat) {   // the poses' maxima behind q's used part ([B][2 n] float4, H (W + 1) = n + H used): a line per pose if it fits
+        G.cmax = reinterpret_cast<unsigned*>(G.q + (size_t)B * G.qn);
+        const int room = 4 * (n - n / gw);
+        G.cmax_stride = room < CMAX_STRIDE ? room : CMAX_STRIDE;
     }
+    if (psplat) G.bd[0] = G.bd[1] = G.bd[2] = 16;
     if (splat) G.bd[0] = G.bd[1] = G.bd[2] = 16;
     G.cull = reinterpret_cast<unsigned*>(ws + ws_cull_off(B, n));
     G.words = (B + 31) / 32;
@@ -1767,6 +2044,18 @@ int xvr_detail::launch_gather(bool siddon, const float* source, const float* tar
     }
     else if (siddon && siddon_v1) hipLaunchKernelGGL(k_siddon_gather_vol, dim3((unsigned)bricks), dim3(WG), 0, (hipStream_t)stream, G);
     else if (siddon) hipLaunchKernelGGL(k_siddon_gather_vol2, dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
+    else if (psplat) {
+        const void* kern = G.clip ? (G.mask ? (const void*)k_trilinear_splat_px<true, true> : (const void*)k_trilinear_splat_px<true, false>)
+                                  : (const void*)k_trilinear_splat_px<false, true>;
+        int per_cu = 0, dev = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        const long long resident = (long long)per_cu * cus;
+        const dim3 grid((unsigned)(bricks < resident ? bricks : resident));
+        if (G.clip && G.mask) hipLaunchKernelGGL((k_trilinear_splat_px<true, true>), grid, dim3(256), 0, (hipStream_t)stream, G);
+        else if (G.clip) hipLaunchKernelGGL((k_trilinear_splat_px<true, false>), grid, dim3(256), 0, (hipStream_t)stream, G);
+        else hipLaunchKernelGGL((k_trilinear_splat_px<false, true>), grid, dim3(256), 0, (hipStream_t)stream, G);
+    }
     else if (G.clip && G.mask) hipLaunchKernelGGL((k_trilinear_gather_px<true, true>), dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
     else if (G.clip) hipLaunchKernelGGL((k_trilinear_gather_px<true, false>), dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
     else if (G.mask) hipLaunchKernelGGL((k_trilinear_gather_px<false, true>), dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
