@@ -105,9 +105,9 @@ int xvr_drr_trilinear_forward(const float* volume, const float* mask, int D0, in
  *                brick-local splat whose per-voxel sums are exact 32-bit fixed-point integers in LDS (every product
  *                w * c is rounded to 2^-30 of a rigorous bound on the voxel's sum over one pose: ~4e-8 of the pose's
  *                largest |grad_out * raylen / n_points| at the benchmark geometry; a non-finite grad_out turns the
- *                voxels of the 16^3 bricks that pose touches into NaN), by a voxel-driven pixel-major gather in fp32
- *                under clip_to_volume and / or a mask (a mask whose grad_out is the same for every channel should be
- *                passed as mask = NULL, C = 1: the gradient is then the unmasked one).  Otherwise -- or when the kernel
+ *                voxels of the 16^3 bricks that pose touches into NaN) -- sample runs on the shared planes for the plain
+ *                render, ray by ray under clip_to_volume and / or a mask (a mask whose grad_out is the same for every
+ *                channel should be passed as mask = NULL, C = 1: the gradient is then the unmasked one).  Otherwise -- or when the kernel
  *                finds on the device that the targets are not a lattice -- it falls back to a scatter with fp32 atomics:
  *                same result up to summation order, more than an order of magnitude slower on MI355X.
  */
