@@ -101,15 +101,15 @@ int xvr_drr_trilinear_forward(const float* volume, const float* mask, int D0, in
  *   grad_source/grad_target must be both null or both non-null.
  *   workspace    nullable device scratch of xvr_drr_backward_workspace_bytes(B, n, D0, D1, D2) bytes, 16-B aligned.
  *                With it, and when the rays are a detector lattice (spec.ray_grid_w > 1), grad_volume is computed without
- *                global atomics, as the exact transpose of the forward, bit-reproducibly: for the plain render by a
- *                brick-local splat whose per-voxel sums are exact 32-bit fixed-point integers in LDS (every product
- *                w * c is rounded to 2^-30 of a rigorous bound on the voxel's sum over one pose: ~4e-8 of the pose's
- *                largest |grad_out * raylen / n_points| at the benchmark geometry; a non-finite grad_out turns the
- *                voxels of the 16^3 bricks that pose touches into NaN) -- sample runs on the shared planes for the plain
- *                render, ray by ray under clip_to_volume and / or a mask (a mask whose grad_out is the same for every
- *                channel should be passed as mask = NULL, C = 1: the gradient is then the unmasked one).  Otherwise -- or when the kernel
- *                finds on the device that the targets are not a lattice -- it falls back to a scatter with fp32 atomics:
- *                same result up to summation order, more than an order of magnitude slower on MI355X.
+ *                global atomics, as the exact transpose of the forward, bit-reproducibly: by a brick-local splat whose
+ *                per-voxel sums are exact 32-bit fixed-point integers in LDS -- over sample runs on the shared planes for
+ *                the plain render, ray by ray under clip_to_volume and / or a mask (a mask whose grad_out is the same for
+ *                every channel should be passed as mask = NULL, C = 1: the gradient is then the unmasked one).  Every
+ *                product w * c is rounded to 2^-30 of a rigorous bound on the voxel's sum over one pose: ~4e-8 of the
+ *                pose's largest |grad_out * raylen / n_points| at the benchmark geometry.  A non-finite grad_out turns
+ *                the voxels of the 16^3 bricks its pose touches into NaN.  Otherwise -- or when the kernel finds on the
+ *                device that the targets are not a lattice -- it falls back to a scatter with fp32 atomics: same result
+ *                up to summation order, more than an order of magnitude slower on MI355X.
  */
 int xvr_drr_trilinear_backward(const float* volume, const float* mask, int D0, int D1, int D2, int C,
                                const float* source, const float* target, const float* raylen,
