@@ -143,9 +143,10 @@ def test_ypair_volume_layout_is_bit_identical(kw, shape, monkeypatch):
             t.requires_grad_(True)
         renderers.PROFILER = []
         with torch.no_grad():
-            first = render(vol, src, tgt, img, spec, ray_grid_w=128)     # first sight of this volume: natural layout
+            first = render(vol, src, tgt, img, spec, ray_grid_w=128)     # first and second sight of this volume: natural layout
+            assert torch.equal(first, render(vol, src, tgt, img, spec, ray_grid_w=128))
         assert "pack_ypairs" not in [e[0] for e in renderers.PROFILER]
-        out = render(vol, src, tgt, img, spec, ray_grid_w=128)           # rendered again unchanged: the copy is built and used
+        out = render(vol, src, tgt, img, spec, ray_grid_w=128)           # rendered a third time unchanged: the copy is built and used
         names = [e[0] for e in renderers.PROFILER]
         renderers.PROFILER = None
         assert ("pack_ypairs" in names) == flag                       # the layout really was (not) used
@@ -165,6 +166,7 @@ def test_ypair_volume_layout_is_bit_identical(kw, shape, monkeypatch):
             monkeypatch.setattr(renderers, "YPAIR_LAYOUT", flag)
             vol, src, tgt, img, msk = (case[k].cuda() for k in ("volume", "source", "target", "img", "mask"))
             with torch.no_grad():
+                render(vol, src, tgt, img, spec, msk, ray_grid_w=128)
                 render(vol, src, tgt, img, spec, msk, ray_grid_w=128)
                 renderers.PROFILER = []
                 masked.append(render(vol, src, tgt, img, spec, msk, ray_grid_w=128))

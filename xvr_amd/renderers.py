@@ -130,32 +130,33 @@ def _packed_volume(lib, volume, mask):
 # One-channel trilinear renders of LARGE launches march a y-pair interleaved copy of the volume (xvr_drr_pack_ypairs): two
 # 16-byte gathers per sample instead of four 8-byte ones -- the march is bound by the texture-address rate per gather
 # instruction -- with identical output bits.  Costs twice the volume's memory (cached ON the volume tensor object, keyed by
-# its version counter, built the second time a version is rendered: see _ypair_volume).  False (or XVR_DRR_YPAIRS=0):
+# its version counter, built the third time a version is rendered: see _ypair_volume).  False (or XVR_DRR_YPAIRS=0):
 # natural layout.
 YPAIR_LAYOUT = _os.environ.get("XVR_DRR_YPAIRS", "1") != "0"
 YPAIR_MIN_WAVEFRONTS = 2048     # smaller launches take the sample-split kernels on the natural layout
 
 
 def _ypair_volume(lib, volume):
-    """The y-pair copy of ``volume``, or None the FIRST time a version of it is seen: the copy costs 0.76 ms at 512^3 and
-    saves ~0.5 ms per render, so it only pays for a volume that is rendered again unchanged (registration, pose-regressor
-    training on a fixed CT, the benchmark); a volume that changes between renders -- voxels being optimised, a fresh
-    HU -> density map every training step -- stays on the natural layout."""
+    """The y-pair copy of ``volume``, or None the first TWO times a version of it is seen: the copy costs 0.76 ms at 512^3
+    and saves ~0.25-0.5 ms per render, so it only pays for a volume that is rendered again and again unchanged
+    (registration, the benchmark, a fixed CT); a volume that changes between renders -- voxels being optimised, or the fresh
+    HU -> density map of every training step, rendered exactly twice (trainer.py:185-230) -- stays on the natural layout."""
     D0, D1, D2 = volume.shape
     key = volume._version
-    hit = getattr(volume, "_xvr_ypairs", None)
+    hit = getattr(volume, "_xvr_ypairs", None)      # (version, copy or None, buffer kept for reuse, renders seen)
     if hit is not None and hit[0] == key and hit[1] is not None:
         return hit[1]
-    if hit is None or hit[0] != key:      # first sight of this version: remember it, keep any old buffer for reuse
+    seen = hit[3] + 1 if hit is not None and hit[0] == key else 1
+    if seen <= 2:
         try:
-            volume._xvr_ypairs = (key, None, hit[2] if hit is not None else None)
+            volume._xvr_ypairs = (key, None, hit[2] if hit is not None else None, seen)
         except AttributeError:   # pragma: no cover
             pass
         return None
     pairs = hit[2] if hit[2] is not None else torch.empty(lib.xvr_drr_ypairs_bytes(D0, D1, D2) // 4, device=volume.device, dtype=torch.float32)
     rc = _timed("pack_ypairs", lib.xvr_drr_pack_ypairs, _ptr(volume), D0, D1, D2, _ptr(pairs), _stream())
     _lib.check(rc, "xvr_drr_pack_ypairs")
-    volume._xvr_ypairs = (key, pairs, pairs)
+    volume._xvr_ypairs = (key, pairs, pairs, seen)
     return pairs
 
 
