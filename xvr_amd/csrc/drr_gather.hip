@@ -1093,7 +1093,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XVR_S16_WAV
                     if (tid == 0) { ctl[0] = 0; ctl[1] = 0; ctl[2] = 0; }
                     // the brick's voxels are cells 1..16 on every axis; a thread reads its 16 and clears them (the outer cells
                     // are never read: they may hold anything, and wrap around)
-                    // (measured and not adopted: nine 8-byte reads / clears of the column's 18 cells instead of 32 4-byte ones --
+                    // (measured and not adopted: deferring this flush past the next visit's pose set-up so that the two latency
+                    //  chains overlap in one basic block -- no gain, 7.74 against 7.70 ms; nine 8-byte reads / clears of the column's 18 cells instead of 32 4-byte ones --
                     //  4 550 against 3 660 clocks; rows padded to 20 cells so that four 128-bit operations do -- no difference)
                     int* col = cell + ((lx + 1) * S16_DIM + (ly + 1)) * S16_DIM + 1;
 #pragma unroll
