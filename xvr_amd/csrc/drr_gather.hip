@@ -751,772 +751,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(XVR_TAB_WAVE
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Brick-local splat (round 2): the same voxel gradient, SAMPLE-driven, with the sums of a brick of voxels held in LDS as
-// 32-bit fixed point.
-//
-// Why: the counters say the table gather above is limited twice over -- the vector ALUs are 64 % busy on work of which
-// 70 % is multiplications by a zero weight (a candidate of a 2x2x2 block has 2.4 non-zero weights of 8, and 41 of 64
-// lanes are live), and the L1 is 85-89 % busy because every lane's 16-byte candidate load is its own cache access (39
-// accesses per load instruction; tools/profile_mempipe.sh).  A sample-driven pass has neither problem: every sample is
-// evaluated once per brick whose support holds it, with all eight weights useful, and neighbouring lanes read
-// neighbouring pixels.  What it needs is an accumulate into shared memory, and tools/microbench/lds_atomics.hip measured
-// the one that works: ds_add_f32 retires 0.33 lanes per clock and CU (it is serialised), ds_add_u32 11.5 (random words;
-// 4.4 clocks per wavefront instruction when no two lanes share a word), ds_add_u64 half that.  So the sums are integers:
-//   * per (brick, pose) visit the workgroup enumerates, with the lattice arithmetic of the table kernel applied to the
-//     brick's whole support box, the runs (row, first pixel, count) of samples inside the box -- one row per lane, packed
-//     into an LDS list;
-//   * the scale is a power of two that keeps (most samples that can touch one voxel) x (the pose's max |c|, from
-//     k_gather_prep) below 2^30, so no sum can overflow; a sample's eight products w * c * scale are rounded to nearest
-//     (v_cvt_rpi_i32_f32) and added with ds_add_u32 to an array of cells, the brick and one cell around it (the outer
-//     cells are never read);
-//   * after the pose's samples the threads read their voxels, convert, add them to fp32 registers and clear the cells.
-// Integer sums are exact and order-free: the result is deterministic, and differs from the table kernel's by the
-// rounding of the products, ~0.3 LSB per add with LSB = bound / 2^30.
-// A pose whose upstream gradient holds a non-finite value poisons the voxels of the bricks it visits (NaN).
-// ---------------------------------------------------------------------------------------------
-#ifndef XVR_SP_ABLATE_ADDS
-#define XVR_SP_ABLATE_ADDS 0
-#endif
-// a value every lane holds alike, moved to a scalar register (gfx950 has no scalar float ALU: uniform float arithmetic is
-// done by the vector ALU and would otherwise sit in a vector register for as long as it lives)
-__device__ __forceinline__ float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
-
-__device__ __forceinline__ int cvt_nearest(float v) {
-    int r;
-    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(v));   // floor(v + 0.5)
-    return r;
-}
-
-// ---------------------------------------------------------------------------------------------
-// The same splat on 16^3-voxel bricks, four wavefronts per brick: the per-visit work that does not depend on the number of
-// samples (pose constants, one window set-up per step, the flush) is paid once for 8 x the voxels, and the support box
-// holds 1.20 x the brick's samples instead of 1.42 x.
-//   enumeration  wavefront w takes steps klo + w, klo + w + 4, ...; lane = detector row; the runs are packed into ONE list by
-//                an LDS counter (one ds_add_rtn per wavefront and 64 rows);
-//   splat        64 groups of four lanes; group g takes runs g, g + 64, ..., lane c of the group the c-th quarter of a run;
-//   flush        thread t owns the 16 voxels (t / 16, t % 16, 0..15).
-// A visit whose list would overflow, that has more steps than the alpha table holds, or that meets a step at alpha = 0 is
-// redone in "safe mode": one step at a time over all four wavefronts, drained after every step.
-// ---------------------------------------------------------------------------------------------
-#if defined(XVR_S16_ABLATE_LOADS)   // diagnostic build only: no memory traffic for the samples -- WRONG sums
-#define XVR_S16_LOAD(p) make_float4(0.25f, 0.5f, 0.125f, (float)((size_t)(p) & 255u))
-#else
-#define XVR_S16_LOAD(p) (*(p))
-#endif
-#ifndef XVR_S16_DEPTH
-#define XVR_S16_DEPTH 2
-#endif
-#ifndef XVR_S16_SHARES   // 1: every thread the same number of samples (prefix over the list); 0: quarters of runs, round robin
-#define XVR_S16_SHARES 1
-#endif
-#ifndef XVR_S16_GROUP_STRIDE
-#define XVR_S16_GROUP_STRIDE 19
-#endif
-#ifndef XVR_S16_TAB
-#define XVR_S16_TAB 896
-#endif
-constexpr int S16_DIM = 18, S16_CELLS = S16_DIM * S16_DIM * S16_DIM, S16_TAB = XVR_S16_TAB, S16_STEPS = 128;
-
-#ifndef XVR_S16_CENTRE_OUT
-#define XVR_S16_CENTRE_OUT 1
-#endif
-#ifndef XVR_S16_WAVES   // wavefronts per SIMD the register budget is set for (tools/tune_splat.py)
-#define XVR_S16_WAVES 4
-#endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XVR_S16_WAVES, XVR_S16_WAVES))) void k_trilinear_splat_b16(GatherArgs G) {
-    if (*G.flag > __float_as_uint(GATHER_DEV_TOL)) return;  // not a lattice: the scatter kernel runs instead
-    __shared__ __attribute__((aligned(16))) int cell[S16_CELLS];
-    __shared__ uint2 tab[S16_TAB];          // x = first element of the run in q;  y = count << 8 | step - kbase
-    // list length, samples in the list, "redo in safe mode": two sets, alternating between visits, so that the set of visit
-    // v is cleared (by thread 0, after v's second barrier) while nobody reads or writes it -- two barriers per visit suffice
-    __shared__ __attribute__((aligned(16))) int s_ctl[2][4];   // [0] runs in the list, [1] samples in the list, [2] redo
-#if XVR_S16_SHARES
-    __shared__ unsigned run_start[S16_TAB]; // samples in the runs before this one (list order)
-#endif
-    // the pose constants of this visit and of the next one (PoseLattice's floats + max|c|): the next pose's are fetched
-    // while this pose's samples are splatted -- a visit's first use of them was 7000 clocks of exposed memory latency
-    constexpr int PW = (int)(sizeof(PoseLattice) / sizeof(float));
-    __shared__ float s_P[2][PW + 4];
-    __shared__ int s_next[2];   // the brick this workgroup takes next (two slots: written for turn t + 1 while t may still be read)
-    int par = 0;
-    constexpr float HS = 8.5f, CO = 7.5f;   // samples that touch voxels 0..15 sit in [-1, 16): centre 7.5, half 8.5
-    constexpr float HSR = HS / 1.5f;        // PoseLattice.hsr is made for the 2x2x2 block's half-size 1.5
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int lx = tid >> 4, ly = tid & 15;                     // this thread's column of 16 voxels along z
-    const int N = G.sp.n_points;
-    const float near_ = G.sp.near_, far_ = G.sp.far_;
-    const float step = N > 1 ? (far_ - near_) / (float)(N - 1) : 0.f;
-    const float inv_step = step > 0.f ? 1.f / step : 0.f;
-    const float a0 = G.sp.a[0], a1 = G.sp.a[1], a2 = G.sp.a[2];
-    const float b0 = G.sp.b[0], b1 = G.sp.b[1], b2 = G.sp.b[2];
-    const float jmargin = GATHER_DEV_TOL + 0.01f;
-    const float Hm1 = (float)(G.H - 1), Wm1 = (float)(G.W - 1);
-    const int n0 = (G.D0 + 15) / 16, n1 = (G.D1 + 15) / 16, n2 = (G.D2 + 15) / 16;
-    for (int i = tid; i < S16_CELLS / 4; i += 256) reinterpret_cast<int4*>(cell)[i] = make_int4(0, 0, 0, 0);
-    if (tid < 8) s_ctl[tid >> 2][tid & 3] = 0;
-#ifdef XVR_S16_TRACE
-#define XVR_TICK(i) do { const unsigned long long now_ = clock64(); tk[i] += now_ - tl; tl = now_; } while (0)
-#else
-#define XVR_TICK(i) ((void)0)
-#endif
-
-    // Persistent workgroups: the launch holds as many as the chip runs at once and every one takes bricks off a queue (a
-    // counter next to the lattice flag) until it is empty.  One workgroup per brick left 42 % of the workgroup slots idle
-    // for the whole launch (tools/splat_trace.py) -- the dispatcher does not keep up with 31 KiB / 4-wavefront workgroups
-    // of very unequal length.
-    for (int turn = 0;; turn ^= 1) {
-    if (tid == 0) s_next[turn] = (int)atomicAdd(G.flag + 1, 1u);
-    __syncthreads();   // (also: the cells are clear, the previous brick's flush is done)
-    const int blk = __builtin_amdgcn_readfirstlane(s_next[turn]);   // (scalar: everything per brick and per pose below is uniform)
-    if (blk >= n0 * n1 * n2) break;
-    int bx = blk / (n1 * n2), by = (blk / n2) % n1, bz = blk % n2;
-#if XVR_S16_CENTRE_OUT
-    // bricks from the middle of the volume outwards: the ones most poses cross first, the empty corners last
-    bx = (bx & 1) ? (n0 >> 1) - ((bx + 1) >> 1) : (n0 >> 1) + (bx >> 1);
-    by = (by & 1) ? (n1 >> 1) - ((by + 1) >> 1) : (n1 >> 1) + (by >> 1);
-    bz = (bz & 1) ? (n2 >> 1) - ((bz + 1) >> 1) : (n2 >> 1) + (bz >> 1);
-#endif
-    const int brick_id = (bx * n1 + by) * n2 + bz;
-#ifdef XVR_S16_TRACE
-    const unsigned long long t_start = wall_clock64();
-    unsigned long long n_visits = 0, n_samples = 0, tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = clock64();
-#endif
-    const int ox = bx * 16, oy = by * 16, oz = bz * 16;         // first voxel of the brick
-    const float fv[3] = {(float)ox, (float)oy, (float)oz};
-    float xv[3];  // centre of the support box in x coordinates
-#pragma unroll
-    for (int i = 0; i < 3; ++i) xv[i] = uni((fv[i] + CO - G.sp.b[i]) / G.sp.a[i]);
-    float acc[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-
-    // the brick's poses, one ahead: pc is this visit's pose, pn the next one's
-    int wd = 0;
-    unsigned bits = G.cull[(size_t)brick_id * G.words];  // uniform: scalar load
-    auto next_pose = [&]() -> int {
-        while (!bits) {
-            if (++wd >= G.words) return -1;
-            bits = G.cull[(size_t)brick_id * G.words + wd];
-        }
-        const int p = wd * 32 + __builtin_ctz(bits);
-        bits &= bits - 1;
-        return p;
-    };
-    auto fetch = [&](const int p) -> float {   // thread t <= PW: word t of the pose's constants
-        return tid < PW ? reinterpret_cast<const float*>(G.poses + p)[tid] : __uint_as_float(G.cmax[(size_t)p * G.cmax_stride]);
-    };
-    int pc = next_pose(), visit = 0;
-    if (pc >= 0 && tid <= PW) s_P[0][tid] = fetch(pc);
-    __syncthreads();
-    while (pc >= 0) {
-        {
-            const int p = pc, pn = next_pose();
-            float pre = 0.f;
-            if (pn >= 0 && tid <= PW) pre = fetch(pn);    // in flight during the visit; parked in s_P before the visit's last barrier
-            const int cur = visit & 1;
-            ++visit;
-            auto park = [&]() { if (pn >= 0 && tid <= PW) s_P[cur ^ 1][tid] = pre; };
-            pc = pn;
-            const float* Pf = s_P[cur];
-            const PoseLattice& P = *reinterpret_cast<const PoseLattice*>(Pf);
-            const float cmax = Pf[PW];
-            if (cmax == 0.f) { park(); __syncthreads(); continue; }   // the pose's upstream gradient is all zeros
-            const float s0 = P.s[0], s1 = P.s[1], s2 = P.s[2];
-            const float w0 = xv[0] - s0, w1 = xv[1] - s1, w2 = xv[2] - s2;
-            const float av = uni(P.nh[0] * w0 + P.nh[1] * w1 + P.nh[2] * w2);
-            const float da = HS * P.dalpha;
-            int klo, khi;
-            if (step > 0.f) {
-                const float k0 = (av - da - near_) * inv_step, k1 = (av + da - near_) * inv_step;
-                klo = (int)ceilf(fmaxf(k0 - GATHER_K_SLACK, 0.f));
-                khi = (int)floorf(fminf(k1 + GATHER_K_SLACK, (float)(N - 1)));
-            } else {
-                klo = 0;
-                khi = (fabsf(av - near_) <= da) ? 0 : -1;
-            }
-            if (!(av == av)) khi = -1;
-            if (khi < klo) { park(); __syncthreads(); continue; }
-            const float grw = uni(P.gr[0] * w0 + P.gr[1] * w1 + P.gr[2] * w2);
-            const float4* __restrict__ q = G.q + (size_t)p * G.qn;
-            // a s + b - (first cell of the array): array index of a sample = floor of this + alpha (a d); the brick's voxel v
-            // is cell v + 1 (a sample in [-1, 16) has its lower tap in cells 0..16)
-            const float Bx = uni(fmaf(a0, s0, b0 - (fv[0] - 1.f))), By = uni(fmaf(a1, s1, b1 - (fv[1] - 1.f))), Bz = uni(fmaf(a2, s2, b2 - (fv[2] - 1.f)));
-            // ... and relative to the centre of the support box, for the windows
-            const float Cx = uni(fmaf(a0, s0, b0 - fv[0]) - CO), Cy = uni(fmaf(a1, s1, b1 - fv[1]) - CO), Cz = uni(fmaf(a2, s2, b2 - fv[2]) - CO);
-            const float rcx = HS * P.rc[0], rcy = HS * P.rc[1], rcz = HS * P.rc[2], rcw = HS * P.hwr;
-            // A voxel's sum of weights over the pose's samples is at most `tcell`: the samples are a lattice (pixel spacing dc
-            // along a row, rows dr apart, planes dn apart, all in voxels at the box's smallest alpha) and the weight w =
-            // hat x hat x hat is log-concave, so along a row sum <= integral / dc + max (<= 1), the row integrals are
-            // unimodal in the row index (sum <= plane integral / dr + max line integral <= sqrt 3), the plane integrals in the
-            // plane index (sum <= 1 / dn + max plane integral <= sqrt 3), and at most mr rows per plane and mp planes touch the
-            // voxel's 2-cube:   sum w <= (1 / (dc dr)) (1 / dn + sqrt 3) + mp (sqrt 3 / dc + mr).
-            // (The plain count of lattice points in the 2-cube is 4-11 x larger; the fixed-point LSB scales with this bound.)
-            float tcell = INFINITY;
-            {
-                const float amin = av - da;
-                if (amin > 1e-6f && step > 0.f) {
-                    const float r3 = 1.7320508f;
-                    const float idc = __builtin_amdgcn_rcpf(amin * P.ecl), idr = __builtin_amdgcn_rcpf(amin * P.rperp), idn = P.gn * inv_step;
-                    const float mp = 2.f * r3 * idn + 1.f, mr = 2.f * r3 * idr + 1.f;
-                    tcell = 1.02f * (idc * idr * (idn + r3) + mp * (r3 * idc + mr));
-                    if (!(tcell == tcell)) tcell = INFINITY;
-                }
-                tcell = uni(tcell);
-            }
-
-            int kbase = klo;    // step of slot 0 of the list
-            // ---- the list's samples into the cells, the cells into the threads' registers.  Called by ALL threads, after the
-            // barrier that completes the list; ends with the barrier after which the cells may be added to again.
-            auto drain = [&]() {
-                int* ctl = s_ctl[par];
-                const int cnt = ctl[0];
-#ifdef XVR_S16_TRACE
-                n_visits += 1; n_samples += (unsigned long long)cnt;
-#endif
-                if (cnt > 0 && cmax < INFINITY) {
-                    // scale = the power of two that puts (bound on a voxel's sum) into [2^29, 2^30): exact to apply and undo.
-                    // Where the lattice bound does not exist (the box reaches the source plane) the samples in the list stand
-                    // in, counted generously: runs x detector width.  (An exact count would be a same-word add by every lane of
-                    // every append: 128 clocks of the LDS pipe each.)
-                    const float bound = fminf((float)cnt * (float)G.W, tcell) * cmax;
-                    const int ex = (int)(__float_as_uint(bound) >> 23) - 126;   // bound < 2^ex
-                    const float cs = uni(__uint_as_float((unsigned)(127 + 30 - ex) << 23)), ics = uni(__uint_as_float((unsigned)(127 - 30 + ex) << 23));
-#if XVR_S16_SHARES
-                    // every thread the same number of samples (+-1): thread t takes samples [t T / 256, (t + 1) T / 256) of the
-                    // list, found by bisection on the runs' offsets; neighbouring threads are a share (~13 pixels, 7 voxels)
-                    // apart.  (Static quarters of runs left the slowest thread 18-20 trips for a mean of 13.)
-                    const unsigned T = (unsigned)ctl[1];
-                    const unsigned lo = (unsigned)(((unsigned long long)tid * T) >> 8), hi = (unsigned)(((unsigned long long)(tid + 1) * T) >> 8);
-                    int e = 0;
-#pragma unroll
-                    for (int stp = 512; stp > 0; stp >>= 1) {
-                        const int c = e + stp;
-                        if (c < cnt && run_start[c] <= lo) e = c;
-                    }
-                    int left = (int)(hi - lo), rem = 0;   // samples of the share / of the current run still to come (incl. this one)
-                    const float4* __restrict__ ptr = q;
-                    float al = 0.f;
-                    int first = (int)(lo - run_start[e]);       // (only the first run of a share is entered in its middle)
-                    --e;
-                    // on to the thread's next sample: 1 = there is one at (ptr, al), -1 = the thread is done
-                    auto advance = [&]() -> int {
-                        if (left <= 0) return -1;
-                        --left;
-                        --rem;
-                        ++ptr;
-                        if (rem > 0) return 1;
-                        ++e;
-                        const uint2 en = tab[e < cnt ? e : cnt - 1];
-                        rem = (int)(en.y >> 8) - first;
-                        ptr = q + en.x + first;
-                        first = 0;
-                        al = linspace_sel(kbase + (int)(en.y & 255u), N, near_, far_, step);   // (recomputed: no second LDS read)
-                        return 1;
-                    };
-#else
-                    const int c4 = tid & 3;
-                    // group g starts at run (19 g) mod 64: the 16 groups of a wavefront then work on runs at least two detector
-                    // rows apart (neighbouring rows' samples fall into the same cells: same-word adds serialise).  Static shares
-                    // leave the slowest thread 18-20 trips for a mean of 13; handing quarters out by a counter instead was
-                    // measured SLOWER (10.7 against 8.9 ms: a ds_add_rtn and a dependent read on every pull).
-                    int idx = (XVR_S16_GROUP_STRIDE * (tid >> 2)) & 63, rem = 0;
-                    const float4* __restrict__ ptr = q;
-                    float al = 0.f;
-                    // on to the thread's next sample: 1 = there is one at (ptr, al), 0 = an idle trip (the run is shorter than
-                    // this lane's quarter starts), -1 = the thread is done
-                    auto advance = [&]() -> int {
-                        --rem;
-                        ++ptr;
-                        if (rem > 0) return 1;
-                        if (idx >= cnt) return -1;
-                        const uint2 e = tab[idx];
-                        idx += 64;
-                        const int n = (int)(e.y >> 8), m = (n + 3) >> 2, first = c4 * m;
-                        rem = n - first < m ? n - first : m;
-                        ptr = q + e.x + first;
-                        al = linspace_sel(kbase + (int)(e.y & 255u), N, near_, far_, step);   // (recomputed: no second LDS read)
-                        return rem > 0 ? 1 : 0;
-                    };
-#endif
-                    auto splat = [&](const float4 t, const float alc) {
-                        const float px = fmaf(alc, t.x, Bx), py = fmaf(alc, t.y, By), pz = fmaf(alc, t.z, Bz);
-                        const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
-                        const float rx = px - fx, ry = py - fy, rz = pz - fz;
-                        const int ix = (int)fx, iy = (int)fy, iz = (int)fz;
-                        // a sample outside [-1, 16) on some axis (the windows are conservative by a fraction of a pixel) touches
-                        // no voxel of the brick
-                        const bool ok = (unsigned)ix < (unsigned)(S16_DIM - 1) && (unsigned)iy < (unsigned)(S16_DIM - 1) && (unsigned)iz < (unsigned)(S16_DIM - 1);
-                        const float cz = ok ? t.w * cs : 0.f;
-                        const int base = ok ? (ix * S16_DIM + iy) * S16_DIM + iz : 0;
-                        const float z1 = rz * cz, z0 = cz - z1;   // (1 - rz) cz
-                        const float x1 = rx, x0 = 1.f - rx, y1 = ry, y0 = 1.f - ry;
-                        const float p00 = x0 * y0, p01 = x0 * y1, p10 = x1 * y0, p11 = x1 * y1;
-                        int* c = cell + base;
-#if XVR_SP_ABLATE_ADDS   // diagnostic build only (tools/tune_splat.py): one add instead of eight -- WRONG sums, the price of seven adds
-                        __hip_atomic_fetch_add(c, cvt_nearest(p00 * z0) + cvt_nearest(p00 * z1) + cvt_nearest(p01 * z0) + cvt_nearest(p01 * z1) +
-                                               cvt_nearest(p10 * z0) + cvt_nearest(p10 * z1) + cvt_nearest(p11 * z0) + cvt_nearest(p11 * z1),
-                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        return;
-#endif
-                        __hip_atomic_fetch_add(c, cvt_nearest(p00 * z0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_add(c + 1, cvt_nearest(p00 * z1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_add(c + S16_DIM, cvt_nearest(p01 * z0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_add(c + S16_DIM + 1, cvt_nearest(p01 * z1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_add(c + S16_DIM * S16_DIM, cvt_nearest(p10 * z0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_add(c + S16_DIM * S16_DIM + 1, cvt_nearest(p10 * z1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_add(c + S16_DIM * S16_DIM + S16_DIM, cvt_nearest(p11 * z0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_add(c + S16_DIM * S16_DIM + S16_DIM + 1, cvt_nearest(p11 * z1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    };
-                    // two samples in flight per thread, in two register sets (deeper rings measured no faster).  Unconditional
-                    // loads (ptr always points into q, at worst one element past a run) so that no exec-masked join sits
-                    // between a load and its use; the only LDS read of the loop is the run's entry, consumed where it is
-                    // read -- a pending LDS result anywhere else makes the compiler drain the eight adds on every trip.
-                    int sa = advance(), sb;
-                    float4 ta = XVR_S16_LOAD(ptr), tb;
-                    float ala = al, alb;
-                    while (sa >= 0) {
-                        sb = advance();
-                        tb = XVR_S16_LOAD(ptr);
-                        alb = al;
-                        if (sa > 0) splat(ta, ala);
-                        if (sb < 0) break;
-                        sa = advance();
-                        ta = XVR_S16_LOAD(ptr);
-                        ala = al;
-                        if (sb > 0) splat(tb, alb);
-                    }
-                    XVR_TICK(3);
-                    park();
-                    __syncthreads();   // every sample is in the cells
-                    XVR_TICK(4);
-                    if (tid == 0) { ctl[0] = 0; ctl[1] = 0; ctl[2] = 0; }
-                    // the brick's voxels are cells 1..16 on every axis; a thread reads its 16 and clears them (the outer cells
-                    // are never read: they may hold anything, and wrap around)
-                    // (measured and not adopted: deferring this flush past the next visit's pose set-up so that the two latency
-                    //  chains overlap in one basic block -- no gain, 7.74 against 7.70 ms; nine 8-byte reads / clears of the column's 18 cells instead of 32 4-byte ones --
-                    //  4 550 against 3 660 clocks; rows padded to 20 cells so that four 128-bit operations do -- no difference)
-                    int* col = cell + ((lx + 1) * S16_DIM + (ly + 1)) * S16_DIM + 1;
-#pragma unroll
-                    for (int z = 0; z < 16; ++z) {
-                        acc[z] = fmaf((float)col[z], ics, acc[z]);
-                        col[z] = 0;
-                    }
-                    XVR_TICK(5);
-                } else {
-                    if (cnt > 0) {   // a non-finite upstream gradient poisons the brick
-#pragma unroll
-                        for (int z = 0; z < 16; ++z) acc[z] = NAN;
-                    }
-                    park();
-                    __syncthreads();
-                    if (tid == 0) { ctl[0] = 0; ctl[1] = 0; ctl[2] = 0; }
-                }
-                par ^= 1;
-            };
-            // one run per lane of the calling wavefront (n <= 0: none) into the shared list; false = it does not fit
-            auto append = [&](const int off, int n, const int slot) -> bool {
-                n = n > 0 ? (n < 0xffffff ? n : 0xffffff) : 0;
-                const unsigned long long has = __ballot(n > 0);
-                const int np = __popcll(has);
-                if (np == 0) return true;
-#if XVR_S16_SHARES
-                // samples of the lanes before this one (wavefront scan by DPP: four shifts within the rows of 16 lanes, two
-                // row broadcasts) and of the whole wavefront; runs and samples are reserved by ONE 64-bit add, so that the
-                // list's order is the order of the sample offsets
-                int x = n;
-                x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);   // row_shr:1
-                x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);   // row_shr:2
-                x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);   // row_shr:4
-                x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);   // row_shr:8
-                x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
-                x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
-                const int wsum = __builtin_amdgcn_readlane(x, 63);
-                unsigned long long got = 0ull;
-                if (lane == 0)
-                    got = __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(&s_ctl[par][0]),
-                                                 (unsigned long long)(unsigned)np | ((unsigned long long)(unsigned)wsum << 32),
-                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const int base = __builtin_amdgcn_readfirstlane((int)(unsigned)got);
-                const int sbase = __builtin_amdgcn_readfirstlane((int)(unsigned)(got >> 32));
-                if (base + np > S16_TAB) return false;
-                if (n > 0) {
-                    const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(has >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)has, 0u));
-                    tab[pos] = make_uint2((unsigned)off, ((unsigned)n << 8) | (unsigned)slot);
-                    run_start[pos] = (unsigned)(sbase + x - n);
-                }
-                return true;
-#else
-                int base = 0;
-                if (lane == 0) base = __hip_atomic_fetch_add(&s_ctl[par][0], np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (base + np > S16_TAB) return false;
-                if (n > 0) {
-                    const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(has >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)has, 0u));
-                    tab[pos] = make_uint2((unsigned)off, ((unsigned)n << 8) | (unsigned)slot);
-                }
-                return true;
-#endif
-            };
-            // the rows i0 + lane of step alpha = al (the table kernel's window arithmetic on the brick's support box)
-            struct StepC { float q0x, q0y, q0z, urx, ury, urz, rx, ry, rz, hx, hy, hz; int ilo, ihi; };
-            auto step_setup = [&](const float al, StepC& S) {
-                const float inv = __builtin_amdgcn_rcpf(al);
-                const float ic = fmaf(grw, inv, P.gr0);
-                const float dlt = al - av;
-                const float up = fminf(fminf(fmaf(P.rl[0], dlt, rcx), fmaf(P.rl[1], dlt, rcy)), fminf(fmaf(P.rl[2], dlt, rcz), rcw));
-                const float dn = fminf(fminf(fmaf(-P.rl[0], dlt, rcx), fmaf(-P.rl[1], dlt, rcy)), fminf(fmaf(-P.rl[2], dlt, rcz), rcw));
-                S.ilo = (int)ceilf(fmaxf(ic - fmaf(fmaxf(dn, 0.f), inv, GATHER_WIN_MARGIN), 0.f));
-                S.ihi = (int)floorf(fminf(ic + fmaf(fmaxf(up, 0.f), inv, GATHER_WIN_MARGIN), Hm1));
-                S.q0x = fmaf(al, P.e0[0], Cx); S.q0y = fmaf(al, P.e0[1], Cy); S.q0z = fmaf(al, P.e0[2], Cz);
-                S.urx = al * P.era[0]; S.ury = al * P.era[1]; S.urz = al * P.era[2];
-                S.rx = inv * P.rec[0]; S.ry = inv * P.rec[1]; S.rz = inv * P.rec[2];
-                S.hx = fmaf(inv, HSR * P.hsr[0], jmargin); S.hy = fmaf(inv, HSR * P.hsr[1], jmargin); S.hz = fmaf(inv, HSR * P.hsr[2], jmargin);
-            };
-            auto rows = [&](const StepC& S, const int i, int& off, int& n) {
-                const float fi = (float)i;
-                const float qx = fmaf(fi, S.urx, S.q0x), qy = fmaf(fi, S.ury, S.q0y), qz = fmaf(fi, S.urz, S.q0z);
-                const float mx = -qx * S.rx, my = -qy * S.ry, mz = -qz * S.rz;
-                const float lo = fmaxf(fmaxf(mx - S.hx, my - S.hy), mz - S.hz);
-                const float hiJ = fminf(fminf(mx + S.hx, my + S.hy), mz + S.hz);
-                const int jlo = (int)ceilf(fmaxf(lo, 0.f));
-                const int jhi = (int)floorf(fminf(hiJ, Wm1));
-                off = i * G.qs + jlo;
-                n = i <= S.ihi ? jhi - jlo + 1 : 0;
-            };
-
-            // ---- fast mode: every wavefront its own steps, one list for the whole visit
-            XVR_TICK(0);
-            bool redo = khi - klo >= S16_STEPS;
-            if (!redo) {
-                for (int k = klo + wave; k <= khi; k += 4) {
-                    const float al = linspace_sel(k, N, near_, far_, step);
-                    if (!(al > 1e-12f)) { redo = true; break; }
-                    StepC S;
-                    step_setup(al, S);
-                    for (int i0 = S.ilo; i0 <= S.ihi && !redo; i0 += 64) {
-                        int off, n;
-                        rows(S, i0 + lane, off, n);
-                        if (!append(off, n, k - klo)) redo = true;
-                    }
-                    if (redo) break;
-                }
-                if (redo && lane == 0) s_ctl[par][2] = 1;
-            }
-            XVR_TICK(1);
-            __syncthreads();   // the list is complete
-            XVR_TICK(2);
-            redo = redo || s_ctl[par][2] != 0;   // (uniform: the first operand is, where it is set before the barrier)
-            if (!redo) {
-                drain();
-            } else {
-                // ---- safe mode (rare): the list is thrown away; one step at a time, all four wavefronts on its rows, drained
-                // whenever another 256 runs might not fit and after every step
-                __syncthreads();
-                if (tid == 0) { s_ctl[par][0] = 0; s_ctl[par][1] = 0; s_ctl[par][2] = 0; }
-                __syncthreads();
-                for (int k = klo; k <= khi; ++k) {
-                    kbase = k;
-                    const float al = linspace_sel(k, N, near_, far_, step);
-                    if (al > 1e-12f) {
-                        StepC S;
-                        step_setup(al, S);
-                        for (int i0 = S.ilo; i0 <= S.ihi; i0 += 256) {
-                            int off, n;
-                            rows(S, i0 + tid, off, n);
-                            append(off, n, 0);
-                            if (i0 + 256 <= S.ihi) {   // (uniform) more rows to come: make room
-                                __syncthreads();
-                                if (s_ctl[par][0] > S16_TAB - 256) drain(); else __syncthreads();
-                            }
-                        }
-                    } else {
-                        // alpha_k = 0: every ray's sample sits on the source; all pixels, if the source is inside the support box
-                        const bool hit = fabsf(Cx) < HS && fabsf(Cy) < HS && fabsf(Cz) < HS;
-                        if (hit)
-                            for (int i0 = 0; i0 < G.H; i0 += 256) {
-                                append((i0 + tid) * G.qs, i0 + tid < G.H ? G.W : 0, 0);
-                                if (i0 + 256 < G.H) {
-                                    __syncthreads();
-                                    if (s_ctl[par][0] > S16_TAB - 256) drain(); else __syncthreads();
-                                }
-                            }
-                    }
-                    __syncthreads();
-                    drain();
-                    __syncthreads();   // (the flush's clears before the next step's adds; fast mode has the list barrier there)
-                }
-            }
-        }
-    }
-#ifdef XVR_S16_TRACE
-    if (tid == 0 && blk < 65536) {
-        unsigned long long* o = g_s16_trace + 12 * blk;
-        o[0] = t_start; o[1] = wall_clock64(); o[2] = n_visits; o[3] = n_samples;
-        for (int i = 0; i < 8; ++i) o[4 + i] = tk[i];
-    }
-#endif
-    float* out = G.gvol + ((size_t)(ox + lx) * G.D1 + (oy + ly)) * G.D2 + oz;
-    if (ox + lx < G.D0 && oy + ly < G.D1) {
-#pragma unroll
-        for (int z = 0; z < 16; ++z)
-            if (oz + z < G.D2 && acc[z] != 0.f) out[z] += acc[z];
-    }
-    }   // next brick
-}
-
-// ---------------------------------------------------------------------------------------------
-// The brick-local splat, RAY-major: for the renders whose samples cannot be enumerated as runs on shared planes.
-//   CLIP  spec.clip_to_volume: alpha_k = alpha_min(ray) + u_k (alpha_max - alpha_min)(ray) (k_trilinear_gather_px below);
-//   MASK  mask -> channels with a gradient that differs between channels: a sample's upstream value is
-//         gout[b][label(sample)][ray].
-// Same bricks, cells, fixed point, flush, persistent workgroups and pose prefetch as k_trilinear_splat_b16; per (brick, pose)
-// visit the threads take the rays f = thread, thread + 256, ... of the brick's pixel footprint (bounding box of the 8
-// projected corners of its support box), clip each against the support box (slab test) and evaluate its samples inside with
-// the forward's own alpha arithmetic.  A ray has ~5-25 samples in a brick and many rays of the footprint miss it: a lane
-// whose ray is done waits until a quarter of the wavefront is idle, then those lanes set up their next rays together.
-// The scale's bound on a voxel's sum: MASK alone -- the samples are the lattice of k_trilinear_splat_b16, same bound, with
-// max |c g| over rays and channels; CLIP -- (rays that can cross a voxel's 2-cube) x max over the rays of (samples of the ray
-// inside the 2-cube x |c| span), both from k_gather_prep.
-// ---------------------------------------------------------------------------------------------
-template <bool CLIP, bool MASK>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 6))) void k_trilinear_splat_px(GatherArgs G) {
-    if (*G.flag > __float_as_uint(GATHER_DEV_TOL)) return;  // not a lattice: the scatter kernel runs instead
-    __shared__ __attribute__((aligned(16))) int cell[S16_CELLS];
-    constexpr int PW = (int)(sizeof(PoseLattice) / sizeof(float));
-    __shared__ float s_P[2][PW + 4];
-    __shared__ int s_next[2];
-    constexpr float HS = 8.5f, CO = 7.5f;
-    const int tid = threadIdx.x;
-    const int lx = tid >> 4, ly = tid & 15;
-    const int N = G.sp.n_points;
-    const float near_ = G.sp.near_, far_ = G.sp.far_;
-    const float step = N > 1 ? (far_ - near_) / (float)(N - 1) : 0.f;
-    const float inv_step = step > 0.f ? 1.f / step : 0.f;
-    const float a0 = G.sp.a[0], a1 = G.sp.a[1], a2 = G.sp.a[2];
-    const float b0 = G.sp.b[0], b1 = G.sp.b[1], b2 = G.sp.b[2];
-    const float ea0 = HS / a0, ea1 = HS / a1, ea2 = HS / a2;   // half-size of the support box, in x coordinates
-    const int n0 = (G.D0 + 15) / 16, n1 = (G.D1 + 15) / 16, n2 = (G.D2 + 15) / 16;
-    for (int i = tid; i < S16_CELLS / 4; i += 256) reinterpret_cast<int4*>(cell)[i] = make_int4(0, 0, 0, 0);
-
-    for (int turn = 0;; turn ^= 1) {
-    if (tid == 0) s_next[turn] = (int)atomicAdd(G.flag + 1, 1u);
-    __syncthreads();   // (also: the cells are clear, the previous brick's flush is done)
-    const int blk = __builtin_amdgcn_readfirstlane(s_next[turn]);
-    if (blk >= n0 * n1 * n2) break;
-    int bx = blk / (n1 * n2), by = (blk / n2) % n1, bz = blk % n2;
-    bx = (bx & 1) ? (n0 >> 1) - ((bx + 1) >> 1) : (n0 >> 1) + (bx >> 1);
-    by = (by & 1) ? (n1 >> 1) - ((by + 1) >> 1) : (n1 >> 1) + (by >> 1);
-    bz = (bz & 1) ? (n2 >> 1) - ((bz + 1) >> 1) : (n2 >> 1) + (bz >> 1);
-    const int brick_id = (bx * n1 + by) * n2 + bz;
-    const int ox = bx * 16, oy = by * 16, oz = bz * 16;
-    const float fv[3] = {(float)ox, (float)oy, (float)oz};
-    float xv[3];  // centre of the support box in x coordinates
-#pragma unroll
-    for (int i = 0; i < 3; ++i) xv[i] = uni((fv[i] + CO - G.sp.b[i]) / G.sp.a[i]);
-    float acc[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-
-    int wd = 0;
-    unsigned bits = G.cull[(size_t)brick_id * G.words];
-    auto next_pose = [&]() -> int {
-        while (!bits) {
-            if (++wd >= G.words) return -1;
-            bits = G.cull[(size_t)brick_id * G.words + wd];
-        }
-        const int p = wd * 32 + __builtin_ctz(bits);
-        bits &= bits - 1;
-        return p;
-    };
-    auto fetch = [&](const int p) -> float {
-        return tid < PW ? reinterpret_cast<const float*>(G.poses + p)[tid] : __uint_as_float(G.cmax[(size_t)p * G.cmax_stride]);
-    };
-    int pc = next_pose(), visit = 0;
-    if (pc >= 0 && tid <= PW) s_P[0][tid] = fetch(pc);
-    __syncthreads();
-    while (pc >= 0) {
-        const int p = pc, pn = next_pose();
-        float pre = 0.f;
-        if (pn >= 0 && tid <= PW) pre = fetch(pn);
-        const int cur = visit & 1;
-        ++visit;
-        pc = pn;
-        const float* Pf = s_P[cur];
-        const PoseLattice& P = *reinterpret_cast<const PoseLattice*>(Pf);
-        const float cmax = Pf[PW];
-        const float s0 = P.s[0], s1 = P.s[1], s2 = P.s[2];
-        const float w0 = xv[0] - s0, w1 = xv[1] - s1, w2 = xv[2] - s2;
-        const float av = uni(P.nh[0] * w0 + P.nh[1] * w1 + P.nh[2] * w2);
-        const float en0 = P.nh[0] * ea0, en1 = P.nh[1] * ea1, en2 = P.nh[2] * ea2;
-        const float da = fabsf(en0) + fabsf(en1) + fabsf(en2);
-        const float amin = av - da, amax = av + da;   // alpha range of the support box on this pose's rays
-        // pixel footprint: bounding box of the box's 8 projected corners; every ray when the box reaches the source plane
-        int jlo = 0, jhi = -1, ilo = 0, ihi = -1;
-        if (cmax != 0.f && amin > 1e-6f && amax >= G.cull_lo && amin <= G.cull_hi) {
-            const float nj = P.gc[0] * w0 + P.gc[1] * w1 + P.gc[2] * w2;
-            const float ni = P.gr[0] * w0 + P.gr[1] * w1 + P.gr[2] * w2;
-            const float ec0 = P.gc[0] * ea0, ec1 = P.gc[1] * ea1, ec2 = P.gc[2] * ea2;
-            const float er0 = P.gr[0] * ea0, er1 = P.gr[1] * ea1, er2 = P.gr[2] * ea2;
-            float jmn = INFINITY, jmx = -INFINITY, imn = INFINITY, imx = -INFINITY;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const float sx = (c & 4) ? 1.f : -1.f, sy = (c & 2) ? 1.f : -1.f, sz = (c & 1) ? 1.f : -1.f;
-                const float inv = 1.f / (av + sx * en0 + sy * en1 + sz * en2);
-                const float jv = (nj + sx * ec0 + sy * ec1 + sz * ec2) * inv, iv = (ni + sx * er0 + sy * er1 + sz * er2) * inv;
-                jmn = fminf(jmn, jv); jmx = fmaxf(jmx, jv);
-                imn = fminf(imn, iv); imx = fmaxf(imx, iv);
-            }
-            jlo = (int)ceilf(fmaxf(jmn + P.gc0 - GATHER_WIN_MARGIN, 0.f));
-            jhi = (int)floorf(fminf(jmx + P.gc0 + GATHER_WIN_MARGIN, (float)(G.W - 1)));
-            ilo = (int)ceilf(fmaxf(imn + P.gr0 - GATHER_WIN_MARGIN, 0.f));
-            ihi = (int)floorf(fminf(imx + P.gr0 + GATHER_WIN_MARGIN, (float)(G.H - 1)));
-        } else if (cmax != 0.f && amin <= 1e-6f && amax >= G.cull_lo) {
-            jhi = G.W - 1;
-            ihi = G.H - 1;
-        }
-        const int nc = __builtin_amdgcn_readfirstlane(jhi - jlo + 1), nr = __builtin_amdgcn_readfirstlane(ihi - ilo + 1);
-        const int total = (nc > 0 && nr > 0) ? nc * nr : 0;
-        if (total > 0 && cmax < INFINITY) {
-            // bound on one voxel's sum over this pose (see the header)
-            float tsum = (float)total * (CLIP ? 1.f : (float)N);
-            if (amin > 1e-6f) {
-                const float r3 = 1.7320508f;
-                const float idc = __builtin_amdgcn_rcpf(amin * P.ecl), idr = __builtin_amdgcn_rcpf(amin * P.rperp);
-                if (CLIP) {
-                    tsum = fminf(tsum, 1.02f * (2.f * r3 * idc + 1.f) * (2.f * r3 * idr + 1.f));
-                } else if (step > 0.f) {
-                    const float idn = P.gn * inv_step;
-                    const float mp = 2.f * r3 * idn + 1.f, mr = 2.f * r3 * idr + 1.f;
-                    tsum = fminf(tsum, 1.02f * (idc * idr * (idn + r3) + mp * (r3 * idc + mr)));
-                }
-            }
-            if (!(tsum == tsum)) tsum = (float)total * (float)N;
-            const float bound = uni(tsum * cmax);
-            const int ex = (int)(__float_as_uint(bound) >> 23) - 126;   // bound < 2^ex
-            const float cs = uni(__uint_as_float((unsigned)(127 + 30 - ex) << 23)), ics = uni(__uint_as_float((unsigned)(127 - 30 + ex) << 23));
-            const float4* __restrict__ q = G.q + (size_t)p * G.qn;
-            const float2* __restrict__ q2 = G.q2 + (size_t)p * G.n;
-            // a s + b - (first cell of the array) for the cells, relative to the centre of the support box for the slab test
-            const float Bx = uni(fmaf(a0, s0, b0 - (fv[0] - 1.f))), By = uni(fmaf(a1, s1, b1 - (fv[1] - 1.f))), Bz = uni(fmaf(a2, s2, b2 - (fv[2] - 1.f)));
-            const float Cx = uni(fmaf(a0, s0, b0 - fv[0]) - CO), Cy = uni(fmaf(a1, s1, b1 - fv[1]) - CO), Cz = uni(fmaf(a2, s2, b2 - fv[2]) - CO);
-            const float inc = 1.f / (float)nc;
-
-            int f = tid;             // the lane's next ray of the footprint
-            bool active = false;
-            float tx = 0.f, ty = 0.f, tz = 0.f, tw = 0.f, lo = 0.f, span = 1.f;
-            float ddx = 0.f, ddy = 0.f, ddz = 0.f;   // MASK: the forward's own d, for the label
-            int k = 0, khi = -1, ray = 0;
-            while (true) {
-                const unsigned long long idle = __ballot(!active && f < total);
-                if (idle != 0ull && (__popcll(idle) >= 16 || __ballot(active) == 0ull)) {
-                    if (!active && f < total) {
-                        // ---- set up ray f: the alphas where it is inside the support box -> its sample indices
-                        const int ri = (int)(((float)f + 0.5f) * inc), rj = f - ri * nc;
-                        const int i = ilo + ri, j = jlo + rj;
-                        f += 256;
-                        const float4 t = q[(size_t)i * G.qs + j];   // a * d, (g *) L / N (* span)
-                        ray = i * G.W + j;
-                        if (CLIP) {
-                            const float2 ab = q2[ray];
-                            lo = ab.x;
-                            span = ab.y - ab.x;      // exactly the forward's (amax - amin)
-                        }
-                        tx = t.x; ty = t.y; tz = t.z; tw = t.w * cs;
-                        if (MASK) {   // d exactly as the forward forms it, (target - source) + eps
-                            const float* T = G.target + ((size_t)p * G.n + ray) * 3;
-                            ddx = (T[0] - s0) + G.sp.eps; ddy = (T[1] - s1) + G.sp.eps; ddz = (T[2] - s2) + G.sp.eps;
-                        }
-                        const float ix = fabsf(tx) < 1e-12f ? copysignf(1e12f, tx) : 1.f / tx;
-                        const float iy = fabsf(ty) < 1e-12f ? copysignf(1e12f, ty) : 1.f / ty;
-                        const float iz = fabsf(tz) < 1e-12f ? copysignf(1e12f, tz) : 1.f / tz;
-                        const float x0 = (-HS - Cx) * ix, x1 = (HS - Cx) * ix, y0 = (-HS - Cy) * iy, y1 = (HS - Cy) * iy;
-                        const float z0 = (-HS - Cz) * iz, z1 = (HS - Cz) * iz;
-                        const float e0 = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
-                        const float e1 = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-                        k = 0;
-                        khi = -1;
-                        if (e1 >= e0 && (!CLIP || span > 0.f) && tw != 0.f) {
-                            const float u0 = CLIP ? (e0 - lo) / span : e0, u1 = CLIP ? (e1 - lo) / span : e1;
-                            if (step > 0.f) {   // one step of slack each side: the cell test decides, not the window
-                                k = (int)ceilf(fmaxf((u0 - near_) * inv_step - 1.f, 0.f));
-                                khi = (int)floorf(fminf((u1 - near_) * inv_step + 1.f, (float)(N - 1)));
-                            } else {
-                                khi = 0;
-                            }
-                        }
-                        active = k <= khi;
-                    }
-                }
-                if (__ballot(active) == 0ull) {
-                    if (__ballot(f < total) == 0ull) break;
-                    continue;
-                }
-                if (active) {
-                    // ---- one sample, with the forward's alpha and position arithmetic
-                    const float u = linspace_at(k, N, near_, far_, step);
-                    const float al = CLIP ? fmaf(u, span, lo) : u;
-                    const float px = fmaf(al, tx, Bx), py = fmaf(al, ty, By), pz = fmaf(al, tz, Bz);
-                    const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
-                    const float rx = px - fx, ry = py - fy, rz = pz - fz;
-                    const int ix = (int)fx, iy = (int)fy, iz = (int)fz;
-                    const bool ok = (unsigned)ix < (unsigned)(S16_DIM - 1) && (unsigned)iy < (unsigned)(S16_DIM - 1) && (unsigned)iz < (unsigned)(S16_DIM - 1);
-                    float cw = tw;
-                    if (MASK) {
-                        // the channel of the sample = the label of its nearest voxel (0 outside the volume), from the forward's own
-                        // position arithmetic, a (s + alpha d) + b as two fmas, bit for bit: a sample within an ulp of the middle
-                        // between two voxels must get the label the forward gave it
-                        const int mx = (int)rintf(fmaf(a0, fmaf(al, ddx, s0), b0)), my = (int)rintf(fmaf(a1, fmaf(al, ddy, s1), b1)),
-                                  mz = (int)rintf(fmaf(a2, fmaf(al, ddz, s2), b2));
-                        const bool in = (unsigned)mx < (unsigned)G.D0 && (unsigned)my < (unsigned)G.D1 && (unsigned)mz < (unsigned)G.D2;
-                        int lab = 0;
-                        if (ok && in) lab = min(max((int)G.mask[((size_t)mx * G.D1 + my) * G.D2 + mz], 0), G.C - 1);
-                        cw *= ok ? G.gout[((size_t)p * G.C + lab) * G.n + ray] : 0.f;
-                    }
-                    const float cz = ok ? cw : 0.f;
-                    const int base = ok ? (ix * S16_DIM + iy) * S16_DIM + iz : 0;
-                    const float z1 = rz * cz, z0 = cz - z1;
-                    const float x1 = rx, x0 = 1.f - rx, y1 = ry, y0 = 1.f - ry;
-                    const float p00 = x0 * y0, p01 = x0 * y1, p10 = x1 * y0, p11 = x1 * y1;
-                    int* c = cell + base;
-                    __hip_atomic_fetch_add(c, cvt_nearest(p00 * z0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(c + 1, cvt_nearest(p00 * z1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(c + S16_DIM, cvt_nearest(p01 * z0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(c + S16_DIM + 1, cvt_nearest(p01 * z1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(c + S16_DIM * S16_DIM, cvt_nearest(p10 * z0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(c + S16_DIM * S16_DIM + 1, cvt_nearest(p10 * z1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(c + S16_DIM * S16_DIM + S16_DIM, cvt_nearest(p11 * z0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(c + S16_DIM * S16_DIM + S16_DIM + 1, cvt_nearest(p11 * z1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    ++k;
-                    active = k <= khi;
-                }
-            }
-            if (pn >= 0 && tid <= PW) s_P[cur ^ 1][tid] = pre;
-            __syncthreads();   // every sample is in the cells
-            int* col = cell + ((lx + 1) * S16_DIM + (ly + 1)) * S16_DIM + 1;
-#pragma unroll
-            for (int z = 0; z < 16; ++z) {
-                acc[z] = fmaf((float)col[z], ics, acc[z]);
-                col[z] = 0;
-            }
-            __syncthreads();   // the cells are clear
-        } else {
-            if (total > 0) {   // a non-finite upstream gradient poisons the brick
-#pragma unroll
-                for (int z = 0; z < 16; ++z) acc[z] = NAN;
-            }
-            if (pn >= 0 && tid <= PW) s_P[cur ^ 1][tid] = pre;
-            __syncthreads();
-        }
-    }
-    float* out = G.gvol + ((size_t)(ox + lx) * G.D1 + (oy + ly)) * G.D2 + oz;
-    if (ox + lx < G.D0 && oy + ly < G.D1) {
-#pragma unroll
-        for (int z = 0; z < 16; ++z)
-            if (oz + z < G.D2 && acc[z] != 0.f) out[z] += acc[z];
-    }
-    }   // next brick
-}
+#include "drr_splat.hiph"   // k_trilinear_splat_b16, k_trilinear_splat_px: the brick-local fixed-point splats (the default)
 
 // ---------------------------------------------------------------------------------------------
 // Pixel-major voxel gather for the renders the lattice-of-planes kernels above cannot take (round 2):
