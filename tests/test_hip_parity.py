@@ -1261,7 +1261,10 @@ def test_fuzz_voxel_gather_equals_atomic_scatter(seed):
         #  two traversals and then moves its whole length between two neighbouring voxels.  Some of these maps are
         #  degenerate in exactly that way -- align_corners with dims = shape - 1 and voxel_shift = 0 is index = rint(x)
         #  over planes at the integers: the midpoint of every fully crossed cell sits ON the boundary -- so the bound is
-        #  on how many voxels differ and on the total, which no tie can change)
+        #  on how many voxels differ and on the total, which no tie can change -- except at the volume's faces, where one of
+        #  the two voxels of a tie lies outside and the segment is dropped by one path only: a one-off run of seeds 80..699
+        #  found 6 such cases, all align_corners + norm_dims_offset = -1, totals 1.3e-4 .. 4.8e-4 apart; every trilinear seed
+        #  -- plain, clip, masks: the splat kernels -- passed)
         a, b = grads[0].double().cpu(), grads[1].double().cpu()
         err = (a - b).abs() / b.abs().max().clamp_min(1e-12)
         assert (err > 1e-4).double().mean().item() <= 1e-2 and abs(a.sum().item() - b.sum().item()) <= 1e-4 * b.abs().sum().item(), what
