@@ -52,6 +52,7 @@ print("duration of a workgroup with work: median %.3f ms, 90 %% %.3f, 99 %% %.3f
 tk = t[:, 4:10].sum(axis=0)
 names = ["pose set-up", "enumeration", "wait: list barrier", "splat loop", "wait: cells barrier", "flush"]
 print("wavefront 0's shader clocks per visit: " + ", ".join(f"{nm} {v / visits.sum():.0f}" for nm, v in zip(names, tk)) + f" (sum {tk.sum() / visits.sum():.0f})")
+print(f"visits with an empty list: {t[:, 10].sum() / visits.sum():.1%}; with fewer than 32 runs: {t[:, 11].sum() / visits.sum():.1%}")
 edges = np.linspace(0, t1.max(), 8)
 for a, b in zip(edges[:-1], edges[1:]):
     mid = 0.5 * (a + b)
