@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define XVR_DRR_ABI_VERSION 3   /* 3: xvr_drr_spec.volume_layout + xvr_drr_pack_ypairs; 2: xvr_sim_spec grew, camera-driven forwards, packed labels, xvr_pose.h */
+#define XVR_DRR_ABI_VERSION 4   /* 4: volume_layout 2 + xvr_drr_pack_bricks (siddon forward); 3: xvr_drr_spec.volume_layout + xvr_drr_pack_ypairs; 2: xvr_sim_spec grew, camera-driven forwards, packed labels, xvr_pose.h */
 
 #define XVR_DRR_OK 0
 #define XVR_DRR_E_ARG (-1)     /* bad argument (null pointer, non-positive size, unsupported combo) */
@@ -60,8 +60,9 @@ typedef struct xvr_drr_spec {
     /* launch shaping (performance only, never changes results) */
     int32_t ray_grid_w;    /* >0: the n rays form an (n / ray_grid_w) x ray_grid_w row-major detector and
                               lanes are mapped to 8x8 pixel tiles; 0: rays are mapped linearly             */
-    int32_t volume_layout; /* trilinear forward, one channel: 0 = `volume` is [D0][D1][D2]; 1 = it is the y-pair
-                              interleaved copy written by xvr_drr_pack_ypairs (same results, bit for bit)  */
+    int32_t volume_layout; /* forward only: 0 = `volume` is [D0][D1][D2]; 1 (trilinear) = it is the y-pair interleaved
+                              copy written by xvr_drr_pack_ypairs; 2 (siddon) = the 4 x 2 x 4 bricks written by
+                              xvr_drr_pack_bricks (same results, bit for bit)                               */
 } xvr_drr_spec;
 
 int xvr_drr_abi_version(void);
@@ -193,6 +194,16 @@ int xvr_drr_pack_labels(const float* volume, const float* mask, long long n, flo
  */
 size_t xvr_drr_ypairs_bytes(int D0, int D1, int D2);
 int xvr_drr_pack_ypairs(const float* volume, int D0, int D1, int D2, float* pairs, void* stream);
+
+/*
+ * Bricked copy of a volume for the Siddon forward (spec.volume_layout = 2):
+ *     bricks[x / 4][y / 2][z / 4][x % 4][y % 2][z % 4],  zeros beyond the volume
+ * i.e. one 128-byte cache line per 4 x 2 x 4 block of voxels; ceil(D0/4) ceil(D1/2) ceil(D2/4) 32 floats =
+ * xvr_drr_bricks_bytes().  The traversal is bound by the number of distinct lines one wavefront load touches (its 64 rays
+ * sit at different depths): the bricks halve it (tools/sim_siddon_lines.py).  Same arithmetic, identical output bits.
+ */
+size_t xvr_drr_bricks_bytes(int D0, int D1, int D2);
+int xvr_drr_pack_bricks(const float* volume, int D0, int D1, int D2, float* bricks, void* stream);
 
 /*
  * Jacobian -> camera in one pass (= xvr_drr_backward_from_jac followed by xvr_drr_rays_backward, without

@@ -11,7 +11,7 @@ import warnings
 
 from .build import LIB, HipccMissing, build_library, is_stale
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 JAC_STRIDE = 8
 
 
@@ -111,6 +111,8 @@ EXPORTS = {
     "xvr_drr_pack_labels": ([_P, _P, ctypes.c_longlong, _P, _P], ctypes.c_int),
     "xvr_drr_ypairs_bytes": ([_I, _I, _I], ctypes.c_size_t),
     "xvr_drr_pack_ypairs": ([_P, _I, _I, _I, _P, _P], ctypes.c_int),
+    "xvr_drr_bricks_bytes": ([_I, _I, _I], ctypes.c_size_t),
+    "xvr_drr_pack_bricks": ([_P, _I, _I, _I, _P, _P], ctypes.c_int),
     "xvr_drr_jac_to_camera_workspace_bytes": ([_I, _I, _I], ctypes.c_size_t),
     "xvr_drr_jac_to_camera_backward": ([_P, _P, _P, _I, _I, _I, _P, _P, ctypes.c_size_t, _P], ctypes.c_int),
     "xvr_pose_camera_forward": ([_P, _P, _I, _AX, _P, _P, _P, _P], ctypes.c_int),

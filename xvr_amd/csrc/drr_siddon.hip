@@ -18,7 +18,7 @@ namespace {
 // so only the rounding of that one product differs from the unsplit walk.
 // (at most 5 wavefronts per SIMD: the walk is bound by the texture-address unit; 10.7 ms at C3 against 11.5 ms at
 //  the 8 its register count would allow and at 4)
-template <int MODE, int MASK, bool GPOSE, bool GVOL, bool EXACT, int SPLIT = 0>
+template <int MODE, int MASK, bool GPOSE, bool GVOL, bool EXACT, int SPLIT = 0, bool BRICK = false>
 __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAX : WG) __attribute__((amdgpu_waves_per_eu(1, 5))) void k_siddon(RenderArgs A) {
     extern __shared__ float lds[];  // MASK: fwd -> channel accumulators, bwd -> upstream gradients; SPLIT: partial sums
     static_assert(!SPLIT || (MODE != 2 && !MASK && EXACT), "split walk: forward, unmasked, exact geometry");
@@ -30,6 +30,8 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAX : WG) __attribute__((amdgpu_
     ray_setup(A, b, r, valid, R);
     const float* __restrict__ vol = A.volume;
     const int D0 = A.D0, D1 = A.D1, D2 = A.D2;
+    constexpr bool bricked = BRICK;   // (forward, one channel, exact map, unsplit: the only instantiations)
+    const int nby = (D1 + 1) >> 1, nbz = (D2 + 3) >> 2;
     constexpr bool BWD = MODE == 2;
     constexpr bool DERIV = MODE == 1 || (BWD && GPOSE);
 
@@ -145,7 +147,11 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAX : WG) __attribute__((amdgpu_
         }
         const bool inb = (unsigned)ix < (unsigned)D0 && (unsigned)iy < (unsigned)D1 && (unsigned)iz < (unsigned)D2;
         const int off = inb ? (ix * D1 + iy) * D2 + iz : 0;
-        const float v_new = vol[off];                       // always loadable (offset 0 when outside)
+        // volume_layout 2: 4 x 2 x 4 voxel bricks, one per 128-byte line (xvr_drr_pack_bricks) -- the lanes of a wavefront sit
+        // at different depths of neighbouring rays, and their voxels fall into half as many lines as in [x][y][z] rows
+        const int voff = !bricked ? off
+                                  : (inb ? ((((ix >> 2) * nby + (iy >> 1)) * nbz + (iz >> 2)) << 5) + ((ix & 3) << 3) + ((iy & 1) << 2) + (iz & 3) : 0);
+        const float v_new = vol[voff];                      // always loadable (offset 0 when outside)
         // MASK == 2: the label rides in the low mantissa bits of the voxel just loaded (xvr_drr_pack_labels)
         const float lab_new = MASK == 2 ? (float)(__float_as_uint(v_new) & LABEL_MASK) : (MASK ? A.mask[off] : 0.f);
         if (inb && !first_of_slice && (!SPLIT || an > ac)) ++cnt;
@@ -249,8 +255,11 @@ static int siddon_forward_impl(const float* volume, const float* mask, int D0, i
     int rc = check_common(volume, D0, D1, D2, C, source, target, raylen, B, n, sp, cam);
     if (rc) return rc;
     if (!out) return fail(XVR_DRR_E_ARG, "out is null");
-    if (sp->volume_layout != 0) return fail(XVR_DRR_E_UNSUPPORTED, "siddon takes the natural volume layout");
-    const bool packed = !mask && C > 1;   // labels in the low mantissa bits of `volume` (xvr_drr_pack_labels)
+    if (sp->volume_layout != 0 && sp->volume_layout != 2) return fail(XVR_DRR_E_UNSUPPORTED, "siddon takes the natural or the bricked volume layout");
+    const bool packed = !mask && C > 1;
+    // (bricks: one channel, exact index map -- where they pay; masked / non-exact walks measured slower with them)
+    if (sp->volume_layout == 2 && (mask || packed || !siddon_exact_geometry(sp)))
+        return fail(XVR_DRR_E_UNSUPPORTED, "the bricked layout serves the one-channel forward with the exact index map");   // labels in the low mantissa bits of `volume` (xvr_drr_pack_labels)
     if (packed && C > (1 << LABEL_BITS)) return fail(XVR_DRR_E_ARG, "packed labels hold at most 16 channels");
     RenderArgs A;
     fill_args(A, volume, mask, D0, D1, D2, C, source, target, raylen, B, n, sp, cam);
@@ -262,6 +271,10 @@ static int siddon_forward_impl(const float* volume, const float* mask, int D0, i
     if (mask && jac) return (ex ? launch(k_siddon<1, true, false, false, true>, A, lds, stream) : launch(k_siddon<1, true, false, false, false>, A, lds, stream));
     if (mask) return (ex ? launch(k_siddon<0, true, false, false, true>, A, lds, stream) : launch(k_siddon<0, true, false, false, false>, A, lds, stream));
     bool tile16 = false;
+    if (sp->volume_layout == 2) {
+        if (jac) return launch(k_siddon<1, false, false, false, true, 0, true>, A, 0, stream);
+        return launch(k_siddon<0, false, false, false, true, 0, true>, A, 0, stream);
+    }
     const int ns = ex ? split_factor(B, n, (long long)D0 * D1 * D2, true, &tile16) : 1;
     if (ns > 1) {
         if (jac) return tile16 ? launch_split(k_siddon<1, false, false, false, true, 2>, A, ns, true, 7, stream)
