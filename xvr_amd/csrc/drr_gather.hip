@@ -125,6 +125,14 @@ __global__ __launch_bounds__(WG) void k_gather_prep(GatherArgs G) {
                 lo = fmaxf(lo, fminf(a0, a1));
                 hi = fminf(hi, fmaxf(a0, a1));
             }
+            // A ray whose range is cut by alpha = 0 or 1 (source or detector inside the volume) needs its (lo, hi) in the gather;
+            // for a pose none of whose rays is cut, every voxel's cube lies inside every ray's own range and the gather leaves
+            // the q2 loads out (one word per pose, GatherArgs.cmax; one atomic per wavefront that has such a ray and does not see
+            // the word set yet)
+            const bool cut = (lo < hi) && (!(lo > 0.f) || !(hi < 1.f));
+            if (G.cmax && __any(cut) && (threadIdx.x & 63) == __builtin_ctzll(__ballot(cut)) &&
+                __hip_atomic_load(G.cmax + (size_t)b * G.cmax_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+                atomicMax(G.cmax + (size_t)b * G.cmax_stride, 1u);
             if (!(lo > 0.f)) lo = 0.f;
             if (!(hi < 1.f)) hi = 1.f;
             G.q[(size_t)b * G.n + r] = make_float4(1.f / ddx, 1.f / ddy, 1.f / ddz,
@@ -1110,6 +1118,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
             const int p = wd * 32 + __builtin_ctz(bits);
             bits &= bits - 1;
             const PoseLattice& P = G.poses[p];
+            // (uniform) does any ray of this pose end at alpha = 0 or 1?  If none does, the rays' (lo, hi) are not loaded: the
+            // kernel is bound by the L1's access rate (TCP 91 % busy, one access per lane and load), and they are a third of its loads
+            const bool cut_rays = !G.cmax || G.cmax[(size_t)p * G.cmax_stride] != 0u;
             const float s0 = P.s[0], s1 = P.s[1], s2 = P.s[2];
             const float w0 = cx - s0, w1 = cy - s1, w2 = cz - s2;
             const float av = P.nh[0] * w0 + P.nh[1] * w1 + P.nh[2] * w2;
@@ -1156,7 +1167,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
                 for (int j = jlo; j <= jhi; j += 2) {
                     const int j1 = j < jhi ? j + 1 : j;
                     float4 tt[2] = {row[j], row[j1]};
-                    const float2 aa[2] = {row2[j], row2[j1]};
+                    float2 aa[2] = {make_float2(-INFINITY, INFINITY), make_float2(-INFINITY, INFINITY)};
+                    if (cut_rays) { aa[0] = row2[j]; aa[1] = row2[j1]; }
                     if (j1 == j) tt[1].w = 0.f;
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
@@ -1257,6 +1269,10 @@ int xvr_detail::launch_gather(bool siddon, const float* source, const float* tar
         G.cmax = reinterpret_cast<unsigned*>(G.q + (size_t)B * G.qn);
         const int room = 4 * (n - n / gw);
         G.cmax_stride = room < CMAX_STRIDE ? room : CMAX_STRIDE;
+    }
+    if (siddon && !siddon_v1 && !G.cells) {   // per-pose "a ray is cut at alpha = 0 / 1" words behind q's used half ([B][2 n] float4, [B][n] used)
+        G.cmax = reinterpret_cast<unsigned*>(G.q + (size_t)B * n);
+        G.cmax_stride = 4 * n < CMAX_STRIDE ? 4 * n : CMAX_STRIDE;
     }
     if (psplat) G.bd[0] = G.bd[1] = G.bd[2] = 16;
     if (splat) G.bd[0] = G.bd[1] = G.bd[2] = 16;
