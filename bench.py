@@ -58,12 +58,16 @@ def pmc_traffic(tag):
     keys = TRAFFIC_KERNELS.get(base)
     if not keys:
         return None
-    tot, hit = 0.0, False
+    fam = {}   # kernel family (name up to its template list) -> traffic of each profiled instantiation that matches
     for name, v in table.items():
+        if "k_siddon<" in name:   # k_siddon<MODE, ...>: 0 forward, 1 forward + jacobian, 2 backward
+            mode = "2" if base == "siddon_backward" else ("1" if "+jac" in tag else "0")
+            if f"k_siddon<{mode}," not in name:
+                continue
         if any(k in name for k in keys) and (("fwd<true" in name) == ("+jac" in tag) or "fwd<" not in name):
-            tot += v.get("fetch_bytes", 0.0) + v.get("write_bytes", 0.0)
-            hit = True
-    return tot if hit else None
+            fam.setdefault(name.split("<")[0], []).append(v.get("fetch_bytes", 0.0) + v.get("write_bytes", 0.0))
+    # different kernels of one call add up; instantiations of one kernel (volume layouts) are alternatives: their mean
+    return sum(sum(v) / len(v) for v in fam.values()) if fam else None
 
 
 def deepfluoro_poses(batch, seed):
