@@ -65,3 +65,21 @@ def test_bench_two_ranks_strong_scaling_contract(batch):
     d = _torchrun_bench(["--batch", str(batch), "--scaling", "strong"], 29612 + batch)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["global_batch"] == batch
     assert abs(d["value"] - batch * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+
+
+def test_pmc_traffic_reads_the_committed_counter_table():
+    """`roofline.traffic` comes from profiles/traffic.json (FETCH_SIZE + WRITE_SIZE per launch of the committed PMC passes):
+    the kernels of one timed call add up, the instantiations of one kernel (volume layouts) count once, and Siddon's
+    forward, forward + jacobian and backward instantiations are told apart."""
+    sys.path.insert(0, str(ROOT))
+    import bench
+
+    table = json.loads((ROOT / "profiles" / "traffic.json").read_text())
+    splat = sum(v["fetch_bytes"] + v["write_bytes"] for k, v in table.items()
+                if any(t in k for t in ("k_trilinear_splat_b16", "k_gather_prep", "k_gather_cull", "k_trilinear_bwd")))
+    assert bench.pmc_traffic("trilinear_backward[vol]") == pytest.approx(splat)
+    fwd = [v["fetch_bytes"] + v["write_bytes"] for k, v in table.items() if "k_trilinear_fwd<true" in k]
+    assert len(fwd) >= 1 and bench.pmc_traffic("trilinear_forward+jac") == pytest.approx(sum(fwd) / len(fwd))
+    jac = [v["fetch_bytes"] + v["write_bytes"] for k, v in table.items() if "k_siddon<1," in k]
+    assert bench.pmc_traffic("siddon_forward+jac") == pytest.approx(sum(jac) / len(jac))
+    assert bench.pmc_traffic("no_such_call") is None
