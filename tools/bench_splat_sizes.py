@@ -1,4 +1,5 @@
-"""The brick-local splat (XVR_DRR_GATHER_SPLAT=1, default) against the fp32 table gather (=0) at smaller volumes / batches:\n    python tools/bench_splat_sizes.py        (on the GPU box)"""
+"""The brick-local splat (XVR_DRR_GATHER_SPLAT=1, default) against the fp32 table gather (=0) at smaller volumes / batches:
+    python tools/bench_splat_sizes.py        (on the GPU box)"""
 import os, subprocess, sys, json
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
