@@ -228,3 +228,20 @@ def test_full_size_siddon_pose_gradient_matches_finite_differences():
             else:
                 fd = (loss(rot0, xyz0 + e) - loss(rot0, xyz0 - e)).item() / (2 * h)
             assert abs(g[0, i].item() - fd) <= 0.02 * max(abs(fd), 0.05 * abs(g).max().item()), (i, g[0, i].item(), fd)
+
+
+def test_full_size_trilinear_voxel_gradient_is_bit_reproducible():
+    """The brick-local splat sums in integers: the whole benchmark batch (116 poses, 512^3 -> 256^2) twice, same bits --
+    whatever order the persistent workgroups took the bricks in."""
+    vol, sub, drr, rot, xyz = _bench_setup("trilinear", 116)
+    w = torch.rand(116, 1, 256, 256, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2))
+
+    def voxel_gradient():
+        density = drr.density.clone().requires_grad_(True)
+        out = drr(rot.cuda(), xyz.cuda(), parameterization="euler_angles", convention="ZXY", density=density, n_points=500)
+        (out * w).sum().backward()
+        return density.grad
+
+    a = voxel_gradient()
+    for _ in range(2):
+        assert torch.equal(a, voxel_gradient())
