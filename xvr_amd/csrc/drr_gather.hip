@@ -144,12 +144,17 @@ __global__ __launch_bounds__(WG) void k_gather_prep(GatherArgs G) {
     if (G.cmax) {   // max |c| of the pose: the fixed-point scale of the brick-local splat
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) cabs = fmaxf(cabs, __shfl_xor(cabs, o));
-        // (a thousand wavefronts per pose meet in its word: the poses' words sit in different cache lines -- packed, the 116
+        // (256 workgroups per pose meet in its word: the poses' words sit in different cache lines -- packed, the 116
         //  of the benchmark shared four lines and 1.2e5 L2 atomics queued up behind each other for 0.6 ms -- and only a
         //  wavefront that would RAISE the maximum writes.  A stale read only costs a redundant atomic.)
-        if ((threadIdx.x & 63) == 0 && cabs > 0.f &&
-            __float_as_uint(cabs) > __hip_atomic_load(G.cmax + (size_t)b * G.cmax_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            atomicMax(G.cmax + (size_t)b * G.cmax_stride, __float_as_uint(cabs));
+        __shared__ float s_cabs[WG / 64];
+        if ((threadIdx.x & 63) == 0) s_cabs[threadIdx.x >> 6] = cabs;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < WG / 64; ++w) cabs = fmaxf(cabs, s_cabs[w]);
+            if (cabs > 0.f && __float_as_uint(cabs) > __hip_atomic_load(G.cmax + (size_t)b * G.cmax_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                atomicMax(G.cmax + (size_t)b * G.cmax_stride, __float_as_uint(cabs));
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) dev = fmaxf(dev, __shfl_xor(dev, o));
