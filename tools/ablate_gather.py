@@ -11,8 +11,8 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
-LIB = ROOT / "xvr_amd" / "lib" / "libxvr_drr_ablate.so"
-LIB2 = ROOT / "xvr_amd" / "lib" / "libxvr_drr_ablate2.so"
+LIB = ROOT / "tools" / "_build" / "libxvr_drr_ablate.so"
+LIB2 = ROOT / "tools" / "_build" / "libxvr_drr_ablate2.so"
 if sys.argv[1:] == ["build"]:
     from xvr_amd.build import build_diagnostic_library
     print(build_diagnostic_library("XVR_GATHER_ABLATE=1", LIB))

@@ -11,7 +11,7 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 from xvr_amd.build import build_diagnostic_library  # noqa: E402
 
-stats_lib = build_diagnostic_library("XVR_GATHER_STATS", ROOT / "xvr_amd" / "lib" / "libxvr_drr_stats.so")
+stats_lib = build_diagnostic_library("XVR_GATHER_STATS", ROOT / "tools" / "_build" / "libxvr_drr_stats.so")
 os.environ["XVR_DRR_LIBRARY"] = str(stats_lib)
 
 import torch  # noqa: E402

@@ -4,7 +4,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 WAVES = [3, 4, 5, 6, 8]
-lib = lambda w: ROOT / "xvr_amd" / "lib" / f"libxvr_drr_fwd_w{w}.so"
+lib = lambda w: ROOT / "tools" / "_build" / f"libxvr_drr_fwd_w{w}.so"
 if sys.argv[1:] == ["build"]:
     from xvr_amd.build import build_diagnostic_library
     for w in WAVES:

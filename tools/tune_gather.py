@@ -15,7 +15,7 @@ VARIANTS = [(6, 13), (5, 15), (7, 11)]
 
 
 def lib(w, t):
-    return ROOT / "xvr_amd" / "lib" / f"libxvr_drr_tune_w{w}_t{t}.so"
+    return ROOT / "tools" / "_build" / f"libxvr_drr_tune_w{w}_t{t}.so"
 
 
 if sys.argv[1:] == ["build"]:

@@ -22,7 +22,7 @@ RENDERER = "trilinear"
 
 
 def lib(name):
-    return ROOT / "xvr_amd" / "lib" / f"libxvr_drr_tune_{name}.so"
+    return ROOT / "tools" / "_build" / f"libxvr_drr_tune_{name}.so"
 
 
 if sys.argv[1:] == ["build"]:

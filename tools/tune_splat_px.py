@@ -4,7 +4,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 VARIANTS = [("r1", ["XVR_SPX_REFILL=1"]), ("r2", ["XVR_SPX_REFILL=2"]), ("r4", ["XVR_SPX_REFILL=4"]), ("r8", ["XVR_SPX_REFILL=8"])]
-lib = lambda n: ROOT / "xvr_amd" / "lib" / f"libxvr_drr_tune_px_{n}.so"
+lib = lambda n: ROOT / "tools" / "_build" / f"libxvr_drr_tune_px_{n}.so"
 if sys.argv[1:] == ["build"]:
     from xvr_amd.build import build_diagnostic_library
     for n, d in VARIANTS:

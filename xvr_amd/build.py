@@ -30,16 +30,43 @@ HIPCC_FLAGS = [
 ]
 
 
-def build_diagnostic_library(define, out: Path) -> Path:
+DIAG = ROOT / "tools" / "_build"   # diagnostic / tuning builds live with the tools, never next to the product library
+
+
+def diagnostic_path(name: str) -> Path:
+    return DIAG / f"libxvr_drr_{name}.so"
+
+
+def build_diagnostic_library(define, out: Path, only=None) -> Path:
     """A separate library with extra -D's (e.g. XVR_GATHER_STATS; a string or a list of them) for the measuring tools
-    under tools/; never loaded by the package itself."""
+    under tools/; never loaded by the package itself and never written into xvr_amd/lib/ (some of these builds compute
+    deliberately wrong sums).  ``only``: the translation units the defines touch (file names) -- the others are taken from
+    the product build's objects, which must be up to date (build_library())."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    out = Path(out)
+    if out.parent.resolve() == (PKG / "lib").resolve():
+        raise ValueError("diagnostic libraries do not belong in xvr_amd/lib/: use xvr_amd.build.diagnostic_path(name)")
     out.parent.mkdir(parents=True, exist_ok=True)
     defines = [define] if isinstance(define, str) else list(define)
-    cmd = [hipcc, *HIPCC_FLAGS, *[f"-D{d}" for d in defines], "-shared", "-o", str(out), *map(str, SRC)]
-    proc = subprocess.run(cmd, capture_output=True, text=True)
-    if proc.returncode != 0:
-        raise RuntimeError(f"hipcc failed ({proc.returncode}):\n{proc.stdout}\n{proc.stderr}")
+    def run(cmd):
+        proc = subprocess.run(cmd, capture_output=True, text=True)
+        if proc.returncode != 0:
+            raise RuntimeError(f"hipcc failed ({proc.returncode}):\n{proc.stdout[-4000:]}\n{proc.stderr[-4000:]}")
+
+    if only is None:
+        run([hipcc, *HIPCC_FLAGS, *[f"-D{d}" for d in defines], "-shared", "-o", str(out), *map(str, SRC)])
+        return out
+    build_library()
+    assert any(s.name in only for s in SRC), only
+    objs = []
+    for s in SRC:
+        if s.name in only:   # compile, then link: hipcc takes every input of a mixed command line for HIP source
+            obj = out.with_name(out.stem + "_" + s.stem + ".o")
+            run([hipcc, *HIPCC_FLAGS, *[f"-D{d}" for d in defines], "-c", str(s), "-o", str(obj)])
+            objs.append(obj)
+        else:
+            objs.append(OBJ / (s.stem + ".o"))
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(out), *map(str, objs)])
     return out
 
 

@@ -140,6 +140,211 @@ __device__ __forceinline__ void tri_march(const RenderArgs& A, const Ray& R, con
     acc.E1 = E1;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same march, software-pipelined: the gathers of trip i + 1 (U samples) are issued BEFORE trip i is consumed, so
+// a wavefront keeps 2 U samples' loads in flight (the plain march: U = 2, and every trip exposes the full latency of
+// its slowest tap -- half of the forward's L1 misses also miss the L2).  Only the sample's position and its load
+// offsets live across the loads; the weights are rebuilt from the position when the sample is consumed.  Same
+// arithmetic per sample, same order of the running sums: identical output bits.
+// ---------------------------------------------------------------------------------------------
+template <bool YP>
+struct TapAddr {
+    float px, py, pz, u, al;
+    bool act;
+    int off[YP ? 2 : 4];
+};
+
+#ifndef XVR_FWD_PIPE_ASM  // 1: the y-pair loads of the pipelined march as inline asm with hand-placed s_waitcnt (tuning builds)
+#define XVR_FWD_PIPE_ASM 0
+#endif
+typedef float f4v __attribute__((ext_vector_type(4)));
+template <int I> struct IntC { static constexpr int value = I; };
+template <int I, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < E) {
+        f(IntC<I>{});
+        static_for<I + 1, E>(f);
+    }
+}
+template <bool YP> struct RawTaps;
+#if XVR_FWD_PIPE_ASM
+template <> struct RawTaps<true> { f4v q[2]; };
+// The compiler knows nothing of these loads: it neither waits for them nor keeps other values out of their destination
+// registers by itself.  Every use goes through taps_wait<N>(), which ties the registers to an s_waitcnt vmcnt(N) (N = loads
+// issued after the ones wanted; loads return in order), and a set that is never consumed is drained the same way.
+__device__ __forceinline__ void taps_issue(RawTaps<true>& W, const float* p0, const float* p1) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(W.q[0]) : "v"(p0));
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(W.q[1]) : "v"(p1));
+}
+template <int N>
+__device__ __forceinline__ void taps_wait(RawTaps<true>& W) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(W.q[0]), "+v"(W.q[1]) : "n"(N));
+}
+#else
+template <> struct RawTaps<true> { fquad q[2]; };
+#endif
+template <> struct RawTaps<false> { fpair q[4]; };
+
+template <bool YP>
+__device__ __forceinline__ void tap_offsets(float px, float py, float pz, int D0, int D1, int D2, int (&off)[YP ? 2 : 4]) {
+    const int ix = (int)floorf(px), iy = (int)floorf(py), iz = (int)floorf(pz);
+    const int cx0 = min(max(ix, 0), D0 - 1), cx1 = min(max(ix + 1, 0), D0 - 1);
+    const int zc = min(max(iz, 0), D2 - 2);
+    if constexpr (YP) {
+        const int ypc = min(max(iy, -1), D1 - 1) + 1;
+        off[0] = ((cx0 * (D1 + 1) + ypc) * D2 + zc) * 2;
+        off[1] = ((cx1 * (D1 + 1) + ypc) * D2 + zc) * 2;
+    } else {
+        const int cy0 = min(max(iy, 0), D1 - 1), cy1 = min(max(iy + 1, 0), D1 - 1);
+        off[0] = (cx0 * D1 + cy0) * D2 + zc;
+        off[1] = (cx0 * D1 + cy1) * D2 + zc;
+        off[2] = (cx1 * D1 + cy0) * D2 + zc;
+        off[3] = (cx1 * D1 + cy1) * D2 + zc;
+    }
+}
+
+template <bool JAC, int MASK, bool CLIP, bool YP, int U>
+__device__ __forceinline__ void tri_march_pipe(const RenderArgs& A, const Ray& R, const KRange K, const int kbeg, const int kend,
+                                               const float step, float* lds, const int tid, TriAcc& acc) {
+    const int N = A.sp.n_points;
+    const float* __restrict__ vol = A.volume;
+    const int D0 = A.D0, D1 = A.D1, D2 = A.D2;
+    float S = 0.f;
+    float G[3] = {0.f, 0.f, 0.f}, H[3] = {0.f, 0.f, 0.f};
+    float E0 = 0.f, E1 = 0.f;
+    unsigned cnt = 0;
+    const float adx = A.sp.a[0] * R.d[0], ady = A.sp.a[1] * R.d[1], adz = A.sp.a[2] * R.d[2];
+
+    auto address = [&](const int k, TapAddr<YP>& a) {
+        a.act = k >= K.lo && k <= K.hi && k <= kend;
+        a.u = linspace_at(k, N, A.sp.near_, A.sp.far_, step);
+        a.al = CLIP ? fmaf(a.u, R.amax - R.amin, R.amin) : a.u;
+        a.px = fmaf(A.sp.a[0], fmaf(a.al, R.d[0], R.s[0]), A.sp.b[0]);
+        a.py = fmaf(A.sp.a[1], fmaf(a.al, R.d[1], R.s[1]), A.sp.b[1]);
+        a.pz = fmaf(A.sp.a[2], fmaf(a.al, R.d[2], R.s[2]), A.sp.b[2]);
+        tap_offsets<YP>(a.px, a.py, a.pz, D0, D1, D2, a.off);
+    };
+    // (the loaded registers are carried across the loop as they arrive: re-filing them here would be a copy that waits
+    // for the load at the end of the trip that issued it)
+    auto fetch = [&](const TapAddr<YP>& a, RawTaps<YP>& W) {
+        if constexpr (YP) {
+#if XVR_FWD_PIPE_ASM
+            taps_issue(W, vol + a.off[0], vol + a.off[1]);
+#else
+#pragma unroll
+            for (int q = 0; q < 2; ++q) W.q[q] = load_quad(vol + a.off[q]);
+#endif
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) W.q[q] = load_pair(vol + a.off[q]);
+        }
+    };
+    auto consume = [&](const TapAddr<YP>& a, const RawTaps<YP>& W) {
+        if (!a.act) return;
+        fpair P[4];
+        if constexpr (YP) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                P[2 * q] = fpair{W.q[q].x, W.q[q].z};
+                P[2 * q + 1] = fpair{W.q[q].y, W.q[q].w};
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) P[q] = W.q[q];
+        }
+        Taps t;
+        make_taps(a.px, a.py, a.pz, D0, D1, D2, t);
+        int lab = 0;
+        if (MASK == 2) {
+            lab = packed_label(P, a.px, a.py, a.pz, D0, D1, D2, A.C);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                P[q].x = __uint_as_float(__float_as_uint(P[q].x) & ~LABEL_MASK);
+                P[q].y = __uint_as_float(__float_as_uint(P[q].y) & ~LABEL_MASK);
+            }
+        } else if (MASK == 1) {
+            lab = nearest_label(A.mask, a.px, a.py, a.pz, D0, D1, D2, A.C);
+        }
+        const float v0 = fmaf(t.pz1, P[0].y, t.pz0 * P[0].x), v1 = fmaf(t.pz1, P[1].y, t.pz0 * P[1].x);
+        const float v2 = fmaf(t.pz1, P[2].y, t.pz0 * P[2].x), v3 = fmaf(t.pz1, P[3].y, t.pz0 * P[3].x);
+        const float r0 = fmaf(t.wy1, v1, t.wy0 * v0), r1 = fmaf(t.wy1, v3, t.wy0 * v2);
+        const float v = fmaf(t.wx1, r1, t.wx0 * r0);
+        ++cnt;
+        if (MASK) {
+            lds[lab * WG + tid] += v;
+            if (JAC) S += v;
+        } else {
+            S += v;
+        }
+        if (JAC) {
+            const float d0 = fmaf(t.qz1, P[0].y, t.qz0 * P[0].x), d1 = fmaf(t.qz1, P[1].y, t.qz0 * P[1].x);
+            const float d2 = fmaf(t.qz1, P[2].y, t.qz0 * P[2].x), d3 = fmaf(t.qz1, P[3].y, t.qz0 * P[3].x);
+            const float gz = fmaf(t.wx1, fmaf(t.wy1, d3, t.wy0 * d2), t.wx0 * fmaf(t.wy1, d1, t.wy0 * d0));
+            const float gx = fmaf(t.sx1, r1, t.sx0 * r0);
+            const float gy = fmaf(t.wx1, fmaf(t.sy1, v3, t.sy0 * v2), t.wx0 * fmaf(t.sy1, v1, t.sy0 * v0));
+            G[0] += gx; G[1] += gy; G[2] += gz;
+            H[0] = fmaf(a.al, gx, H[0]); H[1] = fmaf(a.al, gy, H[1]); H[2] = fmaf(a.al, gz, H[2]);
+            if (CLIP) {
+                const float gd = fmaf(gx, adx, fmaf(gy, ady, gz * adz));
+                E0 = fmaf(gd, 1.f - a.u, E0);
+                E1 = fmaf(gd, a.u, E1);
+            }
+        }
+    };
+
+    // two register sets, ping-pong (no copies): while set A is consumed, set B's loads are in flight, and vice versa
+    TapAddr<YP> Aa[U], Ab[U];
+    RawTaps<YP> Pa[U], Pb[U];
+    constexpr int LPS = YP ? 2 : 4;   // loads per sample
+    // sample h of the set being consumed: U samples' loads of the other set and U - 1 - h of its own were issued after it
+#if XVR_FWD_PIPE_ASM
+#define TRI_PIPE_WAIT(SET, h) if constexpr (YP) taps_wait<LPS * (2 * U - 1 - (h))>(SET[h])
+#else
+#define TRI_PIPE_WAIT(SET, h) (void)0
+#endif
+    if (kbeg <= kend) {
+#pragma unroll
+        for (int h = 0; h < U; ++h) address(kbeg + h, Aa[h]);
+#pragma unroll
+        for (int h = 0; h < U; ++h) fetch(Aa[h], Pa[h]);
+        bool a_pending = false;   // which set holds loads that nobody consumed when the loop ends
+        for (int kk = kbeg;; kk += 2 * U) {
+            // (the trip behind the last one is addressed too: offsets are clamped into the volume, its samples are inactive)
+#pragma unroll
+            for (int h = 0; h < U; ++h) address(kk + U + h, Ab[h]);
+#pragma unroll
+            for (int h = 0; h < U; ++h) fetch(Ab[h], Pb[h]);
+            static_for<0, U>([&](auto hc) { constexpr int h = decltype(hc)::value; TRI_PIPE_WAIT(Pa, h); consume(Aa[h], Pa[h]); });
+            if (kk + U > kend) break;
+#pragma unroll
+            for (int h = 0; h < U; ++h) address(kk + 2 * U + h, Aa[h]);
+#pragma unroll
+            for (int h = 0; h < U; ++h) fetch(Aa[h], Pa[h]);
+            static_for<0, U>([&](auto hc) { constexpr int h = decltype(hc)::value; TRI_PIPE_WAIT(Pb, h); consume(Ab[h], Pb[h]); });
+            if (kk + 2 * U > kend) { a_pending = true; break; }
+        }
+#if XVR_FWD_PIPE_ASM
+        if constexpr (YP) {   // drain the set that was fetched and never used: its registers stay ours until the loads have landed
+            if (a_pending) {
+#pragma unroll
+                for (int h = 0; h < U; ++h) taps_wait<0>(Pa[h]);
+            } else {
+#pragma unroll
+                for (int h = 0; h < U; ++h) taps_wait<0>(Pb[h]);
+            }
+        }
+#endif
+        (void)a_pending;
+    }
+#undef TRI_PIPE_WAIT
+    acc.S = S;
+    acc.cnt = cnt;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { acc.G[i] = G[i]; acc.H[i] = H[i]; }
+    acc.E0 = E0;
+    acc.E1 = E1;
+}
+
 // Scale the sums and write the pixel (and its jacobian row).
 template <bool JAC, int MASK, bool CLIP>
 __device__ __forceinline__ void tri_finish(const RenderArgs& A, const Ray& R, const int b, const int r, const float* lds,
@@ -187,6 +392,9 @@ __device__ __forceinline__ void tri_finish(const RenderArgs& A, const Ray& R, co
 #ifndef XVR_FWD_WAVES   // (overridable for tuning builds)
 #define XVR_FWD_WAVES 4
 #endif
+#ifndef XVR_FWD_PIPE_U  // > 0: the software-pipelined march with that many samples per trip (tuning builds)
+#define XVR_FWD_PIPE_U 0
+#endif
 template <bool JAC, int MASK, bool CLIP, bool YP = false>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, XVR_FWD_WAVES))) void k_trilinear_fwd(RenderArgs A) {
     extern __shared__ float lds[];  // MASK: per-lane channel accumulators [C][WG]
@@ -204,7 +412,11 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, XVR_FWD_W
         for (int c = 0; c < A.C; ++c) lds[c * WG + tid] = 0.f;
     }
     TriAcc acc;
+#if XVR_FWD_PIPE_U > 0
+    tri_march_pipe<JAC, MASK, CLIP, YP, XVR_FWD_PIPE_U>(A, R, K, kbeg, kend, step, lds, tid, acc);
+#else
     tri_march<JAC, MASK, CLIP, YP>(A, R, K, kbeg, kend, step, lds, tid, acc);
+#endif
     if (valid) tri_finish<JAC, MASK, CLIP>(A, R, b, r, lds, tid, acc);
     if (A.work) {
         unsigned tot = wave_sum_u(acc.cnt);
