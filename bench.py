@@ -32,6 +32,33 @@ HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s
 HBM_COPY_GBS = 6290.0
 TAP_BYTES_PER_SAMPLE = 32   # 8 taps x 4 B; the voxel backward accumulates into the same 8
 
+# What actually binds the render kernels (their taps are served by L1 / L2 / LDS, not by HBM): unit costs measured on this
+# chip by the committed microbenchmarks, applied to the live unit count.  floor_ms = the time the launch would take if the
+# binding unit were busy every clock and nothing else cost anything.
+CUS, CLK_GHZ = 256, 2.4
+BINDING = {
+    # tools/microbench/lds_atomics.hip, profiles/r02_microbench_lds_atomics.txt: a ds_add_u32 wavefront instruction costs
+    # >= 4.4 LDS clocks however few lanes are live; 8 per sample; 53.9 of 64 lanes live (profiles/r02_trilinear_rocprof_summary.md)
+    "trilinear_backward": {"unit": "lds_atomic_issue", "wave_instr_per_64_units": 8 / (53.9 / 64), "clk_per_wave_instr": 4.4,
+                           "source": "profiles/r02_microbench_lds_atomics.txt"},
+    # tools/microbench/gather.hip, profiles/r01_microbench_gather_lines.txt: a 64-lane gather costs ~15 clk per CU on one
+    # 128-B line and 10-14 more per further line; the forward's two 16-byte gathers per sample (y-pair copy) touch ~3 lines
+    "trilinear_forward": {"unit": "texture_address", "wave_instr_per_64_units": 2, "clk_per_wave_instr": 36.0,
+                          "source": "profiles/r01_microbench_gather_lines.txt"},
+    # one 4-byte gather per segment over ~10 lines (bricked copy; tools/sim_siddon_lines.py): 15 + 9 x 12 clk
+    "siddon_forward": {"unit": "texture_address", "wave_instr_per_64_units": 1, "clk_per_wave_instr": 90.0,
+                       "source": "profiles/r01_microbench_gather_lines.txt, tools/sim_siddon_lines.py"},
+}
+
+
+def binding_floor(tag, units, avg_ms):
+    b = BINDING.get(tag.split("[")[0].split("+")[0])
+    if not b or not units:
+        return None
+    floor_ms = units / 64.0 * b["wave_instr_per_64_units"] * b["clk_per_wave_instr"] / CUS / (CLK_GHZ * 1e9) * 1e3
+    return {"unit": b["unit"], "floor_ms": floor_ms, "frac": floor_ms / avg_ms, "clk_per_wave_instr": b["clk_per_wave_instr"],
+            "source": b["source"]}
+
 
 # which profiled kernels make up each timed C-ABI call (one call may launch several kernels)
 TRAFFIC_KERNELS = {
@@ -96,6 +123,12 @@ def main():
     ap.add_argument("--cpu-rays", type=int, default=16384, help="rays of one DRR rendered by the CPU baseline")
     ap.add_argument("--no-c1-plumbing", action="store_true", help="skip the whole-DRR configs[0] leg of the CPU baseline")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--update-volume", action="store_true",
+                    help="change the volume in place before every step (its version counter moves: no cached render-ready "
+                         "layout survives) -- the scenario the voxel gradient exists for")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="with --gpus 1: initialise the process group (RCCL for --backend nccl) and run the all-gather on one rank")
+    ap.add_argument("--no-variants", action="store_true", help="skip the short secondary loops (volume changing, clip_to_volume)")
     ap.add_argument("--single-device", action="store_true",
                     help="testing hook: every rank uses cuda:0 (with --backend gloo), to exercise the N > 1 code path on a 1-GPU box")
     args = ap.parse_args()
@@ -109,11 +142,19 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        kw_pg = {}
+        if world == 1 and "RANK" not in os.environ:   # --force-dist outside a launcher: a one-rank group on the loopback
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            kw_pg = dict(init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, **kw_pg)
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, **kw_pg)
 
     from xvr_amd import renderers
     from xvr_amd.data import make_phantom, read
@@ -145,18 +186,21 @@ def main():
     # the exchange step: every rank ends up with every DRR (one all_gather_into_tensor).  The unequal shares of a ragged
     # strong-scaling split are padded to the largest share: no backend gathers uneven tensors in one collective
     Bmax = B if args.scaling == "weak" else -(-B_total // world)
-    gathered = torch.empty(world * Bmax, 1, H, H, device=dev) if world > 1 else None
-    send = torch.zeros(Bmax, 1, H, H, device=dev) if world > 1 and Bmax != B else None
+    gathered = torch.empty(world * Bmax, 1, H, H, device=dev) if use_dist else None
+    send = torch.zeros(Bmax, 1, H, H, device=dev) if use_dist and Bmax != B else None
 
-    def step():
+    def step(module=None, update_volume=args.update_volume):
         density.grad = None
         rot.grad = None
         xyz.grad = None
+        if update_volume:   # an optimiser that USES dL/dvoxel writes the volume every step
+            with torch.no_grad():
+                density.add_(0.0)
         # DRR.forward from the pose parameters (Euler ZXY, xvr's registration parameterisation): pose -> camera is
         # one HIP launch, then rays -> render, [B,1,H,H]
-        img = drr(rot, xyz, parameterization="euler_angles", convention="ZXY", density=density, **kw)
+        img = (module or drr)(rot, xyz, parameterization="euler_angles", convention="ZXY", density=density, **kw)
         handle = None
-        if world > 1:  # the exchange step of the path: every rank gets every rendered DRR (RCCL over xGMI)
+        if use_dist:  # the exchange step of the path: every rank gets every rendered DRR (RCCL over xGMI)
             if send is not None:
                 send[:B].copy_(img.detach())
             handle = dist.all_gather_into_tensor(gathered, img.detach() if send is None else send, async_op=True)
@@ -186,7 +230,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     renderers.PROFILER = []
     torch.cuda.synchronize()
@@ -194,7 +238,7 @@ def main():
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     events, renderers.PROFILER = renderers.PROFILER, None
@@ -218,8 +262,14 @@ def main():
         v["algorithmic_GBps"] = (units * bytes_per_unit / (v["avg_ms"] * 1e-3) / 1e9) if tapk else None
     dom = kernels[dominant]
     nominal_units = B * H * H * (args.n_points if args.renderer == "trilinear" else 0)
+    for k, v in kernels.items():
+        bf = binding_floor(k, units, v["avg_ms"])
+        if bf:
+            v["binding"] = bf
     roofline = {
-        "bound": "hbm", "kernel": dominant,
+        # (`frac` prices SURVEY 8d's algorithmic tap bytes against the HBM peak -- the survey's metric.  The taps are served
+        #  on-chip: what the memory side moved is `hbm_physical`, and the unit that really binds the kernel is `binding`.)
+        "bound": "hbm", "bound_detail": "algorithmic tap bandwidth (cache-served); binding unit under `binding`", "kernel": dominant,
         "achieved": dom["algorithmic_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": (dom["algorithmic_GBps"] or 0.0) / HBM_PEAK_GBS,
         "frac_of_measured_copy_peak": (dom["algorithmic_GBps"] or 0.0) / HBM_COPY_GBS,
@@ -228,6 +278,8 @@ def main():
         "bytes_per_unit": bytes_per_unit, "avg_launch_ms": dom["avg_ms"],
         "nominal_units_per_launch": nominal_units or None,
     }
+    if "binding" in dom:
+        roofline["binding"] = dom["binding"]
     # Three ways to price the same launch, side by side: `frac` = counted algorithmic taps (the kernel
     # skips, exactly, the samples that only read padding); `nominal_frac` = SURVEY 8d's nominal B*H*W*N samples -- it can
     # exceed 1 because more than half of them lie outside the volume; `hbm_physical` = what the memory side actually
@@ -265,11 +317,33 @@ def main():
         "roofline": roofline, "kernels": kernels,
     }
 
+    # The headline is conditional on two things the driver's record should show next to it: (i) the benchmark
+    # never changes the volume, so the renderer's cached y-pair copy serves every step -- an optimiser that uses dL/dvoxel
+    # does, and falls back to the natural layout; (ii) `clip_to_volume` is an unpinned semantic knob of the reference's
+    # trilinear renderer, and the other setting has 2.1 x the volume-touching samples.  Two short secondary loops.
+    if world == 1 and not args.no_variants and args.renderer == "trilinear" and not args.no_voxel_grad:
+        def timed_loop(n, **kws):
+            step(**kws)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(n):
+                step(**kws)
+            torch.cuda.synchronize()
+            return 1e3 * (time.perf_counter() - t) / n
+
+        variants = {"ms_per_step_volume_changing": timed_loop(5, update_volume=True)}
+        drr_clip = DRR(subject, 1020.0, H, delx, renderer="trilinear", reverse_x_axis=False, clip_to_volume=True).to(dev)
+        variants["clip_to_volume_ms_per_step"] = timed_loop(3, module=drr_clip, update_volume=False)
+        del drr_clip
+        result["variants"] = variants
+        result["ms_per_step_volume_changing"] = variants["ms_per_step_volume_changing"]
+        result["clip_to_volume_ms_per_step"] = variants["clip_to_volume_ms_per_step"]
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(vol, drr, rot, xyz, spec, args)
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

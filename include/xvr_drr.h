@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define XVR_DRR_ABI_VERSION 4   /* 4: volume_layout 2 + xvr_drr_pack_bricks (siddon forward); 3: xvr_drr_spec.volume_layout + xvr_drr_pack_ypairs; 2: xvr_sim_spec grew, camera-driven forwards, packed labels, xvr_pose.h */
+#define XVR_DRR_ABI_VERSION 5   /* 5: xvr_drr_set_option / xvr_drr_get_option (the A/B switches are no longer getenv calls per launch); 4: volume_layout 2 + xvr_drr_pack_bricks (siddon forward); 3: xvr_drr_spec.volume_layout + xvr_drr_pack_ypairs; 2: xvr_sim_spec grew, camera-driven forwards, packed labels, xvr_pose.h */
 
 #define XVR_DRR_OK 0
 #define XVR_DRR_E_ARG (-1)     /* bad argument (null pointer, non-positive size, unsupported combo) */
@@ -67,6 +67,22 @@ typedef struct xvr_drr_spec {
 
 int xvr_drr_abi_version(void);
 const char* xvr_drr_last_error(void);
+
+/*
+ * A/B switches of the launch logic -- every setting selects among CORRECT kernels (same results up to the documented
+ * rounding); they exist for measurements and for tests that compare the alternatives inside one process.  The table is
+ * read ONCE from the environment when the library is loaded (XVR_DRR_<NAME>, upper case) and changed afterwards only through
+ * xvr_drr_set_option; no entry point calls getenv.  Names and values:
+ *   "fwd_lds"       0 | 1      1: the LDS-staged trilinear forward (slower; natural volume layout only)          [0]
+ *   "tile_shape"    -1 | 0-2   pixels a wavefront takes out of a 16x16 tile: per workgroup | 8x8 | 16x4 | 4x16   [-1]
+ *   "block_order"   -1 | 0-4   logical block -> (pose, tile) map; -1: by batch size                              [-1]
+ *   "order_group"   0 | gx + 256 gy   tiles per group of the grouped block orders; 0: full-width strips          [0]
+ *   "fwd_split"     0 | n | 100 + n   sample slices per ray of small forwards: measured table | 8x8 tiles x n | 16x16 tiles x n [0]
+ *   "gather_splat"  1 | 0      trilinear voxel gradient: brick-local fixed-point splat | fp32 voxel-driven gathers [1]
+ * Returns XVR_DRR_E_ARG for an unknown name or a value outside the option's range.
+ */
+int xvr_drr_set_option(const char* name, int value);
+int xvr_drr_get_option(const char* name, int* value);
 
 /* Bytes of device scratch the backward entry points can use (see `workspace` below). */
 size_t xvr_drr_backward_workspace_bytes(int B, int n, int D0, int D1, int D2);

@@ -49,3 +49,36 @@ def make_case(shape=(20, 24, 28), height=12, width=10, sdd=400.0, delx=6.0, n_la
     affinv = torch.linalg.inv(affine)[None]
     return dict(volume=vol, mask=mask, source=_apply(affinv, src), target=_apply(affinv, tgt), img=img,
                 affine=affine, pose=pose, height=height, width=width, sdd=sdd, delx=delx)
+
+
+def accuracy_by_magnitude(ref, candidates, decades=7):
+    """Relative error of voxel gradients binned by the magnitude of the reference: for decade d, the voxels with
+    10^-(d+1) < |ref| / max|ref| <= 10^-d.  ``candidates``: name -> tensor.  Returns a list of rows
+    {"decade": d, "voxels": n, name: {"median": ..., "p99": ..., "max": ...}} (relative to each voxel's OWN reference
+    value -- what a per-voxel optimiser such as Adam sees -- not to the largest gradient)."""
+    import torch
+
+    ref = ref.detach().double().cpu().flatten()
+    top = ref.abs().max().item()
+    rows = []
+    for d in range(decades):
+        sel = (ref.abs() <= top * 10.0 ** -d) & (ref.abs() > top * 10.0 ** -(d + 1))
+        n = int(sel.sum())
+        row = {"decade": d, "voxels": n}
+        if n:
+            r = ref[sel]
+            for name, g in candidates.items():
+                e = ((g.detach().double().cpu().flatten()[sel] - r).abs() / r.abs())
+                k99 = max(int(0.99 * n) - 1, 0)
+                row[name] = {"median": e.median().item(), "p99": e.kthvalue(k99 + 1).values.item(), "max": e.max().item()}
+        rows.append(row)
+    return rows
+
+
+def format_accuracy_table(rows, names):
+    lines = ["| |g| / max|g| | voxels | " + " | ".join(f"{n}: median / p99 / max" for n in names) + " |",
+             "|---|---|" + "---|" * len(names)]
+    for r in rows:
+        cells = [f"{r[n]['median']:.1e} / {r[n]['p99']:.1e} / {r[n]['max']:.1e}" if n in r else "-" for n in names]
+        lines.append(f"| 1e-{r['decade'] + 1} .. 1e-{r['decade']} | {r['voxels']} | " + " | ".join(cells) + " |")
+    return "\n".join(lines)

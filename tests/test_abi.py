@@ -72,3 +72,27 @@ def test_product_path_has_no_cpu_fallback():
 def test_product_never_imports_the_oracle():
     for p in (ROOT / "xvr_amd").rglob("*.py"):
         assert "oracle" not in p.read_text().replace("oracle/", "").replace("oracle-only", ""), p
+
+
+def test_options_table_is_set_through_the_abi_and_seeded_from_the_environment_once():
+    """The A/B switches of the launch logic are a table behind xvr_drr_set_option / xvr_drr_get_option (include/xvr_drr.h);
+    the environment seeds it when the library is loaded and is never consulted again (no getenv on the hot path)."""
+    import subprocess
+    import sys
+
+    from xvr_amd import _lib
+
+    assert _lib.get_option("gather_splat") in (0, 1)
+    with _lib.option("fwd_split", 104):
+        assert _lib.get_option("fwd_split") == 104
+    assert _lib.get_option("fwd_split") == 0
+    lib = _lib.load()
+    assert lib.xvr_drr_set_option(b"no_such_option", 1) == -1
+    assert lib.xvr_drr_set_option(b"tile_shape", 7) == -1 and _lib.get_option("tile_shape") == -1
+    assert b"getenv" not in b"".join(p.read_bytes() for p in (ROOT / "xvr_amd" / "csrc").glob("drr_[!a]*.hip*")), \
+        "a render translation unit calls getenv (only drr_api.hip's load-time table may)"
+    code = ("import os; os.environ['XVR_DRR_GATHER_SPLAT'] = '0'; os.environ['XVR_DRR_ORDER_GROUP'] = '8x2';"
+            "from xvr_amd import _lib; print(_lib.get_option('gather_splat'), _lib.get_option('order_group'));"
+            "os.environ['XVR_DRR_GATHER_SPLAT'] = '1'; print(_lib.get_option('gather_splat'))")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, check=True).stdout.split()
+    assert out == ["0", str(8 | 2 << 8), "0"]

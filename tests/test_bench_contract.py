@@ -32,10 +32,27 @@ def test_bench_json_contract(renderer):
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "DRRs/s" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
     assert c["threads"] >= c["cores"] and "median of" in c["sample"]
+    # what really binds the dominant kernel (its taps are cache-served): a floor from the committed microbenchmarks
+    assert r["binding"]["unit"] in ("lds_atomic_issue", "texture_address") and 0 < r["binding"]["floor_ms"]
+    assert abs(r["binding"]["frac"] - r["binding"]["floor_ms"] / r["avg_launch_ms"]) < 1e-9
     if renderer == "trilinear":
+        # the knob- and scenario-conditional figures next to the headline
+        assert d["ms_per_step_volume_changing"] > 0 and d["clip_to_volume_ms_per_step"] > 0
         assert r["nominal_frac"] >= r["frac"]            # nominal samples >= volume-touching samples
         p1 = c["c1_plumbing"]                            # BASELINE.json configs[0], whole DRRs, on the CPU
         assert p1["value"] > 0 and p1["reps"] >= 3 and "128x128" in p1["config"] and "batch_size 4" in p1["config"]
+
+
+@pytest.mark.gpu
+def test_bench_one_rank_over_rccl():
+    """--force-dist --backend nccl: the process group is RCCL and the step's all_gather_into_tensor runs on it -- on ONE rank, so
+    that the first RCCL call of this project does not happen on the driver's 8-GPU node (missing 4)."""
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--steps", "2", "--warmup", "1", "--size", "64", "--det", "32", "--batch", "4",
+           "--n-points", "80", "--no-cpu-baseline", "--no-variants", "--force-dist", "--backend", "nccl", "--update-volume"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["global_batch"] == 4
 
 
 def _torchrun_bench(extra, port):

@@ -100,7 +100,8 @@ def test_sample_split_forward_and_jacobian(ns, kw, grid, monkeypatch):
     image and the pose-side gradients that come from the jacobian written in the same sweep."""
     from xvr_amd.spec import RenderSpec
 
-    monkeypatch.setenv("XVR_DRR_FWD_SPLIT", str(ns))
+    from xvr_amd import _lib
+
     spec = RenderSpec(**kw)
     # (even sizes: the centre pixel of an odd detector looks exactly through the volume's centre, a corner of
     #  eight voxels, where Siddon's one-sided derivatives are a matter of tie-breaking)
@@ -111,8 +112,9 @@ def test_sample_split_forward_and_jacobian(ns, kw, grid, monkeypatch):
     for t in (src, tgt, img):
         t.requires_grad_(True)
     from xvr_amd.renderers import render
-    out = render(vol, src, tgt, img, spec, None, ray_grid_w=gw)
-    (out * w.cuda()).sum().backward()
+    with _lib.option("fwd_split", ns):
+        out = render(vol, src, tgt, img, spec, None, ray_grid_w=gw)
+        (out * w.cuda()).sum().backward()
     ref = _oracle_render(case, spec, grads=True, w=w)
     _close(out, ref[0], FWD_TOL, f"forward ns={ns}")
     for h, r, name in zip((src.grad, tgt.grad, img.grad), ref[2:], ("grad_source", "grad_target", "grad_img")):
@@ -175,6 +177,58 @@ def test_ypair_volume_layout_is_bit_identical(kw, shape, monkeypatch):
                 assert ("pack_ypairs" in [e[0] for e in renderers.PROFILER]) == flag
                 renderers.PROFILER = None
         assert masked[0].shape[1] == 3 and torch.equal(masked[0], masked[1])
+
+
+@pytest.mark.parametrize("renderer", ["trilinear", "siddon"])
+def test_layout_copies_follow_the_volume_through_deepcopy_data_writes_and_invalidate(renderer, monkeypatch):
+    """The render-ready copies (y-pair / bricked) live in a registry validated by a weak reference to the volume tensor
+    (ADVICE r2): a deepcopy of the volume -- Registrar.run deep-copies the DRR, registrar/base.py:161,192 -- starts with no
+    copy of its own (a clone's version counter restarts, so a carried-over key could match different data), in-place torch ops
+    rebuild the copy through the version counter, and a write through ``.data`` (which does NOT bump it) is honoured after
+    ``invalidate_volume_cache``."""
+    import copy
+
+    from xvr_amd import renderers
+    from xvr_amd.renderers import render
+    from xvr_amd.spec import RenderSpec
+
+    spec = RenderSpec(renderer=renderer, n_points=90) if renderer == "trilinear" else RenderSpec(renderer="siddon")
+    monkeypatch.setattr(renderers, "YPAIR_MIN_WAVEFRONTS", 1)
+    case = make_case(seed=5, shape=(30, 34, 38), height=32, width=32)
+    vol, src, tgt, img = (case[k].cuda() for k in ("volume", "source", "target", "img"))
+    kind = "ypairs" if renderer == "trilinear" else "bricks"
+
+    def fresh(v):   # what the natural layout gives for the same data: the reference for "not stale"
+        monkeypatch.setattr(renderers, "YPAIR_LAYOUT", False)
+        monkeypatch.setattr(renderers, "BRICK_LAYOUT", False)
+        try:
+            return render(v.clone(), src, tgt, img, spec, ray_grid_w=32)
+        finally:
+            monkeypatch.setattr(renderers, "YPAIR_LAYOUT", True)
+            monkeypatch.setattr(renderers, "BRICK_LAYOUT", True)
+
+    for _ in range(3):
+        a = render(vol, src, tgt, img, spec, ray_grid_w=32)
+    assert renderers._VOLUME_CACHE[id(vol)][kind][1] is not None and not any(k.startswith("_xvr") for k in vol.__dict__)
+    assert torch.equal(a, fresh(vol))
+    vol.mul_(0.5)                                    # version bump: the copy is stale and must not be used
+    assert torch.equal(render(vol, src, tgt, img, spec, ray_grid_w=32), fresh(vol))
+    for _ in range(3):
+        render(vol, src, tgt, img, spec, ray_grid_w=32)
+    assert renderers._VOLUME_CACHE[id(vol)][kind][1] is not None
+    clone = copy.deepcopy(vol)
+    assert id(clone) not in renderers._VOLUME_CACHE          # nothing travels with a deepcopy
+    clone.add_(1.0)                                          # version 1 on the clone, whatever the original's counter says
+    for _ in range(4):
+        c = render(clone, src, tgt, img, spec, ray_grid_w=32)
+    assert torch.equal(c, fresh(clone)) and not torch.equal(c, a)
+    vol.data.mul_(2.0)                                       # does not bump the version counter ...
+    renderers.invalidate_volume_cache(vol)                   # ... so the caller says so
+    assert torch.equal(render(vol, src, tgt, img, spec, ray_grid_w=32), fresh(vol))
+    key = id(clone)
+    del clone, c
+    assert key not in renderers._VOLUME_CACHE                # an entry dies with its tensor
+
 
 
 @pytest.mark.parametrize("packed", [True, False], ids=["packed-labels", "mask-lookup"])
@@ -1025,7 +1079,7 @@ def test_packed_labels_are_the_mask_lookup_up_to_15_ulp_of_density(renderer, mon
         outs[packed] = render(vol, src, tgt, img, spec, mask, ray_grid_w=24)
     assert outs[True].shape[1] == 16
     _close(outs[True], outs[False], 1e-5, "packed vs lookup")
-    assert getattr(vol, "_xvr_packed", None) is not None
+    assert renderers._VOLUME_CACHE[id(vol)].get("packed") is not None and "_xvr_packed" not in vol.__dict__
     # in-place edits invalidate the packed copy
     monkeypatch.setattr(renderers, "PACK_LABELS", True)
     mask.fmod_(4.0)
@@ -1136,7 +1190,7 @@ def test_gradient_ncc_module_dispatches_to_hip_and_matches_torch(shape, monkeypa
 def test_fuzz_random_configurations_against_the_oracle(seed):
     """Randomised parity: random volume shape / spacing, detector shape, intrinsics, poses (incl. sources inside
     the volume and rays that miss it), renderer and every RenderSpec knob -- forward and all four gradients against
-    the oracle.  Small launches take the split kernels; XVR_DRR_FWD_SPLIT=1 in the second half of the seeds forces
+    the oracle.  Small launches take the split kernels; the option fwd_split = 1 in the second half of the seeds forces
     the unsplit ones."""
     import os
 
@@ -1172,12 +1226,10 @@ def test_fuzz_random_configurations_against_the_oracle(seed):
     mask = case["mask"] if masked else None
     C = int(case["mask"].max().item()) + 1 if masked else 1
     w = torch.rand(B, C, H * W, generator=torch.Generator().manual_seed(seed))
-    if seed % 2:
-        os.environ["XVR_DRR_FWD_SPLIT"] = "1"
-    try:
+    from xvr_amd import _lib
+
+    with _lib.option("fwd_split", 1 if seed % 2 else 0):
         hip = _hip_render(case, spec, mask=mask, grid_w=W if rng.random() < 0.8 else 0, grads=True, w=w)
-    finally:
-        os.environ.pop("XVR_DRR_FWD_SPLIT", None)
     ref = _oracle_render(case, spec, mask=mask, grads=True, w=w)
     what = f"seed {seed}: {kw} shape {shape} det {H}x{W} B {B} masked {masked} inside {inside}"
     named = dict(zip(("out", "grad_volume", "grad_source", "grad_target", "grad_img"), zip(hip, ref)))

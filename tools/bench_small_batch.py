@@ -1,5 +1,5 @@
 """Forward(+jacobian) render time for SMALL batches (one registration pose) at several detector sizes, with the
-sample-split factor forced (XVR_DRR_FWD_SPLIT) vs chosen automatically.  Run on the GPU box."""
+sample-split factor forced (the option fwd_split) vs chosen automatically.  Run on the GPU box."""
 import os
 import sys
 from pathlib import Path
@@ -18,7 +18,7 @@ sub = read(vol, spacing=(256.0 / size,) * 3, orientation="AP")
 rot, xyz = torch.tensor([[3.1, 0.05, -0.02]]), torch.tensor([[5.0, 750.0, -8.0]])
 
 
-from xvr_amd import renderers  # noqa: E402
+from xvr_amd import _lib, renderers  # noqa: E402
 
 
 def timed(fn, n=30):
@@ -43,9 +43,6 @@ for renderer in (sys.argv[2:] or ["trilinear", "siddon"]):
             pose_args = (r, xyz.repeat(B, 1).cuda())
             row = []
             for ns in ("1", "2", "4", "8", "16", "102", "104", "auto"):
-                if ns == "auto":
-                    os.environ.pop("XVR_DRR_FWD_SPLIT", None)
-                else:
-                    os.environ["XVR_DRR_FWD_SPLIT"] = ns
+                _lib.set_option("fwd_split", 0 if ns == "auto" else int(ns))
                 row.append(f"{ns}:{timed(lambda: drr(*pose_args, parameterization='euler_angles', convention='ZXY')):7.1f}")
             print(f"{renderer:9s} B={B} det={det:3d}  fwd+jac us  " + "  ".join(row), flush=True)

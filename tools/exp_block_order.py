@@ -1,5 +1,5 @@
-"""Forward time of the benchmark batch under the block -> (pose, tile) orders of map_ray (XVR_DRR_BLOCK_ORDER /
-XVR_DRR_ORDER_GROUP).  Run on the GPU box."""
+"""Forward time of the benchmark batch under the block -> (pose, tile) orders of map_ray (options block_order /
+order_group).  Run on the GPU box."""
 import os
 import sys
 from pathlib import Path
@@ -8,7 +8,7 @@ import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from bench import deepfluoro_poses  # noqa: E402
-from xvr_amd import renderers  # noqa: E402
+from xvr_amd import _lib, renderers  # noqa: E402
 from xvr_amd.data import make_phantom, read  # noqa: E402
 from xvr_amd.drr import DRR  # noqa: E402
 
@@ -21,7 +21,9 @@ for renderer in ("trilinear", "siddon"):
     kw = {"n_points": 500} if renderer == "trilinear" else {}
     r = rot.clone().requires_grad_(True)
     for order, group in ((0, "16x4"), (2, "16x4"), (2, "4x16"), (2, "2x16"), (2, "1x16"), (2, "16x1"), (2, "8x16"), (2, "8x2")):
-        os.environ["XVR_DRR_BLOCK_ORDER"], os.environ["XVR_DRR_ORDER_GROUP"] = str(order), group
+        gx, gy = map(int, group.split("x"))
+        _lib.set_option("block_order", order)
+        _lib.set_option("order_group", gx | gy << 8)
         for _ in range(2):
             drr(r, xyz, parameterization="euler_angles", convention="ZXY", **kw)
         renderers.PROFILER = []

@@ -14,7 +14,6 @@ from xvr_amd.build import build_diagnostic_library  # noqa: E402
 
 extra = sys.argv[1:]   # further -D's, e.g. XVR_S16_TAB=512 XVR_S16_WAVES=5
 os.environ["XVR_DRR_LIBRARY"] = str(build_diagnostic_library(["XVR_S16_TRACE"] + extra, ROOT / "tools" / "_build" / "libxvr_drr_s16trace.so"))
-os.environ["XVR_DRR_GATHER_SPLAT"] = "16"
 
 import torch  # noqa: E402
 

@@ -11,7 +11,7 @@ import warnings
 
 from .build import LIB, HipccMissing, build_library, is_stale
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 JAC_STRIDE = 8
 
 
@@ -89,6 +89,8 @@ _BWD = [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, ctypes.POINTER(CSpec), _P, _
 EXPORTS = {
     "xvr_drr_abi_version": ([], ctypes.c_int),
     "xvr_drr_last_error": ([], ctypes.c_char_p),
+    "xvr_drr_set_option": ([ctypes.c_char_p, ctypes.c_int], ctypes.c_int),
+    "xvr_drr_get_option": ([ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)], ctypes.c_int),
     "xvr_drr_backward_workspace_bytes": ([_I, _I, _I, _I, _I], ctypes.c_size_t),
     "xvr_drr_siddon_backward_workspace_bytes": ([_I, _I, _I, _I, _I, ctypes.POINTER(CSpec)], ctypes.c_size_t),
     "xvr_drr_trilinear_forward": (_FWD, ctypes.c_int),
@@ -177,3 +179,31 @@ def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = load().xvr_drr_last_error().decode(errors="replace")
         raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def set_option(name: str, value: int) -> None:
+    """One of the library's A/B switches (include/xvr_drr.h: xvr_drr_set_option).  Process-wide; every setting selects among
+    correct kernels.  The XVR_DRR_<NAME> environment variables set the initial values when the library is loaded."""
+    check(load().xvr_drr_set_option(name.encode(), int(value)), f"xvr_drr_set_option({name!r}, {value})")
+
+
+def get_option(name: str) -> int:
+    v = ctypes.c_int(0)
+    check(load().xvr_drr_get_option(name.encode(), ctypes.byref(v)), f"xvr_drr_get_option({name!r})")
+    return v.value
+
+
+class option:
+    """``with _lib.option("gather_splat", 0): ...`` -- the switch is put back on exit."""
+
+    def __init__(self, name: str, value: int):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.old = get_option(self.name)
+        set_option(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.name, self.old)
+        return False

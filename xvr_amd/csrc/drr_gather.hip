@@ -311,182 +311,11 @@ __device__ __forceinline__ float linspace_sel(int k, int N, float near_, float f
     return (k < N / 2 || N == 1) ? lo : hi;
 }
 
-// (register budget set for 7 wavefronts per SIMD: 72 VGPRs, no spills, 14.4 ms at C2 against 14.6 at the 6 the
-//  compiler chose; 8 spills, 4 takes 17.7 ms)
-template <int V>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_trilinear_gather_vol(GatherArgs G) {
-    if (*G.flag > __float_as_uint(GATHER_DEV_TOL)) return;  // not a lattice: the scatter kernel runs instead
-    constexpr float HS = V == 2 ? 1.5f : 1.0f;  // half-size of the block's interpolation support
-    constexpr float CO = V == 2 ? 0.5f : 0.0f;  // block centre relative to its first voxel
-    int bx, by, bz;
-    brick_coords(blockIdx.x, G.D1, G.D2, G.bd, bx, by, bz);
-    const int tid = threadIdx.x;  // one wavefront: 4 x 4 x 4 blocks
-    const int vx = (bx * 4 + (tid >> 4)) * V, vy = (by * 4 + ((tid >> 2) & 3)) * V, vz = (bz * 4 + (tid & 3)) * V;
-    const bool inb = vx < G.D0 && vy < G.D1 && vz < G.D2;
-    const float fv[3] = {(float)vx, (float)vy, (float)vz};
-    float xv[3];  // block centre in x coordinates
-#pragma unroll
-    for (int i = 0; i < 3; ++i) xv[i] = (fv[i] + CO - G.sp.b[i]) / G.sp.a[i];
-    const int N = G.sp.n_points;
-    const float near_ = G.sp.near_, far_ = G.sp.far_;
-    const float step = N > 1 ? (far_ - near_) / (float)(N - 1) : 0.f;
-    const float inv_step = step > 0.f ? 1.f / step : 0.f;
-    const float a0 = G.sp.a[0], a1 = G.sp.a[1], a2 = G.sp.a[2];
-    const float b0 = G.sp.b[0], b1 = G.sp.b[1], b2 = G.sp.b[2];
-    // p - v for the first voxel of the block (b - v is exact, and so is folding it into the fmaf for
-    // every |p| < 2^23: these are the forward's interpolation weights); the second voxel gets its own
-    // constant so that its weight is formed by the same single fmaf
-    const float bv0 = b0 - fv[0], bv1 = b1 - fv[1], bv2 = b2 - fv[2];
-    const float bw0 = bv0 - 1.f, bw1 = bv1 - 1.f, bw2 = bv2 - 1.f;
-    const float jmargin = GATHER_DEV_TOL + 0.01f;
-#ifdef XVR_GATHER_STATS
-    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-    float acc[V * V * V];
-#pragma unroll
-    for (int i = 0; i < V * V * V; ++i) acc[i] = 0.f;
-
-    for (int wd = 0; wd < G.words; ++wd) {
-        unsigned bits = G.cull[(size_t)blockIdx.x * G.words + wd];  // uniform: scalar load
-        while (bits) {
-            const int p = wd * 32 + __builtin_ctz(bits);
-            bits &= bits - 1;
-            const PoseLattice& P = G.poses[p];
-            const float s0 = P.s[0], s1 = P.s[1], s2 = P.s[2];
-            const float w0 = xv[0] - s0, w1 = xv[1] - s1, w2 = xv[2] - s2;
-            const float av = P.nh[0] * w0 + P.nh[1] * w1 + P.nh[2] * w2;
-            const float da = HS * P.dalpha;
-            int klo, khi;
-            if (step > 0.f) {
-                const float k0 = (av - da - near_) * inv_step, k1 = (av + da - near_) * inv_step;
-                klo = (int)ceilf(fmaxf(k0 - GATHER_K_SLACK, 0.f));
-                khi = (int)floorf(fminf(k1 + GATHER_K_SLACK, (float)(N - 1)));
-            } else {
-                klo = 0;
-                khi = (fabsf(av - near_) <= da) ? 0 : -1;
-            }
-            if (!inb || !(av == av)) khi = -1;
-            XVR_STAT(0, inb ? 1 : 0);
-            XVR_STAT_WAVE(7);
-            const float grw = P.gr[0] * w0 + P.gr[1] * w1 + P.gr[2] * w2;
-            const float4* __restrict__ q = G.q + (size_t)p * G.qn;
-            const float Bx = fmaf(a0, s0, bv0), By = fmaf(a1, s1, bv1), Bz = fmaf(a2, s2, bv2);
-            for (int k = klo; k <= khi; ++k) {
-                const float al = linspace_at(k, N, near_, far_, step);
-                XVR_STAT(1, 1);
-                if (al > 1e-12f) {
-                    const float inv = 1.f / al;
-                    const float ic = fmaf(grw, inv, P.gr0);
-                    // exact extent, along the detector's row axis, of the block's slice at this alpha (PoseLattice.rl/rc):
-                    // the whole-cube window has 45 % empty rows
-                    const float dlt = al - av;
-                    const float up = fminf(fminf(fmaf(P.rl[0], dlt, HS * P.rc[0]), fmaf(P.rl[1], dlt, HS * P.rc[1])),
-                                           fminf(fmaf(P.rl[2], dlt, HS * P.rc[2]), HS * P.hwr));
-                    const float dn = fminf(fminf(fmaf(-P.rl[0], dlt, HS * P.rc[0]), fmaf(-P.rl[1], dlt, HS * P.rc[1])),
-                                           fminf(fmaf(-P.rl[2], dlt, HS * P.rc[2]), HS * P.hwr));
-                    const int ilo = (int)ceilf(fmaxf(ic - fmaf(fmaxf(dn, 0.f), inv, GATHER_WIN_MARGIN), 0.f));
-                    const int ihi = (int)floorf(fminf(ic + fmaf(fmaxf(up, 0.f), inv, GATHER_WIN_MARGIN), (float)(G.H - 1)));
-                    // lattice model of the sample positions relative to the block centre, in index space:
-                    // Q0 + i Ur + j Uc.  Used ONLY to find which pixels to visit; the weights below come
-                    // from the real targets.
-                    const float ucx = al * a0 * P.ec[0], ucy = al * a1 * P.ec[1], ucz = al * a2 * P.ec[2];
-                    const float urx = al * a0 * P.er[0], ury = al * a1 * P.er[1], urz = al * a2 * P.er[2];
-                    const float q0x = fmaf(a0, fmaf(al, P.st[0], s0), b0) - (fv[0] + CO);
-                    const float q0y = fmaf(a1, fmaf(al, P.st[1], s1), b1) - (fv[1] + CO);
-                    const float q0z = fmaf(a2, fmaf(al, P.st[2], s2), b2) - (fv[2] + CO);
-                    // reciprocal of the per-column step, clamped: an axis the row does not move along
-                    // (|uc| ~ 0) then yields (-huge, +huge) when |q| < HS and an empty interval otherwise
-                    const float rx = fabsf(ucx) < 1e-9f ? 1e9f : 1.f / ucx;
-                    const float ry = fabsf(ucy) < 1e-9f ? 1e9f : 1.f / ucy;
-                    const float rz = fabsf(ucz) < 1e-9f ? 1e9f : 1.f / ucz;
-                    const float ax_ = HS * fabsf(rx), ay_ = HS * fabsf(ry), az_ = HS * fabsf(rz);
-                    const float Ax = al, Ay = al, Az = al;   // (q holds a * d)
-                    for (int i = ilo; i <= ihi; ++i) {
-                        const float fi = (float)i;
-                        const float qx = fmaf(fi, urx, q0x), qy = fmaf(fi, ury, q0y), qz = fmaf(fi, urz, q0z);
-                        // exact j-interval on this row where |q + j Uc| < HS on all three axes
-                        const float mx = -qx * rx, my = -qy * ry, mz = -qz * rz;
-                        const float lo = fmaxf(fmaxf(mx - ax_, my - ay_), mz - az_);
-                        const float hiJ = fminf(fminf(mx + ax_, my + ay_), mz + az_);
-                        const int jlo = (int)ceilf(fmaxf(lo - jmargin, 0.f));
-                        const int jhi = (int)floorf(fminf(hiJ + jmargin, (float)(G.W - 1)));
-                        const float4* __restrict__ row = q + (size_t)i * G.qs;
-                        XVR_STAT(2, 1);
-                        XVR_STAT(3, jlo > jhi ? 1 : 0);
-                        // two candidates per trip: both 16-byte loads are issued before either is used
-                        for (int j = jlo; j <= jhi; j += 2) {
-                            const bool two = j < jhi;
-                            XVR_STAT(4, two ? 2 : 1);
-                            XVR_STAT_WAVE(6);
-                            float4 ta = row[j], tb = row[two ? j + 1 : j];
-                            tb.w = two ? tb.w : 0.f;
-#pragma unroll
-                            for (int h = 0; h < 2; ++h) {
-                                const float4 t = h ? tb : ta;
-                                // signed distance of the sample from the block's first voxel, per axis:
-                                // a (s + alpha d) + b - v folded into one fma (within an ulp of the
-                                // forward's two-fma chain); the second voxel sits exactly 1 further
-                                const float dx = fmaf(Ax, t.x, Bx), dy = fmaf(Ay, t.y, By), dz = fmaf(Az, t.z, Bz);
-                                const float ux0 = hat01(dx);
-                                const float uy0 = hat01(dy);
-                                const float uz0 = hat01(dz) * t.w;
-                                if (V == 1) {
-                                    acc[0] = fmaf(ux0 * uy0, uz0, acc[0]);
-                                } else {
-                                    const float ux1 = hat01(dx - 1.f);
-                                    const float uy1 = hat01(dy - 1.f);
-                                    const float uz1 = hat01(dz - 1.f) * t.w;
-                                    // (packed v_pk_mul/fma_f32 on (z, z+1) pairs measured SLOWER, 15.9 vs 14.7 ms:
-                                    //  the pair building / broadcast moves cost more than the halved fma count)
-                                    const float p00 = ux0 * uy0, p01 = ux0 * uy1, p10 = ux1 * uy0, p11 = ux1 * uy1;
-                                    acc[0] = fmaf(p00, uz0, acc[0]);
-                                    acc[1 % (V * V * V)] = fmaf(p00, uz1, acc[1 % (V * V * V)]);
-                                    acc[2 % (V * V * V)] = fmaf(p01, uz0, acc[2 % (V * V * V)]);
-                                    acc[3 % (V * V * V)] = fmaf(p01, uz1, acc[3 % (V * V * V)]);
-                                    acc[4 % (V * V * V)] = fmaf(p10, uz0, acc[4 % (V * V * V)]);
-                                    acc[5 % (V * V * V)] = fmaf(p10, uz1, acc[5 % (V * V * V)]);
-                                    acc[6 % (V * V * V)] = fmaf(p11, uz0, acc[6 % (V * V * V)]);
-                                    acc[7 % (V * V * V)] = fmaf(p11, uz1, acc[7 % (V * V * V)]);
-                                }
-                            }
-                        }
-                    }
-                } else {
-                    // alpha_k = 0: every ray's sample sits on the source; all pixels are candidates for the
-                    // blocks whose support contains it (a source inside the volume only)
-                    const bool hit = fabsf(fmaf(a0, s0, b0) - (fv[0] + CO)) < HS && fabsf(fmaf(a1, s1, b1) - (fv[1] + CO)) < HS &&
-                                     fabsf(fmaf(a2, s2, b2) - (fv[2] + CO)) < HS;
-                    const int cnt = hit ? G.qn : 0;   // (the rows' closing elements carry weight 0)
-                    for (int r = 0; r < cnt; ++r) {
-                        const float4 t = q[r];
-#pragma unroll
-                        for (int e = 0; e < V * V * V; ++e) {
-                            const float ox = (float)(e >> 2 & 1), oy = (float)(e >> 1 & 1), oz = (float)(e & 1);
-                            const float ux = hat01(fmaf(al, t.x, Bx - ox));
-                            const float uy = hat01(fmaf(al, t.y, By - oy));
-                            const float uz = hat01(fmaf(al, t.z, Bz - oz));
-                            acc[e] = fmaf(ux * uy * uz, t.w, acc[e]);
-                        }
-                    }
-                }
-            }
-        }
-    }
-#ifdef XVR_GATHER_STATS
-    for (int i = 0; i < 8; ++i)
-        if (st[i]) atomicAdd(&g_gather_stats[i], st[i]);
-#endif
-#pragma unroll
-    for (int e = 0; e < V * V * V; ++e) {
-        const int x = vx + (V == 2 ? (e >> 2 & 1) : 0), y = vy + (V == 2 ? (e >> 1 & 1) : 0), z = vz + (V == 2 ? (e & 1) : 0);
-        if (x < G.D0 && y < G.D1 && z < G.D2 && acc[e] != 0.f) G.gvol[((size_t)x * G.D1 + y) * G.D2 + z] += acc[e];
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // The same gather with the loop nest FLATTENED per lane (round 2; DESIGN.md section 4.1, tools/sim_gather_divergence.py).
 //
-// In the nested kernel above the 64 lanes of a wavefront walk step -> row -> pixel loops whose trip counts differ per
+// In the round-1 kernel (one nest of step -> row -> pixel loops per lane; retired in round 3) the 64 lanes of a wavefront walk step -> row -> pixel loops whose trip counts differ per
 // lane: at the benchmark geometry a wavefront's inner trip fills 47 of its 128 candidate slots and a (wavefront, pose)
 // visit costs 27 inner trips where the lanes' own work is 12 (10.3 if no lane ever idled).  Here every pose is done in
 // two phases:
@@ -907,85 +736,13 @@ __global__ __launch_bounds__(64) void k_trilinear_gather_px(GatherArgs G) {
     }
 }
 
-// Siddon voxel gradient as a gather (exact-geometry index map only: a = 1, b = shift - 1/2, so the
-// voxel a segment is credited to is the voxel whose box contains it).  d out / d V[v] for one ray is
-// L x (length of the ray inside v's box, clipped to the ray's own [alpha_lo, alpha_hi]); the box's
-// entry/exit alphas use the forward's expression ((plane + plane0) - s) * (1 / d), so they are the
-// very crossing values the forward traversal produced.
-__global__ __launch_bounds__(WG) void k_siddon_gather_vol(GatherArgs G) {
-    if (*G.flag > __float_as_uint(GATHER_DEV_TOL)) return;
-    int bx, by, bz;
-    brick_coords(blockIdx.x, G.D1, G.D2, G.bd, bx, by, bz);
-    // 256 lanes on 4 x 8 x 8 voxels (one voxel per lane: the per-pose setup dominates, so a larger
-    // workgroup that amortises the cull words and pose constants wins here -- 4^3 bricks measured 10 % slower)
-    const int tid = threadIdx.x;
-    const int vx = bx * 4 + (tid >> 6), vy = by * 8 + ((tid >> 3) & 7), vz = bz * 8 + (tid & 7);
-    const bool inb = vx < G.D0 && vy < G.D1 && vz < G.D2;
-    // planes of the voxel's box and its centre, in x coordinates
-    const float p0x = (float)vx + G.sp.plane0[0], p0y = (float)vy + G.sp.plane0[1], p0z = (float)vz + G.sp.plane0[2];
-    const float p1x = (float)(vx + 1) + G.sp.plane0[0], p1y = (float)(vy + 1) + G.sp.plane0[1],
-                p1z = (float)(vz + 1) + G.sp.plane0[2];
-    const float cx = p0x + 0.5f, cy = p0y + 0.5f, cz = p0z + 0.5f;
-    float acc = 0.f;
-    for (int wd = 0; wd < G.words; ++wd) {
-        unsigned bits = G.cull[(size_t)blockIdx.x * G.words + wd];
-        while (bits) {
-            const int p = wd * 32 + __builtin_ctz(bits);
-            bits &= bits - 1;
-            const PoseLattice& P = G.poses[p];
-            const float s0 = P.s[0], s1 = P.s[1], s2 = P.s[2];
-            const float w0 = cx - s0, w1 = cy - s1, w2 = cz - s2;
-            const float av = P.nh[0] * w0 + P.nh[1] * w1 + P.nh[2] * w2;
-            const float da = 0.5f * P.dalpha;
-            const float amin = av - da, amax = av + da;
-            // pixel = g0 + N / alpha with N in [N0 - dN, N0 + dN], alpha in [amin, amax]
-            const float nj = P.gc[0] * w0 + P.gc[1] * w1 + P.gc[2] * w2, dnj = 0.5f * P.hwc;
-            const float ni = P.gr[0] * w0 + P.gr[1] * w1 + P.gr[2] * w2, dni = 0.5f * P.hwr;
-            int jlo = 0, jhi = -1, ilo = 0, ihi = -1;
-            if (inb && amin > 1e-6f && amax >= 0.f && amin <= 1.f) {
-                const float i0 = 1.f / amin, i1 = 1.f / amax;
-                const float ja = (nj - dnj) * i0, jb = (nj - dnj) * i1, jc = (nj + dnj) * i0, jd = (nj + dnj) * i1;
-                const float ia = (ni - dni) * i0, ib = (ni - dni) * i1, ic = (ni + dni) * i0, id = (ni + dni) * i1;
-                const float jmn = fminf(fminf(ja, jb), fminf(jc, jd)) + P.gc0 - GATHER_WIN_MARGIN;
-                const float jmx = fmaxf(fmaxf(ja, jb), fmaxf(jc, jd)) + P.gc0 + GATHER_WIN_MARGIN;
-                const float imn = fminf(fminf(ia, ib), fminf(ic, id)) + P.gr0 - GATHER_WIN_MARGIN;
-                const float imx = fmaxf(fmaxf(ia, ib), fmaxf(ic, id)) + P.gr0 + GATHER_WIN_MARGIN;
-                jlo = (int)ceilf(fmaxf(jmn, 0.f));
-                jhi = (int)floorf(fminf(jmx, (float)(G.W - 1)));
-                ilo = (int)ceilf(fmaxf(imn, 0.f));
-                ihi = (int)floorf(fminf(imx, (float)(G.H - 1)));
-            } else if (inb && amin <= 1e-6f && amax >= 0.f) {
-                // the box reaches the source plane: no perspective bound -- visit every ray
-                jhi = G.W - 1;
-                ihi = G.H - 1;
-            }
-            const float lx = p0x - s0, ly = p0y - s1, lz = p0z - s2;
-            const float hx = p1x - s0, hy = p1y - s1, hz = p1z - s2;
-            const float4* __restrict__ q = G.q + (size_t)p * G.n;
-            const float2* __restrict__ q2 = G.q2 + (size_t)p * G.n;
-            for (int i = ilo; i <= ihi; ++i) {
-                for (int j = jlo; j <= jhi; ++j) {
-                    const float4 t = q[(size_t)i * G.W + j];
-                    const float2 ab = q2[(size_t)i * G.W + j];
-                    const float x0 = lx * t.x, x1 = hx * t.x, y0 = ly * t.y, y1 = hy * t.y, z0 = lz * t.z, z1 = hz * t.z;
-                    float en = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
-                    float ex = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-                    en = fmaxf(en, ab.x);
-                    ex = fminf(ex, ab.y);
-                    acc = fmaf(fmaxf(ex - en, 0.f), t.w, acc);
-                }
-            }
-        }
-    }
-    if (inb && acc != 0.f) G.gvol[((size_t)vx * G.D1 + vy) * G.D2 + vz] += acc;
-}
 
 
 // ---------------------------------------------------------------------------------------------
 // Siddon voxel gradient for NON-exact index maps (norm_dims_offset = +-1, align_corners = True: the variants SURVEY.md
 // Appendix A recalls for upstream), round 2.  The voxel a segment is credited to is rint(a x_mid + b) of its MIDPOINT, which
 // inside plane cell c is c + olo or c + olo + 1 per axis (the map drifts by less than a voxel over the volume:
-// siddon_cell_offsets).  One lane owns one CELL and gathers, as k_siddon_gather_vol does for a voxel, the length of every
+// siddon_cell_offsets).  One lane owns one CELL and gathers, as k_siddon_gather_vol2 does for its voxels, the length of every
 // ray inside it -- but splits it over 8 sums by where the forward's own midpoint arithmetic sends the segment.  The sums go
 // to a [cell][8] scratch; k_siddon_cells_to_voxels then adds, for every voxel, the eight (cell, octant) entries that
 // name it.  No atomics, deterministic; before this the non-exact maps took the fp32-atomic scatter (151 ms per C3 batch).
@@ -1250,19 +1007,12 @@ int xvr_detail::launch_gather(bool siddon, const float* source, const float* tar
     G.siddon = siddon ? 1 : 0;
     G.qs = siddon ? gw : gw + 1;
     G.qn = siddon ? n : (n / gw) * (gw + 1);
-    G.V = siddon ? 1 : gather_block();
-    // Siddon: 2x2x2 voxels per lane in 8^3 bricks unless XVR_DRR_SIDDON_GATHER_BLOCK=1 (A/B switch: one voxel per
-    // lane, 256 lanes on a 4 x 8 x 8 brick)
-    // trilinear: the per-lane flattened (table) kernel unless XVR_DRR_GATHER_TABLE=0 (A/B switch: the round-1 nested kernel;
-    // both are exact and give identical sums)
-    static const bool use_table = [] { const char* e = getenv("XVR_DRR_GATHER_TABLE"); return !(e && e[0] == '0'); }();
-    static const bool siddon_v1 = [] { const char* e = getenv("XVR_DRR_SIDDON_GATHER_BLOCK"); return e && e[0] == '1'; }();
+    G.V = siddon ? 1 : 2;   // voxels per lane and axis
     // trilinear without clip / per-channel masks: the brick-local fixed-point splat on 16^3 bricks (k_trilinear_splat_b16)
-    // unless XVR_DRR_GATHER_SPLAT=0 (A/B switch: the voxel-driven table gather)
-    // (read at every launch -- a getenv -- so that the tests can compare the two in one process)
-    const bool use_splat = [] { const char* e = getenv("XVR_DRR_GATHER_SPLAT"); return !(e && e[0] == '0'); }();
+    // unless the option "gather_splat" is 0 (A/B switch: the fp32 voxel-driven table gather)
+    const bool use_splat = xvr_detail::option(xvr_detail::OPT_GATHER_SPLAT) != 0;
     const bool splat = !siddon && use_splat && !sp->clip_to_volume && !mask;
-    if (siddon && (siddon_v1 || G.cells)) { G.bd[0] = 4; G.bd[1] = 8; G.bd[2] = 8; }
+    if (siddon && G.cells) { G.bd[0] = 4; G.bd[1] = 8; G.bd[2] = 8; }
     else if (siddon) { G.bd[0] = G.bd[1] = G.bd[2] = 8; }
     else {
         if (G.clip || G.mask) G.V = 2;   // (the pixel-major kernel is written for 2x2x2 blocks)
@@ -1275,7 +1025,7 @@ int xvr_detail::launch_gather(bool siddon, const float* source, const float* tar
         const int room = 4 * (n - n / gw);
         G.cmax_stride = room < CMAX_STRIDE ? room : CMAX_STRIDE;
     }
-    if (siddon && !siddon_v1 && !G.cells) {   // per-pose "a ray is cut at alpha = 0 / 1" words behind q's used half ([B][2 n] float4, [B][n] used)
+    if (siddon && !G.cells) {   // per-pose "a ray is cut at alpha = 0 / 1" words behind q's used half ([B][2 n] float4, [B][n] used)
         G.cmax = reinterpret_cast<unsigned*>(G.q + (size_t)B * n);
         G.cmax_stride = 4 * n < CMAX_STRIDE ? 4 * n : CMAX_STRIDE;
     }
@@ -1299,7 +1049,6 @@ int xvr_detail::launch_gather(bool siddon, const float* source, const float* tar
         const long long nvox = (long long)D0 * D1 * D2;
         hipLaunchKernelGGL(k_siddon_cells_to_voxels, dim3((unsigned)((nvox + WG - 1) / WG)), dim3(WG), 0, (hipStream_t)stream, G);
     }
-    else if (siddon && siddon_v1) hipLaunchKernelGGL(k_siddon_gather_vol, dim3((unsigned)bricks), dim3(WG), 0, (hipStream_t)stream, G);
     else if (siddon) hipLaunchKernelGGL(k_siddon_gather_vol2, dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
     else if (psplat) {
         const void* kern = G.clip ? (G.mask ? (const void*)k_trilinear_splat_px<true, true> : (const void*)k_trilinear_splat_px<true, false>)
@@ -1326,9 +1075,7 @@ int xvr_detail::launch_gather(bool siddon, const float* source, const float* tar
         }();
         hipLaunchKernelGGL(k_trilinear_splat_b16, dim3((unsigned)(bricks < resident ? bricks : resident)), dim3(256), 0, (hipStream_t)stream, G);
     }
-    else if (G.V == 2 && use_table && (unsigned)G.qn <= TAB_MAX_RAYS) hipLaunchKernelGGL(k_trilinear_gather_tab, dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
-    else if (G.V == 2) hipLaunchKernelGGL(k_trilinear_gather_vol<2>, dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
-    else hipLaunchKernelGGL(k_trilinear_gather_vol<1>, dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
+    else hipLaunchKernelGGL(k_trilinear_gather_tab, dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);   // (qn <= TAB_MAX_RAYS: gather_usable)
     e = hipGetLastError();
     if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
     return XVR_DRR_OK;

@@ -15,7 +15,7 @@
 //   drr_trilinear.hip this file: tri_march / tri_finish / k_trilinear_fwd, k_trilinear_fwd_split (small launches),
 //                     k_trilinear_fwd_lds (opt-in, slower), k_trilinear_bwd (re-march / atomic scatter fallback)
 //   drr_siddon.hip    k_siddon: forward / jacobian / backward / alpha-split
-//   drr_gather.hip    voxel gradient as a gather: k_gather_prep, k_gather_cull, k_trilinear_gather_vol, k_siddon_gather_vol2
+//   drr_gather.hip    voxel gradient as a gather: k_gather_prep, k_gather_cull, the brick-local splats (drr_splat.hiph), k_trilinear_gather_tab / _px, k_siddon_gather_vol2 / _cells
 //   drr_rays.hip      k_backward_from_jac, k_rays_fwd, k_rays_bwd, k_jac_to_cam
 //   drr_api.hip       ABI version, error text
 //
@@ -832,12 +832,9 @@ static int trilinear_forward_impl(const float* volume, const float* mask, int D0
                                  : launch(k_trilinear_fwd<true, 1, false>, A, lds, stream);
     if (mask) return clip ? launch(k_trilinear_fwd<false, 1, true>, A, lds, stream)
                           : launch(k_trilinear_fwd<false, 1, false>, A, lds, stream);
-    // LDS-staged bricks are opt-in: measured 2.25x SLOWER than the direct kernel at C2 (19.8 vs 8.8 ms;
+    // LDS-staged bricks are opt-in (option "fwd_lds"; natural layout only): measured 2.25x SLOWER than the direct kernel at C2 (19.8 vs 8.8 ms;
     // with ~4 taps per voxel the L1/L2 already capture the reuse)
-    static const bool use_lds = [] {
-        const char* e = getenv("XVR_DRR_FWD_LDS");
-        return e && e[0] == '1';
-    }();
+    const bool use_lds = xvr_detail::option(xvr_detail::OPT_FWD_LDS) == 1 && sp->volume_layout == 0;
     if (use_lds && !clip && A.grid_w > 0) {
         const size_t bytes = (size_t)(LDS_HDR + LDS_BRICK_CAP) * sizeof(float);
         return jac ? launch(k_trilinear_fwd_lds<true>, A, bytes, stream) : launch(k_trilinear_fwd_lds<false>, A, bytes, stream);

@@ -131,9 +131,10 @@ class GradientNormalizedCrossCorrelation2d(NormalizedCrossCorrelation2d):
             from .similarity import fused_gncc
 
             if self.sobel.sigma and self.sobel.sigma > 0:   # pre-blur as a HIP kernel pair, then the plain Sobel pair
-                if getattr(self, "_sobel0", None) is None:
-                    self._sobel0 = Sobel(0.0).to(x1.device)
-                return fused_gncc(x1, x2, p, self.eps, self._sobel0, self.sobel.sigma)
+                # (this module's own 3x3 weights without its blur: no submodule is created in forward -- state_dict()
+                #  stays what __init__ made it, and nothing is copied to the device under a graph capture)
+                plain = lambda img: F.conv2d(img, self.sobel.weight.to(img), padding=1)  # noqa: E731
+                return fused_gncc(x1, x2, p, self.eps, plain, self.sobel.sigma)
             return fused_gncc(x1, x2, p, self.eps, self.sobel)
         return super().forward(self.sobel(x1), self.sobel(x2))
 

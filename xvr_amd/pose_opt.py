@@ -177,7 +177,14 @@ class RegistrationStage:
             k = min(check_every, n_itr - taken)
             t0 = time.perf_counter()
             if use_graph and self.graph is None and taken >= 2:
-                self.capture()   # capture enqueues nothing: the k replays below are the iterations
+                try:
+                    self.capture()   # capture enqueues nothing: the k replays below are the iterations
+                except Exception:    # capture is an optimisation, never a requirement (the general similarity path runs
+                    # autograd and torch transforms inside it): carry on eagerly, as registrar.py's torch-optimiser loop does
+                    if self.sim_is_fused:
+                        raise
+                    self.graph, use_graph = None, False
+                    torch.cuda.synchronize()
             for _ in range(k if (self.graph is not None or not use_graph) else min(k, 2 - taken)):
                 if self.graph is not None:
                     self.graph.replay()

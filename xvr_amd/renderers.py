@@ -25,7 +25,7 @@ import torch
 from . import _lib
 from .spec import RenderSpec
 
-__all__ = ["Siddon", "Trilinear", "render", "render_from_camera", "make_cspec"]
+__all__ = ["Siddon", "Trilinear", "render", "render_from_camera", "make_cspec", "invalidate_volume_cache"]
 
 
 def make_cspec(shape, spec: RenderSpec, ray_grid_w: int = 0, volume_layout: int = 0) -> _lib.CSpec:
@@ -87,12 +87,24 @@ VOXEL_GATHER = True
 _WORKSPACES = {}
 
 
-def _workspace(lib, B, n, shape, device, cspec=None):
+# Siddon under a non-exact index map gathers per plane cell into octant sums first: 32 bytes per voxel MORE scratch
+# (4 GiB at 512^3).  That part is allocated for the one call that uses it and handed back to the caching allocator
+# afterwards, never parked in the per-stream cache, and not at all above this cap (the atomic scatter then serves).
+SIDDON_CELLS_SCRATCH_CAP = 16 << 30
+
+
+def _workspace(lib, B, n, shape, device, cspec=None, cells=False):
     if not VOXEL_GATHER:
         return None, 0
-    # (siddon under a non-exact index map: room for the per-cell octant sums as well)
-    nbytes = (lib.xvr_drr_siddon_backward_workspace_bytes(B, n, *shape, ctypes.byref(cspec)) if cspec is not None
-              else lib.xvr_drr_backward_workspace_bytes(B, n, *shape))
+    nbytes = lib.xvr_drr_backward_workspace_bytes(B, n, *shape)
+    if cells and cspec is not None:
+        full = lib.xvr_drr_siddon_backward_workspace_bytes(B, n, *shape, ctypes.byref(cspec))
+        if nbytes < full <= nbytes + SIDDON_CELLS_SCRATCH_CAP:
+            try:   # transient: lives until the caller drops it (stream-ordered reuse by the caching allocator)
+                ws = torch.empty((full + 3) // 4, device=device, dtype=torch.float32)
+                return ws, ws.numel() * 4
+            except torch.OutOfMemoryError:
+                pass   # the smaller scratch below: the dispatcher falls back to the scatter
     key = (device, torch.cuda.current_stream(device).cuda_stream)   # one scratch per stream: concurrent backwards
     ws = _WORKSPACES.get(key)                                        # on two streams must not share it
     if ws is None or ws.numel() * 4 < nbytes:
@@ -110,20 +122,52 @@ import weakref
 PACK_LABELS = _os.environ.get("XVR_DRR_PACK_LABELS", "1") != "0"
 
 
+# Render-ready copies of a volume (label-carrying, y-pair interleaved, bricked) are cached per volume TENSOR OBJECT in a
+# registry keyed by id() and validated by a weak reference -- never in the tensor's __dict__: copy.deepcopy (what
+# Registrar.run does to the DRR on every call, /root/reference/src/xvr/registrar/base.py:161,192) would carry such an
+# attribute to the clone, whose fresh version counter can equal a cached key taken from different data, and would
+# duplicate a buffer twice the volume's size per clone.  An entry dies with its tensor.  Contents are keyed by the
+# tensor's version counter, which in-place torch ops bump.  Writes that do NOT bump it -- through ``volume.data`` or through a raw
+# pointer (a custom kernel) -- must be followed by ``invalidate_volume_cache(volume)``.
+_VOLUME_CACHE = {}
+
+
+def _cache_slot(volume):
+    key = id(volume)
+    slot = _VOLUME_CACHE.get(key)
+    if slot is None or slot["ref"]() is not volume:
+        def _drop(ref, key=key):
+            cur = _VOLUME_CACHE.get(key)
+            if cur is not None and cur["ref"] is ref:
+                del _VOLUME_CACHE[key]
+        slot = _VOLUME_CACHE[key] = {"ref": weakref.ref(volume, _drop)}
+    return slot
+
+
+def invalidate_volume_cache(volume=None):
+    """Forget the render-ready copies (y-pair / bricked / label-carrying) of ``volume`` -- of every volume when None.
+    Needed only after a write that does not bump the tensor's version counter: ``volume.data.<op>_()``, or a kernel that
+    writes through ``data_ptr()``."""
+    if volume is None:
+        _VOLUME_CACHE.clear()
+    else:
+        slot = _VOLUME_CACHE.get(id(volume))
+        if slot is not None and slot["ref"]() is volume:
+            del _VOLUME_CACHE[id(volume)]
+
+
 def _packed_volume(lib, volume, mask):
-    """The label-carrying copy of ``volume``; cached ON the volume tensor object (an address-keyed cache goes
+    """The label-carrying copy of ``volume``; cached per volume tensor object (an address-keyed cache goes
     stale when the allocator hands the same address to the next step's density)."""
     key = (mask.data_ptr(), mask._version, volume._version)
-    hit = getattr(volume, "_xvr_packed", None)
+    slot = _cache_slot(volume)
+    hit = slot.get("packed")
     if hit is not None and hit[0] == key and hit[2]() is mask:   # (weak reference: an id() can be recycled)
         return hit[1]
     packed = torch.empty_like(volume)
     rc = _timed("pack_labels", lib.xvr_drr_pack_labels, _ptr(volume), _ptr(mask), volume.numel(), _ptr(packed), _stream())
     _lib.check(rc, "xvr_drr_pack_labels")
-    try:
-        volume._xvr_packed = (key, packed, weakref.ref(mask))
-    except AttributeError:   # pragma: no cover  (exotic tensor subclasses without a __dict__)
-        pass
+    slot["packed"] = (key, packed, weakref.ref(mask))
     return packed
 
 
@@ -138,50 +182,40 @@ YPAIR_MIN_WAVEFRONTS = 2048     # smaller launches take the sample-split kernels
 BRICK_LAYOUT = _os.environ.get("XVR_DRR_BRICKS", "1") != "0"
 
 
-def _ypair_volume(lib, volume):
-    """The y-pair copy of ``volume``, or None the first TWO times a version of it is seen: the copy costs 0.76 ms at 512^3
-    and saves ~0.25-0.5 ms per render, so it only pays for a volume that is rendered again and again unchanged
-    (registration, the benchmark, a fixed CT); a volume that changes between renders -- voxels being optimised, or the fresh
-    HU -> density map of every training step, rendered exactly twice (trainer.py:185-230) -- stays on the natural layout."""
+def _layout_copy(lib, volume, kind):
+    """The y-pair (``kind`` = "ypairs") or bricked ("bricks") copy of ``volume``, or None the first TWO times a version of
+    it is seen: the copy costs 0.76 ms at 512^3 and saves ~0.25-0.5 ms per render, so it only pays for a volume that is
+    rendered again and again unchanged (registration, the benchmark, a fixed CT); a volume that changes between renders --
+    voxels being optimised, or the fresh HU -> density map of every training step, rendered exactly twice
+    (trainer.py:185-230) -- stays on the natural layout."""
     D0, D1, D2 = volume.shape
     key = volume._version
-    hit = getattr(volume, "_xvr_ypairs", None)      # (version, copy or None, buffer kept for reuse, renders seen)
+    slot = _cache_slot(volume)
+    hit = slot.get(kind)      # (version, copy or None, buffer kept for reuse, renders seen)
     if hit is not None and hit[0] == key and hit[1] is not None:
         return hit[1]
     seen = hit[3] + 1 if hit is not None and hit[0] == key else 1
+    buf = hit[2] if hit is not None else None
     if seen <= 2:
-        try:
-            volume._xvr_ypairs = (key, None, hit[2] if hit is not None else None, seen)
-        except AttributeError:   # pragma: no cover
-            pass
+        slot[kind] = (key, None, buf, seen)
         return None
-    pairs = hit[2] if hit[2] is not None else torch.empty(lib.xvr_drr_ypairs_bytes(D0, D1, D2) // 4, device=volume.device, dtype=torch.float32)
-    rc = _timed("pack_ypairs", lib.xvr_drr_pack_ypairs, _ptr(volume), D0, D1, D2, _ptr(pairs), _stream())
-    _lib.check(rc, "xvr_drr_pack_ypairs")
-    volume._xvr_ypairs = (key, pairs, pairs, seen)
-    return pairs
+    nbytes, pack, name = ((lib.xvr_drr_ypairs_bytes, lib.xvr_drr_pack_ypairs, "pack_ypairs") if kind == "ypairs"
+                          else (lib.xvr_drr_bricks_bytes, lib.xvr_drr_pack_bricks, "pack_bricks"))
+    if buf is None:
+        buf = torch.empty(nbytes(D0, D1, D2) // 4, device=volume.device, dtype=torch.float32)
+    rc = _timed(name, pack, _ptr(volume), D0, D1, D2, _ptr(buf), _stream())
+    _lib.check(rc, f"xvr_drr_{name}")
+    slot[kind] = (key, buf, buf, seen)
+    return buf
+
+
+def _ypair_volume(lib, volume):
+    return _layout_copy(lib, volume, "ypairs")
 
 
 def _brick_volume(lib, volume):
-    """The 4 x 2 x 4-bricked copy of ``volume`` for the Siddon forward (xvr_drr_pack_bricks), cached on the tensor like the
-    y-pair copy and by the same rule: None the first two times a version is seen."""
-    D0, D1, D2 = volume.shape
-    key = volume._version
-    hit = getattr(volume, "_xvr_bricks", None)      # (version, copy or None, buffer kept for reuse, renders seen)
-    if hit is not None and hit[0] == key and hit[1] is not None:
-        return hit[1]
-    seen = hit[3] + 1 if hit is not None and hit[0] == key else 1
-    if seen <= 2:
-        try:
-            volume._xvr_bricks = (key, None, hit[2] if hit is not None else None, seen)
-        except AttributeError:   # pragma: no cover
-            pass
-        return None
-    bricks = hit[2] if hit[2] is not None else torch.empty(lib.xvr_drr_bricks_bytes(D0, D1, D2) // 4, device=volume.device, dtype=torch.float32)
-    rc = _timed("pack_bricks", lib.xvr_drr_pack_bricks, _ptr(volume), D0, D1, D2, _ptr(bricks), _stream())
-    _lib.check(rc, "xvr_drr_pack_bricks")
-    volume._xvr_bricks = (key, bricks, bricks, seen)
-    return bricks
+    """(4 x 2 x 4-voxel bricks for the Siddon forward, xvr_drr_pack_bricks; cached by the y-pair copy's rule)"""
+    return _layout_copy(lib, volume, "bricks")
 
 
 def _use_bricks(spec, volume, B, n, C=1):
@@ -270,12 +304,16 @@ class _Render(torch.autograd.Function):
             cs = make_cspec((D0, D1, D2), spec, ctx.ray_grid_w)
             fn = lib.xvr_drr_trilinear_backward if spec.renderer == "trilinear" else lib.xvr_drr_siddon_backward
             pose_here = need_pose and not from_jac
-            ws, ws_bytes = (_workspace(lib, B, n, (D0, D1, D2), dev, cs if spec.renderer == "siddon" else None) if need_vol else (None, 0))
+            ws, ws_bytes = None, 0
             tag = ("pose" if pose_here else "") + ("+vol" if need_vol else "")
             if msk_c is not None and uniform and not pose_here:
                 # every sample lands in exactly one channel, so a gradient that is the same for all channels (the backward
                 # of xvr's `img.sum(dim=1)`) reaches the voxels as if there were no mask: the plain one-channel gather
                 msk_c, C, gout = None, 1, g_uniform
+            if need_vol:
+                # (the per-cell scratch only when the cells gather will really run: Siddon, no mask left, rays on a lattice)
+                ws, ws_bytes = _workspace(lib, B, n, (D0, D1, D2), dev, cs,
+                                          cells=spec.renderer == "siddon" and msk_c is None and ctx.ray_grid_w > 1)
             rc = _timed(f"{spec.renderer}_backward[{tag.strip('+')}]", fn,
                         _ptr(vol_c), _ptr(msk_c), D0, D1, D2, C, _ptr(src_c), _ptr(tgt_c), _ptr(len_c), B, n,
                         ctypes.byref(cs), _ptr(gout), _ptr(gvol),
