@@ -46,6 +46,10 @@ class RenderSpec:
     voxel_shift: float = 0.5
     # A3: added to (target - source) before both the alpha and the xyz computations.
     eps: float = 1e-8
+    # A3': False = eps guards the alpha divisions only, the sample points are s + alpha (t - s).  The two differ by
+    # alpha * eps <= 1e-8 voxels -- below fp32 resolution of any coordinate >= 0.1, so ONE kernel serves both
+    # (tests/test_oracle.py bounds the difference); the knob exists so that the pin grid can name the upstream form.
+    eps_in_xyz: bool = True
     # A6: grid_sample's align_corners.
     align_corners: bool = False
     # A5: xyz is normalised with dims = shape + norm_dims_offset before grid_sample.  0 makes
@@ -61,7 +65,11 @@ class RenderSpec:
     # False: alphas = linspace(near, far) over the whole source->target segment, shared by all rays
     #        (samples outside the volume read zeros).  True: alphas rescaled per ray to
     #        [alphamin, alphamax] and the sum additionally scaled by (alphamax - alphamin).
-    clip_to_volume: bool = False
+    # "batch": ONE window for the whole call -- alphas = A + linspace * (Z - A) with A = min over rays of alphamin and
+    #        Z = max over rays of alphamax (rays that miss the volume aside), shared by all rays, the sum scaled by (Z - A).
+    #        A third plausible upstream form of the same call (SURVEY App. A marks the alpha rule "uncertain"); A and Z
+    #        are differentiable (min / max route the gradient to the two extremal rays), as torch autograd would have them.
+    clip_to_volume: bool | str = False
     # --- siddon only ---
     # True: each ray integrates only over its own [max(alphamin,0), min(alphamax,1)], crossings
     # clipped into that interval (what a per-ray traversal does).  False: literal sort formulation, whose batch-wide column filter
@@ -118,7 +126,7 @@ def _filter_columns(alphas, alphamin, alphamax):
 
 def _xyzs(alpha, source, target, shape, spec: RenderSpec):
     """Points at parameter alpha on each ray, normalised to grid_sample's [-1, 1]^3."""
-    xyz = (source.unsqueeze(-2) + alpha.unsqueeze(-1) * (target - source + spec.eps).unsqueeze(2)).unsqueeze(1)
+    xyz = (source.unsqueeze(-2) + alpha.unsqueeze(-1) * (target - source + (spec.eps if spec.eps_in_xyz else 0.0)).unsqueeze(2)).unsqueeze(1)
     dims = torch.tensor(list(shape)).to(source) + spec.norm_dims_offset
     return 2 * (xyz + spec.voxel_shift) / dims - 1
 
@@ -150,13 +158,29 @@ def _to_channels(samples, volume, mask, xyzs, spec):
 # --------------------------------------------------------------------------------------
 # renderers
 # --------------------------------------------------------------------------------------
-def trilinear(volume, source, target, img, spec: RenderSpec, mask=None):
-    """Trilinear ray-marching.  volume[D0,D1,D2]; source[B,1,3]; target[B,n,3]; img[B,1,n] -> [B,C,n]."""
+def batch_window(source, target, shape, spec: RenderSpec):
+    """(A, Z): the smallest alphamin and the largest alphamax over every ray of the call that meets the volume
+    ((0, 0) when none does: the image is then zero)."""
+    alphamin, alphamax = _alpha_minmax(source, target, shape, spec)
+    hit = alphamax > alphamin
+    if not bool(hit.any()):
+        z = (source.sum() + target.sum()) * 0
+        return z, z
+    return alphamin[hit].min(), alphamax[hit].max()
+
+
+def trilinear(volume, source, target, img, spec: RenderSpec, mask=None, window=None):
+    """Trilinear ray-marching.  volume[D0,D1,D2]; source[B,1,3]; target[B,n,3]; img[B,1,n] -> [B,C,n].
+    ``window``: the (A, Z) of ``clip_to_volume="batch"`` when the caller has computed it over MORE rays than it passes here
+    (``render`` chunks over rays; the window belongs to the whole call)."""
     shape = volume.shape
     N = spec.n_points
     alphas = torch.linspace(spec.near, spec.far, N)[None, None].to(volume)
     alphamin, alphamax = _alpha_minmax(source, target, shape, spec)
-    if spec.clip_to_volume:
+    if spec.clip_to_volume == "batch":
+        A, Z = window if window is not None else batch_window(source, target, shape, spec)
+        alphas = A + alphas * (Z - A)                       # [1, 1, N], shared by all rays
+    elif spec.clip_to_volume:
         alphas = alphamin + alphas * (alphamax - alphamin)  # [B, n, N]
     elif spec.filter_intersections_outside_volume:
         # numerically a no-op (dropped columns only ever sample zero padding) -- widen the window by
@@ -170,7 +194,9 @@ def trilinear(volume, source, target, img, spec: RenderSpec, mask=None):
     out = _to_channels(samples, volume, mask, xyzs, spec)
     denom = N if spec.step_mode == "n_points" else N - 1
     scale = img / denom
-    if spec.clip_to_volume:
+    if spec.clip_to_volume == "batch":
+        scale = scale * (Z - A)
+    elif spec.clip_to_volume:
         scale = scale * (alphamax - alphamin).clamp_min(0).squeeze(-1).unsqueeze(1)
     return out * scale
 
@@ -215,10 +241,13 @@ def render(volume, source, target, img, spec: RenderSpec, mask=None, chunk: int 
         return fn(volume, source, target, img, spec, mask)
     if spec.renderer == "siddon" and not spec.per_ray_clamp:
         raise ValueError("the literal (batch-filtered) siddon cannot be chunked without changing its result")
+    kw = {}
+    if spec.renderer == "trilinear" and spec.clip_to_volume == "batch":
+        kw["window"] = batch_window(source, target, volume.shape, spec)   # of the whole call, not of a chunk
     outs = []
     for lo in range(0, target.shape[1], chunk):
         sl = slice(lo, lo + chunk)
-        outs.append(fn(volume, source, target[:, sl], img[..., sl], spec, mask))
+        outs.append(fn(volume, source, target[:, sl], img[..., sl], spec, mask, **kw))
     return torch.cat(outs, dim=-1)
 
 

@@ -1,0 +1,206 @@
+"""BASELINE.json configs[3] (C4: multiscale multi-start registration) and configs[4] (C5: the training step's two renders)
+against the oracle pipeline and at their stated sizes.
+
+* C5 in miniature: render #1 (masked, channels), ``keep``, render #2 and d loss / d pred_pose against
+  ``oracle.diffdrr_restated.drr_from_pose(mask=...)`` + ``oracle/metrics_restated.py`` -- the call sequence of
+  /root/reference/src/xvr/model/trainer.py:185-230,279-304 on both sides.
+* C5 at 512^3 -> 256^2, B = 116, 8 labels: channel sum == unmasked render, air exactly 0, ``keep`` == the reference's
+  thresholds (trainer.py:292-302) evaluated on the oracle's render of two of the poses.
+* C4 at 512^3, 2048^2 X-ray, pyramid "8,4" (256^2 -> 512^2), 8 starts through ``Registrar.run_batch``: converges, is
+  bit-identical across two runs, and an iteration stays under 0.5 ms per pose.
+"""
+import pytest
+import torch
+
+from conftest import to_oracle_spec
+from test_hip_parity import FWD_TOL, _close
+
+pytestmark = pytest.mark.gpu
+
+
+def _reference_keep(img_channels, img_threshold=0.10, mask_threshold=0.05):
+    """The tail of Trainer.render_samples (/root/reference/src/xvr/model/trainer.py:292-302) on a [B,C,H,W] render."""
+    mask = img_channels > 0
+    img = img_channels.sum(dim=1, keepdim=True)
+    if mask.shape[1] == 1:
+        keep = mask.to(img).flatten(1).mean(1) > img_threshold
+    else:
+        keep = mask[:, 1:].sum(dim=1, keepdim=True)
+        keep = (keep > 0).to(img).flatten(1).mean(1) > mask_threshold
+    return img, mask, keep
+
+
+def _c5_miniature():
+    from xvr_amd.data import make_phantom, read, transform_hu_to_density
+    from xvr_amd.drr import DRR
+
+    vol, lab = make_phantom(48, n_ellipsoids=10, n_labels=4, seed=11)
+    hu = vol * 1400 - 1000
+    sub = read(hu, lab, spacing=(2.5, 2.5, 2.5), orientation="AP", hu=True)
+    H = 32
+    drr = DRR(sub, 1020.0, H, 8.0, renderer="trilinear", reverse_x_axis=False).cuda()
+    tmp = transform_hu_to_density(hu.cuda(), 4.2)
+    return sub, drr, tmp, lab, H
+
+
+def test_c5_miniature_renders_keep_and_pose_gradient_match_the_oracle_pipeline():
+    from oracle.diffdrr_restated import drr_from_pose
+    from oracle.metrics_restated import multiscale_ncc, xray_transforms
+    from xvr_amd.loss import DiceLoss, PoseRegressionLoss
+    from xvr_amd.metrics import DoubleGeodesicSE3, XrayTransforms
+    from xvr_amd.pose import convert
+    from xvr_amd.training import get_random_pose, render_samples
+
+    sub, drr, tmp, lab, H = _c5_miniature()
+    B = 6
+    pose = get_random_pose(170, 190, -10, 10, -5, 5, -20, 20, 600, 800, -20, 20, B, generator=torch.Generator().manual_seed(1))
+    ospec = to_oracle_spec(drr.renderer._spec(n_points=500))
+
+    def oracle_render(p):
+        return drr_from_pose(tmp.cpu(), sub.affine, p.matrix, H, H, 1020.0, 8.0, 8.0, 0.0, 0.0, ospec, orientation="AP",
+                             reverse_x_axis=False, mask=lab, chunk=256)
+
+    # ---- render #1: no grad, masked -> (img, mask, keep)
+    with torch.no_grad():
+        img, mask, keep = render_samples(drr, tmp, drr.mask, drr.affine_inverse, pose.cuda())
+        o_img, o_mask, o_keep = _reference_keep(oracle_render(pose))
+    assert img.shape == (B, 1, H, H) and mask.shape == (B, 4, H, H) and mask.dtype == torch.bool
+    _close(img, o_img, FWD_TOL, "C5 render #1 (channel sum)")
+    # `> 0` per channel: a pixel may differ only where its channel holds a sample on the very border of a structure (an
+    # interpolation weight that is 0 in one evaluation and an ulp in the other)
+    differ = mask.cpu() != o_mask
+    assert differ.float().mean().item() < 2e-3, differ.float().mean().item()
+    assert torch.equal(keep.cpu(), o_keep) and keep.any()
+
+    # ---- render #2 with grad + the loss of trainer.py:207-223, backpropagated to the predicted pose's parameters
+    rot0, xyz0 = pose.convert("euler_angles", "ZXY")
+    g = torch.Generator().manual_seed(2)
+    rot0 = rot0 + 0.03 * torch.randn(B, 3, generator=g)
+    xyz0 = xyz0 + 4.0 * torch.randn(B, 3, generator=g)
+    lossfn = PoseRegressionLoss(1020.0, weight_mvc=1e-3).cuda()
+    tf = XrayTransforms(H)
+    rot, xyz = rot0.cuda().requires_grad_(True), xyz0.cuda().requires_grad_(True)
+    pred = convert(rot, xyz, parameterization="euler_angles", convention="ZXY")
+    p_img, p_mask, _ = render_samples(drr, tmp, drr.mask, drr.affine_inverse, pred)
+    loss, mncc, dgeo, rgeo, tgeo, dice, mvc = lossfn(tf(img), mask, pose.cuda(), tf(p_img), p_mask, pred)
+    loss.mean().backward()
+
+    o_rot, o_xyz = rot0.clone().requires_grad_(True), xyz0.clone().requires_grad_(True)
+    o_pred = convert(o_rot, o_xyz, parameterization="euler_angles", convention="ZXY")
+    o_p_img, o_p_mask, _ = _reference_keep(oracle_render(o_pred))
+    o_mncc = multiscale_ncc(xray_transforms(o_img, H), xray_transforms(o_p_img, H), (None, 9), (0.5, 0.5))
+    o_dice = DiceLoss()(o_mask, o_p_mask)
+    geo = DoubleGeodesicSE3(1020.0)
+    _, _, o_dgeo = geo(pose, o_pred)
+    idx, jdx = torch.triu_indices(B, B, offset=1)
+    _, _, o_mvc = geo(pose[jdx] @ pose[idx].inverse(), o_pred[jdx] @ o_pred[idx].inverse())
+    o_loss = 1.0 * (1 - o_mncc) + 1.0 * o_dice + 1e-2 * o_dgeo + 1e-3 * o_mvc.mean()
+    o_loss.mean().backward()
+
+    _close(p_img, o_p_img, FWD_TOL, "C5 render #2")
+    _close(mncc, o_mncc, 2e-4, "C5 mNCC")
+    _close(dgeo, o_dgeo, 1e-4, "C5 double geodesic")
+    _close(mvc, o_mvc, 1e-4, "C5 multiview consistency")
+    _close(dice, o_dice, 2e-2, "C5 dice (border pixels of the `> 0` masks)")
+    _close(loss, o_loss, 2e-3, "C5 loss")
+    _close(rot.grad, o_rot.grad, 5e-3, "C5 d loss / d rotation")
+    _close(xyz.grad, o_xyz.grad, 5e-3, "C5 d loss / d translation")
+
+
+def test_c5_full_size_masked_renders_512_to_256_batch_116_eight_labels():
+    from bench import deepfluoro_poses
+    from oracle.diffdrr_restated import drr_from_pose
+    from xvr_amd.data import make_phantom, read, transform_hu_to_density
+    from xvr_amd.drr import DRR
+    from xvr_amd.training import render_samples
+
+    B, H = 116, 256
+    vol, lab = make_phantom(512, n_ellipsoids=24, n_labels=8, seed=5, device="cuda")
+    hu = vol * 1400 - 1000
+    sub = read(hu.cpu(), lab.cpu(), orientation="AP", hu=True)
+    drr = DRR(sub, 1020.0, H, 1.08821875, renderer="trilinear", reverse_x_axis=False).cuda()
+    tmp = transform_hu_to_density(hu, 4.2)
+    assert int(lab.max().item()) + 1 == 8 and (tmp == 0).float().mean().item() > 0.1     # eight channels; air is exactly 0
+    pose = deepfluoro_poses(B, seed=0).cuda()
+    with torch.no_grad():
+        img, mask, keep = render_samples(drr, tmp, drr.mask, drr.affine_inverse, pose)
+        plain, plain_mask, plain_keep = render_samples(drr, tmp, None, drr.affine_inverse, pose)
+        source, target = drr.detector(pose, None)
+        L = (target - source).norm(dim=-1).unsqueeze(1)
+        chan = drr.reshape_transform(drr.renderer(tmp, drr.affine_inverse(source), drr.affine_inverse(target), L, mask=drr.mask), B)
+    assert mask.shape == (B, 8, H, H) and chan.shape == (B, 8, H, H)
+    # channels sum to the unmasked render (the label-carrying copy moves a density by <= 15 ulp: 1.8e-6)
+    _close(img, plain, 1e-5, "sum of 8 channels vs unmasked render at B = 116")
+    # air stays exactly 0: a ray that meets no tissue is 0.0 in every channel, and nothing is negative
+    air = plain[:, 0] == 0
+    assert air.any() and (chan.sum(1)[air] == 0).all() and (chan >= 0).all()
+    assert torch.equal(air, img[:, 0] == 0)
+    # ... which is what makes the `> 0` foreground of trainer.py:292 meaningful: channel 0 (background) aside
+    assert torch.equal(mask, chan > 0)
+    # keep: the reference's thresholds on the ORACLE's render of two of the poses
+    two = [0, 57]
+    ospec = to_oracle_spec(drr.renderer._spec(n_points=500))
+    o = drr_from_pose(tmp.cpu(), sub.affine, pose.matrix[two].cpu(), H, H, 1020.0, 1.08821875, 1.08821875, 0.0, 0.0, ospec,
+                      orientation="AP", reverse_x_axis=False, mask=lab.cpu(), chunk=8192)
+    o_img, o_mask, o_keep = _reference_keep(o)
+    _close(img[two], o_img, FWD_TOL, "C5 full-size render vs oracle (2 poses)")
+    assert torch.equal(keep[two].cpu(), o_keep)
+    frac_hip = (mask[two, 1:].sum(1) > 0).float().flatten(1).mean(1).cpu()
+    frac_ref = (o_mask[:, 1:].sum(1) > 0).float().flatten(1).mean(1)
+    assert (frac_hip - frac_ref).abs().max().item() < 2e-3, (frac_hip, frac_ref)
+    assert keep.shape == (B,) and 0 < int(keep.sum()) <= B
+
+
+def test_c4_full_size_multistart_registration_pyramid_8_4_of_a_2048_xray():
+    """512^3 CT, a 2048^2 X-ray at 0.136 mm, scales "8,4" -> 256^2 then 512^2, 8 starts from
+    truth o U(+-10 deg, +-20 mm), all advanced as ONE batch by the device-resident loop."""
+    from xvr_amd.data import make_phantom, read
+    from xvr_amd.drr import DRR
+    from xvr_amd.pose import RigidTransform, convert
+    from xvr_amd.registrar import Registrar
+
+    dev = torch.device("cuda")
+    vol, _ = make_phantom(512, n_ellipsoids=64, seed=0, device=dev)
+    drr = DRR(read(vol, orientation="AP"), 1020.0, 2048, 0.1360, renderer="trilinear", reverse_x_axis=False, voxel_shift=0.0).to(dev)
+    true_rot, true_xyz = torch.tensor([[3.10, 0.05, -0.03]]), torch.tensor([[4.0, 750.0, -6.0]])
+    with torch.no_grad():
+        gt = drr(convert(true_rot, true_xyz, parameterization="euler_angles", convention="ZXY").to(dev))
+    assert gt.shape == (1, 1, 2048, 2048)
+    g = torch.Generator().manual_seed(0)
+    S = 8
+    drot = (torch.rand(S, 3, generator=g) - 0.5) * 2 * 0.1745      # +-10 degrees
+    dxyz = (torch.rand(S, 3, generator=g) - 0.5) * 2 * 20.0        # +-20 mm
+    inits = convert(true_rot + drot, true_xyz + dxyz, parameterization="euler_angles", convention="ZXY")
+    reg = Registrar(drr, scales="8,4", n_itrs="500,500")
+
+    def run():
+        outs = reg.run_batch(gt, inits)
+        torch.cuda.synchronize()
+        return outs
+
+    outs = run()
+    assert [o["drr"].detector.height for o in outs] == [512] * S
+    best = max(range(S), key=lambda b: outs[b]["nccs"][-1])
+    final = outs[best]["final_pose"].matrix[0].cpu().double()
+    truth = convert(true_rot, true_xyz, parameterization="euler_angles", convention="ZXY").matrix[0].double()
+    dR = final[:3, :3] @ truth[:3, :3].T
+    angle = torch.rad2deg(torch.arccos(((dR.trace() - 1) / 2).clamp(-1, 1))).item()
+    # translation error measured where it matters: the displacement of the volume's isocentre (world origin) in camera space
+    dt = (final[:3, 3] - truth[:3, 3]).norm().item()
+    n_close = 0
+    for b in range(S):
+        m = outs[b]["final_pose"].matrix[0].cpu().double()
+        a = torch.rad2deg(torch.arccos((((m[:3, :3] @ truth[:3, :3].T).trace() - 1) / 2).clamp(-1, 1))).item()
+        n_close += int(a < 1.0 and (m[:3, 3] - truth[:3, 3]).norm().item() < 2.0)
+    print(f"C4: best start {best}: {angle:.3f} deg, {dt:.3f} mm, ncc {outs[best]['nccs'][-1]:.4f}; {n_close} of {S} starts within 1 deg / 2 mm; "
+          f"iterations {[len(o['trajectory']) for o in outs]}")
+    assert angle < 1.0 and dt < 2.0, (angle, dt)
+    assert n_close >= S // 2
+    # bit-identical across two runs (fixed-order reductions everywhere on the device loop)
+    again = run()
+    for a, b in zip(outs, again):
+        assert torch.equal(a["final_pose"].matrix, b["final_pose"].matrix) and a["nccs"] == b["nccs"]
+    # iteration time: every pose-iteration of the batched loop under 0.5 ms (8 starts share each launch)
+    per_iter = [t for t in again[0]["times"][1:] if t > 0]
+    steady = sorted(per_iter)[len(per_iter) // 2]
+    assert steady / S < 0.5e-3, f"{1e3 * steady / S:.3f} ms per pose-iteration"

@@ -179,6 +179,51 @@ def test_ypair_volume_layout_is_bit_identical(kw, shape, monkeypatch):
         assert masked[0].shape[1] == 3 and torch.equal(masked[0], masked[1])
 
 
+@pytest.mark.parametrize("kw", [dict(n_points=120), dict(n_points=90, voxel_shift=0.0, step_mode="n_minus_1"),
+                                dict(n_points=100, norm_dims_offset=-1), dict(n_points=80, near=0.2, far=0.9, align_corners=True)], ids=_id)
+@pytest.mark.parametrize("nslabs,axis", [(2, 2), (3, 0), (5, 1), (7, 2)])
+@pytest.mark.parametrize("ypairs", [True, False], ids=["ypairs", "natural"])
+def test_slab_major_forward_partitions_the_samples_exactly(kw, nslabs, axis, ypairs, monkeypatch):
+    """k_trilinear_fwd_slab (large batches over a volume the Infinity Cache cannot hold): one launch per slab of the volume,
+    every launch over all poses, the running sums carried in `out` / `jac`.  The slabs must partition the samples EXACTLY --
+    the kernel's own count of volume-touching samples is identical to the one-launch march's -- and image and jacobian-borne
+    pose gradients agree with it to summation order (and with the oracle to the usual tolerance), for every slab axis, odd
+    slab counts, both volume layouts, with and without the jacobian."""
+    from xvr_amd import _lib, renderers
+    from xvr_amd.renderers import render
+    from xvr_amd.spec import RenderSpec
+
+    spec = RenderSpec(renderer="trilinear", **kw)
+    monkeypatch.setattr(renderers, "YPAIR_MIN_WAVEFRONTS", 1)
+    monkeypatch.setattr(renderers, "YPAIR_LAYOUT", ypairs)
+    case = make_case(seed=17, shape=(44, 40, 36), height=40, width=48, delx=1.4,
+                     rot=((170.0, 25.0, 5.0), (200.0, -30.0, -8.0), (150.0, 5.0, 12.0)), xyz=((5.0, 300.0, -4.0), (-3.0, 250.0, 6.0), (0.0, 280.0, 0.0)))
+    w = torch.rand(3, 1, 40 * 48, generator=torch.Generator().manual_seed(4))
+    vol = case["volume"].cuda()
+
+    def run(n, jac):
+        src, tgt, img = (case[k].cuda().requires_grad_(jac) for k in ("source", "target", "img"))
+        work = torch.zeros(1, dtype=torch.int64, device="cuda")
+        with _lib.option("fwd_slabs", n), _lib.option("fwd_slab_axis", axis):
+            for _ in range(3):   # (the third render of a volume version builds the y-pair copy)
+                out = render(vol, src, tgt, img, spec, ray_grid_w=48, work=work if _ == 2 else None)
+        if jac:
+            (out * w.cuda()).sum().backward()
+            return out.detach(), int(work.item()), src.grad, tgt.grad, img.grad
+        return out.detach(), int(work.item())
+
+    for jac in (False, True):
+        one, many = run(0, jac), run(nslabs, jac)
+        assert one[1] == many[1] > 0, "the slabs do not partition the samples"
+        _close(many[0], one[0], 2e-6, f"slab-major forward, {nslabs} slabs along axis {axis}")
+        for a, b, name in zip(many[2:], one[2:], ("grad_source", "grad_target", "grad_img")):
+            _close(a, b, 2e-5, f"slab-major {name}")
+    ref = _oracle_render(case, spec, grads=True, w=w)
+    _close(many[0], ref[0], FWD_TOL, "slab-major forward vs oracle")
+    for h, r, name in zip(many[2:], ref[2:], ("grad_source", "grad_target", "grad_img")):
+        _close(h, r, GRAD_TOL, f"slab-major {name} vs oracle")
+
+
 @pytest.mark.parametrize("renderer", ["trilinear", "siddon"])
 def test_layout_copies_follow_the_volume_through_deepcopy_data_writes_and_invalidate(renderer, monkeypatch):
     """The render-ready copies (y-pair / bricked) live in a registry validated by a weak reference to the volume tensor

@@ -269,3 +269,47 @@ def test_pose_gradient_of_the_restatement_matches_float64_finite_differences():
             e[1, 5, ax] = h
             fd = (f(s0, t0 + e) - f(s0, t0 - e)) / (2 * h)
             assert abs(fd - tgt.grad[1, 5, ax].item()) <= 2e-3 * max(abs(fd), tgt.grad.abs().max().item()), (r, "target", ax)
+
+
+def test_batch_window_is_the_default_render_on_a_rescaled_alpha_axis():
+    """clip_to_volume="batch": ONE alpha window [A, Z] for the whole call.  It must equal the plain render with
+    near = A + near (Z - A), far = A + far (Z - A) times (Z - A); chunking over rays must not change the window; rays that
+    miss the volume do not define it."""
+    from oracle.diffdrr_restated import batch_window
+
+    c = make_case(seed=9, height=10, width=12)
+    spec = RenderSpec(renderer="trilinear", n_points=40, clip_to_volume="batch", near=0.05, far=0.9)
+    out = render(c["volume"], c["source"], c["target"], c["img"], spec)
+    A, Z = (float(x) for x in batch_window(c["source"], c["target"], c["volume"].shape, spec))
+    assert 0.0 < A < Z < 1.0
+    plain = spec.with_(clip_to_volume=False, near=A + 0.05 * (Z - A), far=A + 0.9 * (Z - A), filter_intersections_outside_volume=False)
+    ref = render(c["volume"], c["source"], c["target"], c["img"], plain) * (Z - A)
+    assert torch.allclose(out, ref, rtol=1e-5, atol=1e-6)
+    chunked = render(c["volume"], c["source"], c["target"], c["img"], spec, chunk=17)
+    assert torch.allclose(out, chunked, rtol=1e-6, atol=1e-7)
+    # per-ray clipping puts every one of a ray's samples inside the volume; the batch window only the extremal rays'
+    per_ray = render(c["volume"], c["source"], c["target"], c["img"], spec.with_(clip_to_volume=True))
+    assert not torch.allclose(out, per_ray, rtol=1e-3, atol=1e-4)
+    # differentiable through A and Z (min / max route the gradient to the extremal rays)
+    t = c["target"].clone().requires_grad_(True)
+    render(c["volume"], c["source"], t, c["img"], spec).sum().backward()
+    assert torch.isfinite(t.grad).all() and t.grad.abs().sum() > 0
+
+
+def test_eps_placement_is_below_float32_resolution():
+    """eps_in_xyz=False (eps guards the alpha divisions only) moves the sample points by alpha * eps <= 1e-8 voxels: the two
+    forms agree to float32 rounding, which is why one kernel serves both."""
+    c = make_case(seed=11)
+    for r in ("trilinear", "siddon"):
+        spec = RenderSpec(renderer=r, n_points=60)
+        a = render(c["volume"], c["source"], c["target"], c["img"], spec)
+        b = render(c["volume"], c["source"], c["target"], c["img"], spec.with_(eps_in_xyz=False))
+        assert (a - b).abs().max() <= 2e-6 * a.abs().max()
+
+
+def test_siddon_column_filter_is_neutral_under_per_ray_clamp():
+    c = make_case(seed=13)
+    spec = RenderSpec(renderer="siddon")
+    a = render(c["volume"], c["source"], c["target"], c["img"], spec)
+    b = render(c["volume"], c["source"], c["target"], c["img"], spec.with_(filter_intersections_outside_volume=False))
+    assert torch.equal(a, b) or (a - b).abs().max() <= 1e-6 * a.abs().max()

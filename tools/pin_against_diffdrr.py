@@ -108,11 +108,14 @@ def real_drr_module(case, renderer, voxel_shift):
 
 
 def knob_grid(renderer):
-    common = dict(norm_dims_offset=[0, +1, -1], align_corners=[False, True])
+    # (eps_in_xyz moves the sample points by <= 1e-8 voxels: it can only ever be told apart in float64 vectors, and one kernel
+    #  serves both; filter_intersections_outside_volume is numerically neutral under per_ray_clamp and is listed so that the
+    #  report names the upstream setting)
+    common = dict(norm_dims_offset=[0, +1, -1], align_corners=[False, True], eps_in_xyz=[True, False])
     if renderer == "trilinear":
-        grid = dict(common, step_mode=["n_points", "n_minus_1"], clip_to_volume=[False, True])
+        grid = dict(common, step_mode=["n_points", "n_minus_1"], clip_to_volume=[False, True, "batch"])
     else:
-        grid = dict(common, per_ray_clamp=[True, False])
+        grid = dict(common, per_ray_clamp=[True, False], filter_intersections_outside_volume=[True, False])
     keys = list(grid)
     for values in itertools.product(*(grid[k] for k in keys)):
         yield dict(zip(keys, values))

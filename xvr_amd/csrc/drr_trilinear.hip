@@ -37,9 +37,16 @@ struct TriAcc {  // per-lane sums of one ray (or of one slice of its samples)
 
 // Samples kbeg..kend (wave-uniform bounds; lanes mask themselves with their own K) of the lane's ray.
 // MASK: 0 = one channel; 1 = labels from a separate mask volume; 2 = labels packed into the volume's taps
-template <bool JAC, int MASK, bool CLIP, bool YP = false>
+// SLAB: only the samples whose index coordinate along `slab.axis` lies in [slab.lo, slab.hi) count (k_trilinear_fwd_slab: the
+// slabs partition the samples exactly, because the test is made on the very coordinate the sample is taken at).
+struct SlabRange {
+    int axis;
+    float lo, hi;
+};
+
+template <bool JAC, int MASK, bool CLIP, bool YP = false, bool SLAB = false>
 __device__ __forceinline__ void tri_march(const RenderArgs& A, const Ray& R, const KRange K, const int kbeg, const int kend,
-                                          const float step, float* lds, const int tid, TriAcc& acc) {
+                                          const float step, float* lds, const int tid, TriAcc& acc, const SlabRange slab = SlabRange{0, 0.f, 0.f}) {
     const int N = A.sp.n_points;
     const float* __restrict__ vol = A.volume;
     const int D0 = A.D0, D1 = A.D1, D2 = A.D2;
@@ -66,6 +73,10 @@ __device__ __forceinline__ void tri_march(const RenderArgs& A, const Ray& R, con
             pxs[h] = fmaf(A.sp.a[0], fmaf(al[h], R.d[0], R.s[0]), A.sp.b[0]);
             pys[h] = fmaf(A.sp.a[1], fmaf(al[h], R.d[1], R.s[1]), A.sp.b[1]);
             pzs[h] = fmaf(A.sp.a[2], fmaf(al[h], R.d[2], R.s[2]), A.sp.b[2]);
+            if (SLAB) {
+                const float pa = slab.axis == 0 ? pxs[h] : (slab.axis == 1 ? pys[h] : pzs[h]);
+                act[h] = act[h] && pa >= slab.lo && pa < slab.hi;
+            }
             if (YP) make_taps_yp(pxs[h], pys[h], pzs[h], D0, D1, D2, T[h], yoff[h]);
             else make_taps(pxs[h], pys[h], pzs[h], D0, D1, D2, T[h]);  // offsets are clamped: always loadable
         }
@@ -140,211 +151,6 @@ __device__ __forceinline__ void tri_march(const RenderArgs& A, const Ray& R, con
     acc.E1 = E1;
 }
 
-// ---------------------------------------------------------------------------------------------
-// The same march, software-pipelined: the gathers of trip i + 1 (U samples) are issued BEFORE trip i is consumed, so
-// a wavefront keeps 2 U samples' loads in flight (the plain march: U = 2, and every trip exposes the full latency of
-// its slowest tap -- half of the forward's L1 misses also miss the L2).  Only the sample's position and its load
-// offsets live across the loads; the weights are rebuilt from the position when the sample is consumed.  Same
-// arithmetic per sample, same order of the running sums: identical output bits.
-// ---------------------------------------------------------------------------------------------
-template <bool YP>
-struct TapAddr {
-    float px, py, pz, u, al;
-    bool act;
-    int off[YP ? 2 : 4];
-};
-
-#ifndef XVR_FWD_PIPE_ASM  // 1: the y-pair loads of the pipelined march as inline asm with hand-placed s_waitcnt (tuning builds)
-#define XVR_FWD_PIPE_ASM 0
-#endif
-typedef float f4v __attribute__((ext_vector_type(4)));
-template <int I> struct IntC { static constexpr int value = I; };
-template <int I, int E, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < E) {
-        f(IntC<I>{});
-        static_for<I + 1, E>(f);
-    }
-}
-template <bool YP> struct RawTaps;
-#if XVR_FWD_PIPE_ASM
-template <> struct RawTaps<true> { f4v q[2]; };
-// The compiler knows nothing of these loads: it neither waits for them nor keeps other values out of their destination
-// registers by itself.  Every use goes through taps_wait<N>(), which ties the registers to an s_waitcnt vmcnt(N) (N = loads
-// issued after the ones wanted; loads return in order), and a set that is never consumed is drained the same way.
-__device__ __forceinline__ void taps_issue(RawTaps<true>& W, const float* p0, const float* p1) {
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(W.q[0]) : "v"(p0));
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(W.q[1]) : "v"(p1));
-}
-template <int N>
-__device__ __forceinline__ void taps_wait(RawTaps<true>& W) {
-    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(W.q[0]), "+v"(W.q[1]) : "n"(N));
-}
-#else
-template <> struct RawTaps<true> { fquad q[2]; };
-#endif
-template <> struct RawTaps<false> { fpair q[4]; };
-
-template <bool YP>
-__device__ __forceinline__ void tap_offsets(float px, float py, float pz, int D0, int D1, int D2, int (&off)[YP ? 2 : 4]) {
-    const int ix = (int)floorf(px), iy = (int)floorf(py), iz = (int)floorf(pz);
-    const int cx0 = min(max(ix, 0), D0 - 1), cx1 = min(max(ix + 1, 0), D0 - 1);
-    const int zc = min(max(iz, 0), D2 - 2);
-    if constexpr (YP) {
-        const int ypc = min(max(iy, -1), D1 - 1) + 1;
-        off[0] = ((cx0 * (D1 + 1) + ypc) * D2 + zc) * 2;
-        off[1] = ((cx1 * (D1 + 1) + ypc) * D2 + zc) * 2;
-    } else {
-        const int cy0 = min(max(iy, 0), D1 - 1), cy1 = min(max(iy + 1, 0), D1 - 1);
-        off[0] = (cx0 * D1 + cy0) * D2 + zc;
-        off[1] = (cx0 * D1 + cy1) * D2 + zc;
-        off[2] = (cx1 * D1 + cy0) * D2 + zc;
-        off[3] = (cx1 * D1 + cy1) * D2 + zc;
-    }
-}
-
-template <bool JAC, int MASK, bool CLIP, bool YP, int U>
-__device__ __forceinline__ void tri_march_pipe(const RenderArgs& A, const Ray& R, const KRange K, const int kbeg, const int kend,
-                                               const float step, float* lds, const int tid, TriAcc& acc) {
-    const int N = A.sp.n_points;
-    const float* __restrict__ vol = A.volume;
-    const int D0 = A.D0, D1 = A.D1, D2 = A.D2;
-    float S = 0.f;
-    float G[3] = {0.f, 0.f, 0.f}, H[3] = {0.f, 0.f, 0.f};
-    float E0 = 0.f, E1 = 0.f;
-    unsigned cnt = 0;
-    const float adx = A.sp.a[0] * R.d[0], ady = A.sp.a[1] * R.d[1], adz = A.sp.a[2] * R.d[2];
-
-    auto address = [&](const int k, TapAddr<YP>& a) {
-        a.act = k >= K.lo && k <= K.hi && k <= kend;
-        a.u = linspace_at(k, N, A.sp.near_, A.sp.far_, step);
-        a.al = CLIP ? fmaf(a.u, R.amax - R.amin, R.amin) : a.u;
-        a.px = fmaf(A.sp.a[0], fmaf(a.al, R.d[0], R.s[0]), A.sp.b[0]);
-        a.py = fmaf(A.sp.a[1], fmaf(a.al, R.d[1], R.s[1]), A.sp.b[1]);
-        a.pz = fmaf(A.sp.a[2], fmaf(a.al, R.d[2], R.s[2]), A.sp.b[2]);
-        tap_offsets<YP>(a.px, a.py, a.pz, D0, D1, D2, a.off);
-    };
-    // (the loaded registers are carried across the loop as they arrive: re-filing them here would be a copy that waits
-    // for the load at the end of the trip that issued it)
-    auto fetch = [&](const TapAddr<YP>& a, RawTaps<YP>& W) {
-        if constexpr (YP) {
-#if XVR_FWD_PIPE_ASM
-            taps_issue(W, vol + a.off[0], vol + a.off[1]);
-#else
-#pragma unroll
-            for (int q = 0; q < 2; ++q) W.q[q] = load_quad(vol + a.off[q]);
-#endif
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) W.q[q] = load_pair(vol + a.off[q]);
-        }
-    };
-    auto consume = [&](const TapAddr<YP>& a, const RawTaps<YP>& W) {
-        if (!a.act) return;
-        fpair P[4];
-        if constexpr (YP) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                P[2 * q] = fpair{W.q[q].x, W.q[q].z};
-                P[2 * q + 1] = fpair{W.q[q].y, W.q[q].w};
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) P[q] = W.q[q];
-        }
-        Taps t;
-        make_taps(a.px, a.py, a.pz, D0, D1, D2, t);
-        int lab = 0;
-        if (MASK == 2) {
-            lab = packed_label(P, a.px, a.py, a.pz, D0, D1, D2, A.C);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                P[q].x = __uint_as_float(__float_as_uint(P[q].x) & ~LABEL_MASK);
-                P[q].y = __uint_as_float(__float_as_uint(P[q].y) & ~LABEL_MASK);
-            }
-        } else if (MASK == 1) {
-            lab = nearest_label(A.mask, a.px, a.py, a.pz, D0, D1, D2, A.C);
-        }
-        const float v0 = fmaf(t.pz1, P[0].y, t.pz0 * P[0].x), v1 = fmaf(t.pz1, P[1].y, t.pz0 * P[1].x);
-        const float v2 = fmaf(t.pz1, P[2].y, t.pz0 * P[2].x), v3 = fmaf(t.pz1, P[3].y, t.pz0 * P[3].x);
-        const float r0 = fmaf(t.wy1, v1, t.wy0 * v0), r1 = fmaf(t.wy1, v3, t.wy0 * v2);
-        const float v = fmaf(t.wx1, r1, t.wx0 * r0);
-        ++cnt;
-        if (MASK) {
-            lds[lab * WG + tid] += v;
-            if (JAC) S += v;
-        } else {
-            S += v;
-        }
-        if (JAC) {
-            const float d0 = fmaf(t.qz1, P[0].y, t.qz0 * P[0].x), d1 = fmaf(t.qz1, P[1].y, t.qz0 * P[1].x);
-            const float d2 = fmaf(t.qz1, P[2].y, t.qz0 * P[2].x), d3 = fmaf(t.qz1, P[3].y, t.qz0 * P[3].x);
-            const float gz = fmaf(t.wx1, fmaf(t.wy1, d3, t.wy0 * d2), t.wx0 * fmaf(t.wy1, d1, t.wy0 * d0));
-            const float gx = fmaf(t.sx1, r1, t.sx0 * r0);
-            const float gy = fmaf(t.wx1, fmaf(t.sy1, v3, t.sy0 * v2), t.wx0 * fmaf(t.sy1, v1, t.sy0 * v0));
-            G[0] += gx; G[1] += gy; G[2] += gz;
-            H[0] = fmaf(a.al, gx, H[0]); H[1] = fmaf(a.al, gy, H[1]); H[2] = fmaf(a.al, gz, H[2]);
-            if (CLIP) {
-                const float gd = fmaf(gx, adx, fmaf(gy, ady, gz * adz));
-                E0 = fmaf(gd, 1.f - a.u, E0);
-                E1 = fmaf(gd, a.u, E1);
-            }
-        }
-    };
-
-    // two register sets, ping-pong (no copies): while set A is consumed, set B's loads are in flight, and vice versa
-    TapAddr<YP> Aa[U], Ab[U];
-    RawTaps<YP> Pa[U], Pb[U];
-    constexpr int LPS = YP ? 2 : 4;   // loads per sample
-    // sample h of the set being consumed: U samples' loads of the other set and U - 1 - h of its own were issued after it
-#if XVR_FWD_PIPE_ASM
-#define TRI_PIPE_WAIT(SET, h) if constexpr (YP) taps_wait<LPS * (2 * U - 1 - (h))>(SET[h])
-#else
-#define TRI_PIPE_WAIT(SET, h) (void)0
-#endif
-    if (kbeg <= kend) {
-#pragma unroll
-        for (int h = 0; h < U; ++h) address(kbeg + h, Aa[h]);
-#pragma unroll
-        for (int h = 0; h < U; ++h) fetch(Aa[h], Pa[h]);
-        bool a_pending = false;   // which set holds loads that nobody consumed when the loop ends
-        for (int kk = kbeg;; kk += 2 * U) {
-            // (the trip behind the last one is addressed too: offsets are clamped into the volume, its samples are inactive)
-#pragma unroll
-            for (int h = 0; h < U; ++h) address(kk + U + h, Ab[h]);
-#pragma unroll
-            for (int h = 0; h < U; ++h) fetch(Ab[h], Pb[h]);
-            static_for<0, U>([&](auto hc) { constexpr int h = decltype(hc)::value; TRI_PIPE_WAIT(Pa, h); consume(Aa[h], Pa[h]); });
-            if (kk + U > kend) break;
-#pragma unroll
-            for (int h = 0; h < U; ++h) address(kk + 2 * U + h, Aa[h]);
-#pragma unroll
-            for (int h = 0; h < U; ++h) fetch(Aa[h], Pa[h]);
-            static_for<0, U>([&](auto hc) { constexpr int h = decltype(hc)::value; TRI_PIPE_WAIT(Pb, h); consume(Ab[h], Pb[h]); });
-            if (kk + 2 * U > kend) { a_pending = true; break; }
-        }
-#if XVR_FWD_PIPE_ASM
-        if constexpr (YP) {   // drain the set that was fetched and never used: its registers stay ours until the loads have landed
-            if (a_pending) {
-#pragma unroll
-                for (int h = 0; h < U; ++h) taps_wait<0>(Pa[h]);
-            } else {
-#pragma unroll
-                for (int h = 0; h < U; ++h) taps_wait<0>(Pb[h]);
-            }
-        }
-#endif
-        (void)a_pending;
-    }
-#undef TRI_PIPE_WAIT
-    acc.S = S;
-    acc.cnt = cnt;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { acc.G[i] = G[i]; acc.H[i] = H[i]; }
-    acc.E0 = E0;
-    acc.E1 = E1;
-}
-
 // Scale the sums and write the pixel (and its jacobian row).
 template <bool JAC, int MASK, bool CLIP>
 __device__ __forceinline__ void tri_finish(const RenderArgs& A, const Ray& R, const int b, const int r, const float* lds,
@@ -389,11 +195,9 @@ __device__ __forceinline__ void tri_finish(const RenderArgs& A, const Ray& R, co
 // more resident wavefronts only thrash the L1/L2 -- the variant without the jacobian needs 64 VGPRs, ran at
 // 8 wavefronts per SIMD and took 8.2 ms where the (heavier) jacobian variant at 6 took 7.0; capped, both take
 // ~7.0 ms (measured flat from 3 to 6, worse at 2 and at 8).
+constexpr double SLAB_TARGET_BYTES = 150e6, SLAB_MIN_VOLUME_BYTES = 192.0 * (1 << 20);   // (the Infinity Cache holds 256 MiB)
 #ifndef XVR_FWD_WAVES   // (overridable for tuning builds)
 #define XVR_FWD_WAVES 4
-#endif
-#ifndef XVR_FWD_PIPE_U  // > 0: the software-pipelined march with that many samples per trip (tuning builds)
-#define XVR_FWD_PIPE_U 0
 #endif
 template <bool JAC, int MASK, bool CLIP, bool YP = false>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, XVR_FWD_WAVES))) void k_trilinear_fwd(RenderArgs A) {
@@ -412,12 +216,94 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, XVR_FWD_W
         for (int c = 0; c < A.C; ++c) lds[c * WG + tid] = 0.f;
     }
     TriAcc acc;
-#if XVR_FWD_PIPE_U > 0
-    tri_march_pipe<JAC, MASK, CLIP, YP, XVR_FWD_PIPE_U>(A, R, K, kbeg, kend, step, lds, tid, acc);
-#else
     tri_march<JAC, MASK, CLIP, YP>(A, R, K, kbeg, kend, step, lds, tid, acc);
-#endif
     if (valid) tri_finish<JAC, MASK, CLIP>(A, R, b, r, lds, tid, acc);
+    if (A.work) {
+        unsigned tot = wave_sum_u(acc.cnt);
+        if ((tid & 63) == 0 && tot) atomicAdd(A.work, (unsigned long long)tot);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Slab-major forward for LARGE batches over a volume that does not fit the 256 MiB Infinity Cache (round 3).
+//
+// Every pose of a batch fetches its own frustum -- ~15 % of the volume -- and the frusta of a batch are as different as
+// its poses: 116 poses pull 116 x 160 MB of the 1 GiB y-pair copy across the fabric, almost all of it from HBM.  The
+// same kernel over 116 copies of ONE pose (the whole launch's footprint then sits in the Infinity Cache) takes 3.9 ms
+// instead of 6.1 (tools/exp_forward_variants.py).  So the march is cut into `nslabs` launches: launch s takes, of EVERY ray
+// of EVERY pose, the samples whose index coordinate along `axis` falls into slab s -- a slice of the volume small enough
+// for the Infinity Cache (<= ~150 MB), which all poses then share: each slab comes from HBM once per batch instead of
+// once per pose.  The running sums of a ray (S, and with the jacobian G[3], H[3]) travel from launch to launch in the
+// buffers the results end up in: `out` (one float per ray) / `jac` (8 floats per ray, raw sums until the last launch
+// scales them).  Only wavefronts that have samples in the slab touch them (the first launch initialises, the last
+// finalises), and a wavefront's rays stay in ~2-4 of the 8 slabs when the slabs run ALONG the rays rather than across.
+// Launches are stream-ordered, so a ray's sums are added in slab order: deterministic, but a different rounding than
+// the one-launch march's single running sum (same tolerance against the oracle; the y-pair / natural layouts of THIS
+// kernel are bit-identical to each other).
+// ---------------------------------------------------------------------------------------------
+template <bool JAC, bool YP>
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, XVR_FWD_WAVES))) void k_trilinear_fwd_slab(RenderArgs A, int slab, int nslabs,
+                                                                                                           SlabRange S) {
+    int b, r;
+    const bool valid = map_ray(A, b, r, threadIdx.x);
+    const int tid = threadIdx.x;
+    Ray R;
+    ray_setup(A, b, r, valid, R);
+    const int N = A.sp.n_points;
+    const float step = N > 1 ? (A.sp.far_ - A.sp.near_) / (float)(N - 1) : 0.f;
+    KRange K = tri_krange(A, R, false, step);
+    // the lane's steps inside the slab, from the linear model p(k) = P0 + k Dl of its coordinate along the slab axis, two steps
+    // of slack on either side (the march's own test on the computed coordinate decides)
+    {
+        const int ax = S.axis;
+        const float a = ax == 0 ? A.sp.a[0] : (ax == 1 ? A.sp.a[1] : A.sp.a[2]), bb = ax == 0 ? A.sp.b[0] : (ax == 1 ? A.sp.b[1] : A.sp.b[2]);
+        const float d = ax == 0 ? R.d[0] : (ax == 1 ? R.d[1] : R.d[2]), s0 = ax == 0 ? R.s[0] : (ax == 1 ? R.s[1] : R.s[2]);
+        const float P0 = fmaf(a, fmaf(A.sp.near_, d, s0), bb), Dl = step * a * d;
+        if (K.lo <= K.hi) {
+            if (fabsf(Dl) > 1e-12f) {
+                const float inv = 1.f / Dl;
+                const float t0 = (S.lo - P0) * inv, t1 = (S.hi - P0) * inv;   // (+-inf at the outer slabs: clamped below)
+                const float tlo = fminf(t0, t1), thi = fmaxf(t0, t1);
+                const float flo = fmaxf(tlo - 2.f, (float)K.lo), fhi = fminf(thi + 2.f, (float)K.hi);
+                if (flo <= fhi) { K.lo = (int)ceilf(flo); K.hi = (int)floorf(fhi); }
+                else { K.lo = INT32_MAX; K.hi = INT32_MIN; }
+            } else if (!(P0 >= S.lo - 1.f && P0 < S.hi + 1.f)) {
+                K.lo = INT32_MAX; K.hi = INT32_MIN;
+            }
+        }
+    }
+    const int kbeg = __builtin_amdgcn_readfirstlane(wave_min_i(K.lo));
+    const int kend = __builtin_amdgcn_readfirstlane(wave_max_i(K.hi));
+    const bool first = slab == 0, last = slab == nslabs - 1;
+    const bool active = kbeg <= kend;            // (wave-uniform: a wavefront owns its 64 rays' sums)
+    if (!active && !first && !last) return;
+    TriAcc acc;
+    acc.S = 0.f; acc.cnt = 0; acc.E0 = acc.E1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) acc.G[i] = acc.H[i] = 0.f;
+    if (active) tri_march<JAC, 0, false, YP, true>(A, R, K, kbeg, kend, step, nullptr, tid, acc, S);
+    if (valid) {
+        float4* jp = JAC ? reinterpret_cast<float4*>(A.jac + ((size_t)b * A.n + r) * XVR_DRR_JAC_STRIDE) : nullptr;
+        float* op = A.out + (size_t)b * A.n + r;
+        if (!first) {   // what the earlier slabs left: added in slab order
+            if (JAC) {
+                const float4 p0 = jp[0], p1 = jp[1];
+                acc.S = p0.x + acc.S;
+                acc.G[0] = p0.y + acc.G[0]; acc.G[1] = p0.z + acc.G[1]; acc.G[2] = p0.w + acc.G[2];
+                acc.H[0] = p1.x + acc.H[0]; acc.H[1] = p1.y + acc.H[1]; acc.H[2] = p1.z + acc.H[2];
+            } else {
+                acc.S = *op + acc.S;
+            }
+        }
+        if (last) {
+            tri_finish<JAC, 0, false>(A, R, b, r, nullptr, tid, acc);
+        } else if (JAC) {
+            jp[0] = make_float4(acc.S, acc.G[0], acc.G[1], acc.G[2]);
+            jp[1] = make_float4(acc.H[0], acc.H[1], acc.H[2], 0.f);
+        } else {
+            *op = acc.S;
+        }
+    }
     if (A.work) {
         unsigned tot = wave_sum_u(acc.cnt);
         if ((tid & 63) == 0 && tot) atomicAdd(A.work, (unsigned long long)tot);
@@ -838,6 +724,38 @@ static int trilinear_forward_impl(const float* volume, const float* mask, int D0
     if (use_lds && !clip && A.grid_w > 0) {
         const size_t bytes = (size_t)(LDS_HDR + LDS_BRICK_CAP) * sizeof(float);
         return jac ? launch(k_trilinear_fwd_lds<true>, A, bytes, stream) : launch(k_trilinear_fwd_lds<false>, A, bytes, stream);
+    }
+    // Large batches over a volume the Infinity Cache cannot hold: the slab-major march (k_trilinear_fwd_slab).  Option
+    // "fwd_slabs": 0 = never, n >= 2 = always n slabs, -1 (default) = as many slabs as keep a slab's bytes under
+    // SLAB_TARGET_BYTES, for launches of >= 8192 workgroups over a volume copy of > 192 MiB.  "fwd_slab_axis": 0-2.
+    {
+        const int want = xvr_detail::option(xvr_detail::OPT_FWD_SLABS);
+        const double layout_bytes = (sp->volume_layout == 1 ? 2.0 * D0 * (D1 + 1) * D2 : 1.0 * D0 * D1 * D2) * sizeof(float);
+        const long long nblocks = (long long)B * A.blocks_per_pose;
+        int nslabs = want;
+        if (want < 0) nslabs = (nblocks >= 8192 && layout_bytes > SLAB_MIN_VOLUME_BYTES) ? (int)ceil(layout_bytes / SLAB_TARGET_BYTES) : 0;
+        const int axis = xvr_detail::option(xvr_detail::OPT_FWD_SLAB_AXIS);
+        const int Daxis = axis == 0 ? D0 : (axis == 1 ? D1 : D2);
+        if (nslabs > Daxis / 4) nslabs = Daxis / 4;
+        if (nslabs >= 2 && !clip && A.grid_w > 0) {
+            for (int s = 0; s < nslabs; ++s) {
+                SlabRange S;
+                S.axis = axis;
+                // slab boundaries on whole voxels of the index coordinate; the outer slabs are open-ended (samples in the
+                // zero-padding margin belong to them)
+                S.lo = s == 0 ? -INFINITY : (float)(((long long)Daxis * s) / nslabs);
+                S.hi = s == nslabs - 1 ? INFINITY : (float)(((long long)Daxis * (s + 1)) / nslabs);
+                const long long nb = (long long)A.B * A.blocks_per_pose;
+                if (nb >= (1LL << 31)) return fail(XVR_DRR_E_UNSUPPORTED, "grid too large");
+#define XVR_SLAB_LAUNCH(J, Y) hipLaunchKernelGGL((k_trilinear_fwd_slab<J, Y>), dim3((unsigned)nb), dim3(WG), 0, (hipStream_t)stream, A, s, nslabs, S)
+                if (sp->volume_layout == 1) { if (jac) XVR_SLAB_LAUNCH(true, true); else XVR_SLAB_LAUNCH(false, true); }
+                else { if (jac) XVR_SLAB_LAUNCH(true, false); else XVR_SLAB_LAUNCH(false, false); }
+#undef XVR_SLAB_LAUNCH
+                hipError_t e = hipGetLastError();
+                if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
+            }
+            return XVR_DRR_OK;
+        }
     }
     if (sp->volume_layout == 1) {   // `volume` is the y-pair interleaved copy: the unsplit kernel, whatever the launch size
         if (jac) return clip ? launch(k_trilinear_fwd<true, 0, true, true>, A, 0, stream)

@@ -41,7 +41,9 @@ def make_cspec(shape, spec: RenderSpec, ray_grid_w: int = 0, volume_layout: int 
     c.n_points = spec.n_points
     c.near_, c.far_ = spec.near, spec.far
     c.inv_denom = 1.0 / (spec.n_points if spec.step_mode == "n_points" else spec.n_points - 1)
-    c.clip_to_volume = int(spec.clip_to_volume)
+    if spec.clip_to_volume == "batch":
+        raise NotImplementedError("clip_to_volume='batch' (one alpha window per call) is oracle-only so far")
+    c.clip_to_volume = int(bool(spec.clip_to_volume))
     c.ray_grid_w = int(ray_grid_w)
     c.volume_layout = int(volume_layout)
     return c

@@ -16,6 +16,9 @@ class RenderSpec:
     renderer: str = "trilinear"  # "trilinear" | "siddon"
     voxel_shift: float = 0.5     # integer coordinate = voxel corner (0.0) or centre (0.5)
     eps: float = 1e-8            # added to (target - source)
+    eps_in_xyz: bool = True      # False: eps only guards the alpha divisions.  The sample points move by alpha * eps <= 1e-8
+                                 # voxels, below fp32 resolution: the kernels are the same for both settings (a knob of the
+                                 # pin grid, tools/pin_against_diffdrr.py)
     align_corners: bool = False  # grid_sample's flag
     norm_dims_offset: int = 0    # xyz normalised with shape + offset (recalled upstream: +1 siddon, -1 trilinear)
     # trilinear
@@ -23,7 +26,8 @@ class RenderSpec:
     near: float = 0.0
     far: float = 1.0
     step_mode: str = "n_points"  # out = L * sum / n_points   |  "n_minus_1": / (n_points - 1)
-    clip_to_volume: bool = False  # rescale alphas per ray to [alphamin, alphamax]
+    clip_to_volume: bool | str = False  # True: rescale alphas per ray to [alphamin, alphamax]; "batch": ONE window for the whole
+                                        # call, [min alphamin, max alphamax] over its rays (computed on the device)
     # siddon (the HIP traversal is per ray by construction)
     per_ray_clamp: bool = True
     filter_intersections_outside_volume: bool = True
@@ -38,6 +42,8 @@ class RenderSpec:
             raise ValueError(f"unknown step_mode {self.step_mode!r}")
         if self.n_points < 1 or (self.step_mode == "n_minus_1" and self.n_points < 2):
             raise ValueError("n_points too small")
+        if self.clip_to_volume not in (False, True, "batch"):
+            raise ValueError(f"clip_to_volume must be False, True or 'batch', got {self.clip_to_volume!r}")
         if not self.far >= self.near:
             raise ValueError("far must be >= near")
         if self.renderer == "siddon" and not self.per_ray_clamp:
