@@ -79,8 +79,9 @@ const char* xvr_drr_last_error(void);
  *   "order_group"   0 | gx + 256 gy   tiles per group of the grouped block orders; 0: full-width strips          [0]
  *   "fwd_split"     0 | n | 100 + n   sample slices per ray of small forwards: measured table | 8x8 tiles x n | 16x16 tiles x n [0]
  *   "gather_splat"  1 | 0      trilinear voxel gradient: brick-local fixed-point splat | fp32 voxel-driven gathers [1]
- *   "fwd_slabs"     -1 | 0 | n  slab-major trilinear forward (one launch per slab of the volume, all poses): by size | never | n slabs [-1]
- *   "fwd_slab_axis" 0-2        volume axis the slabs are cut along                                               [2]
+ *   "fwd_slabs"     0 | -1 | n  slab-major trilinear forward (one launch per slab of the volume, all poses; measured SLOWER,
+ *                              DESIGN.md 4.4): never | by size | n slabs                                         [0]
+ *   "fwd_slab_axis" 0-2        volume axis the slabs are cut along                                               [1]
  * Returns XVR_DRR_E_ARG for an unknown name or a value outside the option's range.
  */
 int xvr_drr_set_option(const char* name, int value);

@@ -27,8 +27,8 @@ const OptionDef OPTIONS[] = {
     {"order_group", "XVR_DRR_ORDER_GROUP", 0, 0, 0xffff},
     {"fwd_split", "XVR_DRR_FWD_SPLIT", 0, 0, 199},
     {"gather_splat", "XVR_DRR_GATHER_SPLAT", 1, 0, 1},
-    {"fwd_slabs", "XVR_DRR_FWD_SLABS", -1, -1, 64},
-    {"fwd_slab_axis", "XVR_DRR_FWD_SLAB_AXIS", 2, 0, 2},
+    {"fwd_slabs", "XVR_DRR_FWD_SLABS", 0, -1, 64},
+    {"fwd_slab_axis", "XVR_DRR_FWD_SLAB_AXIS", 1, 0, 2},
 };
 constexpr int N_OPTIONS = sizeof(OPTIONS) / sizeof(OPTIONS[0]);
 std::atomic<int> g_opt[N_OPTIONS];
