@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define XVR_DRR_ABI_VERSION 5   /* 5: xvr_drr_set_option / xvr_drr_get_option (the A/B switches are no longer getenv calls per launch); 4: volume_layout 2 + xvr_drr_pack_bricks (siddon forward); 3: xvr_drr_spec.volume_layout + xvr_drr_pack_ypairs; 2: xvr_sim_spec grew, camera-driven forwards, packed labels, xvr_pose.h */
+#define XVR_DRR_ABI_VERSION 6   /* 6: xvr_drr_spec.alpha_window + xvr_drr_alpha_window (clip_to_volume = 2); 5: xvr_drr_set_option / xvr_drr_get_option (the A/B switches are no longer getenv calls per launch); 4: volume_layout 2 + xvr_drr_pack_bricks (siddon forward); 3: xvr_drr_spec.volume_layout + xvr_drr_pack_ypairs; 2: xvr_sim_spec grew, camera-driven forwards, packed labels, xvr_pose.h */
 
 #define XVR_DRR_OK 0
 #define XVR_DRR_E_ARG (-1)     /* bad argument (null pointer, non-positive size, unsupported combo) */
@@ -56,14 +56,22 @@ typedef struct xvr_drr_spec {
     int32_t n_points;      /* samples per ray                                                              */
     float near_, far_;     /* alphas = linspace(near, far, n_points)                                       */
     float inv_denom;       /* out = raylen * sum * inv_denom   (1/n_points or 1/(n_points-1))              */
-    int32_t clip_to_volume;/* 0: alphas span source->target; 1: rescaled per ray to [alphamin, alphamax]   */
+    int32_t clip_to_volume;/* 0: alphas span source->target; 1: rescaled per ray to [alphamin, alphamax];
+                              2: ONE window for the whole call -- alphas = A + linspace(near, far) (Z - A), A / Z the
+                              smallest alphamin / largest alphamax over the call's rays that meet the volume, the
+                              image scaled by (Z - A); needs `alpha_window` (below)                          */
     /* launch shaping (performance only, never changes results) */
     int32_t ray_grid_w;    /* >0: the n rays form an (n / ray_grid_w) x ray_grid_w row-major detector and
                               lanes are mapped to 8x8 pixel tiles; 0: rays are mapped linearly             */
     int32_t volume_layout; /* forward only: 0 = `volume` is [D0][D1][D2]; 1 (trilinear) = it is the y-pair interleaved
                               copy written by xvr_drr_pack_ypairs; 2 (siddon) = the 4 x 2 x 4 bricks written by
                               xvr_drr_pack_bricks (same results, bit for bit)                               */
+    const float* alpha_window; /* clip_to_volume == 2: device buffer of XVR_DRR_ALPHA_WINDOW_FLOATS floats written by
+                              xvr_drr_alpha_window() on the same stream before the render (the kernels read the call's
+                              near / far / scale from it: no host round trip); NULL otherwise                  */
 } xvr_drr_spec;
+
+#define XVR_DRR_ALPHA_WINDOW_FLOATS 16
 
 int xvr_drr_abi_version(void);
 const char* xvr_drr_last_error(void);
@@ -86,6 +94,20 @@ const char* xvr_drr_last_error(void);
  */
 int xvr_drr_set_option(const char* name, int value);
 int xvr_drr_get_option(const char* name, int* value);
+
+/*
+ * clip_to_volume == 2 (trilinear; a third plausible reading of the alpha rule of diffdrr's Trilinear.forward, reached from
+ * /root/reference/src/xvr/model/trainer.py:288 -- SURVEY.md Appendix A marks it "uncertain"): reduce, on the device, the rays
+ * of the call to its alpha window and leave { A, Z, near', far', inv_denom', Z - A, ... } in `window`; `spec` is the render's
+ * spec (its alpha_window field is ignored here).  The backward of the window itself -- min / max route their gradient to
+ * the two extremal rays -- is xvr_drr_alpha_window_backward: call it after xvr_drr_backward_from_jac with the same jacobian
+ * and upstream gradient; it ADDS to grad_source / grad_target.  One channel only.
+ */
+int xvr_drr_alpha_window(const float* source, const float* target, int B, int n, int D0, int D1, int D2,
+                         const xvr_drr_spec* spec, float* window, void* stream);
+int xvr_drr_alpha_window_backward(const float* jac, const float* grad_out, const float* source, const float* target,
+                                  const float* raylen, int B, int n, const xvr_drr_spec* spec, float* window,
+                                  float* grad_source, float* grad_target, void* stream);
 
 /* Bytes of device scratch the backward entry points can use (see `workspace` below). */
 size_t xvr_drr_backward_workspace_bytes(int B, int n, int D0, int D1, int D2);

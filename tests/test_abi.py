@@ -52,7 +52,8 @@ def test_cspec_layout_matches_header():
     from xvr_amd.renderers import make_cspec
     from xvr_amd.spec import RenderSpec
 
-    assert ctypes.sizeof(_lib.CSpec) == (15 + 1 + 1 + 2 + 1 + 1 + 1 + 1) * 4   # ... ray_grid_w, volume_layout
+    # 23 four-byte fields (... ray_grid_w, volume_layout), padding to 8, the alpha_window pointer
+    assert ctypes.sizeof(_lib.CSpec) == (15 + 1 + 1 + 2 + 1 + 1 + 1 + 1) * 4 + 4 + 8 and _lib.CSpec.alpha_window.offset == 96
     c = make_cspec((10, 20, 30), RenderSpec(voxel_shift=0.5, n_points=200), ray_grid_w=16)
     assert list(c.a) == [1.0, 1.0, 1.0] and list(c.b) == [0.0, 0.0, 0.0]
     assert list(c.hi) == [9.5, 19.5, 29.5] and c.ray_grid_w == 16 and abs(c.inv_denom - 1 / 200) < 1e-9

@@ -38,7 +38,7 @@ def test_pin_tool_is_importable_and_refuses_to_run_without_diffdrr():
     spec = importlib.util.spec_from_file_location("pin_against_diffdrr", PIN.parents[2] / "tools" / "pin_against_diffdrr.py")
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    assert callable(mod.main) and len(list(mod.knob_grid("trilinear"))) == 24 and len(list(mod.knob_grid("siddon"))) == 12
+    assert callable(mod.main) and len(list(mod.knob_grid("trilinear"))) == 72 and len(list(mod.knob_grid("siddon"))) == 48
     c1 = mod.c1_case()
     assert c1["target"].shape == (1, 128 * 128, 3) and c1["img"].shape == (1, 1, 128 * 128)
     if importlib.util.find_spec("diffdrr") is None:

@@ -180,7 +180,7 @@ def test_ypair_volume_layout_is_bit_identical(kw, shape, monkeypatch):
 
 
 @pytest.mark.parametrize("kw", [dict(n_points=120), dict(n_points=90, voxel_shift=0.0, step_mode="n_minus_1"),
-                                dict(n_points=100, norm_dims_offset=-1), dict(n_points=80, near=0.2, far=0.9, align_corners=True)], ids=_id)
+                                dict(n_points=100, norm_dims_offset=-1), dict(n_points=80, near=0.2, far=0.9)], ids=_id)
 @pytest.mark.parametrize("nslabs,axis", [(2, 2), (3, 0), (5, 1), (7, 2)])
 @pytest.mark.parametrize("ypairs", [True, False], ids=["ypairs", "natural"])
 def test_slab_major_forward_partitions_the_samples_exactly(kw, nslabs, axis, ypairs, monkeypatch):
@@ -224,8 +224,67 @@ def test_slab_major_forward_partitions_the_samples_exactly(kw, nslabs, axis, ypa
         _close(h, r, GRAD_TOL, f"slab-major {name} vs oracle")
 
 
+@pytest.mark.parametrize("kw", [dict(n_points=120), dict(n_points=90, near=0.05, far=0.95, step_mode="n_minus_1"),
+                                dict(n_points=100, voxel_shift=0.0, norm_dims_offset=-1)], ids=_id)
+@pytest.mark.parametrize("grid", ["tiled", "linear"])
+def test_batch_alpha_window_matches_the_oracle(kw, grid, monkeypatch):
+    """clip_to_volume="batch" (missing 2): ONE alpha window [A, Z] for the whole call -- the smallest alphamin and
+    the largest alphamax over its rays, reduced ON THE DEVICE (xvr_drr_alpha_window), alphas = A + linspace (Z - A), the image
+    scaled by (Z - A).  Forward and every gradient against autograd through the oracle, where A and Z are differentiable
+    (min / max route the gradient to the two extremal rays: xvr_drr_alpha_window_backward); the voxel gradient by the
+    default splat, the fp32 gather and the scatter."""
+    from xvr_amd import _lib, renderers
+    from xvr_amd.spec import RenderSpec
+
+    spec = RenderSpec(renderer="trilinear", clip_to_volume="batch", **kw)
+    case = make_case(seed=19, shape=(36, 40, 44), height=24, width=32, delx=1.6,
+                     rot=((170.0, 25.0, 5.0), (200.0, -30.0, -8.0), (150.0, 5.0, 12.0)), xyz=((5.0, 300.0, -4.0), (-3.0, 250.0, 6.0), (0.0, 280.0, 0.0)))
+    w = torch.rand(3, 1, 24 * 32, generator=torch.Generator().manual_seed(6))
+    gw = 32 if grid == "tiled" else 0
+    ref = _oracle_render(case, spec, grads=True, w=w)
+    hip = _hip_render(case, spec, grid_w=gw, grads=True, w=w)
+    plain = _hip_render(case, spec.with_(clip_to_volume=False), grid_w=gw)
+    assert not torch.allclose(hip[0], plain, rtol=1e-3, atol=1e-4), "the window changed nothing"
+    for (h, r), name in zip(zip(hip, ref), ("out", "grad_volume", "grad_source", "grad_target", "grad_img")):
+        _close(h, r, FWD_TOL if name == "out" else GRAD_TOL, f"batch window, {name}")
+    if gw:   # the other voxel-gradient kernels read the same window
+        for flag, gather in ((0, True), (1, False)):
+            monkeypatch.setattr(renderers, "VOXEL_GATHER", gather)
+            with _lib.option("gather_splat", flag):
+                _close(_hip_render(case, spec, grid_w=gw, grads=True, w=w)[1], ref[1], GRAD_TOL, f"batch window, grad_volume (splat {flag}, gather {gather})")
+        monkeypatch.setattr(renderers, "VOXEL_GATHER", True)
+
+
+def test_batch_alpha_window_through_the_drr_module_and_when_no_ray_meets_the_volume():
+    from oracle.diffdrr_restated import drr_from_pose
+    from xvr_amd.data import make_phantom, read
+    from xvr_amd.drr import DRR
+    from xvr_amd.pose import convert
+
+    vol, _ = make_phantom(40, n_ellipsoids=8, seed=4)
+    sub = read(vol, spacing=(2.0, 2.0, 2.0), orientation="AP")
+    drr = DRR(sub, 600.0, 28, 4.0, renderer="trilinear", reverse_x_axis=False, clip_to_volume="batch").cuda()
+    rot = torch.tensor([[3.0, 0.2, -0.1], [3.3, -0.15, 0.05]])
+    xyz = torch.tensor([[3.0, 400.0, -5.0], [-6.0, 350.0, 4.0]])
+    r, t = rot.cuda().requires_grad_(True), xyz.cuda().requires_grad_(True)
+    w = torch.rand(2, 1, 28, 28, generator=torch.Generator().manual_seed(3))
+    img = drr(r, t, parameterization="euler_angles", convention="ZXY", n_points=150)
+    (img * w.cuda()).sum().backward()
+    ro, to = rot.clone().requires_grad_(True), xyz.clone().requires_grad_(True)
+    pose = convert(ro, to, parameterization="euler_angles", convention="ZXY")
+    ref = drr_from_pose(vol, sub.affine, pose.matrix, 28, 28, 600.0, 4.0, 4.0, 0.0, 0.0, to_oracle_spec(drr.renderer._spec(n_points=150)),
+                        orientation="AP", reverse_x_axis=False)
+    (ref * w).sum().backward()
+    _close(img, ref, FWD_TOL, "DRR.forward under the batch window")
+    _close(r.grad, ro.grad, 5e-3, "d/d rotation under the batch window")
+    _close(t.grad, to.grad, 5e-3, "d/d translation under the batch window")
+    # every ray misses the volume: the window is empty and the image is exactly zero (no NaN from 0 / 0)
+    far_away = drr(torch.tensor([[3.0, 0.0, 0.0]]).cuda(), torch.tensor([[4000.0, 400.0, 0.0]]).cuda(), parameterization="euler_angles", convention="ZXY")
+    assert float(far_away.abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("renderer", ["trilinear", "siddon"])
-def test_layout_copies_follow_the_volume_through_deepcopy_data_writes_and_invalidate(renderer, monkeypatch):
+def test_layout_copies_follow_the_volume_through_deepcopy_data_writes_and_invalidate(renderer, monkeypatch, request):
     """The render-ready copies (y-pair / bricked) live in a registry validated by a weak reference to the volume tensor
     (ADVICE r2): a deepcopy of the volume -- Registrar.run deep-copies the DRR, registrar/base.py:161,192 -- starts with no
     copy of its own (a clone's version counter restarts, so a carried-over key could match different data), in-place torch ops
@@ -233,12 +292,16 @@ def test_layout_copies_follow_the_volume_through_deepcopy_data_writes_and_invali
     ``invalidate_volume_cache``."""
     import copy
 
-    from xvr_amd import renderers
+    from xvr_amd import _lib, renderers
     from xvr_amd.renderers import render
     from xvr_amd.spec import RenderSpec
 
     spec = RenderSpec(renderer=renderer, n_points=90) if renderer == "trilinear" else RenderSpec(renderer="siddon")
     monkeypatch.setattr(renderers, "YPAIR_MIN_WAVEFRONTS", 1)
+    # (a launch this small would take the sample-split kernels on the natural layout -- another summation order; unsplit, the
+    #  layouts are bit-identical, which makes "not stale" an equality)
+    request.addfinalizer(lambda: _lib.set_option("fwd_split", 0))
+    _lib.set_option("fwd_split", 1)
     case = make_case(seed=5, shape=(30, 34, 38), height=32, width=32)
     vol, src, tgt, img = (case[k].cuda() for k in ("volume", "source", "target", "img"))
     kind = "ypairs" if renderer == "trilinear" else "bricks"

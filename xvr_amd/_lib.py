@@ -11,8 +11,9 @@ import warnings
 
 from .build import LIB, HipccMissing, build_library, is_stale
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 JAC_STRIDE = 8
+ALPHA_WINDOW_FLOATS = 16   # XVR_DRR_ALPHA_WINDOW_FLOATS
 
 
 class CSpec(ctypes.Structure):
@@ -30,6 +31,7 @@ class CSpec(ctypes.Structure):
         ("clip_to_volume", ctypes.c_int32),
         ("ray_grid_w", ctypes.c_int32),
         ("volume_layout", ctypes.c_int32),
+        ("alpha_window", ctypes.c_void_p),
     ]
 
 
@@ -98,6 +100,8 @@ EXPORTS = {
     "xvr_drr_siddon_forward": (_FWD, ctypes.c_int),
     "xvr_drr_siddon_backward": (_BWD, ctypes.c_int),
     "xvr_drr_backward_from_jac": ([_P, _P, _I, _I, _P, _P, _P, _P], ctypes.c_int),
+    "xvr_drr_alpha_window": ([_P, _P, _I, _I, _I, _I, _I, ctypes.POINTER(CSpec), _P, _P], ctypes.c_int),
+    "xvr_drr_alpha_window_backward": ([_P, _P, _P, _P, _P, _I, _I, ctypes.POINTER(CSpec), _P, _P, _P, _P], ctypes.c_int),
     "xvr_sim_workspace_bytes": ([_I, _I, _I], ctypes.c_size_t),
     "xvr_sim_ncc_forward_backward": ([_P, _P, _P, _I, _I, _I, ctypes.POINTER(CSimSpec), _P, _P, _P, ctypes.c_size_t, _P], ctypes.c_int),
     "xvr_sim_equalize_workspace_bytes": ([_I, _I], ctypes.c_size_t),

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(WG) void k_gather_prep(GatherArgs G) {
         dev = pitch > 0.f ? dev / pitch : INFINITY;
         if (!(dev == dev)) dev = INFINITY;
         // (mask -> channels: the upstream gradient depends on the sample's label and is looked up per candidate)
-        float c = (G.mask ? 1.f : G.gout[(size_t)b * G.n + r]) * G.raylen[(size_t)b * G.n + r] * G.sp.inv_denom;
+        float c = (G.mask ? 1.f : G.gout[(size_t)b * G.n + r]) * G.raylen[(size_t)b * G.n + r] * spec_window(G.sp).inv_denom;
         // d exactly as the forward forms it, (t - s) + eps, so that the gather's fmaf chain below
         // reproduces the forward's sample positions bit for bit
         const float sx = G.source[3 * b], sy = G.source[3 * b + 1], sz = G.source[3 * b + 2];
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(WG) void k_gather_prep(GatherArgs G) {
                     // inside one voxel's 2-cube, each worth |c| span at most
                     const float span = fmaxf(hi - lo, 0.f), N1 = (float)(G.sp.n_points > 1 ? G.sp.n_points - 1 : 1);
                     const float lx = sqrtf(G.sp.a[0] * ddx * G.sp.a[0] * ddx + G.sp.a[1] * ddy * G.sp.a[1] * ddy + G.sp.a[2] * ddz * G.sp.a[2] * ddz);
-                    const float gap = span * lx * (G.sp.far_ - G.sp.near_) / N1;
+                    const float gap = span * lx * (spec_window(G.sp).far_ - spec_window(G.sp).near_) / N1;
                     const float m = gap > 0.f ? fminf(3.4641016f / gap + 1.f, (float)G.sp.n_points) : (float)G.sp.n_points;
                     cabs = cabs * span * m;
                     if (!(cabs == cabs)) cabs = INFINITY;
@@ -256,6 +256,8 @@ __global__ __launch_bounds__(WG) void k_gather_cull(GatherArgs G, int nbricks) {
     // half extent to the outermost voxel centre + 1 (interpolation support) + 0.5 (slack), in x units
     const float hx = (0.5f * (G.bd[0] - 1) + 1.5f) / G.sp.a[0], hy = (0.5f * (G.bd[1] - 1) + 1.5f) / G.sp.a[1],
                 hz = (0.5f * (G.bd[2] - 1) + 1.5f) / G.sp.a[2];
+    // (clip_to_volume == 2: the range of alpha any sample can take is the call's window, known on the device only)
+    const float cull_lo = G.sp.alpha_window ? spec_window(G.sp).near_ : G.cull_lo, cull_hi = G.sp.alpha_window ? spec_window(G.sp).far_ : G.cull_hi;
     for (int wd = 0; wd < G.words; ++wd) {
         const int p = wd * 32 + lane;
         bool hit = false;
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(WG) void k_gather_cull(GatherArgs G, int nbricks) {
             const float en0 = P.nh[0] * hx, en1 = P.nh[1] * hy, en2 = P.nh[2] * hz;
             const float av = dot3(P.nh, w), da = fabsf(en0) + fabsf(en1) + fabsf(en2);
             const float amin = av - da, amax = av + da;
-            if (amax >= G.cull_lo && amin <= G.cull_hi) {
+            if (amax >= cull_lo && amin <= cull_hi) {
                 if (amin <= 1e-6f) {
                     hit = true;  // the box reaches the source plane: no perspective bound, keep
                 } else {
@@ -411,7 +413,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(XVR_TAB_WAVE
 #pragma unroll
     for (int i = 0; i < 3; ++i) xv[i] = (fv[i] + CO - G.sp.b[i]) / G.sp.a[i];
     const int N = G.sp.n_points;
-    const float near_ = G.sp.near_, far_ = G.sp.far_;
+    const float near_ = spec_window(G.sp).near_, far_ = spec_window(G.sp).far_;
     const float step = N > 1 ? (far_ - near_) / (float)(N - 1) : 0.f;
     const float inv_step = step > 0.f ? 1.f / step : 0.f;
     const float a0 = G.sp.a[0], a1 = G.sp.a[1], a2 = G.sp.a[2];
@@ -624,7 +626,7 @@ __global__ __launch_bounds__(64) void k_trilinear_gather_px(GatherArgs G) {
     for (int i = 0; i < 3; ++i) xv[i] = (fv[i] + CO - G.sp.b[i]) / G.sp.a[i];
     const float ea0 = HS / a0, ea1 = HS / a1, ea2 = HS / a2;   // half-size of the support, in x coordinates
     const int N = G.sp.n_points;
-    const float near_ = G.sp.near_, far_ = G.sp.far_;
+    const float near_ = spec_window(G.sp).near_, far_ = spec_window(G.sp).far_;
     const float step = N > 1 ? (far_ - near_) / (float)(N - 1) : 0.f;
     const float inv_step = step > 0.f ? 1.f / step : 0.f;
     float acc[8];
@@ -992,7 +994,7 @@ int xvr_detail::launch_gather(bool siddon, const float* source, const float* tar
     }
     G.mask = siddon ? nullptr : mask;
     G.C = C;
-    G.clip = (!siddon && sp->clip_to_volume) ? 1 : 0;
+    G.clip = (!siddon && sp->clip_to_volume == 1) ? 1 : 0;
     // alphas any sample can take: [near, far] on the shared planes; under clip alpha = amin + u (amax - amin) with
     // 0 <= amin, amin + span <= 1, i.e. within [min(0, near), max(1, far)]
     G.cull_lo = G.clip ? fminf(0.f, sp->near_) : sp->near_;
@@ -1011,7 +1013,7 @@ int xvr_detail::launch_gather(bool siddon, const float* source, const float* tar
     // trilinear without clip / per-channel masks: the brick-local fixed-point splat on 16^3 bricks (k_trilinear_splat_b16)
     // unless the option "gather_splat" is 0 (A/B switch: the fp32 voxel-driven table gather)
     const bool use_splat = xvr_detail::option(xvr_detail::OPT_GATHER_SPLAT) != 0;
-    const bool splat = !siddon && use_splat && !sp->clip_to_volume && !mask;
+    const bool splat = !siddon && use_splat && sp->clip_to_volume != 1 && !mask;
     if (siddon && G.cells) { G.bd[0] = 4; G.bd[1] = 8; G.bd[2] = 8; }
     else if (siddon) { G.bd[0] = G.bd[1] = G.bd[2] = 8; }
     else {

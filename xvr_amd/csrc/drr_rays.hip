@@ -202,7 +202,131 @@ __global__ __launch_bounds__(WG) void k_jac_to_cam(const float* __restrict__ jac
     if (threadIdx.x == 0) counter[b] = 0;   // ready for the next call
 }
 
+// =============================================================================================
+// clip_to_volume == 2: the alpha window of a whole call (include/xvr_drr.h: xvr_drr_alpha_window).
+// A = the smallest alpha_min and Z = the largest alpha_max over the rays that meet the volume, by 64-bit atomic max on
+// (float bits << 32 | ray index) keys -- the value and WHICH ray holds it in one word (ties: the lowest ray index), because
+// the backward routes the window's gradient to exactly those two rays (torch's min() / max()).
+// =============================================================================================
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned lo = __shfl_xor((unsigned)v, o), hi = __shfl_xor((unsigned)(v >> 32), o);
+        const unsigned long long w = ((unsigned long long)hi << 32) | lo;
+        v = w > v ? w : v;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(WG) void k_alpha_window_reduce(const float* __restrict__ source, const float* __restrict__ target, int n,
+                                                           xvr_drr_spec sp, unsigned long long* keys) {
+    const int b = blockIdx.y;
+    const int r = blockIdx.x * WG + threadIdx.x;
+    unsigned long long kmin_inv = 0ull, kmax = 0ull;   // 0 = no ray
+    if (r < n) {
+        const float* tp = target + ((size_t)b * n + r) * 3;
+        float s[3], d[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { s[i] = source[3 * b + i]; d[i] = (tp[i] - s[i]) + sp.eps; }
+        float amin, amax;
+        int ain, aout;
+        alpha_range(sp, s, d, amin, amax, ain, aout);
+        if (amax > amin) {   // (both in [0, 1]: their bit patterns order like the values)
+            const unsigned idx = (unsigned)((size_t)b * n + r);
+            kmin_inv = ~(((unsigned long long)__float_as_uint(amin) << 32) | idx);
+            kmax = ((unsigned long long)__float_as_uint(amax) << 32) | (0xffffffffu - idx);
+        }
+    }
+    kmin_inv = wave_max_u64(kmin_inv);
+    kmax = wave_max_u64(kmax);
+    if ((threadIdx.x & 63) == 0) {
+        if (kmin_inv) atomicMax(keys, kmin_inv);
+        if (kmax) atomicMax(keys + 1, kmax);
+    }
+}
+
+__global__ void k_alpha_window_final(float* window, float near_, float far_, float inv_denom) {
+    const unsigned long long* keys = reinterpret_cast<const unsigned long long*>(window + WIN_KEYS);
+    float A = 0.f, Z = 0.f;
+    if (keys[0] && keys[1]) {
+        A = __uint_as_float((unsigned)((~keys[0]) >> 32));
+        Z = __uint_as_float((unsigned)(keys[1] >> 32));
+    }
+    const float W = Z - A;
+    window[WIN_A] = A; window[WIN_Z] = Z;
+    window[WIN_NEAR] = fmaf(near_, W, A); window[WIN_FAR] = fmaf(far_, W, A);
+    window[WIN_INV] = inv_denom * W; window[WIN_W] = W;
+    window[WIN_GA] = 0.f; window[WIN_GZ] = 0.f;
+}
+
+// d loss / d A and d loss / d Z from the saved jacobian: with alpha_k = A + u_k W (W = Z - A) and the image scaled by W,
+//   d out / d A |_W = sum_k d out / d alpha_k = sum_i d_i (js_i + jt_i)
+//   d out / d W |_A = out / W + sum_k u_k d out / d alpha_k = (out + sum_i d_i (jt_i - A (js_i + jt_i))) / W
+// (js, jt: the per-ray jacobian rows, which already hold scale * a (G - H) and scale * a H), and d/dA|_Z = d/dA|_W - d/dW, d/dZ = d/dW.
+__global__ __launch_bounds__(WG) void k_alpha_window_bwd_reduce(const float* __restrict__ jac, const float* __restrict__ gout,
+                                                               const float* __restrict__ source, const float* __restrict__ target,
+                                                               const float* __restrict__ raylen, int n, float eps, float* window) {
+    __shared__ float part[2][WG / 64];
+    const int b = blockIdx.y;
+    const int r = blockIdx.x * WG + threadIdx.x;
+    const float A = window[WIN_A], W = window[WIN_W];
+    float ga = 0.f, gz = 0.f;
+    if (r < n && W > 0.f) {
+        const size_t ray = (size_t)b * n + r;
+        const float g = gout[ray];
+        const float4* jp = reinterpret_cast<const float4*>(jac + ray * XVR_DRR_JAC_STRIDE);
+        const float4 j0 = jp[0], j1 = jp[1];
+        const float* tp = target + ray * 3;
+        const float js[3] = {j0.y, j0.z, j0.w}, jt[3] = {j1.x, j1.y, j1.z};
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float d = (tp[i] - source[3 * b + i]) + eps;
+            s1 = fmaf(d, js[i] + jt[i], s1);
+            s2 = fmaf(d, jt[i], s2);
+        }
+        const float dW = (fmaf(j0.x, raylen[ray], s2) - A * s1) / W;
+        ga = g * (s1 - dW);
+        gz = g * dW;
+    }
+    ga = wave_sum_f(ga);
+    gz = wave_sum_f(gz);
+    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = ga; part[1][threadIdx.x >> 6] = gz; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const float tot = part[threadIdx.x][0] + part[threadIdx.x][1] + part[threadIdx.x][2] + part[threadIdx.x][3];
+        if (tot != 0.f) atomic_add_f32(window + WIN_GA + threadIdx.x, tot);
+    }
+}
+
+// ... and on to the two extremal rays: A = (plane - s_i) / d_i on the axis the ray enters through, Z likewise on its exit
+// axis (no gradient where the value is the clamp 0 / 1)
+__global__ void k_alpha_window_bwd_apply(const float* __restrict__ source, const float* __restrict__ target, int n, xvr_drr_spec sp,
+                                         const float* window, float* gsrc, float* gtgt) {
+    const unsigned long long* keys = reinterpret_cast<const unsigned long long*>(window + WIN_KEYS);
+    if (!(keys[0] && keys[1])) return;
+    const unsigned idx[2] = {(unsigned)(~keys[0]), 0xffffffffu - (unsigned)keys[1]};
+    const float gr[2] = {window[WIN_GA], window[WIN_GZ]};
+    for (int e = 0; e < 2; ++e) {
+        const int b = (int)(idx[e] / (unsigned)n);
+        const size_t ray = idx[e];
+        float s[3], d[3];
+        for (int i = 0; i < 3; ++i) { s[i] = source[3 * b + i]; d[i] = (target[ray * 3 + i] - s[i]) + sp.eps; }
+        float amin, amax;
+        int ain, aout;
+        alpha_range(sp, s, d, amin, amax, ain, aout);
+        const int ax = e == 0 ? ain : aout;
+        const float al = e == 0 ? amin : amax;
+        if (ax >= 0 && gr[e] != 0.f) {
+            const float dd = ax == 0 ? d[0] : (ax == 1 ? d[1] : d[2]);
+            gsrc[3 * b + ax] += gr[e] * (al - 1.f) / dd;
+            gtgt[ray * 3 + ax] += gr[e] * (-al) / dd;
+        }
+    }
+}
+
 }  // namespace
+
 
 extern "C" {
 
@@ -259,6 +383,39 @@ int xvr_drr_backward_from_jac(const float* jac, const float* grad_out, int B, in
     hipLaunchKernelGGL(k_backward_from_jac, grid, dim3(WG), 0, (hipStream_t)stream, jac, grad_out, n,
                        grad_source, grad_target, grad_raylen);
     hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
+    return XVR_DRR_OK;
+}
+
+int xvr_drr_alpha_window(const float* source, const float* target, int B, int n, int D0, int D1, int D2,
+                         const xvr_drr_spec* sp, float* window, void* stream) {
+    if (!source || !target || !sp || !window) return fail(XVR_DRR_E_ARG, "null pointer argument");
+    if (B <= 0 || n <= 0 || D0 < 2 || D1 < 2 || D2 < 2) return fail(XVR_DRR_E_ARG, "B, n must be positive and every volume dimension >= 2");
+    if ((long long)B * n >= (1LL << 32) - 1) return fail(XVR_DRR_E_UNSUPPORTED, "the alpha window indexes rays with 32 bits");
+    if (reinterpret_cast<uintptr_t>(window) & 15u) return fail(XVR_DRR_E_ARG, "window must be 16-byte aligned");
+    hipError_t e = hipMemsetAsync(window, 0, XVR_DRR_ALPHA_WINDOW_FLOATS * sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
+    hipLaunchKernelGGL(k_alpha_window_reduce, dim3((unsigned)((n + WG - 1) / WG), (unsigned)B), dim3(WG), 0, (hipStream_t)stream,
+                       source, target, n, *sp, reinterpret_cast<unsigned long long*>(window + WIN_KEYS));
+    hipLaunchKernelGGL(k_alpha_window_final, dim3(1), dim3(1), 0, (hipStream_t)stream, window, sp->near_, sp->far_, sp->inv_denom);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
+    return XVR_DRR_OK;
+}
+
+int xvr_drr_alpha_window_backward(const float* jac, const float* grad_out, const float* source, const float* target,
+                                  const float* raylen, int B, int n, const xvr_drr_spec* sp, float* window,
+                                  float* grad_source, float* grad_target, void* stream) {
+    if (!jac || !grad_out || !source || !target || !raylen || !sp || !window || !grad_source || !grad_target)
+        return fail(XVR_DRR_E_ARG, "null pointer argument");
+    if (B <= 0 || n <= 0) return fail(XVR_DRR_E_ARG, "B and n must be positive");
+    hipError_t e = hipMemsetAsync(window + WIN_GA, 0, 2 * sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
+    hipLaunchKernelGGL(k_alpha_window_bwd_reduce, dim3((unsigned)((n + WG - 1) / WG), (unsigned)B), dim3(WG), 0, (hipStream_t)stream,
+                       jac, grad_out, source, target, raylen, n, sp->eps, window);
+    hipLaunchKernelGGL(k_alpha_window_bwd_apply, dim3(1), dim3(1), 0, (hipStream_t)stream, source, target, n, *sp, window,
+                       grad_source, grad_target);
+    e = hipGetLastError();
     if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
     return XVR_DRR_OK;
 }

@@ -46,7 +46,8 @@ struct SlabRange {
 
 template <bool JAC, int MASK, bool CLIP, bool YP = false, bool SLAB = false>
 __device__ __forceinline__ void tri_march(const RenderArgs& A, const Ray& R, const KRange K, const int kbeg, const int kend,
-                                          const float step, float* lds, const int tid, TriAcc& acc, const SlabRange slab = SlabRange{0, 0.f, 0.f}) {
+                                          const float step, const SpecWin Wn, float* lds, const int tid, TriAcc& acc,
+                                          const SlabRange slab = SlabRange{0, 0.f, 0.f}) {
     const int N = A.sp.n_points;
     const float* __restrict__ vol = A.volume;
     const int D0 = A.D0, D1 = A.D1, D2 = A.D2;
@@ -68,7 +69,7 @@ __device__ __forceinline__ void tri_march(const RenderArgs& A, const Ray& R, con
         for (int h = 0; h < 2; ++h) {
             const int k = kk + h;
             act[h] = k >= K.lo && k <= K.hi && k <= kend;
-            u[h] = linspace_at(k, N, A.sp.near_, A.sp.far_, step);
+            u[h] = linspace_at(k, N, Wn.near_, Wn.far_, step);
             al[h] = CLIP ? fmaf(u[h], R.amax - R.amin, R.amin) : u[h];
             pxs[h] = fmaf(A.sp.a[0], fmaf(al[h], R.d[0], R.s[0]), A.sp.b[0]);
             pys[h] = fmaf(A.sp.a[1], fmaf(al[h], R.d[1], R.s[1]), A.sp.b[1]);
@@ -153,11 +154,11 @@ __device__ __forceinline__ void tri_march(const RenderArgs& A, const Ray& R, con
 
 // Scale the sums and write the pixel (and its jacobian row).
 template <bool JAC, int MASK, bool CLIP>
-__device__ __forceinline__ void tri_finish(const RenderArgs& A, const Ray& R, const int b, const int r, const float* lds,
+__device__ __forceinline__ void tri_finish(const RenderArgs& A, const Ray& R, const int b, const int r, const SpecWin Wn, const float* lds,
                                            const int tid, const TriAcc& acc) {
     const float S = acc.S;
     const float span = fmaxf(R.amax - R.amin, 0.f);
-    const float base_scale = R.L * A.sp.inv_denom;
+    const float base_scale = R.L * Wn.inv_denom;
     const float scale = CLIP ? base_scale * span : base_scale;
     if (MASK) {
         for (int c = 0; c < A.C; ++c) A.out[((size_t)b * A.C + c) * A.n + r] = lds[c * WG + tid] * scale;
@@ -186,7 +187,7 @@ __device__ __forceinline__ void tri_finish(const RenderArgs& A, const Ray& R, co
             }
         }
         float4* jp = reinterpret_cast<float4*>(A.jac + ((size_t)b * A.n + r) * XVR_DRR_JAC_STRIDE);
-        jp[0] = make_float4(S * (CLIP ? A.sp.inv_denom * span : A.sp.inv_denom), js[0], js[1], js[2]);
+        jp[0] = make_float4(S * (CLIP ? Wn.inv_denom * span : Wn.inv_denom), js[0], js[1], js[2]);
         jp[1] = make_float4(jt[0], jt[1], jt[2], 0.f);
     }
 }
@@ -208,16 +209,17 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, XVR_FWD_W
     Ray R;
     ray_setup(A, b, r, valid, R);
     const int N = A.sp.n_points;
-    const float step = N > 1 ? (A.sp.far_ - A.sp.near_) / (float)(N - 1) : 0.f;
-    const KRange K = tri_krange(A, R, CLIP, step);
+    const SpecWin Wn = spec_window(A.sp);
+    const float step = N > 1 ? (Wn.far_ - Wn.near_) / (float)(N - 1) : 0.f;
+    const KRange K = tri_krange(A, R, CLIP, step, Wn.near_);
     const int kbeg = __builtin_amdgcn_readfirstlane(wave_min_i(K.lo));
     const int kend = __builtin_amdgcn_readfirstlane(wave_max_i(K.hi));
     if (MASK) {
         for (int c = 0; c < A.C; ++c) lds[c * WG + tid] = 0.f;
     }
     TriAcc acc;
-    tri_march<JAC, MASK, CLIP, YP>(A, R, K, kbeg, kend, step, lds, tid, acc);
-    if (valid) tri_finish<JAC, MASK, CLIP>(A, R, b, r, lds, tid, acc);
+    tri_march<JAC, MASK, CLIP, YP>(A, R, K, kbeg, kend, step, Wn, lds, tid, acc);
+    if (valid) tri_finish<JAC, MASK, CLIP>(A, R, b, r, Wn, lds, tid, acc);
     if (A.work) {
         unsigned tot = wave_sum_u(acc.cnt);
         if ((tid & 63) == 0 && tot) atomicAdd(A.work, (unsigned long long)tot);
@@ -250,15 +252,16 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, XVR_FWD_W
     Ray R;
     ray_setup(A, b, r, valid, R);
     const int N = A.sp.n_points;
-    const float step = N > 1 ? (A.sp.far_ - A.sp.near_) / (float)(N - 1) : 0.f;
-    KRange K = tri_krange(A, R, false, step);
+    const SpecWin Wn = spec_window(A.sp);
+    const float step = N > 1 ? (Wn.far_ - Wn.near_) / (float)(N - 1) : 0.f;
+    KRange K = tri_krange(A, R, false, step, Wn.near_);
     // the lane's steps inside the slab, from the linear model p(k) = P0 + k Dl of its coordinate along the slab axis, two steps
     // of slack on either side (the march's own test on the computed coordinate decides)
     {
         const int ax = S.axis;
         const float a = ax == 0 ? A.sp.a[0] : (ax == 1 ? A.sp.a[1] : A.sp.a[2]), bb = ax == 0 ? A.sp.b[0] : (ax == 1 ? A.sp.b[1] : A.sp.b[2]);
         const float d = ax == 0 ? R.d[0] : (ax == 1 ? R.d[1] : R.d[2]), s0 = ax == 0 ? R.s[0] : (ax == 1 ? R.s[1] : R.s[2]);
-        const float P0 = fmaf(a, fmaf(A.sp.near_, d, s0), bb), Dl = step * a * d;
+        const float P0 = fmaf(a, fmaf(Wn.near_, d, s0), bb), Dl = step * a * d;
         if (K.lo <= K.hi) {
             if (fabsf(Dl) > 1e-12f) {
                 const float inv = 1.f / Dl;
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, XVR_FWD_W
     acc.S = 0.f; acc.cnt = 0; acc.E0 = acc.E1 = 0.f;
 #pragma unroll
     for (int i = 0; i < 3; ++i) acc.G[i] = acc.H[i] = 0.f;
-    if (active) tri_march<JAC, 0, false, YP, true>(A, R, K, kbeg, kend, step, nullptr, tid, acc, S);
+    if (active) tri_march<JAC, 0, false, YP, true>(A, R, K, kbeg, kend, step, Wn, nullptr, tid, acc, S);
     if (valid) {
         float4* jp = JAC ? reinterpret_cast<float4*>(A.jac + ((size_t)b * A.n + r) * XVR_DRR_JAC_STRIDE) : nullptr;
         float* op = A.out + (size_t)b * A.n + r;
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, XVR_FWD_W
             }
         }
         if (last) {
-            tri_finish<JAC, 0, false>(A, R, b, r, nullptr, tid, acc);
+            tri_finish<JAC, 0, false>(A, R, b, r, Wn, nullptr, tid, acc);
         } else if (JAC) {
             jp[0] = make_float4(acc.S, acc.G[0], acc.G[1], acc.G[2]);
             jp[1] = make_float4(acc.H[0], acc.H[1], acc.H[2], 0.f);
@@ -330,8 +333,9 @@ __global__ __launch_bounds__(64 * SPLIT_MAX) void k_trilinear_fwd_split(RenderAr
     Ray R;
     ray_setup(A, b, r, valid, R);
     const int N = A.sp.n_points;
-    const float step = N > 1 ? (A.sp.far_ - A.sp.near_) / (float)(N - 1) : 0.f;
-    const KRange K = tri_krange(A, R, CLIP, step);
+    const SpecWin Wn = spec_window(A.sp);
+    const float step = N > 1 ? (Wn.far_ - Wn.near_) / (float)(N - 1) : 0.f;
+    const KRange K = tri_krange(A, R, CLIP, step, Wn.near_);
     const int kbeg = __builtin_amdgcn_readfirstlane(wave_min_i(K.lo));
     const int kend = __builtin_amdgcn_readfirstlane(wave_max_i(K.hi));
     TriAcc acc;
@@ -340,7 +344,7 @@ __global__ __launch_bounds__(64 * SPLIT_MAX) void k_trilinear_fwd_split(RenderAr
         const int chunk = (((len + NS - 1) / NS) + 1) & ~1;   // even: the march takes two samples per trip
         const int my_beg = kbeg + w * chunk;
         const int my_end = min(kend, my_beg + chunk - 1);
-        tri_march<JAC, 0, CLIP>(A, R, K, my_beg, my_end, step, nullptr, tid, acc);
+        tri_march<JAC, 0, CLIP>(A, R, K, my_beg, my_end, step, Wn, nullptr, tid, acc);
     }
     if (w > 0) {
         float* p = lds + (size_t)(w - 1) * SPLIT_VALS * TL + l;
@@ -362,7 +366,7 @@ __global__ __launch_bounds__(64 * SPLIT_MAX) void k_trilinear_fwd_split(RenderAr
                 if (CLIP) { acc.E0 += p[7 * TL]; acc.E1 += p[8 * TL]; }
             }
         }
-        if (valid) tri_finish<JAC, 0, CLIP>(A, R, b, r, nullptr, tid, acc);
+        if (valid) tri_finish<JAC, 0, CLIP>(A, R, b, r, Wn, nullptr, tid, acc);
     }
     if (A.work) {
         unsigned tot = wave_sum_u(acc.cnt);
@@ -400,7 +404,7 @@ __global__ __launch_bounds__(WG) void k_trilinear_fwd_lds(RenderArgs A) {
     ray_setup(A, b, r, valid, R);
     const int N = A.sp.n_points;
     const float step = N > 1 ? (A.sp.far_ - A.sp.near_) / (float)(N - 1) : 0.f;
-    const KRange K = tri_krange(A, R, false, step);
+    const KRange K = tri_krange(A, R, false, step, A.sp.near_);
     const bool live = K.lo <= K.hi;
     const float* __restrict__ vol = A.volume;
     const int D0 = A.D0, D1 = A.D1, D2 = A.D2;
@@ -572,14 +576,15 @@ __global__ __launch_bounds__(WG) void k_trilinear_bwd(RenderArgs A) {
     Ray R;
     ray_setup(A, b, r, valid, R);
     const int N = A.sp.n_points;
-    const float step = N > 1 ? (A.sp.far_ - A.sp.near_) / (float)(N - 1) : 0.f;
-    const KRange K = tri_krange(A, R, CLIP, step);
+    const SpecWin Wn = spec_window(A.sp);
+    const float step = N > 1 ? (Wn.far_ - Wn.near_) / (float)(N - 1) : 0.f;
+    const KRange K = tri_krange(A, R, CLIP, step, Wn.near_);
     const int kbeg = __builtin_amdgcn_readfirstlane(wave_min_i(K.lo));
     const int kend = __builtin_amdgcn_readfirstlane(wave_max_i(K.hi));
     const float span = fmaxf(R.amax - R.amin, 0.f);
     const float* __restrict__ vol = A.volume;
     const int D0 = A.D0, D1 = A.D1, D2 = A.D2;
-    const float base_scale = R.L * A.sp.inv_denom;
+    const float base_scale = R.L * Wn.inv_denom;
     const float scale = CLIP ? base_scale * span : base_scale;
 
     float g0 = 0.f;
@@ -595,7 +600,7 @@ __global__ __launch_bounds__(WG) void k_trilinear_bwd(RenderArgs A) {
 
     for (int k = kbeg; k <= kend; ++k) {
         if (k < K.lo || k > K.hi) continue;
-        const float u = linspace_at(k, N, A.sp.near_, A.sp.far_, step);
+        const float u = linspace_at(k, N, Wn.near_, Wn.far_, step);
         const float al = CLIP ? fmaf(u, R.amax - R.amin, R.amin) : u;
         const float px = fmaf(A.sp.a[0], fmaf(al, R.d[0], R.s[0]), A.sp.b[0]);
         const float py = fmaf(A.sp.a[1], fmaf(al, R.d[1], R.s[1]), A.sp.b[1]);
@@ -668,7 +673,7 @@ __global__ __launch_bounds__(WG) void k_trilinear_bwd(RenderArgs A) {
         if (valid) {
             float* tp = A.gtgt + ((size_t)b * A.n + r) * 3;
             tp[0] = jt[0]; tp[1] = jt[1]; tp[2] = jt[2];
-            if (A.glen) A.glen[(size_t)b * A.n + r] = SV * (CLIP ? A.sp.inv_denom * span : A.sp.inv_denom);
+            if (A.glen) A.glen[(size_t)b * A.n + r] = SV * (CLIP ? Wn.inv_denom * span : Wn.inv_denom);
         }
         // grad_source is shared by all rays of the pose: wave butterfly, then one atomic per wave
 #pragma unroll
@@ -702,7 +707,10 @@ static int trilinear_forward_impl(const float* volume, const float* mask, int D0
     RenderArgs A;
     fill_args(A, volume, mask, D0, D1, D2, C, source, target, raylen, B, n, sp, cam);
     A.out = out; A.jac = jac; A.work = work;
-    const bool clip = sp->clip_to_volume != 0;
+    if (sp->clip_to_volume < 0 || sp->clip_to_volume > 2) return fail(XVR_DRR_E_ARG, "clip_to_volume must be 0, 1 or 2");
+    if ((sp->clip_to_volume == 2) != (sp->alpha_window != nullptr))
+        return fail(XVR_DRR_E_ARG, "clip_to_volume == 2 needs spec.alpha_window (xvr_drr_alpha_window), and only it");
+    const bool clip = sp->clip_to_volume == 1;
     const size_t lds = C > 1 || mask ? (size_t)C * WG * sizeof(float) : 0;
     if (packed && sp->volume_layout == 1) {   // the y-pair copy of the label-carrying volume
         if (jac) return clip ? launch(k_trilinear_fwd<true, 2, true, true>, A, lds, stream)
@@ -720,7 +728,7 @@ static int trilinear_forward_impl(const float* volume, const float* mask, int D0
                           : launch(k_trilinear_fwd<false, 1, false>, A, lds, stream);
     // LDS-staged bricks are opt-in (option "fwd_lds"; natural layout only): measured 2.25x SLOWER than the direct kernel at C2 (19.8 vs 8.8 ms;
     // with ~4 taps per voxel the L1/L2 already capture the reuse)
-    const bool use_lds = xvr_detail::option(xvr_detail::OPT_FWD_LDS) == 1 && sp->volume_layout == 0;
+    const bool use_lds = xvr_detail::option(xvr_detail::OPT_FWD_LDS) == 1 && sp->volume_layout == 0 && !sp->alpha_window;
     if (use_lds && !clip && A.grid_w > 0) {
         const size_t bytes = (size_t)(LDS_HDR + LDS_BRICK_CAP) * sizeof(float);
         return jac ? launch(k_trilinear_fwd_lds<true>, A, bytes, stream) : launch(k_trilinear_fwd_lds<false>, A, bytes, stream);
@@ -813,7 +821,11 @@ int xvr_drr_trilinear_backward(const float* volume, const float* mask, int D0, i
     RenderArgs A;
     fill_args(A, volume, mask, D0, D1, D2, C, source, target, raylen, B, n, sp);
     A.gout = grad_out; A.gvol = grad_volume; A.gsrc = grad_source; A.gtgt = grad_target; A.glen = grad_raylen;
-    const bool clip = sp->clip_to_volume != 0;
+    if ((sp->clip_to_volume == 2) != (sp->alpha_window != nullptr))
+        return fail(XVR_DRR_E_ARG, "clip_to_volume == 2 needs spec.alpha_window (xvr_drr_alpha_window), and only it");
+    if (sp->clip_to_volume == 2 && (mask || grad_target))
+        return fail(XVR_DRR_E_UNSUPPORTED, "the alpha window's pose gradient comes from the jacobian (xvr_drr_backward_from_jac + xvr_drr_alpha_window_backward); one channel");
+    const bool clip = sp->clip_to_volume == 1;
     const size_t lds = mask ? (size_t)C * WG * sizeof(float) : 0;
 
     // Voxel gradient by the atomic-free voxel-driven gather when the rays are a detector lattice: the per-lane flattened

@@ -141,8 +141,9 @@ class DRR(torch.nn.Module):
                 batch_size = len(pose)
                 cam = torch.addmm(c, pose.matrix[:, :3, :].reshape(batch_size, 12), G.T)
             spec_keys = {"n_points", "align_corners"} if self.renderer.renderer_name == "trilinear" else {"align_corners"}
+            batch_window = self.renderer.spec_overrides.get("clip_to_volume") == "batch"   # (needs the rays in memory)
             if (not mask_to_channels and set(kwargs) <= spec_keys and not density.requires_grad and self.detector.width > 1
-                    and density.dtype == torch.float32 and density.dim() == 3):
+                    and density.dtype == torch.float32 and density.dim() == 3 and not batch_window):
                 # pose gradient only, one channel (the registration loop): the render kernel generates the rays
                 # itself and the backward is one fixed-order kernel -- no [B, n, 3] targets in between
                 img = render_from_camera(density, cam, self.renderer.make_spec(**kwargs), self.detector.height,

@@ -41,9 +41,7 @@ def make_cspec(shape, spec: RenderSpec, ray_grid_w: int = 0, volume_layout: int 
     c.n_points = spec.n_points
     c.near_, c.far_ = spec.near, spec.far
     c.inv_denom = 1.0 / (spec.n_points if spec.step_mode == "n_points" else spec.n_points - 1)
-    if spec.clip_to_volume == "batch":
-        raise NotImplementedError("clip_to_volume='batch' (one alpha window per call) is oracle-only so far")
-    c.clip_to_volume = int(bool(spec.clip_to_volume))
+    c.clip_to_volume = 2 if spec.clip_to_volume == "batch" else int(bool(spec.clip_to_volume))   # (2: + alpha_window, set by the caller)
     c.ray_grid_w = int(ray_grid_w)
     c.volume_layout = int(volume_layout)
     return c
@@ -265,12 +263,24 @@ class _Render(torch.autograd.Function):
         if bricks is not None:
             vol_f = bricks
         cs = make_cspec((D0, D1, D2), spec, ray_grid_w, volume_layout=1 if pairs is not None else (2 if bricks is not None else 0))
+        window = None
+        if spec.renderer == "trilinear" and spec.clip_to_volume == "batch":
+            # ONE alpha window for the whole call, reduced on the device from its rays (no host round trip): the kernels read
+            # near / far / scale from this buffer
+            window = torch.empty(_lib.ALPHA_WINDOW_FLOATS, device=volume.device, dtype=torch.float32)
+            rc = _timed("alpha_window", lib.xvr_drr_alpha_window, _ptr(src_c), _ptr(tgt_c), B, n, D0, D1, D2, ctypes.byref(cs),
+                        _ptr(window), _stream())
+            _lib.check(rc, "xvr_drr_alpha_window")
+            cs.alpha_window = window.data_ptr()
+        elif spec.renderer == "siddon":
+            cs.clip_to_volume = 0
         rc = _timed(f"{spec.renderer}_forward" + ("+jac" if use_jac else ""), fn,
                     _ptr(vol_f), _ptr(msk_f), D0, D1, D2, C, _ptr(src_c), _ptr(tgt_c), _ptr(len_c), B, n,
                     ctypes.byref(cs), _ptr(out), _ptr(jac), _ptr(work), _stream())
         _lib.check(rc, f"xvr_drr_{spec.renderer}_forward")
         ctx.spec, ctx.ray_grid_w, ctx.C = spec, ray_grid_w, C
         ctx.src_shape, ctx.img_shape = source.shape, img.shape
+        ctx.window = window
         ctx.save_for_backward(vol_c, src_c, tgt_c, len_c, msk_c, jac)
         return out
 
@@ -298,12 +308,26 @@ class _Render(torch.autograd.Function):
             gtgt = torch.empty(B, n, 3, device=dev, dtype=torch.float32)
             glen = torch.empty(B, n, device=dev, dtype=torch.float32)
         from_jac = need_pose and jac is not None and uniform
+        window = ctx.window
+        if window is not None and ((need_pose and not from_jac) or (need_vol and msk_c is not None and not uniform)):
+            raise NotImplementedError("clip_to_volume='batch': gradients are implemented for one channel (or a gradient that is "
+                                      "the same for every channel)")
         if from_jac:
             rc = _timed("backward_from_jac", lib.xvr_drr_backward_from_jac,
                         _ptr(jac), _ptr(g_uniform), B, n, _ptr(gsrc), _ptr(gtgt), _ptr(glen), _stream())
             _lib.check(rc, "xvr_drr_backward_from_jac")
+            if window is not None:   # the window itself depends on the pose: min / max route their gradient to two rays
+                cw = make_cspec((D0, D1, D2), spec, ctx.ray_grid_w)
+                cw.alpha_window = window.data_ptr()
+                rc = _timed("alpha_window_backward", lib.xvr_drr_alpha_window_backward, _ptr(jac), _ptr(g_uniform), _ptr(src_c),
+                            _ptr(tgt_c), _ptr(len_c), B, n, ctypes.byref(cw), _ptr(window), _ptr(gsrc), _ptr(gtgt), _stream())
+                _lib.check(rc, "xvr_drr_alpha_window_backward")
         if need_vol or (need_pose and not from_jac):
             cs = make_cspec((D0, D1, D2), spec, ctx.ray_grid_w)
+            if window is not None:
+                cs.alpha_window = window.data_ptr()
+            elif spec.renderer == "siddon":
+                cs.clip_to_volume = 0
             fn = lib.xvr_drr_trilinear_backward if spec.renderer == "trilinear" else lib.xvr_drr_siddon_backward
             pose_here = need_pose and not from_jac
             ws, ws_bytes = None, 0
