@@ -66,12 +66,12 @@ typedef struct xvr_drr_spec {
     int32_t volume_layout; /* forward only: 0 = `volume` is [D0][D1][D2]; 1 (trilinear) = it is the y-pair interleaved
                               copy written by xvr_drr_pack_ypairs; 2 (siddon) = the 4 x 2 x 4 bricks written by
                               xvr_drr_pack_bricks (same results, bit for bit)                               */
-    const float* alpha_window; /* clip_to_volume == 2: device buffer of XVR_DRR_ALPHA_WINDOW_FLOATS floats written by
+    const float* alpha_window; /* clip_to_volume == 2: device buffer of xvr_drr_alpha_window_bytes(B) bytes, 16-byte aligned, written by
                               xvr_drr_alpha_window() on the same stream before the render (the kernels read the call's
                               near / far / scale from it: no host round trip); NULL otherwise                  */
 } xvr_drr_spec;
 
-#define XVR_DRR_ALPHA_WINDOW_FLOATS 16
+#define XVR_DRR_ALPHA_WINDOW_FLOATS 16   /* header of the window buffer; xvr_drr_alpha_window_bytes(B) is its whole size */
 
 int xvr_drr_abi_version(void);
 const char* xvr_drr_last_error(void);
@@ -103,6 +103,7 @@ int xvr_drr_get_option(const char* name, int* value);
  * the two extremal rays -- is xvr_drr_alpha_window_backward: call it after xvr_drr_backward_from_jac with the same jacobian
  * and upstream gradient; it ADDS to grad_source / grad_target.  One channel only.
  */
+size_t xvr_drr_alpha_window_bytes(int B);
 int xvr_drr_alpha_window(const float* source, const float* target, int B, int n, int D0, int D1, int D2,
                          const xvr_drr_spec* spec, float* window, void* stream);
 int xvr_drr_alpha_window_backward(const float* jac, const float* grad_out, const float* source, const float* target,

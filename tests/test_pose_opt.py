@@ -492,6 +492,45 @@ def test_fused_similarity_gradient_matches_autograd_through_the_oracle(shape, be
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("beta", [1.0, 0.5])
+def test_fused_similarity_on_drr_like_images_with_a_flat_background(beta):
+    """A DRR is exactly constant over most of its background.  On a flat patch the reference's two-pass (unfold) patch NCC
+    is exactly 0; a one-pass variance in float32 about a tile-wide shift leaves delta^2 * 1e-7 there, which is NOT small
+    against eps = 1e-5 -- round 2's kernel was off by 2-7 % of an image's patch NCC on such images (found by
+    tests/test_c4_c5.py; random-noise test images have no flat patches).  The moments are summed in doubles now."""
+    from oracle import metrics_restated as mref
+    from xvr_amd.metrics import XrayTransforms
+    from xvr_amd.similarity import FusedSimilarity
+
+    B, H, W = 3, 64, 64
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+
+    def blobs(shift):   # the same three discs per image, moved by `shift` pixels: a "moving" image close to the fixed one
+        g = torch.Generator().manual_seed(43)
+        img = torch.zeros(B, 1, H, W)
+        for b in range(B):
+            for _ in range(3):
+                cy, cx, r = (torch.rand(3, generator=g) * torch.tensor([H * 0.5, W * 0.5, 9.0]) + torch.tensor([H * 0.25 + shift, W * 0.25, 5.0])).tolist()
+                img[b, 0] += 20.0 * torch.clamp(1.0 - ((yy - cy) ** 2 + (xx - cx) ** 2) / r ** 2, min=0.0)
+        return img
+    fixed_raw, moving = blobs(0.0), blobs(1.5)
+    assert (fixed_raw == 0).float().mean() > 0.4 and (moving == 0).float().mean() > 0.4      # mostly exactly-flat background
+    moving[:, :, 3, 5] += 31.0   # (a unique maximum, see the test above)
+    fixed = XrayTransforms(H, W)(fixed_raw)
+    sim = FusedSimilarity(fixed.cuda(), 9, 11, beta)
+    mv = moving.cuda().requires_grad_(True)
+    loss = sim(mv)
+    loss.sum().backward()
+    mo = moving.double().requires_grad_(True)
+    yo = mref.xray_transforms(mo, H, W)
+    oref = beta * mref.multiscale_ncc(fixed.double(), yo) + (1 - beta) * mref.gradient_ncc(fixed.double(), yo, 11, 0.0)
+    oref.sum().backward()
+    assert torch.allclose(loss.cpu().double(), oref.detach(), atol=1e-4), (loss.cpu(), oref)
+    err = (mv.grad.cpu().double() - mo.grad).abs().max() / mo.grad.abs().max()
+    assert err <= 5e-3, err
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kw", [dict(sigma=1.0), dict(equalize=True), dict(sigma=0.8, equalize=True)], ids=["sigma", "equalize", "both"])
 def test_device_loop_and_run_batch_take_every_similarity_configuration(kw):
     """sigma > 0 and Equalize used to be refused by the device-resident loop and by run_batch (torch fallback only): now

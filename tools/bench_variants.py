@@ -1,7 +1,7 @@
 """Forward + backward (pose AND voxel gradient) at the benchmark's size for every RenderSpec variant the parity tests
 cover (tests/test_hip_parity.py SPECS) plus the masked renders -- the knobs parity against the real diffdrr may land on
 (DESIGN.md section 2).  One markdown table: ms per step, DRRs/s, and the kernels of the step with their HIP-event times.
-Run on the GPU box:  python tools/bench_variants.py [--batch 116 --size 512 --det 256] > profiles/r02_variants.md"""
+Run on the GPU box:  python tools/bench_variants.py [--batch 116 --size 512 --det 256] > profiles/r03_variants.md"""
 import argparse
 import sys
 import time
@@ -22,6 +22,7 @@ VARIANTS = [
     ("trilinear align_corners, offset -1, shift 0", "trilinear", dict(voxel_shift=0.0, norm_dims_offset=-1), dict(n_points=500, align_corners=True), None),
     ("trilinear near=0.2 far=0.9", "trilinear", dict(near=0.2, far=0.9), dict(n_points=500), None),
     ("trilinear clip_to_volume", "trilinear", dict(clip_to_volume=True), dict(n_points=500), None),
+    ("trilinear clip_to_volume='batch' (one alpha window per call)", "trilinear", dict(clip_to_volume="batch"), dict(n_points=500), None),
     ("trilinear mask -> 8 channels, summed (xvr)", "trilinear", dict(), dict(n_points=500), "sum"),
     ("trilinear mask -> 8 channels, per-channel gradient", "trilinear", dict(), dict(n_points=500), "per-channel"),
     ("siddon (default)", "siddon", dict(), dict(), None),

@@ -100,6 +100,7 @@ EXPORTS = {
     "xvr_drr_siddon_forward": (_FWD, ctypes.c_int),
     "xvr_drr_siddon_backward": (_BWD, ctypes.c_int),
     "xvr_drr_backward_from_jac": ([_P, _P, _I, _I, _P, _P, _P, _P], ctypes.c_int),
+    "xvr_drr_alpha_window_bytes": ([_I], ctypes.c_size_t),
     "xvr_drr_alpha_window": ([_P, _P, _I, _I, _I, _I, _I, ctypes.POINTER(CSpec), _P, _P], ctypes.c_int),
     "xvr_drr_alpha_window_backward": ([_P, _P, _P, _P, _P, _I, _I, ctypes.POINTER(CSpec), _P, _P, _P, _P], ctypes.c_int),
     "xvr_sim_workspace_bytes": ([_I, _I, _I], ctypes.c_size_t),

@@ -237,16 +237,32 @@ __global__ __launch_bounds__(WG) void k_alpha_window_reduce(const float* __restr
             kmax = ((unsigned long long)__float_as_uint(amax) << 32) | (0xffffffffu - idx);
         }
     }
+    // wavefront -> workgroup (LDS) -> ONE atomic per workgroup on the POSE's pair of slots: a few hundred same-address
+    // atomics per slot (all 118 k wavefronts of a batch on two words took 2.7 ms)
+    __shared__ unsigned long long part[2][WG / 64];
     kmin_inv = wave_max_u64(kmin_inv);
     kmax = wave_max_u64(kmax);
-    if ((threadIdx.x & 63) == 0) {
-        if (kmin_inv) atomicMax(keys, kmin_inv);
-        if (kmax) atomicMax(keys + 1, kmax);
+    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = kmin_inv; part[1][threadIdx.x >> 6] = kmax; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        unsigned long long v = part[threadIdx.x][0];
+        for (int w = 1; w < WG / 64; ++w) v = part[threadIdx.x][w] > v ? part[threadIdx.x][w] : v;
+        if (v) atomicMax(keys + 2 * b + threadIdx.x, v);
     }
 }
 
-__global__ void k_alpha_window_final(float* window, float near_, float far_, float inv_denom) {
-    const unsigned long long* keys = reinterpret_cast<const unsigned long long*>(window + WIN_KEYS);
+__global__ __launch_bounds__(64) void k_alpha_window_final(float* window, int B, float near_, float far_, float inv_denom) {
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(window + WIN_KEYS);
+    const unsigned long long* slots = reinterpret_cast<const unsigned long long*>(window + XVR_DRR_ALPHA_WINDOW_FLOATS);
+    unsigned long long k0 = 0ull, k1 = 0ull;
+    for (int b = threadIdx.x; b < B; b += 64) {
+        k0 = slots[2 * b] > k0 ? slots[2 * b] : k0;
+        k1 = slots[2 * b + 1] > k1 ? slots[2 * b + 1] : k1;
+    }
+    k0 = wave_max_u64(k0);
+    k1 = wave_max_u64(k1);
+    if (threadIdx.x != 0) return;
+    keys[0] = k0; keys[1] = k1;
     float A = 0.f, Z = 0.f;
     if (keys[0] && keys[1]) {
         A = __uint_as_float((unsigned)((~keys[0]) >> 32));
@@ -261,7 +277,7 @@ __global__ void k_alpha_window_final(float* window, float near_, float far_, flo
 
 // d loss / d A and d loss / d Z from the saved jacobian: with alpha_k = A + u_k W (W = Z - A) and the image scaled by W,
 //   d out / d A |_W = sum_k d out / d alpha_k = sum_i d_i (js_i + jt_i)
-//   d out / d W |_A = out / W + sum_k u_k d out / d alpha_k = (out + sum_i d_i (jt_i - A (js_i + jt_i))) / W
+//   d out / d W |_A = out / W + sum_k u_k d out / d alpha_k = (out + sum_k (alpha_k - A) d out / d alpha_k) / W   [jacobian row, float 7]
 // (js, jt: the per-ray jacobian rows, which already hold scale * a (G - H) and scale * a H), and d/dA|_Z = d/dA|_W - d/dW, d/dZ = d/dW.
 __global__ __launch_bounds__(WG) void k_alpha_window_bwd_reduce(const float* __restrict__ jac, const float* __restrict__ gout,
                                                                const float* __restrict__ source, const float* __restrict__ target,
@@ -278,14 +294,15 @@ __global__ __launch_bounds__(WG) void k_alpha_window_bwd_reduce(const float* __r
         const float4 j0 = jp[0], j1 = jp[1];
         const float* tp = target + ray * 3;
         const float js[3] = {j0.y, j0.z, j0.w}, jt[3] = {j1.x, j1.y, j1.z};
-        float s1 = 0.f, s2 = 0.f;
+        // (sum_k (alpha_k - A) d out / d alpha_k comes ready-made in the jacobian's spare float: rebuilt as sum_i d_i (jt_i -
+        //  A (js_i + jt_i)) it is a difference of two large sums, 2 % off in float32)
+        float s1 = 0.f;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const float d = (tp[i] - source[3 * b + i]) + eps;
             s1 = fmaf(d, js[i] + jt[i], s1);
-            s2 = fmaf(d, jt[i], s2);
         }
-        const float dW = (fmaf(j0.x, raylen[ray], s2) - A * s1) / W;
+        const float dW = fmaf(j0.x, raylen[ray], j1.w) / W;
         ga = g * (s1 - dW);
         gz = g * dW;
     }
@@ -293,20 +310,25 @@ __global__ __launch_bounds__(WG) void k_alpha_window_bwd_reduce(const float* __r
     gz = wave_sum_f(gz);
     if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = ga; part[1][threadIdx.x >> 6] = gz; }
     __syncthreads();
-    if (threadIdx.x < 2) {
+    if (threadIdx.x < 2) {   // (per-pose slots behind the window's header: see k_alpha_window_reduce)
         const float tot = part[threadIdx.x][0] + part[threadIdx.x][1] + part[threadIdx.x][2] + part[threadIdx.x][3];
-        if (tot != 0.f) atomic_add_f32(window + WIN_GA + threadIdx.x, tot);
+        if (tot != 0.f) atomic_add_f32(window + XVR_DRR_ALPHA_WINDOW_FLOATS + 4 * b + threadIdx.x, tot);
     }
 }
 
 // ... and on to the two extremal rays: A = (plane - s_i) / d_i on the axis the ray enters through, Z likewise on its exit
 // axis (no gradient where the value is the clamp 0 / 1)
-__global__ void k_alpha_window_bwd_apply(const float* __restrict__ source, const float* __restrict__ target, int n, xvr_drr_spec sp,
-                                         const float* window, float* gsrc, float* gtgt) {
+__global__ void k_alpha_window_bwd_apply(const float* __restrict__ source, const float* __restrict__ target, int B, int n, xvr_drr_spec sp,
+                                         float* window, float* gsrc, float* gtgt) {
     const unsigned long long* keys = reinterpret_cast<const unsigned long long*>(window + WIN_KEYS);
     if (!(keys[0] && keys[1])) return;
     const unsigned idx[2] = {(unsigned)(~keys[0]), 0xffffffffu - (unsigned)keys[1]};
-    const float gr[2] = {window[WIN_GA], window[WIN_GZ]};
+    float gr[2] = {0.f, 0.f};
+    for (int b = 0; b < B; ++b) {   // the poses' partial sums, in pose order
+        gr[0] += window[XVR_DRR_ALPHA_WINDOW_FLOATS + 4 * b];
+        gr[1] += window[XVR_DRR_ALPHA_WINDOW_FLOATS + 4 * b + 1];
+    }
+    window[WIN_GA] = gr[0]; window[WIN_GZ] = gr[1];
     for (int e = 0; e < 2; ++e) {
         const int b = (int)(idx[e] / (unsigned)n);
         const size_t ray = idx[e];
@@ -387,17 +409,21 @@ int xvr_drr_backward_from_jac(const float* jac, const float* grad_out, int B, in
     return XVR_DRR_OK;
 }
 
+size_t xvr_drr_alpha_window_bytes(int B) {   // the header + one 16-byte slot per pose (two keys / two partial sums)
+    return B > 0 ? ((size_t)XVR_DRR_ALPHA_WINDOW_FLOATS + 4 * (size_t)B) * sizeof(float) : 0;
+}
+
 int xvr_drr_alpha_window(const float* source, const float* target, int B, int n, int D0, int D1, int D2,
                          const xvr_drr_spec* sp, float* window, void* stream) {
     if (!source || !target || !sp || !window) return fail(XVR_DRR_E_ARG, "null pointer argument");
     if (B <= 0 || n <= 0 || D0 < 2 || D1 < 2 || D2 < 2) return fail(XVR_DRR_E_ARG, "B, n must be positive and every volume dimension >= 2");
     if ((long long)B * n >= (1LL << 32) - 1) return fail(XVR_DRR_E_UNSUPPORTED, "the alpha window indexes rays with 32 bits");
     if (reinterpret_cast<uintptr_t>(window) & 15u) return fail(XVR_DRR_E_ARG, "window must be 16-byte aligned");
-    hipError_t e = hipMemsetAsync(window, 0, XVR_DRR_ALPHA_WINDOW_FLOATS * sizeof(float), (hipStream_t)stream);
+    hipError_t e = hipMemsetAsync(window, 0, xvr_drr_alpha_window_bytes(B), (hipStream_t)stream);
     if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
     hipLaunchKernelGGL(k_alpha_window_reduce, dim3((unsigned)((n + WG - 1) / WG), (unsigned)B), dim3(WG), 0, (hipStream_t)stream,
-                       source, target, n, *sp, reinterpret_cast<unsigned long long*>(window + WIN_KEYS));
-    hipLaunchKernelGGL(k_alpha_window_final, dim3(1), dim3(1), 0, (hipStream_t)stream, window, sp->near_, sp->far_, sp->inv_denom);
+                       source, target, n, *sp, reinterpret_cast<unsigned long long*>(window + XVR_DRR_ALPHA_WINDOW_FLOATS));
+    hipLaunchKernelGGL(k_alpha_window_final, dim3(1), dim3(64), 0, (hipStream_t)stream, window, B, sp->near_, sp->far_, sp->inv_denom);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
     return XVR_DRR_OK;
@@ -409,11 +435,11 @@ int xvr_drr_alpha_window_backward(const float* jac, const float* grad_out, const
     if (!jac || !grad_out || !source || !target || !raylen || !sp || !window || !grad_source || !grad_target)
         return fail(XVR_DRR_E_ARG, "null pointer argument");
     if (B <= 0 || n <= 0) return fail(XVR_DRR_E_ARG, "B and n must be positive");
-    hipError_t e = hipMemsetAsync(window + WIN_GA, 0, 2 * sizeof(float), (hipStream_t)stream);
+    hipError_t e = hipMemsetAsync(window + XVR_DRR_ALPHA_WINDOW_FLOATS, 0, (size_t)4 * B * sizeof(float), (hipStream_t)stream);   // the poses' slots
     if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
     hipLaunchKernelGGL(k_alpha_window_bwd_reduce, dim3((unsigned)((n + WG - 1) / WG), (unsigned)B), dim3(WG), 0, (hipStream_t)stream,
                        jac, grad_out, source, target, raylen, n, sp->eps, window);
-    hipLaunchKernelGGL(k_alpha_window_bwd_apply, dim3(1), dim3(1), 0, (hipStream_t)stream, source, target, n, *sp, window,
+    hipLaunchKernelGGL(k_alpha_window_bwd_apply, dim3(1), dim3(1), 0, (hipStream_t)stream, source, target, B, n, *sp, window,
                        grad_source, grad_target);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));

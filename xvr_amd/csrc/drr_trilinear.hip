@@ -44,7 +44,9 @@ struct SlabRange {
     float lo, hi;
 };
 
-template <bool JAC, int MASK, bool CLIP, bool YP = false, bool SLAB = false>
+// WIN (clip_to_volume == 2, with the jacobian): also E1 = sum (alpha_k - A) (a d . grad V) -- d out / d (window width) needs it
+// directly; rebuilt from G and H it is a difference of two large sums and loses 2 % in float32
+template <bool JAC, int MASK, bool CLIP, bool YP = false, bool SLAB = false, bool WIN = false>
 __device__ __forceinline__ void tri_march(const RenderArgs& A, const Ray& R, const KRange K, const int kbeg, const int kend,
                                           const float step, const SpecWin Wn, float* lds, const int tid, TriAcc& acc,
                                           const SlabRange slab = SlabRange{0, 0.f, 0.f}) {
@@ -141,6 +143,7 @@ __device__ __forceinline__ void tri_march(const RenderArgs& A, const Ray& R, con
                     E0 = fmaf(gd, 1.f - u[h], E0);
                     E1 = fmaf(gd, u[h], E1);
                 }
+                if (WIN) E1 = fmaf(fmaf(gx, adx, fmaf(gy, ady, gz * adz)), al[h] - Wn.A, E1);
             }
         }
     }
@@ -153,7 +156,7 @@ __device__ __forceinline__ void tri_march(const RenderArgs& A, const Ray& R, con
 }
 
 // Scale the sums and write the pixel (and its jacobian row).
-template <bool JAC, int MASK, bool CLIP>
+template <bool JAC, int MASK, bool CLIP, bool WIN = false>
 __device__ __forceinline__ void tri_finish(const RenderArgs& A, const Ray& R, const int b, const int r, const SpecWin Wn, const float* lds,
                                            const int tid, const TriAcc& acc) {
     const float S = acc.S;
@@ -188,7 +191,8 @@ __device__ __forceinline__ void tri_finish(const RenderArgs& A, const Ray& R, co
         }
         float4* jp = reinterpret_cast<float4*>(A.jac + ((size_t)b * A.n + r) * XVR_DRR_JAC_STRIDE);
         jp[0] = make_float4(S * (CLIP ? Wn.inv_denom * span : Wn.inv_denom), js[0], js[1], js[2]);
-        jp[1] = make_float4(jt[0], jt[1], jt[2], 0.f);
+        // (WIN: the spare float carries scale * E1 = the ray's  sum_k (alpha_k - A) d out / d alpha_k  for xvr_drr_alpha_window_backward)
+        jp[1] = make_float4(jt[0], jt[1], jt[2], WIN ? scale * acc.E1 : 0.f);
     }
 }
 
@@ -200,7 +204,7 @@ constexpr double SLAB_TARGET_BYTES = 150e6, SLAB_MIN_VOLUME_BYTES = 192.0 * (1 <
 #ifndef XVR_FWD_WAVES   // (overridable for tuning builds)
 #define XVR_FWD_WAVES 4
 #endif
-template <bool JAC, int MASK, bool CLIP, bool YP = false>
+template <bool JAC, int MASK, bool CLIP, bool YP = false, bool WIN = false>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, XVR_FWD_WAVES))) void k_trilinear_fwd(RenderArgs A) {
     extern __shared__ float lds[];  // MASK: per-lane channel accumulators [C][WG]
     int b, r;
@@ -218,8 +222,8 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, XVR_FWD_W
         for (int c = 0; c < A.C; ++c) lds[c * WG + tid] = 0.f;
     }
     TriAcc acc;
-    tri_march<JAC, MASK, CLIP, YP>(A, R, K, kbeg, kend, step, Wn, lds, tid, acc);
-    if (valid) tri_finish<JAC, MASK, CLIP>(A, R, b, r, Wn, lds, tid, acc);
+    tri_march<JAC, MASK, CLIP, YP, false, WIN>(A, R, K, kbeg, kend, step, Wn, lds, tid, acc);
+    if (valid) tri_finish<JAC, MASK, CLIP, WIN>(A, R, b, r, Wn, lds, tid, acc);
     if (A.work) {
         unsigned tot = wave_sum_u(acc.cnt);
         if ((tid & 63) == 0 && tot) atomicAdd(A.work, (unsigned long long)tot);
@@ -700,6 +704,8 @@ static int trilinear_forward_impl(const float* volume, const float* mask, int D0
     if (!(sp->far_ >= sp->near_)) return fail(XVR_DRR_E_ARG, "far must be >= near");
     const bool packed = !mask && C > 1;   // labels in the low mantissa bits of `volume` (xvr_drr_pack_labels)
     if (packed && C > (1 << LABEL_BITS)) return fail(XVR_DRR_E_ARG, "packed labels hold at most 16 channels");
+    if (sp->alpha_window && jac && (mask || packed))
+        return fail(XVR_DRR_E_UNSUPPORTED, "clip_to_volume == 2: the jacobian is implemented for one channel");
     if (sp->volume_layout != 0 && sp->volume_layout != 1) return fail(XVR_DRR_E_ARG, "unknown volume_layout");
     if (sp->volume_layout == 1 && mask) return fail(XVR_DRR_E_UNSUPPORTED, "the y-pair layout takes labels packed into the volume, not a mask volume");
     if (sp->volume_layout == 1 && (long long)D0 * (D1 + 1) * D2 * 2 >= (1LL << 31))
@@ -732,6 +738,11 @@ static int trilinear_forward_impl(const float* volume, const float* mask, int D0
     if (use_lds && !clip && A.grid_w > 0) {
         const size_t bytes = (size_t)(LDS_HDR + LDS_BRICK_CAP) * sizeof(float);
         return jac ? launch(k_trilinear_fwd_lds<true>, A, bytes, stream) : launch(k_trilinear_fwd_lds<false>, A, bytes, stream);
+    }
+    if (sp->alpha_window && jac) {   // the jacobian of a windowed render also carries d out / d (window width): unsplit kernel
+        RenderArgs Aw = A;
+        return sp->volume_layout == 1 ? launch(k_trilinear_fwd<true, 0, false, true, true>, Aw, 0, stream)
+                                      : launch(k_trilinear_fwd<true, 0, false, false, true>, Aw, 0, stream);
     }
     // Large batches over a volume the Infinity Cache cannot hold: the slab-major march (k_trilinear_fwd_slab).  Option
     // "fwd_slabs": 0 = never, n >= 2 = always n slabs, -1 (default) = as many slabs as keep a slab's bytes under

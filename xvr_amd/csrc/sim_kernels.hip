@@ -7,7 +7,7 @@
 //
 // The reference's patch NCC unfolds every p x p patch into a channel (81x / 121x the image); here
 // each thread evaluates one patch from an LDS tile with separable box sums (p + p reads, not p^2) of the
-// five moments about a tile-wide shift -- robust on the flat patches where eps decides -- and stores four
+// five moments about a tile-wide shift, summed in doubles -- robust on the flat patches where eps decides -- and stores four
 // per-patch maps
 //   A = 1/s, Bm = mu_f/s, Cm = cov/(v_y s), Dm = cov mu_y/(v_y s),   s = sqrt(v_f v_y),
 // from which the gradient is   d ncc / d y_i = (1 / (N_p p^2)) * ( f_i SA - SB - y_i SC + SD ),
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(TB) void k_sim_patch(PatchJobs jobs, int B, int H, 
                                                   double* partial, unsigned* tickets) {
     __shared__ float sf[(TILE + MAXP - 1) * (TILE + MAXP - 1)];
     __shared__ float sy[(TILE + MAXP - 1) * (TILE + MAXP - 1)];
-    __shared__ float hs[5][(TILE + MAXP - 1) * TILE];
+    __shared__ double hs[5][(TILE + MAXP - 1) * TILE];
     const int job = blockIdx.z / B, b = blockIdx.z - job * B;
     const PatchJob J = jobs.j[job];
     const float* __restrict__ fimg = J.f;
@@ -224,18 +224,22 @@ __global__ __launch_bounds__(TB) void k_sim_patch(PatchJobs jobs, int B, int H, 
         sy[t] = in ? Y[rr * W + cc] : 0.f;
     }
     __syncthreads();
-    // Separable box sums of the five moments about a tile-wide shift (cf, cy) = the tile's centre pixel:
-    // p + p reads per output instead of 2 p^2.  Shifting keeps the one-pass variance honest: on a flat patch
-    // the shifted values are tiny, so S2/n - (S1/n)^2 cancels nothing that matters against eps.
+    // Separable box sums of the five moments about a tile-wide shift (cf, cy) = the tile's centre pixel: p + p reads per
+    // output instead of 2 p^2.  The sums are DOUBLES (round 3): a DRR is flat over most of its background, and on a flat patch
+    // away from the tile's centre the one-pass variance S2/n - (S1/n)^2 and covariance cancel delta^2 (delta = the patch's
+    // value minus the shift, ~3 after Normalize) down to exactly 0 -- in float the residue is delta^2 * 1e-7 ~ 1e-6, not small
+    // against eps = 1e-5: whole flat regions contributed +-0.1 per patch instead of 0 (the reference's two-pass unfold
+    // formulation gives 0), 2-7 % of the image's patch NCC (tests/test_c4_c5.py found it).  float x float is exact in double
+    // and 81-225 such terms lose nothing.
     const int ec = min(E / 2, min(H - 1 - oy0, W - 1 - ox0));
     const float cf = sf[ec * E + ec], cy = sy[ec * E + ec];
     for (int t = threadIdx.x; t < E * TILE; t += TB) {   // horizontal: row r of the tile, output column c
         const int r = t / TILE, c = t - r * TILE;
-        float a1 = 0.f, b1 = 0.f, a2 = 0.f, b2 = 0.f, ab = 0.f;
+        double a1 = 0.0, b1 = 0.0, a2 = 0.0, b2 = 0.0, ab = 0.0;
         for (int v = 0; v < p; ++v) {
-            const float a = sf[r * E + c + v] - cf, bb = sy[r * E + c + v] - cy;
+            const double a = (double)(sf[r * E + c + v] - cf), bb = (double)(sy[r * E + c + v] - cy);
             a1 += a; b1 += bb;
-            a2 = fmaf(a, a, a2); b2 = fmaf(bb, bb, b2); ab = fmaf(a, bb, ab);
+            a2 = fma(a, a, a2); b2 = fma(bb, bb, b2); ab = fma(a, bb, ab);
         }
         hs[0][t] = a1; hs[1][t] = b1; hs[2][t] = a2; hs[3][t] = b2; hs[4][t] = ab;
     }
@@ -244,16 +248,16 @@ __global__ __launch_bounds__(TB) void k_sim_patch(PatchJobs jobs, int B, int H, 
     const int oy = oy0 + ty, ox = ox0 + tx;
     double ncc_d = 0.0;
     if (oy < Hp && ox < Wp) {
-        const float inv = 1.f / (float)(p * p);
-        float s1f = 0.f, s1y = 0.f, s2f = 0.f, s2y = 0.f, sfy = 0.f;
+        const double inv = 1.0 / (double)(p * p);
+        double s1f = 0.0, s1y = 0.0, s2f = 0.0, s2y = 0.0, sfy = 0.0;
         for (int u = 0; u < p; ++u) {                     // vertical
             const int t = (ty + u) * TILE + tx;
             s1f += hs[0][t]; s1y += hs[1][t]; s2f += hs[2][t]; s2y += hs[3][t]; sfy += hs[4][t];
         }
-        const float mfs = s1f * inv, mys = s1y * inv;      // means relative to the shift
-        const float mf = mfs + cf, my = mys + cy;
-        const float vf = fmaxf(fmaf(-mfs, mfs, s2f * inv), 0.f) + eps, vy = fmaxf(fmaf(-mys, mys, s2y * inv), 0.f) + eps;
-        const float cv = fmaf(-mfs, mys, sfy * inv);
+        const double mfs = s1f * inv, mys = s1y * inv;      // means relative to the shift
+        const float mf = (float)(mfs + (double)cf), my = (float)(mys + (double)cy);
+        const float vf = (float)fmax(fma(-mfs, mfs, s2f * inv), 0.0) + eps, vy = (float)fmax(fma(-mys, mys, s2y * inv), 0.0) + eps;
+        const float cv = (float)fma(-mfs, mys, sfy * inv);
         const float s = sqrtf(vf * vy);
         const float ncc = cv / s;
         const size_t np = (size_t)Hp * Wp, o = ((size_t)b * Hp + oy) * Wp + ox, st = (size_t)B * np;

@@ -267,7 +267,7 @@ class _Render(torch.autograd.Function):
         if spec.renderer == "trilinear" and spec.clip_to_volume == "batch":
             # ONE alpha window for the whole call, reduced on the device from its rays (no host round trip): the kernels read
             # near / far / scale from this buffer
-            window = torch.empty(_lib.ALPHA_WINDOW_FLOATS, device=volume.device, dtype=torch.float32)
+            window = torch.empty(lib.xvr_drr_alpha_window_bytes(B) // 4, device=volume.device, dtype=torch.float32)
             rc = _timed("alpha_window", lib.xvr_drr_alpha_window, _ptr(src_c), _ptr(tgt_c), B, n, D0, D1, D2, ctypes.byref(cs),
                         _ptr(window), _stream())
             _lib.check(rc, "xvr_drr_alpha_window")
