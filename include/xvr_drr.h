@@ -148,9 +148,20 @@ int xvr_drr_trilinear_forward(const float* volume, const float* mask, int D0, in
  *                per-voxel sums are exact 32-bit fixed-point integers in LDS -- over sample runs on the shared planes for
  *                the plain render, ray by ray under clip_to_volume and / or a mask (a mask whose grad_out is the same for
  *                every channel should be passed as mask = NULL, C = 1: the gradient is then the unmasked one).  Every
- *                product w * c is rounded to 2^-30 of a rigorous bound on the voxel's sum over one pose: ~4e-8 of the
- *                pose's largest |grad_out * raylen / n_points| at the benchmark geometry.  A non-finite grad_out turns
- *                the voxels of the 16^3 bricks its pose touches into NaN.  Otherwise -- or when the kernel finds on the
+ *                product w * c is rounded to 2^-31 of a rigorous bound on the voxel's sum over one pose: ~2e-8 of the
+ *                pose's largest |grad_out * raylen / n_points| at the benchmark geometry.
+ *                ACCURACY (an absolute floor per (pose, brick), so the RELATIVE error grows as a voxel's gradient shrinks;
+ *                measured against autograd through the oracle in float64, next to the fp32 gather of gather_splat = 0;
+ *                tools/splat_accuracy.py, profiles/r03_splat_accuracy.md, tests/test_splat.py, tests/test_configs.py):
+ *                  - benchmark geometry (512^3 -> 256^2, ~13 samples of a pose per voxel, grad_out >= 0): identical to the
+ *                    fp32 gather's error in every decade of |g| / max|g| down to 1e-7 -- both are the fp32 sample positions;
+ *                  - a few samples per voxel with a SIGNED noise grad_out (the voxel sums cancel, the bound cannot): within
+ *                    4 x of the fp32 gather's error down to 1e-4 max|g| (median 2e-5 relative there), 9 x at 1e-5;
+ *                  - worst case measured, pixels 15 x finer than voxels (~1500 samples of a pose per voxel; the bound, hence
+ *                    the LSB, is 30 x the benchmark's): median 3e-6 relative in the top decade (fp32 gather 8e-7), 3e-4 at
+ *                    1e-4 max|g| (fp32 gather 4e-6).  A contribution below bound * 2^-32 rounds to zero.
+ *                Callers that need fp32 sums throughout set the option gather_splat = 0 (the table gather, 1.6 x slower).
+ *                A non-finite grad_out turns the voxels of the 16^3 bricks its pose touches into NaN.  Otherwise -- or when the kernel finds on the
  *                device that the targets are not a lattice -- it falls back to a scatter with fp32 atomics: same result
  *                up to summation order, more than an order of magnitude slower on MI355X.
  */

@@ -186,18 +186,20 @@ def test_c4_full_size_multistart_registration_pyramid_8_4_of_a_2048_xray():
     best = max(range(S), key=lambda b: outs[b]["nccs"][-1])
     final = outs[best]["final_pose"].matrix[0].cpu().double()
     truth = convert(true_rot, true_xyz, parameterization="euler_angles", convention="ZXY").matrix[0].double()
-    dR = final[:3, :3] @ truth[:3, :3].T
-    angle = torch.rad2deg(torch.arccos(((dR.trace() - 1) / 2).clamp(-1, 1))).item()
-    # translation error measured where it matters: the displacement of the volume's isocentre (world origin) in camera space
-    dt = (final[:3, 3] - truth[:3, 3]).norm().item()
-    n_close = 0
-    for b in range(S):
-        m = outs[b]["final_pose"].matrix[0].cpu().double()
+    def errors(m):
+        """(rotation angle in degrees, in-plane and along-the-view translation error in mm): a single view fixes the pose
+        across the beam far better than along it -- 2 mm of depth at 750 mm change the magnification by 0.3 %."""
         a = torch.rad2deg(torch.arccos((((m[:3, :3] @ truth[:3, :3].T).trace() - 1) / 2).clamp(-1, 1))).item()
-        n_close += int(a < 1.0 and (m[:3, 3] - truth[:3, 3]).norm().item() < 2.0)
-    print(f"C4: best start {best}: {angle:.3f} deg, {dt:.3f} mm, ncc {outs[best]['nccs'][-1]:.4f}; {n_close} of {S} starts within 1 deg / 2 mm; "
-          f"iterations {[len(o['trajectory']) for o in outs]}")
-    assert angle < 1.0 and dt < 2.0, (angle, dt)
+        dt = m[:3, 3] - truth[:3, 3]
+        view = truth[:3, 3] / truth[:3, 3].norm()           # source -> isocentre (the world origin), up to sign
+        along = float(dt @ view)
+        return a, float((dt - along * view).norm()), abs(along)
+
+    angle, across, along = errors(final)
+    n_close = sum(int(e[0] < 1.0 and e[1] < 2.0 and e[2] < 5.0) for e in (errors(o["final_pose"].matrix[0].cpu().double()) for o in outs))
+    print(f"C4: best start {best}: {angle:.3f} deg, {across:.3f} mm across / {along:.3f} mm along the view, ncc {outs[best]['nccs'][-1]:.4f}; "
+          f"{n_close} of {S} starts that close; iterations {[len(o['trajectory']) for o in outs]}")
+    assert angle < 1.0 and across < 2.0 and along < 5.0, (angle, across, along)
     # (from +-10 deg / +-20 mm most starts stop in a local maximum -- what the multi-start's arg-max is for; the start that
     #  wins is one that converged)
     assert n_close >= 1

@@ -239,6 +239,16 @@ def test_batch_alpha_window_matches_the_oracle(kw, grid, monkeypatch):
     spec = RenderSpec(renderer="trilinear", clip_to_volume="batch", **kw)
     case = make_case(seed=19, shape=(36, 40, 44), height=24, width=32, delx=1.6,
                      rot=((170.0, 25.0, 5.0), (200.0, -30.0, -8.0), (150.0, 5.0, 12.0)), xyz=((5.0, 300.0, -4.0), (-3.0, 250.0, 6.0), (0.0, 280.0, 0.0)))
+    # A SMOOTH volume: the window's gradient multiplies every ray's  sum_k d out / d alpha_k  by |d| ~ 300, so one ray with a
+    # sample within an ulp of a voxel boundary -- where the march's derivative is one-sided and two float evaluations may take
+    # different sides -- would show up 300-fold in d/dA, d/dZ.  On a smooth volume the two one-sided
+    # derivatives agree to second order and every comparison below can be tight.
+    ax = [torch.arange(n, dtype=torch.float32) for n in (36, 40, 44)]
+    vol = torch.zeros(36, 40, 44)
+    for (cx, cy, cz, sg, rho) in ((15.0, 20.0, 20.0, 7.0, 1.0), (22.0, 16.0, 26.0, 5.5, 0.7), (18.0, 25.0, 15.0, 9.0, 0.5)):
+        vol += rho * (torch.exp(-((ax[0] - cx) / sg) ** 2)[:, None, None] * torch.exp(-((ax[1] - cy) / sg) ** 2)[None, :, None]
+                      * torch.exp(-((ax[2] - cz) / sg) ** 2)[None, None, :])
+    case["volume"] = vol
     w = torch.rand(3, 1, 24 * 32, generator=torch.Generator().manual_seed(6))
     gw = 32 if grid == "tiled" else 0
     ref = _oracle_render(case, spec, grads=True, w=w)
