@@ -29,6 +29,7 @@ VARIANTS = [
     ("siddon voxel_shift=0", "siddon", dict(voxel_shift=0.0), dict(), None),
     ("siddon norm_dims_offset=+1 (not the exact index map)", "siddon", dict(norm_dims_offset=1), dict(), None),
     ("siddon mask -> 8 channels, summed (xvr)", "siddon", dict(), dict(), "sum"),
+    ("siddon mask -> 8 channels, per-channel gradient", "siddon", dict(), dict(), "per-channel"),
 ]
 
 

@@ -5,7 +5,7 @@ set -u
 TAG=${1:-prof}; shift || true
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/$TAG
 mkdir -p $O; export TMPDIR=/tmp; cd /tmp
-B="python $R/bench.py --no-cpu-baseline $*"
+B="python $R/bench.py --no-cpu-baseline --no-variants $*"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $B --steps 3 --warmup 1 > $O/trace.log 2>&1
 timeout 900 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY --output-format csv -d $O/pmc_sq -- $B --steps 1 --warmup 0 > $O/pmc_sq.log 2>&1
 timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $B --steps 1 --warmup 0 > $O/pmc_fetch.log 2>&1

@@ -6,7 +6,7 @@ set -u
 TAG=${1:-gprof}; shift || true
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/$TAG
 mkdir -p $O; export TMPDIR=/tmp; cd /tmp
-B="python $R/bench.py --no-cpu-baseline $* --steps 1 --warmup 0"
+B="python $R/bench.py --no-cpu-baseline --no-variants $* --steps 1 --warmup 0"
 timeout 600 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY --output-format csv -d $O/pmc_sq1 -- $B > $O/pmc_sq1.log 2>&1
 timeout 600 rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_BRANCH --output-format csv -d $O/pmc_sq2 -- $B > $O/pmc_sq2.log 2>&1
 python - "$O" <<'PY'

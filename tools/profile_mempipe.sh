@@ -7,7 +7,7 @@ set -u
 TAG=${1:-mempipe}; shift || true
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/$TAG
 mkdir -p $O; export TMPDIR=/tmp; cd /tmp
-B="python $R/bench.py --no-cpu-baseline $* --steps ${STEPS:-1} --warmup ${WARMUP:-0}"
+B="python $R/bench.py --no-cpu-baseline --no-variants $* --steps ${STEPS:-1} --warmup ${WARMUP:-0}"
 P() { n=$1; shift; timeout 600 rocprofv3 --pmc "$@" --output-format csv -d $O/pmc_$n -- $B > $O/pmc_$n.log 2>&1; }
 P 1 GRBM_GUI_ACTIVE TA_TA_BUSY_sum TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum
 P 2 TA_FLAT_READ_WAVEFRONTS_sum TA_TOTAL_WAVEFRONTS_sum TD_TD_BUSY_sum TD_TC_STALL_sum

@@ -328,15 +328,21 @@ int xvr_drr_siddon_backward(const float* volume, const float* mask, int D0, int 
     int olo[3] = {0, 0, 0};
     const bool cells = !exact_geom && siddon_cell_offsets(sp, D0, D1, D2, olo) &&
                        workspace_bytes >= align256(ws_bytes(B, n, D0, D1, D2)) + siddon_cells_bytes(D0, D1, D2);
-    if (gvol && !mask && (exact_geom || cells) && gather_usable(sp, n, workspace, workspace_bytes, B, D0, D1, D2)) {
+    // (a mask with a per-channel gradient: the one-voxel-per-lane gather that looks the upstream value up by the voxel's own
+    //  label -- exact geometry, where a segment's voxel is the voxel whose box holds it)
+    if (gvol && ((!mask && (exact_geom || cells)) || (mask && exact_geom)) && gather_usable(sp, n, workspace, workspace_bytes, B, D0, D1, D2)) {
         unsigned* flag = nullptr;
         rc = launch_gather(true, source, target, raylen, grad_out, B, n, sp->ray_grid_w, D0, D1, D2, sp, grad_volume,
-                           workspace, stream, &flag, nullptr, 1, exact_geom ? nullptr : olo);
+                           workspace, stream, &flag, mask, C, exact_geom ? nullptr : olo);
         if (rc) return rc;
         RenderArgs Ap = A, Av = A;
         Ap.gvol = nullptr;
         Av.gsrc = nullptr; Av.gtgt = nullptr; Av.glen = nullptr;
         Av.skip_unless_flag_gt = flag;
+        if (exact_geom && mask) {
+            if (gpose) { rc = launch(k_siddon<2, true, true, false, true>, Ap, lds, stream); if (rc) return rc; }
+            return launch(k_siddon<2, true, false, true, true>, Av, lds, stream);
+        }
         if (exact_geom) {
             if (gpose) { rc = launch(k_siddon<2, false, true, false, true>, Ap, 0, stream); if (rc) return rc; }
             return launch(k_siddon<2, false, false, true, true>, Av, 0, stream);
