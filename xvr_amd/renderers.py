@@ -85,7 +85,6 @@ def _check_gpu_f32(name, t):
 # VOXEL_GATHER = False withholds it, which forces the atomic scatter fallback (tests, A/B runs).
 VOXEL_GATHER = True
 _WORKSPACES = {}
-_LAST_WINDOW = None
 
 
 # Siddon under a non-exact index map gathers per plane cell into octant sums first: 32 bytes per voxel MORE scratch
@@ -273,8 +272,6 @@ class _Render(torch.autograd.Function):
                         _ptr(window), _stream())
             _lib.check(rc, "xvr_drr_alpha_window")
             cs.alpha_window = window.data_ptr()
-            global _LAST_WINDOW
-            _LAST_WINDOW = window   # (kept for tools/debug and tests: { A, Z, near', far', inv_denom', Z - A, ..., gA, gZ })
         elif spec.renderer == "siddon":
             cs.clip_to_volume = 0
         rc = _timed(f"{spec.renderer}_forward" + ("+jac" if use_jac else ""), fn,
