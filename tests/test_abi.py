@@ -97,3 +97,37 @@ def test_options_table_is_set_through_the_abi_and_seeded_from_the_environment_on
             "os.environ['XVR_DRR_GATHER_SPLAT'] = '1'; print(_lib.get_option('gather_splat'))")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, check=True).stdout.split()
     assert out == ["0", str(8 | 2 << 8), "0"]
+
+
+def _rank_builds(args):
+    """One 'rank' of an 8-GPU launch importing the package over a stale library (worker of the test below)."""
+    marker, log = args
+    import time
+    from pathlib import Path
+
+    from xvr_amd import build
+
+    build.is_stale = lambda: not Path(marker).exists()          # stale until somebody has built
+
+    def fake_build(hipcc, force, verbose):                     # stands in for the minute of hipcc
+        with open(log, "a") as f:
+            f.write("build\n")
+        time.sleep(0.5)
+        Path(marker).write_text("built")
+        return build.LIB
+
+    build._build_locked = fake_build
+    build.find_hipcc = lambda: "/bin/true"
+    return str(build.build_library())
+
+
+def test_eight_ranks_importing_over_a_stale_library_build_it_once(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 8 bench.py` imports the package in eight processes at once; if the
+    library is stale exactly ONE of them may rebuild it (xvr_amd/build.py's file lock), the others wait and load the result
+    ('the only guard against 8 ranks rebuilding at import -- untested at 8')."""
+    import multiprocessing as mp
+
+    marker, log = tmp_path / "built.marker", tmp_path / "builds.log"
+    with mp.get_context("spawn").Pool(8) as pool:
+        libs = pool.map(_rank_builds, [(str(marker), str(log))] * 8)
+    assert len(set(libs)) == 1 and log.read_text().count("build") == 1
