@@ -16,7 +16,8 @@ ROOT = PKG.parent
 SRC = [PKG / "csrc" / f for f in ("drr_trilinear.hip", "drr_siddon.hip", "drr_gather.hip", "drr_rays.hip", "drr_api.hip",
                                   "sim_kernels.hip", "volume_kernels.hip", "pose_kernels.hip")]
 HDR = [ROOT / "include" / "xvr_drr.h", ROOT / "include" / "xvr_sim.h", ROOT / "include" / "xvr_pose.h",
-       PKG / "csrc" / "drr_common.hiph", PKG / "csrc" / "drr_splat.hiph"]
+       PKG / "csrc" / "drr_common.hiph", PKG / "csrc" / "drr_splat.hiph",
+       Path(__file__).resolve()]   # (this file holds the compiler flags: a change of flags makes the library stale too)
 OBJ = PKG / "lib" / "obj"
 LIB = PKG / "lib" / "libxvr_drr.so"
 
@@ -28,6 +29,16 @@ HIPCC_FLAGS = [
     "-munsafe-fp-atomics",  # fp32 atomic add in hardware (global_atomic_add_f32), no CAS loops
     f"-I{ROOT / 'include'}",
 ]
+# Per translation unit.  -fno-slp-vectorize: the SLP vectoriser pairs scalar fp32 operations into v_pk_{add,mul,fma}_f32, which
+# on gfx950 occupy a SIMD for 7.5 clocks against 2.9 for a plain one (tools/microbench/valu_issue.hip,
+# profiles/r03_microbench_valu_issue.txt): a pair costs 1.3 x two plain instructions.  The Siddon walk and the Siddon voxel
+# gather are vector-issue bound and lose 16 such pairs per trip to it: 9.39 -> 8.91 ms and 11.95 -> 10.56 ms at C3 without it.
+# (The trilinear forward waits on its gathers, not on the vector ALU, and measured 2 % SLOWER without the pairs -- fewer
+# instructions between its loads; the splat is indifferent.)
+EXTRA_FLAGS = {
+    "drr_siddon.hip": ["-fno-slp-vectorize"],
+    "drr_gather.hip": ["-fno-slp-vectorize"],
+}
 
 
 DIAG = ROOT / "tools" / "_build"   # diagnostic / tuning builds live with the tools, never next to the product library
@@ -54,15 +65,15 @@ def build_diagnostic_library(define, out: Path, only=None) -> Path:
             raise RuntimeError(f"hipcc failed ({proc.returncode}):\n{proc.stdout[-4000:]}\n{proc.stderr[-4000:]}")
 
     if only is None:
-        run([hipcc, *HIPCC_FLAGS, *[f"-D{d}" for d in defines], "-shared", "-o", str(out), *map(str, SRC)])
-        return out
-    build_library()
+        only = [s.name for s in SRC]   # (compile every unit with its own flags, then link)
+    else:
+        build_library()
     assert any(s.name in only for s in SRC), only
     objs = []
     for s in SRC:
         if s.name in only:   # compile, then link: hipcc takes every input of a mixed command line for HIP source
             obj = out.with_name(out.stem + "_" + s.stem + ".o")
-            run([hipcc, *HIPCC_FLAGS, *[f"-D{d}" for d in defines], "-c", str(s), "-o", str(obj)])
+            run([hipcc, *HIPCC_FLAGS, *EXTRA_FLAGS.get(s.name, []), *[f"-D{d}" for d in defines], "-c", str(s), "-o", str(obj)])
             objs.append(obj)
         else:
             objs.append(OBJ / (s.stem + ".o"))
@@ -111,7 +122,7 @@ def _build_locked(hipcc: str, force: bool, verbose: bool) -> Path:
         obj = OBJ / (src.stem + ".o")
         if not force and obj.exists() and obj.stat().st_mtime > max(src.stat().st_mtime, newest_header):
             return obj, None
-        cmd = [hipcc, *HIPCC_FLAGS, "-c", str(src), "-o", str(obj)]
+        cmd = [hipcc, *HIPCC_FLAGS, *EXTRA_FLAGS.get(src.name, []), "-c", str(src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd))
         proc = subprocess.run(cmd, capture_output=True, text=True)
