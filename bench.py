@@ -36,38 +36,46 @@ TAP_BYTES_PER_SAMPLE = 32   # 8 taps x 4 B; the voxel backward ac
 # chip by the committed microbenchmarks, applied to the live unit count.  floor_ms = the time the launch would take if the
 # binding unit were busy every clock and nothing else cost anything.
 CUS, CLK_GHZ = 256, 2.4
+VALU_CLK = 3.0   # clocks a plain wave64 vector instruction occupies its SIMD (2.9-3.4 measured with 4 wavefronts per SIMD,
+                 # tools/microbench/valu_issue.hip, profiles/r03_microbench_valu_issue.txt; v_pk_*_f32 7.5, v_mad_u64_u32 6.0)
+# candidate units per timed call: (unit, wavefront instructions per 64 units of work, clocks each on the unit's 256 CU-wide or
+# 1024 SIMD-wide resource, source).  Vector-instruction counts per 64 units are SQ_INSTS_VALU of the committed PMC passes
+# (profiles/r03_*_rocprof_summary.md) over the kernels' own unit counts.
 BINDING = {
-    # tools/microbench/lds_atomics.hip, profiles/r02_microbench_lds_atomics.txt: a ds_add_u32 wavefront instruction costs
-    # >= 4.4 LDS clocks however few lanes are live; 8 per sample; 53.9 of 64 lanes live (profiles/r02_trilinear_rocprof_summary.md)
-    "trilinear_backward": {"unit": "lds_atomic_issue", "wave_instr_per_64_units": 8 / (53.9 / 64), "clk_per_wave_instr": 4.4,
-                           "source": "profiles/r02_microbench_lds_atomics.txt"},
-    # tools/microbench/gather.hip, profiles/r01_microbench_gather_lines.txt: a 64-lane gather costs ~15 clk per CU on one
-    # 128-B line and 10-14 more per further line; the forward's two 16-byte gathers per sample (y-pair copy) touch ~3 lines
-    "trilinear_forward": {"unit": "texture_address", "wave_instr_per_64_units": 2, "clk_per_wave_instr": 36.0,
-                          "source": "profiles/r01_microbench_gather_lines.txt"},
-    # one 4-byte gather per segment over ~10 lines (bricked copy; tools/sim_siddon_lines.py): 15 + 9 x 12 clk
-    "siddon_forward": {"unit": "texture_address", "wave_instr_per_64_units": 1, "clk_per_wave_instr": 90.0,
-                       "source": "profiles/r01_microbench_gather_lines.txt, tools/sim_siddon_lines.py"},
+    "trilinear_backward": [
+        # tools/microbench/lds_atomics.hip: a ds_add_u32 wavefront instruction costs >= 4.4 LDS clocks however few lanes are
+        # live; 8 per sample; 53.9 of 64 lanes live
+        ("lds_atomic_issue", 8 / (53.9 / 64), 4.4, CUS, "profiles/r02_microbench_lds_atomics.txt"),
+        ("valu_issue", 3.714e9 / (1.809e9 / 64), VALU_CLK, 4 * CUS, "profiles/r03_microbench_valu_issue.txt x SQ_INSTS_VALU"),
+    ],
+    "trilinear_forward+jac": [
+        # tools/microbench/gather.hip: a 64-lane gather costs ~15 clk per CU on one 128-B line and 10-14 more per further line;
+        # two 16-byte gathers per sample (y-pair copy), ~3 lines by that estimate (the L1 miss path behind it: DESIGN 4.4)
+        ("texture_address", 2, 36.0, CUS, "profiles/r01_microbench_gather_lines.txt"),
+        ("valu_issue", 3.279e9 / (1.809e9 / 64), VALU_CLK, 4 * CUS, "profiles/r03_microbench_valu_issue.txt x SQ_INSTS_VALU"),
+    ],
+    "trilinear_forward": [
+        ("texture_address", 2, 36.0, CUS, "profiles/r01_microbench_gather_lines.txt"),
+        ("valu_issue", 2.242e9 / (1.809e9 / 64), VALU_CLK, 4 * CUS, "profiles/r03_microbench_valu_issue.txt x SQ_INSTS_VALU"),
+    ],
+    "siddon_forward+jac": [
+        ("valu_issue", 6.3e9 / (5.576e9 / 64), VALU_CLK, 4 * CUS, "profiles/r03_microbench_valu_issue.txt x SQ_INSTS_VALU"),
+    ],
 }
 
 
 def binding_floor(tag, units, avg_ms):
-    b = BINDING.get(tag.split("[")[0].split("+")[0])
-    if not b or not units:
+    """The unit with the largest floor for one timed call, and every candidate's floor next to it."""
+    cands = BINDING.get(tag.split("[")[0]) or BINDING.get(tag.split("[")[0].split("+")[0])
+    if not cands or not units:
         return None
-    floor_ms = units / 64.0 * b["wave_instr_per_64_units"] * b["clk_per_wave_instr"] / CUS / (CLK_GHZ * 1e9) * 1e3
-    return {"unit": b["unit"], "floor_ms": floor_ms, "frac": floor_ms / avg_ms, "clk_per_wave_instr": b["clk_per_wave_instr"],
-            "source": b["source"]}
-
-
-# which profiled kernels make up each timed C-ABI call (one call may launch several kernels)
-TRAFFIC_KERNELS = {
-    "trilinear_forward": ["k_trilinear_fwd"],
-    "trilinear_backward": ["k_trilinear_splat_b16", "k_trilinear_gather_tab", "k_trilinear_gather_vol", "k_gather_prep", "k_gather_cull", "k_trilinear_bwd"],
-    "siddon_forward": ["k_siddon<"],
-    "siddon_backward": ["k_siddon_gather_vol", "k_gather_prep", "k_gather_cull", "k_siddon<"],
-    "backward_from_jac": ["k_backward_from_jac"],
-}
+    floors = {}
+    for unit, per64, clk, width, source in cands:
+        floors[unit] = {"floor_ms": units / 64.0 * per64 * clk / width / (CLK_GHZ * 1e9) * 1e3, "clk_per_wave_instr": clk, "source": source}
+    unit = max(floors, key=lambda u: floors[u]["floor_ms"])
+    return {"unit": unit, "floor_ms": floors[unit]["floor_ms"], "frac": floors[unit]["floor_ms"] / avg_ms,
+            "clk_per_wave_instr": floors[unit]["clk_per_wave_instr"], "source": floors[unit]["source"],
+            "floors_ms": {u: v["floor_ms"] for u, v in floors.items()}}
 
 
 def pmc_traffic(tag):

@@ -18,6 +18,12 @@ namespace {
 // so only the rounding of that one product differs from the unsplit walk.
 // (at most 5 wavefronts per SIMD: the walk is bound by the texture-address unit; 10.7 ms at C3 against 11.5 ms at
 //  the 8 its register count would allow and at 4)
+// XVR_SID_PIPE 1: the voxel of segment i is requested, then segment i - 1 -- whose load has had a whole step to arrive -- is
+// consumed (round 1).  0: every segment is consumed where it is loaded; the other wavefronts of the SIMD cover the latency
+// and the walk saves the hand-over of six values per step.  (tuning builds: -DXVR_SID_PIPE=...)
+#ifndef XVR_SID_PIPE
+#define XVR_SID_PIPE 1
+#endif
 template <int MODE, int MASK, bool GPOSE, bool GVOL, bool EXACT, int SPLIT = 0, bool BRICK = false>
 __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAX : WG) __attribute__((amdgpu_waves_per_eu(1, 5))) void k_siddon(RenderArgs A) {
     extern __shared__ float lds[];  // MASK: fwd -> channel accumulators, bwd -> upstream gradients; SPLIT: partial sums
@@ -82,8 +88,13 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAX : WG) __attribute__((amdgpu_
     const int vo0 = stp[0] > 0 ? 1 : 0, vo1 = stp[1] > 0 ? 1 : 0, vo2 = stp[2] > 0 ? 1 : 0;
 
     float acc = 0.f;                 // sum V * dalpha (C==1 fwd) / sum g V dalpha (bwd)
-    float As[3] = {0.f, 0.f, 0.f};   // sum dW (alpha-1)/d  per axis
-    float At[3] = {0.f, 0.f, 0.f};   // sum dW (-alpha)/d   per axis
+    // The jacobian: d out / d s_i = sum over the crossings of axis i of dW (alpha - 1) / d_i, d out / d t_i = sum dW (-alpha) / d_i
+    // (dW = the jump of the integrand at the crossing).  1 / d_i is the same for every crossing of an axis, so the walk sums
+    // U_i = sum dW alpha and M_i = sum dW per axis and scales once at the end (round 3: the walk is vector-issue bound, and this
+    // is 12 instructions per segment instead of 17).
+    float Uj[3] = {0.f, 0.f, 0.f}, Mj[3] = {0.f, 0.f, 0.f};
+    float As[3] = {0.f, 0.f, 0.f};   // (filled from U, M after the walk)
+    float At[3] = {0.f, 0.f, 0.f};
     float Wprev = 0.f;
     int ax_prev = (SPLIT && sl_w > 0) ? -1 : R.ax_in;  // axis of the crossing that opened the current segment (-1: none)
     float ac = alo;
@@ -125,9 +136,9 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAX : WG) __attribute__((amdgpu_
             const float dW = Wprev - W;  // d out / d alpha at the crossing that opened this segment
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const float m = (p_ax == i) ? dW * inv_d[i] : 0.f;
-                As[i] = fmaf(m, p_ac - 1.f, As[i]);
-                At[i] = fmaf(m, -p_ac, At[i]);
+                const float m = (p_ax == i) ? dW : 0.f;
+                Uj[i] = fmaf(m, p_ac, Uj[i]);
+                Mj[i] += m;
             }
             Wprev = W;
         }
@@ -156,10 +167,16 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAX : WG) __attribute__((amdgpu_
         const float lab_new = MASK == 2 ? (float)(__float_as_uint(v_new) & LABEL_MASK) : (MASK ? A.mask[off] : 0.f);
         if (inb && !first_of_slice && (!SPLIT || an > ac)) ++cnt;
         first_of_slice = false;
+#if XVR_SID_PIPE
         if (have) consume();
+#endif
         // (packed labels: the label bits are cleared from the value -- a voxel of density exactly 0 contributes exactly 0)
         p_v = inb ? (MASK == 2 ? __uint_as_float(__float_as_uint(v_new) & ~LABEL_MASK) : v_new) : 0.f; p_seg = an - ac; p_ac = ac; p_ax = ax_prev; p_off = off; p_inb = inb; p_lab = lab_new;
         have = true;
+#if !XVR_SID_PIPE
+        consume();   // (no software pipeline: see XVR_SID_PIPE)
+        have = false;
+#endif
         // advance every axis whose next plane has been reached (ties advance together), branch-free
         const bool c0 = an3[0] <= an, c1 = an3[1] <= an, c2 = an3[2] <= an;
         // A plane exactly AT a cut (routine: the cuts of opposite-face rays fall on the centre planes) is
@@ -181,9 +198,16 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAX : WG) __attribute__((amdgpu_
     if (DERIV && exited && (!SPLIT || sl_w == sl_n - 1)) {  // exit crossing: beyond it W = 0
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const float m = (R.ax_out == i) ? W * inv_d[i] : 0.f;
-            As[i] = fmaf(m, ahi - 1.f, As[i]);
-            At[i] = fmaf(m, -ahi, At[i]);
+            const float m = (R.ax_out == i) ? W : 0.f;
+            Uj[i] = fmaf(m, ahi, Uj[i]);
+            Mj[i] += m;
+        }
+    }
+    if (DERIV) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            As[i] = inv_d[i] * (Uj[i] - Mj[i]);
+            At[i] = -inv_d[i] * Uj[i];
         }
     }
 
