@@ -78,6 +78,16 @@ def binding_floor(tag, units, avg_ms):
             "floors_ms": {u: v["floor_ms"] for u, v in floors.items()}}
 
 
+# which profiled kernels make up each timed C-ABI call (one call may launch several kernels)
+TRAFFIC_KERNELS = {
+    "trilinear_forward": ["k_trilinear_fwd"],
+    "trilinear_backward": ["k_trilinear_splat_b16", "k_trilinear_gather_tab", "k_gather_prep", "k_gather_cull", "k_trilinear_bwd"],
+    "siddon_forward": ["k_siddon<"],
+    "siddon_backward": ["k_siddon_gather_vol", "k_gather_prep", "k_gather_cull", "k_siddon<"],
+    "backward_from_jac": ["k_backward_from_jac"],
+}
+
+
 def pmc_traffic(tag):
     """HBM-side bytes per launch of the kernels behind one timed call, from the committed rocprofv3 PMC
     passes (profiles/traffic.json, written by tools/summarize_profile.py: FETCH_SIZE + WRITE_SIZE, in

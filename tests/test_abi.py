@@ -131,3 +131,31 @@ def test_eight_ranks_importing_over_a_stale_library_build_it_once(tmp_path):
     with mp.get_context("spawn").Pool(8) as pool:
         libs = pool.map(_rank_builds, [(str(marker), str(log))] * 8)
     assert len(set(libs)) == 1 and log.read_text().count("build") == 1
+
+
+def _undefined_globals(path):
+    """Names a module's functions read as globals that the module never defines (a NameError waiting for the first call that
+    reaches the line -- bench.py's result assembly only runs on a GPU box)."""
+    import builtins
+    import symtable
+
+    src = Path(path).read_text()
+    top = symtable.symtable(src, str(path), "exec")
+    defined = {s.get_name() for s in top.get_symbols() if s.is_assigned() or s.is_imported() or s.is_namespace()}
+    defined |= set(dir(builtins)) | {"__file__", "__name__", "__doc__"}
+    missing = set()
+
+    def walk(table):
+        for s in table.get_symbols():
+            if table.get_type() != "module" and s.is_global() and s.is_referenced() and s.get_name() not in defined:
+                missing.add((table.get_name(), s.get_name()))
+        for child in table.get_children():
+            walk(child)
+
+    walk(top)
+    return missing
+
+
+def test_driver_facing_scripts_reference_no_undefined_globals():
+    for path in [ROOT / "bench.py", ROOT / "__graft_entry__.py", *sorted((ROOT / "xvr_amd").glob("*.py")), *sorted((ROOT / "tools").glob("*.py"))]:
+        assert not _undefined_globals(path), (path.name, _undefined_globals(path))
