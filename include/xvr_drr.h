@@ -86,7 +86,8 @@ const char* xvr_drr_last_error(void);
  *   "block_order"   -1 | 0-4   logical block -> (pose, tile) map; -1: by batch size                              [-1]
  *   "order_group"   0 | gx + 256 gy   tiles per group of the grouped block orders; 0: full-width strips          [0]
  *   "fwd_split"     0 | n | 100 + n   sample slices per ray of small forwards: measured table | 8x8 tiles x n | 16x16 tiles x n [0]
- *   "gather_splat"  1 | 0      trilinear voxel gradient: brick-local fixed-point splat | fp32 voxel-driven gathers [1]
+ *   "gather_splat"  1 | 0 | 2  trilinear voxel gradient: brick-local fixed-point splat | fp32 voxel-driven gathers | the ray-major
+ *                              splat (clip_to_volume = 1 and per-channel masks always use it) for every render (A/B) [1]
  *   "fwd_slabs"     0 | -1 | n  slab-major trilinear forward (one launch per slab of the volume, all poses; measured SLOWER,
  *                              DESIGN.md 4.4): never | by size | n slabs                                         [0]
  *   "fwd_slab_axis" 0-2        volume axis the slabs are cut along                                               [1]

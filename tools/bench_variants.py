@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--det", type=int, default=256)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--slow-steps", type=int, default=1, help="timed steps for variants slower than 100 ms")
+    ap.add_argument("--only", default="", help="run only the variants whose name contains this text")
     args = ap.parse_args()
     dev = torch.device("cuda")
     B, H = args.batch, args.det
@@ -48,6 +49,8 @@ def main():
     print(f"# fwd + bwd(pose + voxel) for every RenderSpec variant, {args.size}^3 -> {H}^2, batch {B} (tools/bench_variants.py)\n")
     print("| variant | ms / step | DRRs/s | kernels (HIP-event ms) |\n|---|---|---|---|")
     for name, renderer, ctor_kw, call_kw, masked in VARIANTS:
+        if args.only and args.only not in name:
+            continue
         ctor_kw = dict(ctor_kw)
         voxel_shift = ctor_kw.pop("voxel_shift", 0.5)
         sub = read(vol, lab if masked else None, orientation="AP")

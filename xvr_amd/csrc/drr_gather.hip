@@ -1094,8 +1094,9 @@ int xvr_detail::launch_gather(bool siddon, const float* source, const float* tar
     G.V = siddon ? 1 : 2;   // voxels per lane and axis
     // trilinear without clip / per-channel masks: the brick-local fixed-point splat on 16^3 bricks (k_trilinear_splat_b16)
     // unless the option "gather_splat" is 0 (A/B switch: the fp32 voxel-driven table gather)
-    const bool use_splat = xvr_detail::option(xvr_detail::OPT_GATHER_SPLAT) != 0;
-    const bool splat = !siddon && use_splat && sp->clip_to_volume != 1 && !mask;
+    const int splat_mode = xvr_detail::option(xvr_detail::OPT_GATHER_SPLAT);   // (2: the ray-major splat for every render, A/B)
+    const bool use_splat = splat_mode != 0;
+    const bool splat = !siddon && splat_mode == 1 && sp->clip_to_volume != 1 && !mask;
     if (siddon && (G.cells || G.mask)) { G.bd[0] = 4; G.bd[1] = 8; G.bd[2] = 8; }
     else if (siddon) { G.bd[0] = G.bd[1] = G.bd[2] = 8; }
     else {
@@ -1103,7 +1104,7 @@ int xvr_detail::launch_gather(bool siddon, const float* source, const float* tar
         G.bd[0] = G.bd[1] = G.bd[2] = 4 * G.V;
     }
     // clip_to_volume / per-channel mask: the ray-major splat unless XVR_DRR_GATHER_SPLAT=0 (A/B: the voxel-driven pixel-major gather)
-    const bool psplat = !siddon && use_splat && !splat;
+    const bool psplat = !siddon && use_splat && !splat && sp->n_points < 65536;   // (its list packs a step and a count into 16 bits each)
     if (splat || psplat) {   // the poses' maxima behind q's used part ([B][2 n] float4, H (W + 1) = n + H used): a line per pose if it fits
         G.cmax = reinterpret_cast<unsigned*>(G.q + (size_t)B * G.qn);
         const int room = 4 * (n - n / gw);
@@ -1137,7 +1138,7 @@ int xvr_detail::launch_gather(bool siddon, const float* source, const float* tar
     else if (siddon) hipLaunchKernelGGL(k_siddon_gather_vol2, dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
     else if (psplat) {
         const void* kern = G.clip ? (G.mask ? (const void*)k_trilinear_splat_px<true, true> : (const void*)k_trilinear_splat_px<true, false>)
-                                  : (const void*)k_trilinear_splat_px<false, true>;
+                                  : (G.mask ? (const void*)k_trilinear_splat_px<false, true> : (const void*)k_trilinear_splat_px<false, false>);
         int per_cu = 0, dev = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
@@ -1145,7 +1146,8 @@ int xvr_detail::launch_gather(bool siddon, const float* source, const float* tar
         const dim3 grid((unsigned)(bricks < resident ? bricks : resident));
         if (G.clip && G.mask) hipLaunchKernelGGL((k_trilinear_splat_px<true, true>), grid, dim3(256), 0, (hipStream_t)stream, G);
         else if (G.clip) hipLaunchKernelGGL((k_trilinear_splat_px<true, false>), grid, dim3(256), 0, (hipStream_t)stream, G);
-        else hipLaunchKernelGGL((k_trilinear_splat_px<false, true>), grid, dim3(256), 0, (hipStream_t)stream, G);
+        else if (G.mask) hipLaunchKernelGGL((k_trilinear_splat_px<false, true>), grid, dim3(256), 0, (hipStream_t)stream, G);
+        else hipLaunchKernelGGL((k_trilinear_splat_px<false, false>), grid, dim3(256), 0, (hipStream_t)stream, G);
     }
     else if (G.clip && G.mask) hipLaunchKernelGGL((k_trilinear_gather_px<true, true>), dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
     else if (G.clip) hipLaunchKernelGGL((k_trilinear_gather_px<true, false>), dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
