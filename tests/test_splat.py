@@ -187,3 +187,49 @@ def test_ray_major_splat_equals_the_voxel_driven_gather_and_the_scatter(kw, mask
     # (under clip the fixed-point bound is a count of rays x samples, 4-10 x looser than the lattice bound of the plain splat)
     _close(out[0], out[1], 4e-5 if kw.get("clip_to_volume") else 2e-5, "ray-major splat vs voxel-driven pixel-major gather")
     _close(out[0], out[2], 4e-5, "ray-major splat vs scatter")
+
+
+@pytest.mark.parametrize("what,shape,hw,kw,case_kw,batch", [
+    ("the default render through the ray-major kernel (option gather_splat = 2)", (40, 36, 44), (48, 40), dict(n_points=70), {}, 2),
+    ("a source inside the volume: a brick's footprint is the whole detector", (40, 36, 44), (24, 20), dict(n_points=60, clip_to_volume=True),
+     dict(sdd=120.0, xyz=((1.0, 12.0, -2.0), (-2.0, 8.0, 3.0))), 2),
+    ("fewer rays than a wavefront, one and two samples per ray", (20, 24, 28), (3, 5), dict(n_points=2, clip_to_volume=True), {}, 2),
+    ("one sample per ray", (20, 24, 28), (6, 5), dict(n_points=1, clip_to_volume=True), {}, 2),
+    ("more poses than one word of the cull mask", (24, 20, 28), (16, 12), dict(n_points=40, clip_to_volume=True), {}, 37),
+    ("more samples per ray than the list's 16-bit step field: the voxel-driven gather takes over", (12, 10, 14), (6, 4),
+     dict(n_points=70000, clip_to_volume=True), {}, 2),
+], ids=["default-render", "source-inside", "tiny-detector", "one-sample", "37-poses", "70000-samples"])
+def test_ray_major_splat_edge_cases(what, shape, hw, kw, case_kw, batch, monkeypatch):
+    """The balanced visit of k_trilinear_splat_px (wavefront-private run lists, sample-exact shares) at the corners of
+    its bookkeeping, against the atomic scatter and, where it is another kernel, the default splat."""
+    from xvr_amd import _lib, renderers
+    from xvr_amd.spec import RenderSpec
+
+    spec = RenderSpec(renderer="trilinear", **kw)
+    g = torch.Generator().manual_seed(5)
+    ckw = dict(seed=43, shape=shape, height=hw[0], width=hw[1], delx=0.9 * max(shape) / max(hw))
+    if batch > 2:   # poses around the default pair
+        rot = torch.tensor([170.0, 10.0, 5.0]) + 25.0 * (torch.rand(batch, 3, generator=g) - 0.5)
+        xyz = torch.tensor([2.0, 300.0, -1.0]) + torch.tensor([6.0, 80.0, 6.0]) * (torch.rand(batch, 3, generator=g) - 0.5)
+        ckw.update(rot=tuple(map(tuple, rot.tolist())), xyz=tuple(map(tuple, xyz.tolist())))
+    else:
+        ckw.update(xyz=((2.0, 300.0, -1.0), (-1.5, 200.0, 3.0)))
+    ckw.update(case_kw)
+    case = make_case(**ckw)
+    w = torch.randn(batch, 1, hw[0] * hw[1], generator=g)
+    mode = 2 if not kw.get("clip_to_volume") else 1
+    with _lib.option("gather_splat", mode):
+        ray_major = _hip_render(case, spec, grid_w=hw[1], grads=True, w=w)[1]
+    renderers.VOXEL_GATHER = False
+    try:
+        scatter = _hip_render(case, spec, grid_w=hw[1], grads=True, w=w)[1]
+    finally:
+        renderers.VOXEL_GATHER = True
+    assert ray_major.abs().max() > 0, what
+    # (70 000 samples per ray: both sides are fp32 sums of ~10^4 terms per voxel in different orders)
+    _close(ray_major, scatter, 4e-5 if kw["n_points"] < 10000 else 5e-4, f"ray-major splat vs scatter: {what}")
+    if mode == 2:
+        with _lib.option("gather_splat", 1):
+            _close(ray_major, _hip_render(case, spec, grid_w=hw[1], grads=True, w=w)[1], 2e-5, f"ray-major vs plane-major splat: {what}")
+    if hw[0] * hw[1] * kw["n_points"] * batch <= 4_000_000:
+        _close(ray_major, _oracle_render(case, spec, grads=True, w=w)[1], GRAD_TOL, f"ray-major splat vs oracle: {what}")
