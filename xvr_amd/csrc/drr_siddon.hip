@@ -21,6 +21,9 @@ namespace {
 // XVR_SID_PIPE 1: the voxel of segment i is requested, then segment i - 1 -- whose load has had a whole step to arrive -- is
 // consumed (round 1).  0: every segment is consumed where it is loaded; the other wavefronts of the SIMD cover the latency
 // and the walk saves the hand-over of six values per step.  (tuning builds: -DXVR_SID_PIPE=...)
+// (Round 3 also tried the trilinear forward's workgroup lockstep here -- a barrier every 1 / 4 / 16 segments for as many trips as
+// the tile's longest ray needs: 12.1 / 12.0 / 11.8 ms against 8.77.  The lanes of a Siddon wavefront are at different depths
+// after a few segments anyway, and the idle trips of the shorter rays cost more than the shared lines save.)
 #ifndef XVR_SID_PIPE
 #define XVR_SID_PIPE 1
 #endif

@@ -46,7 +46,7 @@ struct SlabRange {
 
 // WIN (clip_to_volume == 2, with the jacobian): also E1 = sum (alpha_k - A) (a d . grad V) -- d out / d (window width) needs it
 // directly; rebuilt from G and H it is a difference of two large sums and loses 2 % in float32
-template <bool JAC, int MASK, bool CLIP, bool YP = false, bool SLAB = false, bool WIN = false>
+template <bool JAC, int MASK, bool CLIP, bool YP = false, bool SLAB = false, bool WIN = false, int SYNC = 0>
 __device__ __forceinline__ void tri_march(const RenderArgs& A, const Ray& R, const KRange K, const int kbeg, const int kend,
                                           const float step, const SpecWin Wn, float* lds, const int tid, TriAcc& acc,
                                           const SlabRange slab = SlabRange{0, 0.f, 0.f}) {
@@ -62,6 +62,8 @@ __device__ __forceinline__ void tri_march(const RenderArgs& A, const Ray& R, con
     // Two steps per trip: the 8 independent 8-byte gathers of both samples are issued before either
     // is consumed (the march is latency-bound, not bandwidth-bound: L2 at ~20 %, HBM at ~25 %).
     for (int kk = kbeg; kk <= kend; kk += 2) {
+        // SYNC: the wavefronts of a workgroup march a common step range and meet every SYNC trips (XVR_FWD_SYNC below)
+        if (SYNC && (((kk - kbeg) >> 1) % SYNC) == 0) __builtin_amdgcn_s_barrier();
         bool act[2];
         float u[2], al[2], pxs[2], pys[2], pzs[2];
         Taps T[2];
@@ -201,6 +203,13 @@ __device__ __forceinline__ void tri_finish(const RenderArgs& A, const Ray& R, co
 // 8 wavefronts per SIMD and took 8.2 ms where the (heavier) jacobian variant at 6 took 7.0; capped, both take
 // ~7.0 ms (measured flat from 3 to 6, worse at 2 and at 8).
 constexpr double SLAB_TARGET_BYTES = 150e6, SLAB_MIN_VOLUME_BYTES = 192.0 * (1 << 20);   // (the Infinity Cache holds 256 MiB)
+// XVR_FWD_SYNC (round 3): the four wavefronts of a workgroup march a COMMON step range and meet at a barrier every SYNC trips
+// (a trip = two samples), so that the 8x8 patches of one 16x16 tile touch the cache lines they share while those are in the
+// L1.  C2, forward + jacobian: 6.04 ms without, 5.69 at 1, 5.69 at 4, 5.79 at 16 (profiles/r03_forward_sync.txt); two or four
+// tiles per workgroup of 512 / 1024 threads in lockstep: 5.83 / 7.90 (one workgroup per CU leaves nothing to overlap).
+#ifndef XVR_FWD_SYNC
+#define XVR_FWD_SYNC 1
+#endif
 #ifndef XVR_FWD_WAVES   // (overridable for tuning builds)
 #define XVR_FWD_WAVES 4
 #endif
@@ -216,13 +225,22 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, XVR_FWD_W
     const SpecWin Wn = spec_window(A.sp);
     const float step = N > 1 ? (Wn.far_ - Wn.near_) / (float)(N - 1) : 0.f;
     const KRange K = tri_krange(A, R, CLIP, step, Wn.near_);
-    const int kbeg = __builtin_amdgcn_readfirstlane(wave_min_i(K.lo));
-    const int kend = __builtin_amdgcn_readfirstlane(wave_max_i(K.hi));
+    int kbeg = __builtin_amdgcn_readfirstlane(wave_min_i(K.lo));
+    int kend = __builtin_amdgcn_readfirstlane(wave_max_i(K.hi));
+#if XVR_FWD_SYNC
+    __shared__ int s_k[2];
+    if (tid == 0) { s_k[0] = 0x7fffffff; s_k[1] = -0x7fffffff; }
+    __syncthreads();
+    if ((tid & 63) == 0) { atomicMin(&s_k[0], kbeg); atomicMax(&s_k[1], kend); }
+    __syncthreads();
+    kbeg = __builtin_amdgcn_readfirstlane(s_k[0]);
+    kend = __builtin_amdgcn_readfirstlane(s_k[1]);
+#endif
     if (MASK) {
         for (int c = 0; c < A.C; ++c) lds[c * WG + tid] = 0.f;
     }
     TriAcc acc;
-    tri_march<JAC, MASK, CLIP, YP, false, WIN>(A, R, K, kbeg, kend, step, Wn, lds, tid, acc);
+    tri_march<JAC, MASK, CLIP, YP, false, WIN, XVR_FWD_SYNC>(A, R, K, kbeg, kend, step, Wn, lds, tid, acc);
     if (valid) tri_finish<JAC, MASK, CLIP, WIN>(A, R, b, r, Wn, lds, tid, acc);
     if (A.work) {
         unsigned tot = wave_sum_u(acc.cnt);
