@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define XVR_DRR_ABI_VERSION 6   /* 6: xvr_drr_spec.alpha_window + xvr_drr_alpha_window (clip_to_volume = 2); 5: xvr_drr_set_option / xvr_drr_get_option (the A/B switches are no longer getenv calls per launch); 4: volume_layout 2 + xvr_drr_pack_bricks (siddon forward); 3: xvr_drr_spec.volume_layout + xvr_drr_pack_ypairs; 2: xvr_sim_spec grew, camera-driven forwards, packed labels, xvr_pose.h */
+#define XVR_DRR_ABI_VERSION 7   /* 7: xvr_drr_foreground; 6: xvr_drr_spec.alpha_window + xvr_drr_alpha_window (clip_to_volume = 2); 5: xvr_drr_set_option / xvr_drr_get_option (the A/B switches are no longer getenv calls per launch); 4: volume_layout 2 + xvr_drr_pack_bricks (siddon forward); 3: xvr_drr_spec.volume_layout + xvr_drr_pack_ypairs; 2: xvr_sim_spec grew, camera-driven forwards, packed labels, xvr_pose.h */
 
 #define XVR_DRR_OK 0
 #define XVR_DRR_E_ARG (-1)     /* bad argument (null pointer, non-positive size, unsupported combo) */
@@ -110,6 +110,16 @@ int xvr_drr_alpha_window(const float* source, const float* target, int B, int n,
 int xvr_drr_alpha_window_backward(const float* jac, const float* grad_out, const float* source, const float* target,
                                   const float* raylen, int B, int n, const xvr_drr_spec* spec, float* window,
                                   float* grad_source, float* grad_target, void* stream);
+
+/*
+ * The tail of xvr's render_samples, /root/reference/src/xvr/model/trainer.py:289-304, over a rendered batch img [B][C][n]:
+ *   mask [B][C][n] (bytes, 0 / 1) = img > 0;   sum [B][n] = sum over the channels;
+ *   keep [B] (bytes) = mean over the pixels of (C == 1 ? mask[0] : any(mask[1:])) > threshold
+ * (threshold = the trainer's img_threshold 0.10 for C == 1, mask_threshold 0.05 otherwise).  `count` = B ints of scratch
+ * (on return: the foreground pixels per pose).  One pass over the image instead of five torch launches.
+ */
+int xvr_drr_foreground(const float* img, int B, int C, int n, float threshold, float* sum, unsigned char* mask, int* count,
+                       unsigned char* keep, void* stream);
 
 /* Bytes of device scratch the backward entry points can use (see `workspace` below). */
 size_t xvr_drr_backward_workspace_bytes(int B, int n, int D0, int D1, int D2);

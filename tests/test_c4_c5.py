@@ -211,3 +211,32 @@ def test_c4_full_size_multistart_registration_pyramid_8_4_of_a_2048_xray():
     per_iter = [t for t in again[0]["times"][1:] if t > 0]
     steady = sorted(per_iter)[len(per_iter) // 2]
     assert steady / S < 0.5e-3, f"{1e3 * steady / S:.3f} ms per pose-iteration"
+
+
+@pytest.mark.parametrize("B,C,H,W", [(5, 1, 24, 20), (7, 4, 17, 33), (3, 8, 64, 64), (1, 2, 1, 3), (2, 11, 12, 10)])
+def test_fused_foreground_tail_equals_the_reference_formulation(B, C, H, W):
+    """xvr_drr_foreground (mask, channel sum and keep of render_samples in one pass) against the reference's torch lines
+    (trainer.py:289-304), values straddling the thresholds included; its backward is the expanded upstream gradient."""
+    from xvr_amd.training import _Foreground
+
+    g = torch.Generator().manual_seed(B * 100 + C)
+    img = torch.rand(B, C, H, W, generator=g)
+    img[torch.rand(B, C, H, W, generator=g) < 0.6] = 0.0            # air: exactly zero
+    img[torch.rand(B, C, H, W, generator=g) < 0.05] *= -1.0          # (never rendered, but `> 0` must treat it as background)
+    for b in range(B):                                               # poses far from / at / around the keep threshold
+        frac = [0.0, 0.04, 0.05, 0.06, 0.10, 0.11, 1.0][b % 7]
+        fg = torch.zeros(H * W)
+        fg[: int(round(frac * H * W))] = 1.0
+        ch = slice(1, None) if C > 1 else slice(0, 1)
+        img[b, ch] = img[b, ch].abs().clamp_min(0.1) * fg.view(1, H, W)
+    x = img.cuda().requires_grad_()
+    thr = 0.10 if C == 1 else 0.05
+    total, mask, keep = _Foreground.apply(x, thr)
+    r_total, r_mask, r_keep = _reference_keep(img.cuda())
+    assert mask.dtype == torch.bool and keep.dtype == torch.bool and total.shape == (B, 1, H, W)
+    assert torch.equal(mask, r_mask)
+    assert torch.equal(keep, r_keep)
+    assert torch.allclose(total, r_total, rtol=1e-6, atol=1e-7)
+    w = torch.randn(B, 1, H, W, generator=g).cuda()
+    (grad,) = torch.autograd.grad((total * w).sum(), x)
+    assert (C == 1 or grad.stride(1) == 0) and torch.equal(grad, w.expand(B, C, H, W))

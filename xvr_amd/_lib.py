@@ -11,7 +11,7 @@ import warnings
 
 from .build import LIB, HipccMissing, build_library, is_stale
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 JAC_STRIDE = 8
 ALPHA_WINDOW_FLOATS = 16   # XVR_DRR_ALPHA_WINDOW_FLOATS
 
@@ -112,6 +112,7 @@ EXPORTS = {
     "xvr_drr_hu_stats": ([_P, ctypes.c_longlong, _P, _P], ctypes.c_int),
     "xvr_drr_hu_to_density": ([_P, ctypes.c_longlong, _P, ctypes.c_float, _P, _P], ctypes.c_int),
     "xvr_drr_rays_forward": ([_P, _I, _I, _I, _P, _P, _P, _P], ctypes.c_int),
+    "xvr_drr_foreground": ([_P, _I, _I, _I, ctypes.c_float, _P, _P, _P, _P, _P], ctypes.c_int),
     "xvr_drr_rays_backward": ([_P, _I, _I, _I, _P, _P, _P, _P, _P], ctypes.c_int),
     "xvr_drr_trilinear_forward_camera": ([_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, ctypes.POINTER(CSpec), _P, _P, _P, _P], ctypes.c_int),
     "xvr_drr_siddon_forward_camera": ([_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, ctypes.POINTER(CSpec), _P, _P, _P, _P], ctypes.c_int),

@@ -347,6 +347,75 @@ __global__ void k_alpha_window_bwd_apply(const float* __restrict__ source, const
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The tail of xvr's render_samples (/root/reference/src/xvr/model/trainer.py:289-304) as one pass over the rendered channels:
+//   mask = img > 0;  img = img.sum(dim=1);  keep = mean over the pixels of (C == 1 ? mask : any(mask[1:])) > threshold
+// One thread per ray reads its C channel values once (coalesced per channel), writes the sum, the C mask bytes and adds its
+// foreground bit to the pose's count (wavefront ballot -> one atomic per wavefront); k_foreground_keep turns the counts into
+// `keep` with torch's arithmetic (the mean of 0 / 1 floats is the exact count over n, in float32).  Replaces five torch
+// launches that read the [B][C][n] image three times (0.9 ms per render at C2 with 8 channels).
+// ---------------------------------------------------------------------------------------------
+// V = rays per thread: 4 (float4 loads, one 4-byte store of mask bytes per channel; n % 4 == 0) or 1.  All channel loads of a
+// thread are issued before the first is used (channels in groups of 8): the pass is a stream, not a chain of dependent loads.
+template <int V>
+__global__ __launch_bounds__(WG) void k_foreground(const float* __restrict__ img, int C, int n, float* __restrict__ sum,
+                                                   unsigned char* __restrict__ mask, int* __restrict__ count) {
+    const int b = blockIdx.y, r = (blockIdx.x * WG + threadIdx.x) * V;
+    int fg = 0;
+    if (r < n) {
+        const float* p = img + (size_t)b * C * n + r;
+        unsigned char* m = mask + (size_t)b * C * n + r;
+        float s[V];
+        bool any[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) { s[i] = 0.f; any[i] = false; }
+        for (int c0 = 0; c0 < C; c0 += 8) {
+            float v[8][V];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int c = c0 + k < C ? c0 + k : C - 1;   // (clamped: always loadable)
+                if (V == 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(p + (size_t)c * n);
+                    v[k][0] = t.x; v[k][1 % V] = t.y; v[k][2 % V] = t.z; v[k][3 % V] = t.w;
+                } else {
+                    v[k][0] = p[(size_t)c * n];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int c = c0 + k;
+                if (c < C) {
+                    unsigned bits = 0;
+#pragma unroll
+                    for (int i = 0; i < V; ++i) {
+                        const bool on = v[k][i] > 0.f;
+                        s[i] += v[k][i];
+                        bits |= on ? (1u << (8 * i)) : 0u;
+                        any[i] = any[i] || (on && (c > 0 || C == 1));
+                    }
+                    if (V == 4) *reinterpret_cast<unsigned*>(m + (size_t)c * n) = bits;
+                    else m[(size_t)c * n] = (unsigned char)bits;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < V; ++i) fg += any[i] ? 1 : 0;
+        if (V == 4) *reinterpret_cast<float4*>(sum + (size_t)b * n + r) = make_float4(s[0], s[1 % V], s[2 % V], s[3 % V]);
+        else sum[(size_t)b * n + r] = s[0];
+    }
+    const int tot = (int)wave_sum_u((unsigned)fg);
+    if ((threadIdx.x & 63) == 0 && tot) atomicAdd(count + b, tot);
+}
+
+// (torch's mean on the device is sum * factor with factor = float(outputs) / elements, ATen ReduceMomentKernel: the same
+// float here, so that a pose exactly at the threshold falls on the same side)
+__global__ void k_foreground_keep(const int* __restrict__ count, int B, int n, float threshold, unsigned char* __restrict__ keep) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    const float factor = (float)B / (float)((long long)B * n);
+    if (b < B) keep[b] = ((float)count[b] * factor > threshold) ? 1 : 0;
+}
+
 }  // namespace
 
 
@@ -441,6 +510,22 @@ int xvr_drr_alpha_window_backward(const float* jac, const float* grad_out, const
                        jac, grad_out, source, target, raylen, n, sp->eps, window);
     hipLaunchKernelGGL(k_alpha_window_bwd_apply, dim3(1), dim3(1), 0, (hipStream_t)stream, source, target, B, n, *sp, window,
                        grad_source, grad_target);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
+    return XVR_DRR_OK;
+}
+
+int xvr_drr_foreground(const float* img, int B, int C, int n, float threshold, float* sum, unsigned char* mask, int* count,
+                       unsigned char* keep, void* stream) {
+    if (!img || !sum || !mask || !count || !keep) return fail(XVR_DRR_E_ARG, "null pointer argument");
+    if (B <= 0 || n <= 0 || C < 1) return fail(XVR_DRR_E_ARG, "B, C and n must be positive");
+    if (B > 65535) return fail(XVR_DRR_E_UNSUPPORTED, "more than 65535 poses");
+    hipError_t e = hipMemsetAsync(count, 0, (size_t)B * sizeof(int), (hipStream_t)stream);
+    if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
+    const bool vec = n % 4 == 0 && (reinterpret_cast<uintptr_t>(img) | reinterpret_cast<uintptr_t>(sum)) % 16 == 0 && reinterpret_cast<uintptr_t>(mask) % 4 == 0;
+    if (vec) hipLaunchKernelGGL(k_foreground<4>, dim3((unsigned)((n / 4 + WG - 1) / WG), (unsigned)B), dim3(WG), 0, (hipStream_t)stream, img, C, n, sum, mask, count);
+    else hipLaunchKernelGGL(k_foreground<1>, dim3((unsigned)((n + WG - 1) / WG), (unsigned)B), dim3(WG), 0, (hipStream_t)stream, img, C, n, sum, mask, count);
+    hipLaunchKernelGGL(k_foreground_keep, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, (hipStream_t)stream, count, B, n, threshold, keep);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
     return XVR_DRR_OK;

@@ -32,6 +32,37 @@ def get_random_pose(alphamin, alphamax, betamin, betamax, gammamin, gammamax, tx
     return convert(rot, xyz, parameterization="euler_angles", convention="ZXY", degrees=True)
 
 
+FUSED_FOREGROUND = True   # A/B switch (tools/bench_training_step.py): False = the reference's torch lines
+
+
+class _Foreground(torch.autograd.Function):
+    """mask = img > 0, img.sum(dim=1), keep -- the tail of render_samples -- as one HIP pass (xvr_drr_foreground,
+    include/xvr_drr.h).  The gradient of the channel sum is the upstream gradient EXPANDED over the channels (stride 0): the
+    renderer's backward recognises it and takes the unmasked voxel / pose gradient paths."""
+
+    @staticmethod
+    def forward(ctx, img, threshold):
+        from . import _lib
+        from .renderers import _ptr, _stream, _timed
+
+        B, C, H, W = img.shape
+        x = img.contiguous()
+        total = torch.empty(B, 1, H, W, dtype=img.dtype, device=img.device)
+        mask = torch.empty(B, C, H, W, dtype=torch.bool, device=img.device)
+        keep = torch.empty(B, dtype=torch.bool, device=img.device)
+        count = torch.empty(B, dtype=torch.int32, device=img.device)
+        lib = _lib.load()
+        _lib.check(_timed("foreground", lib.xvr_drr_foreground, _ptr(x), B, C, H * W, float(threshold), _ptr(total), _ptr(mask),
+                          _ptr(count), _ptr(keep), _stream()), "xvr_drr_foreground")
+        ctx.shape = img.shape
+        ctx.mark_non_differentiable(mask, keep)
+        return total, mask, keep
+
+    @staticmethod
+    def backward(ctx, g_total, _g_mask, _g_keep):
+        return g_total.expand(ctx.shape), None
+
+
 def render_samples(drr, volume, seg, affinv, pose, img_threshold=0.10, mask_threshold=0.05):
     """-> (img [B,1,H,W], mask [B,C,H,W] bool, keep [B] bool)."""
     if (volume.is_cuda and getattr(drr, "fused_rays", False)
@@ -49,6 +80,8 @@ def render_samples(drr, volume, seg, affinv, pose, img_threshold=0.10, mask_thre
         source, target = affinv(source), affinv(target)
     img = drr.renderer(volume, source, target, img, mask=seg)
     img = drr.reshape_transform(img, batch_size=len(pose))
+    if FUSED_FOREGROUND and img.is_cuda and img.dtype == torch.float32:
+        return _Foreground.apply(img, img_threshold if img.shape[1] == 1 else mask_threshold)
     mask = img > 0
     img = img.sum(dim=1, keepdim=True)
     if mask.shape[1] == 1:
