@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define XVR_DRR_ABI_VERSION 7   /* 7: xvr_drr_foreground; 6: xvr_drr_spec.alpha_window + xvr_drr_alpha_window (clip_to_volume = 2); 5: xvr_drr_set_option / xvr_drr_get_option (the A/B switches are no longer getenv calls per launch); 4: volume_layout 2 + xvr_drr_pack_bricks (siddon forward); 3: xvr_drr_spec.volume_layout + xvr_drr_pack_ypairs; 2: xvr_sim_spec grew, camera-driven forwards, packed labels, xvr_pose.h */
+#define XVR_DRR_ABI_VERSION 7   /* 7: xvr_drr_foreground, xvr_drr_pack_labels_ypairs, xvr_sim_dice_bool (xvr_sim.h); 6: xvr_drr_spec.alpha_window + xvr_drr_alpha_window (clip_to_volume = 2); 5: xvr_drr_set_option / xvr_drr_get_option (the A/B switches are no longer getenv calls per launch); 4: volume_layout 2 + xvr_drr_pack_bricks (siddon forward); 3: xvr_drr_spec.volume_layout + xvr_drr_pack_ypairs; 2: xvr_sim_spec grew, camera-driven forwards, packed labels, xvr_pose.h */
 
 #define XVR_DRR_OK 0
 #define XVR_DRR_E_ARG (-1)     /* bad argument (null pointer, non-positive size, unsupported combo) */
@@ -258,6 +258,9 @@ int xvr_drr_pack_labels(const float* volume, const float* mask, long long n, flo
  */
 size_t xvr_drr_ypairs_bytes(int D0, int D1, int D2);
 int xvr_drr_pack_ypairs(const float* volume, int D0, int D1, int D2, float* pairs, void* stream);
+/* The y-pair copy of the LABEL-CARRYING volume (xvr_drr_pack_labels then xvr_drr_pack_ypairs) in one pass over volume and mask:
+ * for masked renders of large launches whose volume is new every call (xvr's training step, trainer.py:185-230). */
+int xvr_drr_pack_labels_ypairs(const float* volume, const float* mask, int D0, int D1, int D2, float* pairs, void* stream);
 
 /*
  * Bricked copy of a volume for the Siddon forward (spec.volume_layout = 2):

@@ -82,6 +82,14 @@ int xvr_sim_equalize_forward(const float* x, int B, int n, int n_bins, float tau
 int xvr_sim_equalize_backward(const float* x, const float* y, const float* S, const float* grad_y, int B, int n, int n_bins,
                               float tau, float eps, float* grad_x, void* workspace, size_t workspace_bytes, void* stream);
 
+/*
+ * The in-tree DiceMetric of /root/reference/src/xvr/model/loss.py:5-40 on two BOOLEAN label maps [B][C][n] (one byte per
+ * pixel, as torch.bool; the masks Trainer.render_samples returns): dice[b][c] = 2 |pred & truth| / (|pred| + |truth|) from
+ * integer counts -- bit-identical to the reference's float sums of 0 / 1 (n <= 2^24), NaN for 0 / 0 as there.  The caller
+ * drops channel 0 (background) and takes 1 - nanmean as DiceLoss does.
+ */
+int xvr_sim_dice_bool(const unsigned char* pred, const unsigned char* truth, int B, int C, int n, float* dice, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

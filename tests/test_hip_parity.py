@@ -164,18 +164,23 @@ def test_ypair_volume_layout_is_bit_identical(kw, shape, monkeypatch):
             assert torch.equal(a, b), name
     _close(res[0][0], _oracle_render(case, spec), FWD_TOL, "forward vs oracle")
     if not kw.get("clip_to_volume"):
-        # mask -> channels with the labels packed into the taps: the y-pair copy is then made of the label-carrying volume
+        # mask -> channels with the labels packed into the taps: labels AND the y-pair layout are written in one pass
+        # (xvr_drr_pack_labels_ypairs) the FIRST time a large launch sees the (volume, mask) pair -- a training step's density is
+        # new every step and rendered exactly twice -- and reused from then on
         masked = []
         for flag in (True, False):
             monkeypatch.setattr(renderers, "YPAIR_LAYOUT", flag)
             vol, src, tgt, img, msk = (case[k].cuda() for k in ("volume", "source", "target", "img", "mask"))
             with torch.no_grad():
-                render(vol, src, tgt, img, spec, msk, ray_grid_w=128)
-                render(vol, src, tgt, img, spec, msk, ray_grid_w=128)
+                renderers.PROFILER = []
+                first = render(vol, src, tgt, img, spec, msk, ray_grid_w=128)
+                names = [e[0] for e in renderers.PROFILER]
+                assert ("pack_labels_ypairs" in names) == flag and ("pack_labels" in names) == (not flag)
                 renderers.PROFILER = []
                 masked.append(render(vol, src, tgt, img, spec, msk, ray_grid_w=128))
-                assert ("pack_ypairs" in [e[0] for e in renderers.PROFILER]) == flag
+                assert not [e[0] for e in renderers.PROFILER if e[0].startswith("pack")]      # the copy is reused
                 renderers.PROFILER = None
+                assert torch.equal(first, masked[-1])
         assert masked[0].shape[1] == 3 and torch.equal(masked[0], masked[1])
 
 

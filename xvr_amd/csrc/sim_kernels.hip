@@ -614,6 +614,55 @@ __global__ __launch_bounds__(TB) void k_eq_pixels(const float* __restrict__ x, i
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Dice of two BOOLEAN label maps (the in-tree DiceMetric of /root/reference/src/xvr/model/loss.py:5-40 on the masks
+// render_samples returns): per (pose, channel) the counts |a & b|, |a|, |b| in integers, dice = 2 |a & b| / (|a| + |b|) in
+// float32 -- the reference's float sums of 0 / 1 are exact, so the value is bit-identical; 0 / 0 = NaN as there.  One block per
+// (channel, pose), 16 mask bytes per load.  Replaces two bool -> float casts, a product and three reductions over
+// [B][C][n] floats (0.6 ms per training step at C5's size).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TB) void k_dice_bool(const unsigned char* __restrict__ a, const unsigned char* __restrict__ b, int n,
+                                                  float* __restrict__ dice) {
+    const size_t base = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)n;
+    const unsigned char* pa = a + base;
+    const unsigned char* pb = b + base;
+    int ci = 0, ca = 0, cb = 0;
+    const bool vec = ((reinterpret_cast<uintptr_t>(pa) | reinterpret_cast<uintptr_t>(pb)) & 15u) == 0;
+    const int n16 = vec ? n >> 4 : 0;
+    for (int i = threadIdx.x; i < n16; i += TB) {
+        const uint4 x = reinterpret_cast<const uint4*>(pa)[i], y = reinterpret_cast<const uint4*>(pb)[i];
+        const unsigned xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {   // (bytes are 0 / 1; any other non-zero byte counts as 1)
+            const unsigned u = xs[k] | (xs[k] >> 1), v = ys[k] | (ys[k] >> 1);
+            const unsigned u2 = u | (u >> 2), v2 = v | (v >> 2);
+            const unsigned ub = (u2 | (u2 >> 4)) & 0x01010101u, vb = (v2 | (v2 >> 4)) & 0x01010101u;
+            ci += __popc(ub & vb); ca += __popc(ub); cb += __popc(vb);
+        }
+    }
+    for (int i = (n16 << 4) + threadIdx.x; i < n; i += TB) {
+        const int u = pa[i] != 0, v = pb[i] != 0;
+        ci += u & v; ca += u; cb += v;
+    }
+    __shared__ int red[3][TB / 64];
+    int vals[3] = {ci, ca, cb};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int v = vals[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t[3] = {0, 0, 0};
+        for (int k = 0; k < 3; ++k)
+            for (int w = 0; w < TB / 64; ++w) t[k] += red[k][w];
+        dice[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = (2.0f * (float)t[0]) / ((float)t[1] + (float)t[2]);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -758,6 +807,15 @@ int xvr_sim_ncc_forward_backward(const float* fixed, const float* fixed_sobel, c
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return sim_fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
     return XVR_DRR_OK;
+}
+
+int xvr_sim_dice_bool(const unsigned char* pred, const unsigned char* truth, int B, int C, int n, float* dice, void* stream_) {
+    if (!pred || !truth || !dice) return sim_fail(XVR_DRR_E_ARG, "null pointer argument");
+    if (B <= 0 || C <= 0 || n <= 0 || B > 65535) return sim_fail(XVR_DRR_E_ARG, "bad size");
+    if (n > (1 << 24)) return sim_fail(XVR_DRR_E_UNSUPPORTED, "more than 2^24 pixels: the reference's float counts stop being exact");
+    hipLaunchKernelGGL(k_dice_bool, dim3((unsigned)C, (unsigned)B), dim3(TB), 0, (hipStream_t)stream_, pred, truth, n, dice);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? XVR_DRR_OK : sim_fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
 }
 
 }  // extern "C"

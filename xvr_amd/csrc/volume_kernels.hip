@@ -140,8 +140,12 @@ __global__ __launch_bounds__(TB) void k_pack_labels(const float* __restrict__ vo
     }
 }
 
-// pairs[x][yp][z] = (V[x][yp - 1][z], V[x][yp][z]), yp = 0 .. D1, zeros outside: one thread per two z (a float4 store)
-__global__ __launch_bounds__(TB) void k_pack_ypairs(const float* __restrict__ vol, int D0, int D1, int D2, float* __restrict__ pairs) {
+// pairs[x][yp][z] = (V[x][yp - 1][z], V[x][yp][z]), yp = 0 .. D1, zeros outside: one thread per two z (a float4 store).
+// LABELS: V = the label-carrying voxel of k_pack_labels (mantissa bits 0..3 := the label) -- both copies in one pass over the
+// volume, for the masked renders of a training step, whose density is new every step and rendered twice.
+template <bool LABELS>
+__global__ __launch_bounds__(TB) void k_pack_ypairs(const float* __restrict__ vol, const float* __restrict__ mask, int D0, int D1, int D2,
+                                                    float* __restrict__ pairs) {
     const long long rows = (long long)D0 * (D1 + 1);
     const int zh = (D2 + 1) / 2;
     const long long total = rows * zh;
@@ -149,14 +153,20 @@ __global__ __launch_bounds__(TB) void k_pack_ypairs(const float* __restrict__ vo
         const long long row = t / zh;
         const int z = (int)(t - row * zh) * 2;
         const int x = (int)(row / (D1 + 1)), yp = (int)(row - (long long)x * (D1 + 1));
-        const float* lo = vol + ((long long)x * D1 + (yp - 1)) * D2, * hi = vol + ((long long)x * D1 + yp) * D2;
+        const long long olo = ((long long)x * D1 + (yp - 1)) * D2, ohi = ((long long)x * D1 + yp) * D2;
         const bool has_lo = yp >= 1, has_hi = yp <= D1 - 1, two = z + 1 < D2;
+        auto at = [&](const long long o) {
+            const float d = vol[o];
+            if (!LABELS) return d;
+            const unsigned lab = (unsigned)min(max((int)mask[o], 0), 15);
+            return __uint_as_float((__float_as_uint(d) & ~15u) | lab);
+        };
         float* dst = pairs + (row * D2 + z) * 2;
-        dst[0] = has_lo ? lo[z] : 0.f;
-        dst[1] = has_hi ? hi[z] : 0.f;
+        dst[0] = has_lo ? at(olo + z) : 0.f;
+        dst[1] = has_hi ? at(ohi + z) : 0.f;
         if (two) {
-            dst[2] = has_lo ? lo[z + 1] : 0.f;
-            dst[3] = has_hi ? hi[z + 1] : 0.f;
+            dst[2] = has_lo ? at(olo + z + 1) : 0.f;
+            dst[3] = has_hi ? at(ohi + z + 1) : 0.f;
         }
     }
 }
@@ -214,8 +224,19 @@ int xvr_drr_pack_ypairs(const float* volume, int D0, int D1, int D2, float* pair
     if ((long long)D0 * (D1 + 1) * D2 * 2 >= (1LL << 31)) return vfail(XVR_DRR_E_UNSUPPORTED, "y-pair copy has >= 2^31 elements");
     const long long total = (long long)D0 * (D1 + 1) * ((D2 + 1) / 2);
     const long long blocks = (total + TB - 1) / TB;
-    hipLaunchKernelGGL(k_pack_ypairs, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(TB), 0, (hipStream_t)stream_, volume, D0, D1,
-                       D2, pairs);
+    hipLaunchKernelGGL(k_pack_ypairs<false>, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(TB), 0, (hipStream_t)stream_, volume,
+                       nullptr, D0, D1, D2, pairs);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? XVR_DRR_OK : vfail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
+}
+
+int xvr_drr_pack_labels_ypairs(const float* volume, const float* mask, int D0, int D1, int D2, float* pairs, void* stream_) {
+    if (!volume || !mask || !pairs || D0 < 2 || D1 < 2 || D2 < 2) return vfail(XVR_DRR_E_ARG, "bad argument");
+    if ((long long)D0 * (D1 + 1) * D2 * 2 >= (1LL << 31)) return vfail(XVR_DRR_E_UNSUPPORTED, "y-pair copy has >= 2^31 elements");
+    const long long total = (long long)D0 * (D1 + 1) * ((D2 + 1) / 2);
+    const long long blocks = (total + TB - 1) / TB;
+    hipLaunchKernelGGL(k_pack_ypairs<true>, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(TB), 0, (hipStream_t)stream_, volume,
+                       mask, D0, D1, D2, pairs);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? XVR_DRR_OK : vfail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
 }

@@ -88,7 +88,19 @@ class _Multiview(torch.autograd.Function):
 class DiceMetric(torch.nn.Module):
     """2D Dice between two multi-channel label maps, background (channel 0) excluded; reduction none."""
 
+    FUSED = True   # two boolean CUDA maps: integer counts in one HIP launch (xvr_sim_dice_bool), the same float32 values
+
     def forward(self, y_pred, y_true):
+        if (self.FUSED and y_pred.is_cuda and y_pred.dtype == torch.bool and y_true.dtype == torch.bool and y_pred.shape == y_true.shape
+                and y_pred.dim() >= 3 and y_pred[0, 0].numel() <= 2 ** 24):
+            from . import _lib
+            from .renderers import _ptr, _stream
+
+            B, C = y_pred.shape[:2]
+            a, b = y_pred.contiguous(), y_true.contiguous()
+            dice = torch.empty(B, C, device=a.device, dtype=torch.float32)
+            _lib.check(_lib.load().xvr_sim_dice_bool(_ptr(a), _ptr(b), B, C, a[0, 0].numel(), _ptr(dice), _stream()), "xvr_sim_dice_bool")
+            return dice[:, 1:]
         y_pred = y_pred.reshape(y_pred.shape[0], y_pred.shape[1], -1).to(torch.float32)
         y_true = y_true.reshape(y_true.shape[0], y_true.shape[1], -1).to(torch.float32)
         intersection = (y_pred * y_true).sum(dim=2)
