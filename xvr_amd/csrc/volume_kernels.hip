@@ -143,30 +143,48 @@ __global__ __launch_bounds__(TB) void k_pack_labels(const float* __restrict__ vo
 // pairs[x][yp][z] = (V[x][yp - 1][z], V[x][yp][z]), yp = 0 .. D1, zeros outside: one thread per two z (a float4 store).
 // LABELS: V = the label-carrying voxel of k_pack_labels (mantissa bits 0..3 := the label) -- both copies in one pass over the
 // volume, for the masked renders of a training step, whose density is new every step and rendered twice.
-template <bool LABELS>
+template <bool LABELS, int ZV>   // ZV = z per thread: 2, or 4 where D2 % 4 == 0 and the buffers are 16-byte aligned
 __global__ __launch_bounds__(TB) void k_pack_ypairs(const float* __restrict__ vol, const float* __restrict__ mask, int D0, int D1, int D2,
                                                     float* __restrict__ pairs) {
     const long long rows = (long long)D0 * (D1 + 1);
-    const int zh = (D2 + 1) / 2;
+    const int zh = (D2 + ZV - 1) / ZV;
     const long long total = rows * zh;
+    auto pk = [](const float d, const float l) {
+        const unsigned lab = (unsigned)min(max((int)l, 0), 15);
+        return __uint_as_float((__float_as_uint(d) & ~15u) | lab);
+    };
     for (long long t = (long long)blockIdx.x * TB + threadIdx.x; t < total; t += (long long)gridDim.x * TB) {
         const long long row = t / zh;
-        const int z = (int)(t - row * zh) * 2;
+        const int z = (int)(t - row * zh) * ZV;
         const int x = (int)(row / (D1 + 1)), yp = (int)(row - (long long)x * (D1 + 1));
         const long long olo = ((long long)x * D1 + (yp - 1)) * D2, ohi = ((long long)x * D1 + yp) * D2;
-        const bool has_lo = yp >= 1, has_hi = yp <= D1 - 1, two = z + 1 < D2;
-        auto at = [&](const long long o) {
-            const float d = vol[o];
-            if (!LABELS) return d;
-            const unsigned lab = (unsigned)min(max((int)mask[o], 0), 15);
-            return __uint_as_float((__float_as_uint(d) & ~15u) | lab);
-        };
+        const bool has_lo = yp >= 1, has_hi = yp <= D1 - 1;
         float* dst = pairs + (row * D2 + z) * 2;
-        dst[0] = has_lo ? at(olo + z) : 0.f;
-        dst[1] = has_hi ? at(ohi + z) : 0.f;
-        if (two) {
-            dst[2] = has_lo ? at(olo + z + 1) : 0.f;
-            dst[3] = has_hi ? at(ohi + z + 1) : 0.f;
+        if (ZV == 4) {
+            const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 lo = has_lo ? *reinterpret_cast<const float4*>(vol + olo + z) : zero;
+            float4 hi = has_hi ? *reinterpret_cast<const float4*>(vol + ohi + z) : zero;
+            if (LABELS) {
+                if (has_lo) {
+                    const float4 m = *reinterpret_cast<const float4*>(mask + olo + z);
+                    lo = make_float4(pk(lo.x, m.x), pk(lo.y, m.y), pk(lo.z, m.z), pk(lo.w, m.w));
+                }
+                if (has_hi) {
+                    const float4 m = *reinterpret_cast<const float4*>(mask + ohi + z);
+                    hi = make_float4(pk(hi.x, m.x), pk(hi.y, m.y), pk(hi.z, m.z), pk(hi.w, m.w));
+                }
+            }
+            reinterpret_cast<float4*>(dst)[0] = make_float4(lo.x, hi.x, lo.y, hi.y);
+            reinterpret_cast<float4*>(dst)[1] = make_float4(lo.z, hi.z, lo.w, hi.w);
+        } else {
+            const bool two = z + 1 < D2;
+            auto at = [&](const long long o) { return LABELS ? pk(vol[o], mask[o]) : vol[o]; };
+            dst[0] = has_lo ? at(olo + z) : 0.f;
+            dst[1] = has_hi ? at(ohi + z) : 0.f;
+            if (two) {
+                dst[2] = has_lo ? at(olo + z + 1) : 0.f;
+                dst[3] = has_hi ? at(ohi + z + 1) : 0.f;
+            }
         }
     }
 }
@@ -219,26 +237,29 @@ size_t xvr_drr_ypairs_bytes(int D0, int D1, int D2) {
     return (size_t)D0 * (size_t)(D1 + 1) * (size_t)D2 * 2 * sizeof(float);
 }
 
-int xvr_drr_pack_ypairs(const float* volume, int D0, int D1, int D2, float* pairs, void* stream_) {
+static int pack_ypairs_impl(const float* volume, const float* mask, int D0, int D1, int D2, float* pairs, void* stream_) {
     if (!volume || !pairs || D0 < 2 || D1 < 2 || D2 < 2) return vfail(XVR_DRR_E_ARG, "bad argument");
     if ((long long)D0 * (D1 + 1) * D2 * 2 >= (1LL << 31)) return vfail(XVR_DRR_E_UNSUPPORTED, "y-pair copy has >= 2^31 elements");
-    const long long total = (long long)D0 * (D1 + 1) * ((D2 + 1) / 2);
+    const bool wide = D2 % 4 == 0 && ((reinterpret_cast<uintptr_t>(volume) | reinterpret_cast<uintptr_t>(pairs) | reinterpret_cast<uintptr_t>(mask)) & 15u) == 0;
+    const long long total = (long long)D0 * (D1 + 1) * (wide ? D2 / 4 : (D2 + 1) / 2);
     const long long blocks = (total + TB - 1) / TB;
-    hipLaunchKernelGGL(k_pack_ypairs<false>, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(TB), 0, (hipStream_t)stream_, volume,
-                       nullptr, D0, D1, D2, pairs);
+    const dim3 grid((unsigned)(blocks < 16384 ? blocks : 16384));
+    hipStream_t stream = (hipStream_t)stream_;
+    if (mask && wide) hipLaunchKernelGGL((k_pack_ypairs<true, 4>), grid, dim3(TB), 0, stream, volume, mask, D0, D1, D2, pairs);
+    else if (mask) hipLaunchKernelGGL((k_pack_ypairs<true, 2>), grid, dim3(TB), 0, stream, volume, mask, D0, D1, D2, pairs);
+    else if (wide) hipLaunchKernelGGL((k_pack_ypairs<false, 4>), grid, dim3(TB), 0, stream, volume, mask, D0, D1, D2, pairs);
+    else hipLaunchKernelGGL((k_pack_ypairs<false, 2>), grid, dim3(TB), 0, stream, volume, mask, D0, D1, D2, pairs);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? XVR_DRR_OK : vfail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
 }
 
+int xvr_drr_pack_ypairs(const float* volume, int D0, int D1, int D2, float* pairs, void* stream_) {
+    return pack_ypairs_impl(volume, nullptr, D0, D1, D2, pairs, stream_);
+}
+
 int xvr_drr_pack_labels_ypairs(const float* volume, const float* mask, int D0, int D1, int D2, float* pairs, void* stream_) {
-    if (!volume || !mask || !pairs || D0 < 2 || D1 < 2 || D2 < 2) return vfail(XVR_DRR_E_ARG, "bad argument");
-    if ((long long)D0 * (D1 + 1) * D2 * 2 >= (1LL << 31)) return vfail(XVR_DRR_E_UNSUPPORTED, "y-pair copy has >= 2^31 elements");
-    const long long total = (long long)D0 * (D1 + 1) * ((D2 + 1) / 2);
-    const long long blocks = (total + TB - 1) / TB;
-    hipLaunchKernelGGL(k_pack_ypairs<true>, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(TB), 0, (hipStream_t)stream_, volume,
-                       mask, D0, D1, D2, pairs);
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? XVR_DRR_OK : vfail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
+    if (!mask) return vfail(XVR_DRR_E_ARG, "bad argument");
+    return pack_ypairs_impl(volume, mask, D0, D1, D2, pairs, stream_);
 }
 
 int xvr_drr_pack_labels(const float* volume, const float* mask, long long n, float* packed, void* stream_) {
