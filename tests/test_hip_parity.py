@@ -1636,6 +1636,8 @@ def test_bricked_volume_layout_is_bit_identical_for_siddon(kw, shape, monkeypatc
                      xyz=((5.0, 300.0, -4.0), (-3.0, 200.0, 6.0), (0.0, 30.0, 0.0), (40.0, 250.0, 10.0)) * 3)
     w = torch.rand(12, 1, 128 * 128, generator=torch.Generator().manual_seed(3)).cuda()
     res = []
+    assert renderers.LAYOUT_COPY_AFTER["bricks"] == 0       # the product builds the bricked copy at first sight (it pays at once);
+    monkeypatch.setitem(renderers.LAYOUT_COPY_AFTER, "bricks", 2)   # here: two natural-layout renders first, to compare bits with
     for flag in (True, False):
         monkeypatch.setattr(renderers, "BRICK_LAYOUT", flag)
         vol, src, tgt, img = (case[k].cuda() for k in ("volume", "source", "target", "img"))

@@ -198,14 +198,19 @@ YPAIR_LAYOUT = _os.environ.get("XVR_DRR_YPAIRS", "1") != "0"
 YPAIR_MIN_WAVEFRONTS = 2048     # smaller launches take the sample-split kernels on the natural layout
 # Siddon's counterpart: 4 x 2 x 4-voxel bricks, one per cache line (xvr_drr_pack_bricks); same caching rule.  XVR_DRR_BRICKS=0: off.
 BRICK_LAYOUT = _os.environ.get("XVR_DRR_BRICKS", "1") != "0"
+# renders of a volume version BEFORE its copy is built (measured with the volume changing every step, bench.py --update-volume:
+# the y-pair copy costs 0.54 ms and saves 0.70 of the forward -- 14.75 -> 14.96 ms per step with the splat behind it, no gain --;
+# the bricked copy saves 1.3 ms of the Siddon walk: 21.46 -> 20.51 ms per step when built at first sight)
+LAYOUT_COPY_AFTER = {"ypairs": 2, "bricks": 0}
 
 
 def _layout_copy(lib, volume, kind):
-    """The y-pair (``kind`` = "ypairs") or bricked ("bricks") copy of ``volume``, or None the first TWO times a version of
-    it is seen: the copy costs 0.76 ms at 512^3 and saves ~0.25-0.5 ms per render, so it only pays for a volume that is
-    rendered again and again unchanged (registration, the benchmark, a fixed CT); a volume that changes between renders --
-    voxels being optimised, or the fresh HU -> density map of every training step, rendered exactly twice
-    (trainer.py:185-230) -- stays on the natural layout."""
+    """The y-pair (``kind`` = "ypairs") or bricked ("bricks") copy of ``volume``, or None the first LAYOUT_COPY_AFTER[kind]
+    times a version of it is seen.  The y-pair copy costs 0.54 ms at 512^3 and saves ~0.7 ms per render: it waits for the third
+    render, i.e. for a volume that is rendered again and again unchanged (registration, the benchmark, a fixed CT) -- a volume
+    that changes between renders (voxels being optimised) stays on the natural layout; the fresh HU -> density map of every
+    training step, rendered exactly twice with a mask (trainer.py:185-230), gets labels and y-pairs in one pass at first
+    sight (_packed_ypair_volume).  The bricked copy for Siddon saves 1.3 ms per render and is built at first sight."""
     D0, D1, D2 = volume.shape
     key = volume._version
     slot = _cache_slot(volume)
@@ -214,7 +219,7 @@ def _layout_copy(lib, volume, kind):
         return hit[1]
     seen = hit[3] + 1 if hit is not None and hit[0] == key else 1
     buf = hit[2] if hit is not None else None
-    if seen <= 2:
+    if seen <= LAYOUT_COPY_AFTER[kind]:
         slot[kind] = (key, None, buf, seen)
         return None
     nbytes, pack, name = ((lib.xvr_drr_ypairs_bytes, lib.xvr_drr_pack_ypairs, "pack_ypairs") if kind == "ypairs"
