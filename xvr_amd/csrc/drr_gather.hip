@@ -830,6 +830,10 @@ __global__ __launch_bounds__(WG) void k_siddon_gather_mask(GatherArgs G) {
 // ray inside it -- but splits it over 8 sums by where the forward's own midpoint arithmetic sends the segment.  The sums go
 // to a [cell][8] scratch; k_siddon_cells_to_voxels then adds, for every voxel, the eight (cell, octant) entries that
 // name it.  No atomics, deterministic; before this the non-exact maps took the fp32-atomic scatter (151 ms per C3 batch).
+// (Round 3 built the 2 x 2 x 2-cells-per-lane version in k_siddon_gather_vol2's frame -- window, loads and the nine crossing
+//  alphas shared by eight cells, 64 sums per lane: 34.2 ms against this kernel's 30.3.  Unlike the exact map's three
+//  instructions per voxel, a crossed cell costs ~30 (the forward's midpoint rule); a block's window holds 16 candidates that each
+//  cross ~3 of its 8 cells, a cell's own window 9 that mostly cross it; and 138 registers leave 3 wavefronts per SIMD.)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WG) void k_siddon_gather_cells(GatherArgs G) {
     if (*G.flag > __float_as_uint(GATHER_DEV_TOL)) return;
