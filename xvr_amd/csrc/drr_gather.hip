@@ -1119,7 +1119,7 @@ int xvr_detail::launch_gather(bool siddon, const float* source, const float* tar
         G.cmax_stride = 4 * n < CMAX_STRIDE ? 4 * n : CMAX_STRIDE;
     }
     if (psplat) G.bd[0] = G.bd[1] = G.bd[2] = 16;
-    if (splat) { G.bd[0] = B16_BX; G.bd[1] = G.bd[2] = 16; }
+    if (splat) G.bd[0] = G.bd[1] = G.bd[2] = 16;
     G.cull = reinterpret_cast<unsigned*>(ws + ws_cull_off(B, n));
     G.words = (B + 31) / 32;
     G.gvol = grad_volume;
@@ -1160,11 +1160,11 @@ int xvr_detail::launch_gather(bool siddon, const float* source, const float* tar
         // persistent workgroups: as many as run at once (the occupancy the runtime reports x the CUs), never more than bricks
         static const int resident = [] {
             int per_cu = 0, dev = 0, cus = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trilinear_splat_b16, B16_NT, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trilinear_splat_b16, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
             return per_cu * cus;
         }();
-        hipLaunchKernelGGL(k_trilinear_splat_b16, dim3((unsigned)(bricks < resident ? bricks : resident)), dim3(B16_NT), 0, (hipStream_t)stream, G);
+        hipLaunchKernelGGL(k_trilinear_splat_b16, dim3((unsigned)(bricks < resident ? bricks : resident)), dim3(256), 0, (hipStream_t)stream, G);
     }
     else hipLaunchKernelGGL(k_trilinear_gather_tab, dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);   // (qn <= TAB_MAX_RAYS: gather_usable)
     e = hipGetLastError();
@@ -1188,7 +1188,7 @@ int xvr_drr_debug_gather_stats(unsigned long long* out8, int reset) {
 #ifdef XVR_S16_TRACE
 int xvr_drr_debug_s16_occupancy() {   // workgroups of the 16^3 splat the runtime says fit one CU
     int n = -1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trilinear_splat_b16, B16_NT, 0) != hipSuccess) return -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trilinear_splat_b16, 256, 0) != hipSuccess) return -1;
     return n;
 }
 int xvr_drr_debug_s16_trace(unsigned long long* out, int n_groups) {
