@@ -7,22 +7,40 @@ namespace {
 // =============================================================================================
 // pose-side backward from the saved jacobian (C == 1): elementwise + wave reduction
 // =============================================================================================
+template <int RPT>   // rays per thread, as in k_jac_to_cam
 __global__ __launch_bounds__(WG) void k_backward_from_jac(const float* __restrict__ jac, const float* __restrict__ gout,
                                                          int n, float* gsrc, float* __restrict__ gtgt,
                                                          float* __restrict__ glen) {
     __shared__ float part[3][WG / 64];
     const int b = blockIdx.y;
-    const int r = blockIdx.x * WG + threadIdx.x;
     float js[3] = {0.f, 0.f, 0.f};
-    if (r < n) {
-        const size_t ray = (size_t)b * n + r;
-        const float g = gout[ray];
-        const float4* jp = reinterpret_cast<const float4*>(jac + ray * XVR_DRR_JAC_STRIDE);
-        const float4 j0 = jp[0], j1 = jp[1];
-        js[0] = g * j0.y; js[1] = g * j0.z; js[2] = g * j0.w;
-        float* tp = gtgt + ray * 3;
-        tp[0] = g * j1.x; tp[1] = g * j1.y; tp[2] = g * j1.z;
-        if (glen) glen[ray] = g * j0.x;
+    float g_[RPT];
+    float4 j0_[RPT], j1_[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int r = (blockIdx.x * RPT + k) * WG + threadIdx.x;
+        g_[k] = 0.f;
+        j0_[k] = j1_[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < n) {
+            const size_t ray = (size_t)b * n + r;
+            g_[k] = gout[ray];
+            const float4* jp = reinterpret_cast<const float4*>(jac + ray * XVR_DRR_JAC_STRIDE);
+            j0_[k] = jp[0];
+            j1_[k] = jp[1];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int r = (blockIdx.x * RPT + k) * WG + threadIdx.x;
+        if (r < n) {
+            const size_t ray = (size_t)b * n + r;
+            const float g = g_[k];
+            const float4 j0 = j0_[k], j1 = j1_[k];
+            js[0] += g * j0.y; js[1] += g * j0.z; js[2] += g * j0.w;
+            float* tp = gtgt + ray * 3;
+            tp[0] = g * j1.x; tp[1] = g * j1.y; tp[2] = g * j1.z;
+            if (glen) glen[ray] = g * j0.x;
+        }
     }
     // grad_source is shared by all rays of the pose: wave butterfly (DPP/shfl), then the 4 waves of
     // the block through LDS, then ONE atomic per component per block
@@ -66,36 +84,49 @@ __global__ __launch_bounds__(WG) void k_rays_fwd(const float* __restrict__ cam, 
 }
 
 // backward: 21 sums over a pose's rays (wave butterfly -> LDS across the 4 waves -> one atomic each per block)
+template <int RPT>   // rays per thread, as in k_jac_to_cam: 1 for registration-sized launches, 4 for batches
 __global__ __launch_bounds__(WG) void k_rays_bwd(const float* __restrict__ cam, int H, int W, const float* __restrict__ g_source,
                                                  const float* __restrict__ g_target, const float* __restrict__ g_raylen,
                                                  float* g_cam) {
     __shared__ float part[21][WG / 64];
     const int b = blockIdx.y, n = H * W;
-    const int r = blockIdx.x * WG + threadIdx.x;
     const float* c = cam + 24 * b;
     float acc[21];
 #pragma unroll
     for (int q = 0; q < 21; ++q) acc[q] = 0.f;
-    if (r < n) {
-        const int i = r / W, j = r - i * W;
-        const float pix[3] = {(float)i, (float)j, 1.f};
-        const float* gt = g_target + ((size_t)b * n + r) * 3;
-        float w[3], l2 = 0.f;
+    float gt_[RPT][3], gl_[RPT];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            w[a] = fmaf(c[12 + 3 * a], pix[0], fmaf(c[12 + 3 * a + 1], pix[1], c[12 + 3 * a + 2])) - c[21 + a];
-            l2 = fmaf(w[a], w[a], l2);
+    for (int k = 0; k < RPT; ++k) {   // every load of the thread first
+        const int r = (blockIdx.x * RPT + k) * WG + threadIdx.x;
+        gt_[k][0] = gt_[k][1] = gt_[k][2] = gl_[k] = 0.f;
+        if (r < n) {
+            const float* gt = g_target + ((size_t)b * n + r) * 3;
+            gt_[k][0] = gt[0]; gt_[k][1] = gt[1]; gt_[k][2] = gt[2];
+            gl_[k] = g_raylen ? g_raylen[(size_t)b * n + r] : 0.f;
         }
-        const float gl = g_raylen ? g_raylen[(size_t)b * n + r] : 0.f;
-        const float s = l2 > 0.f ? gl / sqrtf(l2) : 0.f;  // g_L * (unit direction) = s * w
+    }
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
+    for (int k = 0; k < RPT; ++k) {
+        const int r = (blockIdx.x * RPT + k) * WG + threadIdx.x;
+        if (r < n) {
+            const int i = r / W, j = r - i * W;
+            const float pix[3] = {(float)i, (float)j, 1.f};
+            float w[3], l2 = 0.f;
 #pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                acc[3 * a + m] = gt[a] * pix[m];           // d/d Mv[a][m]
-                acc[9 + 3 * a + m] = s * w[a] * pix[m];    // d/d Mw[a][m]
+            for (int a = 0; a < 3; ++a) {
+                w[a] = fmaf(c[12 + 3 * a], pix[0], fmaf(c[12 + 3 * a + 1], pix[1], c[12 + 3 * a + 2])) - c[21 + a];
+                l2 = fmaf(w[a], w[a], l2);
             }
-            acc[18 + a] = -s * w[a];                        // d/d s_w[a]
+            const float s = l2 > 0.f ? gl_[k] / sqrtf(l2) : 0.f;  // g_L * (unit direction) = s * w
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    acc[3 * a + m] += gt_[k][a] * pix[m];       // d/d Mv[a][m]
+                    acc[9 + 3 * a + m] += s * w[a] * pix[m];    // d/d Mw[a][m]
+                }
+                acc[18 + a] += -s * w[a];                        // d/d s_w[a]
+            }
         }
     }
 #pragma unroll
@@ -121,6 +152,10 @@ __global__ __launch_bounds__(WG) void k_rays_bwd(const float* __restrict__ cam, 
 // for a pose (ticket counter) adds them in block order and WRITES grad_cam[b] -- no float atomics, the
 // same bits on every run.
 // ---------------------------------------------------------------------------------------------
+// RPT = rays per thread (ray base + t + k WG of the block's WG * RPT): 1 for registration-sized launches (latency: as many
+// blocks as possible); 4 for batches -- a quarter of the 24 wavefront reductions, stores and tickets per ray, all 12 loads of
+// a thread in flight at once (C2, 116 poses: 0.32 -> see profiles/r03_bench_final_pose_only.json)
+template <int RPT>
 __global__ __launch_bounds__(WG) void k_jac_to_cam(const float* __restrict__ jac, const float* __restrict__ gout,
                                                    const float* __restrict__ cam, int H, int W, float* partial,
                                                    unsigned* counter, float* __restrict__ g_cam) {
@@ -128,36 +163,52 @@ __global__ __launch_bounds__(WG) void k_jac_to_cam(const float* __restrict__ jac
     __shared__ float fin[24][WG + 1];
     __shared__ bool last;
     const int b = blockIdx.y, n = H * W, nblk = gridDim.x;
-    const int r = blockIdx.x * WG + threadIdx.x;
     const float* c = cam + 24 * b;
     float acc[24];
 #pragma unroll
     for (int q = 0; q < 24; ++q) acc[q] = 0.f;
-    if (r < n) {
-        const size_t ray = (size_t)b * n + r;
-        const float g = gout[ray];
-        const float4* jp = reinterpret_cast<const float4*>(jac + ray * XVR_DRR_JAC_STRIDE);
-        const float4 j0 = jp[0], j1 = jp[1];
-        const int i = r / W, j = r - i * W;
-        const float pix[3] = {(float)i, (float)j, 1.f};
-        const float gt[3] = {g * j1.x, g * j1.y, g * j1.z};
-        float w[3], l2 = 0.f;
+    float g_[RPT];
+    float4 j0_[RPT], j1_[RPT];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            w[a] = fmaf(c[12 + 3 * a], pix[0], fmaf(c[12 + 3 * a + 1], pix[1], c[12 + 3 * a + 2])) - c[21 + a];
-            l2 = fmaf(w[a], w[a], l2);
+    for (int k = 0; k < RPT; ++k) {   // every load of the thread first
+        const int r = (blockIdx.x * RPT + k) * WG + threadIdx.x;
+        g_[k] = 0.f;
+        j0_[k] = j1_[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < n) {
+            const size_t ray = (size_t)b * n + r;
+            g_[k] = gout[ray];
+            const float4* jp = reinterpret_cast<const float4*>(jac + ray * XVR_DRR_JAC_STRIDE);
+            j0_[k] = jp[0];
+            j1_[k] = jp[1];
         }
-        const float gl = g * j0.x;
-        const float sc = l2 > 0.f ? gl / sqrtf(l2) : 0.f;  // g_L * (unit direction) = sc * w
-        acc[9] = g * j0.y; acc[10] = g * j0.z; acc[11] = g * j0.w;   // d/d s_v = grad_source
+    }
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
+    for (int k = 0; k < RPT; ++k) {
+        const int r = (blockIdx.x * RPT + k) * WG + threadIdx.x;
+        if (r < n) {
+            const float g = g_[k];
+            const float4 j0 = j0_[k], j1 = j1_[k];
+            const int i = r / W, j = r - i * W;
+            const float pix[3] = {(float)i, (float)j, 1.f};
+            const float gt[3] = {g * j1.x, g * j1.y, g * j1.z};
+            float w[3], l2 = 0.f;
 #pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                acc[3 * a + m] = gt[a] * pix[m];             // d/d Mv[a][m]
-                acc[12 + 3 * a + m] = sc * w[a] * pix[m];    // d/d Mw[a][m]
+            for (int a = 0; a < 3; ++a) {
+                w[a] = fmaf(c[12 + 3 * a], pix[0], fmaf(c[12 + 3 * a + 1], pix[1], c[12 + 3 * a + 2])) - c[21 + a];
+                l2 = fmaf(w[a], w[a], l2);
             }
-            acc[21 + a] = -sc * w[a];                         // d/d s_w[a]
+            const float gl = g * j0.x;
+            const float sc = l2 > 0.f ? gl / sqrtf(l2) : 0.f;  // g_L * (unit direction) = sc * w
+            acc[9] += g * j0.y; acc[10] += g * j0.z; acc[11] += g * j0.w;   // d/d s_v = grad_source
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    acc[3 * a + m] += gt[a] * pix[m];             // d/d Mv[a][m]
+                    acc[12 + 3 * a + m] += sc * w[a] * pix[m];    // d/d Mw[a][m]
+                }
+                acc[21 + a] += -sc * w[a];                         // d/d s_w[a]
+            }
         }
     }
 #pragma unroll
@@ -433,11 +484,15 @@ int xvr_drr_jac_to_camera_backward(const float* jac, const float* grad_out, cons
     if (B <= 0 || H <= 0 || W <= 0) return fail(XVR_DRR_E_ARG, "B, H, W must be positive");
     if (workspace_bytes < xvr_drr_jac_to_camera_workspace_bytes(B, H, W)) return fail(XVR_DRR_E_ARG, "workspace too small");
     if (reinterpret_cast<uintptr_t>(jac) & 15u) return fail(XVR_DRR_E_ARG, "jac must be 16-byte aligned");
-    const unsigned nblk = (unsigned)(((size_t)H * W + WG - 1) / WG);
+    const bool batch = (size_t)B * H * W >= ((size_t)1 << 20);   // (a registration iteration: one to eight 256^2 ... 512^2 images)
+    const unsigned per_block = batch ? 4 * WG : WG;
+    const unsigned nblk = (unsigned)(((size_t)H * W + per_block - 1) / per_block);
     char* ws = static_cast<char*>(workspace);
-    hipLaunchKernelGGL(k_jac_to_cam, dim3(nblk, (unsigned)B), dim3(WG), 0, (hipStream_t)stream, jac, grad_out, cam, H, W,
-                       reinterpret_cast<float*>(ws + align256((size_t)B * sizeof(unsigned))), reinterpret_cast<unsigned*>(ws),
-                       grad_cam);
+    float* partial = reinterpret_cast<float*>(ws + align256((size_t)B * sizeof(unsigned)));
+    if (batch) hipLaunchKernelGGL(k_jac_to_cam<4>, dim3(nblk, (unsigned)B), dim3(WG), 0, (hipStream_t)stream, jac, grad_out, cam, H, W, partial,
+                                  reinterpret_cast<unsigned*>(ws), grad_cam);
+    else hipLaunchKernelGGL(k_jac_to_cam<1>, dim3(nblk, (unsigned)B), dim3(WG), 0, (hipStream_t)stream, jac, grad_out, cam, H, W, partial,
+                            reinterpret_cast<unsigned*>(ws), grad_cam);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
     return XVR_DRR_OK;
@@ -458,9 +513,11 @@ int xvr_drr_rays_backward(const float* cam, int B, int H, int W, const float* gr
                           const float* grad_raylen, float* grad_cam, void* stream) {
     if (!cam || !grad_target || !grad_cam) return fail(XVR_DRR_E_ARG, "null pointer argument");
     if (B <= 0 || H <= 0 || W <= 0) return fail(XVR_DRR_E_ARG, "B, H, W must be positive");
-    dim3 grid((unsigned)(((long long)H * W + WG - 1) / WG), (unsigned)B);
-    hipLaunchKernelGGL(k_rays_bwd, grid, dim3(WG), 0, (hipStream_t)stream, cam, H, W, grad_source, grad_target,
-                       grad_raylen, grad_cam);
+    const bool batch = (size_t)B * H * W >= ((size_t)1 << 20);
+    const long long per_block = batch ? 4 * WG : WG;
+    dim3 grid((unsigned)(((long long)H * W + per_block - 1) / per_block), (unsigned)B);
+    if (batch) hipLaunchKernelGGL(k_rays_bwd<4>, grid, dim3(WG), 0, (hipStream_t)stream, cam, H, W, grad_source, grad_target, grad_raylen, grad_cam);
+    else hipLaunchKernelGGL(k_rays_bwd<1>, grid, dim3(WG), 0, (hipStream_t)stream, cam, H, W, grad_source, grad_target, grad_raylen, grad_cam);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
     return XVR_DRR_OK;
@@ -470,9 +527,11 @@ int xvr_drr_backward_from_jac(const float* jac, const float* grad_out, int B, in
                               float* grad_target, float* grad_raylen, void* stream) {
     if (!jac || !grad_out || !grad_source || !grad_target) return fail(XVR_DRR_E_ARG, "null pointer argument");
     if (B <= 0 || n <= 0) return fail(XVR_DRR_E_ARG, "B and n must be positive");
-    dim3 grid((unsigned)((n + WG - 1) / WG), (unsigned)B);
-    hipLaunchKernelGGL(k_backward_from_jac, grid, dim3(WG), 0, (hipStream_t)stream, jac, grad_out, n,
-                       grad_source, grad_target, grad_raylen);
+    const bool batch = (size_t)B * n >= ((size_t)1 << 20);
+    const int per_block = batch ? 4 * WG : WG;
+    dim3 grid((unsigned)((n + per_block - 1) / per_block), (unsigned)B);
+    if (batch) hipLaunchKernelGGL(k_backward_from_jac<4>, grid, dim3(WG), 0, (hipStream_t)stream, jac, grad_out, n, grad_source, grad_target, grad_raylen);
+    else hipLaunchKernelGGL(k_backward_from_jac<1>, grid, dim3(WG), 0, (hipStream_t)stream, jac, grad_out, n, grad_source, grad_target, grad_raylen);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
     return XVR_DRR_OK;
