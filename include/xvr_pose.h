@@ -103,6 +103,22 @@ int xvr_pose_multiview_forward(const float* true_pose, const float* pred_pose, i
 int xvr_pose_multiview_backward(const float* true_pose, const float* pred_pose, const float* grad_mvc, int B, float sdd,
                                 float eps, float* grad_pred, void* stream);
 
+/*
+ * diffdrr's convert(rotation, translation, parameterization=..., convention=...) -> 4x4 pose and its backward, one launch
+ * each (/root/reference/src/xvr/model/network.py:49-56 on the regressor's output every training step; the registrar with
+ * non-Euler parameterisations, registrar/base.py:168): the framework's 40-110 tiny launches cost 0.8-2.0 ms at 116 poses.
+ *   kind   0 euler_angles (axes = the convention, 0 = X .. 2 = Z; radians)   1 axis_angle   2 quaternion (real first)
+ *          3 quaternion_adjugate (10 numbers)   4 rotation_6d   5 se3_log_map        rot [B][3 | 3 | 4 | 10 | 6 | 3]
+ *   matrix [B][16] row-major;  jac: xvr_pose_convert_jacobian_floats(B) floats, written by the forward (the 12 x (k + 3)
+ *          Jacobian of every pose, by forward-mode differentiation of the same formulas) and read by the backward
+ *   backward: grad_matrix [B][16] (row 3 ignored) -> grad_rot [B][k], grad_xyz [B][3]
+ */
+size_t xvr_pose_convert_jacobian_floats(int B);
+int xvr_pose_convert_forward(const float* rot, const float* xyz, int B, int kind, const int axes[3], float* matrix, float* jac,
+                             void* stream);
+int xvr_pose_convert_backward(const float* jac, const float* grad_matrix, int B, int kind, float* grad_rot, float* grad_xyz,
+                              void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -128,6 +128,9 @@ EXPORTS = {
     "xvr_pose_camera_forward": ([_P, _P, _I, _AX, _P, _P, _P, _P], ctypes.c_int),
     "xvr_pose_camera_backward": ([_P, _P, _I, _AX, _P, _P, _P, _P, _P], ctypes.c_int),
     "xvr_pose_geodesic": ([_P, _P, _I, ctypes.c_float, ctypes.c_float, _P, _P, _P], ctypes.c_int),
+    "xvr_pose_convert_jacobian_floats": ([_I], ctypes.c_size_t),
+    "xvr_pose_convert_forward": ([_P, _P, _I, _I, _AX, _P, _P, _P], ctypes.c_int),
+    "xvr_pose_convert_backward": ([_P, _P, _I, _I, _P, _P, _P], ctypes.c_int),
     "xvr_pose_multiview_forward": ([_P, _P, _I, ctypes.c_float, ctypes.c_float, _P, _P], ctypes.c_int),
     "xvr_pose_multiview_backward": ([_P, _P, _P, _I, ctypes.c_float, ctypes.c_float, _P, _P], ctypes.c_int),
     "xvr_pose_opt_state_bytes": ([], ctypes.c_size_t),

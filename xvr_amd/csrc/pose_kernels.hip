@@ -347,6 +347,169 @@ int launched(const char* what) {
     return pfail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// convert(rotation, translation, parameterization) -> 4x4 pose, and its backward, in ONE launch each
+// (/root/reference/src/xvr/model/network.py:49-56 calls diffdrr's `convert` on the regressor's output every training step;
+// registration does with non-Euler parameterisations).  The framework evaluates it as 40-110 tiny launches forward +
+// backward: 0.8-2.0 ms at 116 poses.  One thread per pose evaluates the map in forward-mode dual numbers -- one tangent per
+// input parameter, at most 10 + 3 -- and stores the 12 x (k + 3) Jacobian; the backward is J^T g.
+//   kind 0 euler_angles (axes = convention, radians)   1 axis_angle   2 quaternion (real first)
+//        3 quaternion_adjugate (10 numbers)   4 rotation_6d   5 se3_log_map
+// The formulas are xvr_amd/pose.py's (the PyTorch3D heritage diffdrr shares), branch for branch.
+// ---------------------------------------------------------------------------------------------
+constexpr int CV_MAXN = 13;
+struct Dual {
+    float v;
+    float d[CV_MAXN];
+};
+__device__ inline Dual dconst(float v) { Dual r; r.v = v; for (int i = 0; i < CV_MAXN; ++i) r.d[i] = 0.f; return r; }
+__device__ inline Dual dvar(float v, int i) { Dual r = dconst(v); r.d[i] = 1.f; return r; }
+__device__ inline Dual operator+(const Dual& a, const Dual& b) { Dual r; r.v = a.v + b.v; for (int i = 0; i < CV_MAXN; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+__device__ inline Dual operator-(const Dual& a, const Dual& b) { Dual r; r.v = a.v - b.v; for (int i = 0; i < CV_MAXN; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
+__device__ inline Dual operator-(const Dual& a) { Dual r; r.v = -a.v; for (int i = 0; i < CV_MAXN; ++i) r.d[i] = -a.d[i]; return r; }
+__device__ inline Dual operator*(const Dual& a, const Dual& b) { Dual r; r.v = a.v * b.v; for (int i = 0; i < CV_MAXN; ++i) r.d[i] = fmaf(a.v, b.d[i], a.d[i] * b.v); return r; }
+__device__ inline Dual operator*(float a, const Dual& b) { Dual r; r.v = a * b.v; for (int i = 0; i < CV_MAXN; ++i) r.d[i] = a * b.d[i]; return r; }
+__device__ inline Dual operator+(float a, const Dual& b) { Dual r = b; r.v = a + b.v; return r; }
+__device__ inline Dual operator-(float a, const Dual& b) { Dual r = -b; r.v = a - b.v; return r; }
+__device__ inline Dual operator/(const Dual& a, const Dual& b) {
+    Dual r; const float inv = 1.f / b.v; r.v = a.v * inv;
+    for (int i = 0; i < CV_MAXN; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * inv;
+    return r;
+}
+__device__ inline Dual operator/(float a, const Dual& b) { return dconst(a) / b; }
+__device__ inline Dual dsqrt(const Dual& a) { Dual r; r.v = sqrtf(a.v); const float h = 0.5f / r.v; for (int i = 0; i < CV_MAXN; ++i) r.d[i] = a.d[i] * h; return r; }
+__device__ inline Dual dsin(const Dual& a) { Dual r; float s, c; sincosf(a.v, &s, &c); r.v = s; for (int i = 0; i < CV_MAXN; ++i) r.d[i] = a.d[i] * c; return r; }
+__device__ inline Dual dcos(const Dual& a) { Dual r; float s, c; sincosf(a.v, &s, &c); r.v = c; for (int i = 0; i < CV_MAXN; ++i) r.d[i] = -a.d[i] * s; return r; }
+
+// sin(t)/t, (1 - cos t)/t^2, (t - sin t)/t^3 with the Taylor branches of pose.py's _so3_coeffs
+__device__ inline void so3_coeffs(const Dual& th2, Dual& a, Dual& b, Dual& c) {
+    if (th2.v < 1e-8f) {
+        a = 1.f - (1.f / 6.f) * th2;
+        b = 0.5f - (1.f / 24.f) * th2;
+        c = (1.f / 6.f) - (1.f / 120.f) * th2;
+    } else {
+        const Dual th = dsqrt(th2), s = dsin(th), co = dcos(th);
+        a = s / th;
+        b = (1.f - co) / th2;
+        c = (th - s) / (th2 * th);
+    }
+}
+// R (row-major 3x3) of a quaternion that need not be unit (pose.py quaternion_to_matrix)
+__device__ inline void quat_to_matrix(const Dual* q, Dual* R) {
+    const Dual& r = q[0]; const Dual& i = q[1]; const Dual& j = q[2]; const Dual& k = q[3];
+    const Dual two_s = 2.f / (r * r + i * i + j * j + k * k);
+    R[0] = 1.f - two_s * (j * j + k * k); R[1] = two_s * (i * j - k * r); R[2] = two_s * (i * k + j * r);
+    R[3] = two_s * (i * j + k * r); R[4] = 1.f - two_s * (i * i + k * k); R[5] = two_s * (j * k - i * r);
+    R[6] = two_s * (i * k - j * r); R[7] = two_s * (j * k + i * r); R[8] = 1.f - two_s * (i * i + j * j);
+}
+// R = I + a K + b K^2 (and optionally V = I + b K + c K^2), K = hat(w)
+__device__ inline void rodrigues(const Dual* w, const Dual& a, const Dual& b, Dual* R) {
+    const Dual x = w[0], y = w[1], z = w[2];
+    const Dual xx = x * x, yy = y * y, zz = z * z, xy = x * y, xz = x * z, yz = y * z;
+    // K^2 = w w^T - |w|^2 I
+    R[0] = 1.f - b * (yy + zz); R[1] = b * xy - a * z;       R[2] = b * xz + a * y;
+    R[3] = b * xy + a * z;       R[4] = 1.f - b * (xx + zz); R[5] = b * yz - a * x;
+    R[6] = b * xz - a * y;       R[7] = b * yz + a * x;       R[8] = 1.f - b * (xx + yy);
+}
+
+__global__ __launch_bounds__(64) void k_pose_convert_fwd(const float* __restrict__ rot, const float* __restrict__ xyz, int B, int kind, int k,
+                                                         Axes ax, float* __restrict__ matrix, float* __restrict__ jac) {
+    const int p = blockIdx.x * 64 + threadIdx.x;
+    if (p >= B) return;
+    const int n = k + 3;
+    Dual r[10], t[3], R[9], T[3];
+    for (int i = 0; i < k; ++i) r[i] = dvar(rot[(size_t)p * k + i], i);
+    for (int i = 0; i < 3; ++i) t[i] = dvar(xyz[(size_t)p * 3 + i], k + i);
+    bool rotate_t = true;
+    if (kind == 0) {   // intrinsic Euler angles: R = R_c0(a0) R_c1(a1) R_c2(a2)
+        Dual M[3][9];
+        for (int e = 0; e < 3; ++e) {
+            const Dual c = dcos(r[e]), s = dsin(r[e]);
+            for (int q = 0; q < 9; ++q) M[e][q] = dconst(0.f);
+            const int a = ax.a[e], i = (a + 1) % 3, j = (a + 2) % 3;
+            M[e][a * 3 + a] = dconst(1.f);
+            M[e][i * 3 + i] = c; M[e][i * 3 + j] = -s;
+            M[e][j * 3 + i] = s; M[e][j * 3 + j] = c;
+        }
+        Dual M01[9];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) M01[i * 3 + j] = M[0][i * 3] * M[1][j] + M[0][i * 3 + 1] * M[1][3 + j] + M[0][i * 3 + 2] * M[1][6 + j];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) R[i * 3 + j] = M01[i * 3] * M[2][j] + M01[i * 3 + 1] * M[2][3 + j] + M01[i * 3 + 2] * M[2][6 + j];
+    } else if (kind == 1) {   // axis-angle: Rodrigues
+        Dual a, b, c;
+        so3_coeffs(r[0] * r[0] + r[1] * r[1] + r[2] * r[2], a, b, c);
+        rodrigues(r, a, b, R);
+    } else if (kind == 2) {
+        quat_to_matrix(r, R);
+    } else if (kind == 3) {   // quaternion adjugate: the column of largest norm of the symmetric 4x4, over that norm
+        Dual A[4][4];
+        int q = 0;
+        for (int i = 0; i < 4; ++i)
+            for (int j = i; j < 4; ++j) { A[i][j] = r[q]; A[j][i] = r[q]; ++q; }
+        int best = 0;
+        float bn = -1.f;
+        for (int j = 0; j < 4; ++j) {
+            const float nn = sqrtf(A[0][j].v * A[0][j].v + A[1][j].v * A[1][j].v + A[2][j].v * A[2][j].v + A[3][j].v * A[3][j].v);
+            if (nn > bn) { bn = nn; best = j; }   // (first maximum, as torch.argmax)
+        }
+        const Dual nrm = dsqrt(A[0][best] * A[0][best] + A[1][best] * A[1][best] + A[2][best] * A[2][best] + A[3][best] * A[3][best]);
+        Dual qq[4];
+        for (int i = 0; i < 4; ++i) qq[i] = A[i][best] / nrm;
+        quat_to_matrix(qq, R);
+    } else if (kind == 4) {   // 6D: Gram-Schmidt of two rows (F.normalize: x / max(|x|, 1e-12))
+        const Dual n1 = dsqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+        const Dual d1 = n1.v > 1e-12f ? n1 : dconst(1e-12f);
+        Dual b1[3], b2[3];
+        for (int i = 0; i < 3; ++i) b1[i] = r[i] / d1;
+        const Dual dp = b1[0] * r[3] + b1[1] * r[4] + b1[2] * r[5];
+        for (int i = 0; i < 3; ++i) b2[i] = r[3 + i] - dp * b1[i];
+        const Dual n2 = dsqrt(b2[0] * b2[0] + b2[1] * b2[1] + b2[2] * b2[2]);
+        const Dual d2 = n2.v > 1e-12f ? n2 : dconst(1e-12f);
+        for (int i = 0; i < 3; ++i) b2[i] = b2[i] / d2;
+        for (int i = 0; i < 3; ++i) { R[i] = b1[i]; R[3 + i] = b2[i]; }
+        R[6] = b1[1] * b2[2] - b1[2] * b2[1];
+        R[7] = b1[2] * b2[0] - b1[0] * b2[2];
+        R[8] = b1[0] * b2[1] - b1[1] * b2[0];
+    } else {   // se(3) twist (omega, v): R = exp(omega), t = V(omega) v -- no further rotation of t
+        Dual a, b, c, V[9];
+        so3_coeffs(r[0] * r[0] + r[1] * r[1] + r[2] * r[2], a, b, c);
+        rodrigues(r, a, b, R);
+        rodrigues(r, b, c, V);
+        for (int i = 0; i < 3; ++i) T[i] = V[i * 3] * t[0] + V[i * 3 + 1] * t[1] + V[i * 3 + 2] * t[2];
+        rotate_t = false;
+    }
+    if (rotate_t)   // C-arm convention: x_world = R (x_cam + t)
+        for (int i = 0; i < 3; ++i) T[i] = R[i * 3] * t[0] + R[i * 3 + 1] * t[1] + R[i * 3 + 2] * t[2];
+    float* M = matrix + (size_t)p * 16;
+    float* J = jac + (size_t)p * 12 * CV_MAXN;
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) {
+            M[i * 4 + j] = R[i * 3 + j].v;
+            for (int d = 0; d < n; ++d) J[(i * 4 + j) * CV_MAXN + d] = R[i * 3 + j].d[d];
+        }
+        M[i * 4 + 3] = T[i].v;
+        for (int d = 0; d < n; ++d) J[(i * 4 + 3) * CV_MAXN + d] = T[i].d[d];
+    }
+    M[12] = M[13] = M[14] = 0.f;
+    M[15] = 1.f;
+}
+
+// grad_rot [B][k], grad_xyz [B][3] = J^T grad_matrix (rows 0..2 of the 4x4): one thread per (pose, parameter)
+__global__ void k_pose_convert_bwd(const float* __restrict__ jac, const float* __restrict__ gmat, int B, int k, float* __restrict__ grot,
+                                   float* __restrict__ gxyz) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x, n = k + 3;
+    if (idx >= B * n) return;
+    const int p = idx / n, d = idx - p * n;
+    const float* J = jac + (size_t)p * 12 * CV_MAXN;
+    const float* g = gmat + (size_t)p * 16;
+    float s = 0.f;
+    for (int e = 0; e < 12; ++e) s = fmaf(J[e * CV_MAXN + d], g[e], s);
+    if (d < k) grot[(size_t)p * k + d] = s;
+    else gxyz[(size_t)p * 3 + (d - k)] = s;
+}
+
 }  // namespace
 
 extern "C" int xvr_pose_camera_forward(const float* rot, const float* xyz, int B, const int axes[3], const float* G,
@@ -409,4 +572,35 @@ extern "C" int xvr_pose_multiview_backward(const float* true_pose, const float* 
     hipLaunchKernelGGL(k_multiview_bwd, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, true_pose, pred_pose, grad_mvc, B,
                        sdd, eps, grad_pred);
     return launched("pose_multiview_backward");
+}
+
+extern "C" size_t xvr_pose_convert_jacobian_floats(int B) { return B > 0 ? (size_t)B * 12 * CV_MAXN : 0; }
+
+extern "C" int xvr_pose_convert_forward(const float* rot, const float* xyz, int B, int kind, const int axes[3], float* matrix,
+                                        float* jac, void* stream) {
+    static const int K[6] = {3, 3, 4, 10, 6, 3};
+    if (!rot || !xyz || !matrix || !jac) return pfail(XVR_DRR_E_ARG, "null pointer argument");
+    if (B <= 0 || kind < 0 || kind > 5) return pfail(XVR_DRR_E_ARG, "bad batch size or parameterisation");
+    Axes ax = {{0, 1, 2}};
+    if (kind == 0) {
+        if (!axes) return pfail(XVR_DRR_E_ARG, "euler angles need a convention");
+        for (int i = 0; i < 3; ++i) {
+            if (axes[i] < 0 || axes[i] > 2) return pfail(XVR_DRR_E_ARG, "axes must be 0, 1 or 2");
+            ax.a[i] = axes[i];
+        }
+    }
+    hipLaunchKernelGGL(k_pose_convert_fwd, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, (hipStream_t)stream, rot, xyz, B, kind, K[kind], ax,
+                       matrix, jac);
+    return launched("xvr_pose_convert_forward");
+}
+
+extern "C" int xvr_pose_convert_backward(const float* jac, const float* grad_matrix, int B, int kind, float* grad_rot, float* grad_xyz,
+                                         void* stream) {
+    static const int K[6] = {3, 3, 4, 10, 6, 3};
+    if (!jac || !grad_matrix || !grad_rot || !grad_xyz) return pfail(XVR_DRR_E_ARG, "null pointer argument");
+    if (B <= 0 || kind < 0 || kind > 5) return pfail(XVR_DRR_E_ARG, "bad batch size or parameterisation");
+    const int n = B * (K[kind] + 3);
+    hipLaunchKernelGGL(k_pose_convert_bwd, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, (hipStream_t)stream, jac, grad_matrix, B, K[kind],
+                       grad_rot, grad_xyz);
+    return launched("xvr_pose_convert_backward");
 }

@@ -381,11 +381,63 @@ class RigidTransform(torch.nn.Module):
         raise ValueError(f"unknown parameterization {parameterization!r}")
 
 
+# parameters -> 4x4 as ONE HIP launch (and one for the backward) for float32 CUDA batches: xvr_pose_convert_forward /
+# _backward (include/xvr_pose.h) evaluate the formulas below in forward-mode dual numbers.  False: the torch formulation
+# (the cross-check in tests/test_pose.py); "rotation_10d" (an eigen-decomposition) and "matrix" always take it.
+FUSED_CONVERT = True
+_FUSED_KINDS = {"euler_angles": 0, "axis_angle": 1, "quaternion": 2, "quaternion_adjugate": 3, "rotation_6d": 4, "se3_log_map": 5}
+
+
+class _ConvertFused(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rotation, translation, kind, axes):
+        import ctypes
+
+        from . import _lib
+        from .renderers import _ptr, _stream
+
+        lib = _lib.load()
+        B = rotation.shape[0]
+        rot, xyz = rotation.contiguous(), translation.contiguous()
+        matrix = torch.empty(B, 4, 4, device=rot.device, dtype=torch.float32)
+        jac = torch.empty(lib.xvr_pose_convert_jacobian_floats(B), device=rot.device, dtype=torch.float32)
+        _lib.check(lib.xvr_pose_convert_forward(_ptr(rot), _ptr(xyz), B, kind, (ctypes.c_int * 3)(*axes), _ptr(matrix), _ptr(jac),
+                                                _stream()), "xvr_pose_convert_forward")
+        ctx.save_for_backward(jac)
+        ctx.cfg = (B, kind, rotation.shape[1])
+        return matrix
+
+    @staticmethod
+    def backward(ctx, g_matrix):
+        from . import _lib
+        from .renderers import _ptr, _stream
+
+        (jac,) = ctx.saved_tensors
+        B, kind, k = ctx.cfg
+        g = g_matrix.contiguous()
+        g_rot = torch.empty(B, k, device=g.device, dtype=torch.float32)
+        g_xyz = torch.empty(B, 3, device=g.device, dtype=torch.float32)
+        _lib.check(_lib.load().xvr_pose_convert_backward(_ptr(jac), _ptr(g), B, kind, _ptr(g_rot), _ptr(g_xyz), _stream()),
+                   "xvr_pose_convert_backward")
+        return g_rot, g_xyz, None, None
+
+
 def convert(*args, parameterization: str, convention: str | None = None, degrees: bool = False) -> RigidTransform:
     """Pose parameters -> :class:`RigidTransform` (camera-to-world; the source sits at ``R @ xyz``)."""
     if parameterization == "matrix" and len(args) == 1:
         return RigidTransform(args[0])
     rotation, translation = args
+    if (FUSED_CONVERT and parameterization in _FUSED_KINDS and torch.is_tensor(rotation) and rotation.is_cuda and rotation.dim() == 2
+            and rotation.dtype == torch.float32 and torch.is_tensor(translation) and translation.shape == (rotation.shape[0], 3)
+            and translation.dtype == torch.float32 and translation.device == rotation.device and rotation.shape[0] > 0
+            and rotation.shape[1] == N_ANGULAR_COMPONENTS[parameterization]):
+        axes = (0, 1, 2)
+        if parameterization == "euler_angles":
+            _check_convention(convention)
+            axes = tuple(_index_from_letter(c) for c in convention)
+            if degrees:
+                rotation = torch.deg2rad(rotation)
+        return RigidTransform(_ConvertFused.apply(rotation, translation, _FUSED_KINDS[parameterization], axes))
     if parameterization == "axis_angle":
         R = axis_angle_to_matrix(rotation)
     elif parameterization == "euler_angles":
