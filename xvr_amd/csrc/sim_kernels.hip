@@ -365,6 +365,10 @@ __global__ __launch_bounds__(TB) void k_sim_final(const float* __restrict__ m, c
         s2[0] = (double)G * (1.0 - x);
         s2[1] = (double)G * x;
     }
+    // the two sums feed Standardize's min / max gradient (k_sim_minmax_grad): a moving image that arrives transformed has none,
+    // and the reduction -- one group of B x blocks partials when the statistics are the batch's -- was most of this kernel's time
+    // at the training loss's 116 images (0.36 ms)
+    if (sp.pre_transformed) return;
     const bool pi = sp.per_image != 0;   // per image: one reduction group per image; else one over the batch
     grid_add_det<2>(s2, partial + (pi ? (size_t)b * gridDim.x * 2 : 0), pi ? (int)blockIdx.x : (int)(blockIdx.y * gridDim.x + blockIdx.x),
                     pi ? (int)gridDim.x : (int)(gridDim.x * gridDim.y), tickets + (pi ? b : 0), &hd->smin);
