@@ -83,6 +83,21 @@ int xvr_sim_equalize_backward(const float* x, const float* y, const float* S, co
                               float tau, float eps, float* grad_x, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * XrayTransforms without Equalize and without a Resize -- Standardize then Normalize,
+ *   y = ((x - lo) / (hi - lo + eps) - mean) / std,   lo / hi = min / max over the whole [B][n] tensor (per_image = 0, the
+ *   reference's transform, /root/reference/src/xvr/utils/preprocess.py:5-31) or over each image (per_image = 1)
+ * -- and its backward, which includes the gradient through lo and hi (torch's rule: shared evenly by the pixels that attain
+ * them).  The trainer applies it to both renders of every step (trainer.py:207,216).  `state`: xvr_sim_transform_state_bytes(B)
+ * bytes, written by the forward and needed, unchanged, by the backward.  y is bit-identical to the torch expression; the
+ * backward's two sums are added in a fixed order (doubles).
+ */
+size_t xvr_sim_transform_state_bytes(int B);
+int xvr_sim_transform_forward(const float* x, int B, long long n, int per_image, float mean, float std, float eps, float* y, void* state,
+                              void* stream);
+int xvr_sim_transform_backward(const float* x, const float* grad_y, int B, long long n, int per_image, float mean, float std, float eps,
+                               float* grad_x, void* state, void* stream);
+
+/*
  * The in-tree DiceMetric of /root/reference/src/xvr/model/loss.py:5-40 on two BOOLEAN label maps [B][C][n] (one byte per
  * pixel, as torch.bool; the masks Trainer.render_samples returns): dice[b][c] = 2 |pred & truth| / (|pred| + |truth|) from
  * integer counts -- bit-identical to the reference's float sums of 0 / 1 (n <= 2^24), NaN for 0 / 0 as there.  The caller

@@ -87,3 +87,42 @@ def test_equalize_matches_reference_lines_and_flattens_the_histogram():
     assert abs(y.median().item() - 0.5) < abs(x.median().item() - 0.5)
     t = metrics.XrayTransforms(24, 20, equalize=True)
     assert torch.isfinite(t(x * 100)).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("per_image", [False, True])
+@pytest.mark.parametrize("shape", [(5, 1, 24, 20), (3, 1, 64, 64), (2, 1, 7, 12)])
+def test_fused_standardize_normalize_equals_the_torch_lines(shape, per_image):
+    """xvr_sim_transform_forward / _backward (XrayTransforms without Equalize / Resize as two HIP calls) against the torch lines:
+    the values bit for bit, the gradient -- including the part that flows through the min and the max, shared by tied pixels --
+    to float32 summation noise."""
+    from xvr_amd.metrics import XrayTransforms
+
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.rand(*shape, generator=g) * 3.0 + 0.5
+    x[:, :, 0, :3] = 0.0                      # three pixels tie for the minimum of every image (air)
+    x[0, 0, 1, 1] = x[0, 0, 2, 2] = 9.0       # two tie for the batch's maximum
+    w = torch.randn(*shape, generator=g)
+    tf = XrayTransforms(shape[2], shape[3], per_image=per_image)
+    res = []
+    for fused in (True, False):
+        XrayTransforms.FUSED = fused
+        try:
+            xx = x.clone().cuda().requires_grad_()
+            y = tf(xx)
+            (y * w.cuda()).sum().backward()
+            res.append((y.detach().cpu(), xx.grad.cpu()))
+        finally:
+            XrayTransforms.FUSED = True
+    (y1, g1), (y0, g0) = res
+    assert torch.equal(y1, y0)
+    scale = g0.abs().max()
+    assert (g1 - g0).abs().max() <= 2e-5 * scale, ((g1 - g0).abs().max(), scale)
+    # float64 autograd on the CPU: the fused backward is at least as close to it as the float32 torch chain
+    xd = x.double().requires_grad_()
+    XrayTransforms.FUSED = False
+    try:
+        (tf(xd) * w.double()).sum().backward()
+    finally:
+        XrayTransforms.FUSED = True
+    assert (g1.double() - xd.grad).abs().max() <= 2.0 * (g0.double() - xd.grad).abs().max() + 1e-6 * scale

@@ -108,6 +108,9 @@ EXPORTS = {
     "xvr_sim_equalize_workspace_bytes": ([_I, _I], ctypes.c_size_t),
     "xvr_sim_equalize_forward": ([_P, _I, _I, _I, ctypes.c_float, ctypes.c_float, _P, _P, _P, ctypes.c_size_t, _P], ctypes.c_int),
     "xvr_sim_equalize_backward": ([_P, _P, _P, _P, _I, _I, _I, ctypes.c_float, ctypes.c_float, _P, _P, ctypes.c_size_t, _P], ctypes.c_int),
+    "xvr_sim_transform_state_bytes": ([_I], ctypes.c_size_t),
+    "xvr_sim_transform_forward": ([_P, _I, ctypes.c_longlong, _I, ctypes.c_float, ctypes.c_float, ctypes.c_float, _P, _P, _P], ctypes.c_int),
+    "xvr_sim_transform_backward": ([_P, _P, _I, ctypes.c_longlong, _I, ctypes.c_float, ctypes.c_float, ctypes.c_float, _P, _P, _P], ctypes.c_int),
     "xvr_sim_dice_bool": ([_P, _P, _I, _I, _I, _P, _P], ctypes.c_int),
     "xvr_sim_gaussian_blur5": ([_P, _P, _P, _I, _I, _I, ctypes.c_float, _I, _P], ctypes.c_int),
     "xvr_drr_hu_stats": ([_P, ctypes.c_longlong, _P, _P], ctypes.c_int),

@@ -667,6 +667,116 @@ __global__ __launch_bounds__(TB) void k_dice_bool(const unsigned char* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// XrayTransforms without Equalize / Resize -- Standardize (min / max over the whole tensor, or per image) then Normalize --
+// as a standalone pair (/root/reference/src/xvr/utils/preprocess.py:5-31; the trainer applies it to both renders of every
+// step, trainer.py:207,216, and autograd then runs ~35 launches of min / max backward bookkeeping over the batch: 0.7 ms at
+// 116 images).  Forward: k_sim_minmax, then y = ((x - lo) / (hi - lo + eps) - mean) / std with torch's own operation order
+// (bit-identical) and the counts of the pixels that attain lo / hi.  Backward: the two sums  sum g (1 - xs),  sum g xs
+// (xs = the standardised pixel) in a fixed order, then  gx = a g  plus the min's / max's share at the pixels that attain
+// them (torch's rule for a full-reduction min / max: spread evenly).  state = one TfState per group (1 or B).
+// ---------------------------------------------------------------------------------------------
+struct TfState {
+    SimHeader h;
+    unsigned ticket, pad;
+};
+
+__global__ __launch_bounds__(TB) void k_tf_init(TfState* st, int groups) {
+    const int i = blockIdx.x * TB + threadIdx.x;
+    if (i < groups) {
+        st[i].h.enc_min = 0xffffffffu; st[i].h.enc_max = 0u; st[i].h.cnt_min = 0; st[i].h.cnt_max = 0;
+        st[i].h.smin = 0.0; st[i].h.smax = 0.0; st[i].ticket = 0u; st[i].pad = 0u;
+    }
+}
+
+__global__ __launch_bounds__(TB) void k_tf_minmax(const float* __restrict__ m, long long n, TfState* st) {
+    __shared__ float plo[TB / 64], phi[TB / 64];
+    float lo = INFINITY, hi = -INFINITY;
+    m += (size_t)blockIdx.y * n;
+    st += blockIdx.y;
+    for (long long i = ((long long)blockIdx.x * TB + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * TB * 4) {
+        if (i + 3 < n) {
+            const float4 v = *reinterpret_cast<const float4*>(m + i);
+            lo = fminf(fminf(lo, v.x), fminf(fminf(v.y, v.z), v.w));
+            hi = fmaxf(fmaxf(hi, v.x), fmaxf(fmaxf(v.y, v.z), v.w));
+        } else {
+            for (long long j = i; j < n; ++j) { lo = fminf(lo, m[j]); hi = fmaxf(hi, m[j]); }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, o));
+        hi = fmaxf(hi, __shfl_xor(hi, o));
+    }
+    if ((threadIdx.x & 63) == 0) { plo[threadIdx.x >> 6] = lo; phi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < TB / 64; ++w) { lo = fminf(lo, plo[w]); hi = fmaxf(hi, phi[w]); }
+        atomicMin(&st->h.enc_min, enc(lo));
+        atomicMax(&st->h.enc_max, enc(hi));
+    }
+}
+
+// BWD = false: y and the counts;  true: gx = a g + the min's / max's share (st->h.smin / smax hold the two sums)
+template <bool BWD>
+__global__ __launch_bounds__(TB) void k_tf_apply(const float* __restrict__ x, const float* __restrict__ g, long long n, float mean, float std_,
+                                                 float eps, TfState* st, float* __restrict__ out) {
+    x += (size_t)blockIdx.y * n;
+    out += (size_t)blockIdx.y * n;
+    if (BWD) g += (size_t)blockIdx.y * n;
+    st += blockIdx.y;
+    const float mn = dec(st->h.enc_min), mx = dec(st->h.enc_max);
+    const float r = (mx - mn) + eps;
+    float a = 0.f, gmin = 0.f, gmax = 0.f;
+    if (BWD) {
+        const double ad = 1.0 / ((double)r * std_);
+        a = (float)ad;
+        gmin = (float)(-ad * st->h.smin / (double)max(st->h.cnt_min, 1));
+        gmax = (float)(-ad * st->h.smax / (double)max(st->h.cnt_max, 1));
+    }
+    const float inv_std = 1.f / std_;
+    int cmin = 0, cmax = 0;
+    for (long long i = (long long)blockIdx.x * TB + threadIdx.x; i < n; i += (long long)gridDim.x * TB) {
+        const float v = x[i];
+        if (BWD) {
+            float t = a * g[i];
+            if (v == mn) t += gmin;
+            if (v == mx) t += gmax;
+            out[i] = t;
+        } else {
+            out[i] = (((v - mn) / r) - mean) * inv_std;   // (torch divides by a Python scalar as a multiplication by its float reciprocal)
+            cmin += v == mn;
+            cmax += v == mx;
+        }
+    }
+    if (!BWD) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { cmin += __shfl_xor(cmin, o); cmax += __shfl_xor(cmax, o); }
+        if ((threadIdx.x & 63) == 0) {   // integer atomics: exact in any order
+            if (cmin) atomicAdd(&st->h.cnt_min, cmin);
+            if (cmax) atomicAdd(&st->h.cnt_max, cmax);
+        }
+    }
+}
+
+__global__ __launch_bounds__(TB) void k_tf_bwd_reduce(const float* __restrict__ x, const float* __restrict__ g, long long n, float eps,
+                                                      TfState* st, double* partial) {
+    x += (size_t)blockIdx.y * n;
+    g += (size_t)blockIdx.y * n;
+    st += blockIdx.y;
+    const float mn = dec(st->h.enc_min), mx = dec(st->h.enc_max);
+    const float r = (mx - mn) + eps;
+    double s2[2] = {0.0, 0.0};
+    for (long long i = (long long)blockIdx.x * TB + threadIdx.x; i < n; i += (long long)gridDim.x * TB) {
+        const float xs = (x[i] - mn) / r;
+        const double gg = (double)g[i];
+        s2[0] += gg * (1.0 - (double)xs);
+        s2[1] += gg * (double)xs;
+    }
+    grid_add_det<2>(s2, partial + (size_t)blockIdx.y * gridDim.x * 2, blockIdx.x, gridDim.x, &st->ticket, &st->h.smin);
+}
+
 }  // namespace
 
 extern "C" {
@@ -821,6 +931,54 @@ int xvr_sim_dice_bool(const unsigned char* pred, const unsigned char* truth, int
     if (B <= 0 || C <= 0 || n <= 0 || B > 65535) return sim_fail(XVR_DRR_E_ARG, "bad size");
     if (n > (1 << 24)) return sim_fail(XVR_DRR_E_UNSUPPORTED, "more than 2^24 pixels: the reference's float counts stop being exact");
     hipLaunchKernelGGL(k_dice_bool, dim3((unsigned)C, (unsigned)B), dim3(TB), 0, (hipStream_t)stream_, pred, truth, n, dice);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? XVR_DRR_OK : sim_fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
+}
+
+constexpr unsigned TF_BLOCKS = 256;   // blocks per group of the transform's reductions
+
+size_t xvr_sim_transform_state_bytes(int B) { return B > 0 ? (size_t)B * (sizeof(TfState) + TF_BLOCKS * 2 * sizeof(double)) : 0; }
+
+static int tf_check(const float* x, int B, long long n, float std_, void* state) {
+    if (!x || !state) return sim_fail(XVR_DRR_E_ARG, "null pointer argument");
+    if (B <= 0 || n <= 0 || !(std_ != 0.f) || B > 65535) return sim_fail(XVR_DRR_E_ARG, "bad size or std");
+    if (reinterpret_cast<uintptr_t>(x) & 15u) return sim_fail(XVR_DRR_E_ARG, "images must be 16-byte aligned");
+    return XVR_DRR_OK;
+}
+
+int xvr_sim_transform_forward(const float* x, int B, long long n, int per_image, float mean, float std_, float eps, float* y, void* state,
+                              void* stream_) {
+    const int rc = tf_check(x, B, n, std_, state);
+    if (rc != XVR_DRR_OK) return rc;
+    if (!y) return sim_fail(XVR_DRR_E_ARG, "null pointer argument");
+    if (per_image && (n & 3)) return sim_fail(XVR_DRR_E_UNSUPPORTED, "per-image statistics need a pixel count that is a multiple of 4");
+    hipStream_t stream = (hipStream_t)stream_;
+    TfState* st = static_cast<TfState*>(state);
+    const int groups = per_image ? B : 1;
+    const long long gn = per_image ? n : (long long)B * n;
+    const unsigned blocks = (unsigned)((gn + TB * 4 - 1) / (TB * 4) < TF_BLOCKS ? (gn + TB * 4 - 1) / (TB * 4) : TF_BLOCKS);
+    const unsigned ablocks = per_image ? (blocks < 64 ? blocks : 64) : (unsigned)((gn + TB * 4 - 1) / (TB * 4) < 4096 ? (gn + TB * 4 - 1) / (TB * 4) : 4096);
+    hipLaunchKernelGGL(k_tf_init, dim3((groups + TB - 1) / TB), dim3(TB), 0, stream, st, groups);
+    hipLaunchKernelGGL(k_tf_minmax, dim3(blocks, groups), dim3(TB), 0, stream, x, gn, st);
+    hipLaunchKernelGGL(k_tf_apply<false>, dim3(ablocks, groups), dim3(TB), 0, stream, x, (const float*)nullptr, gn, mean, std_, eps, st, y);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? XVR_DRR_OK : sim_fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
+}
+
+int xvr_sim_transform_backward(const float* x, const float* grad_y, int B, long long n, int per_image, float mean, float std_, float eps,
+                               float* grad_x, void* state, void* stream_) {
+    const int rc = tf_check(x, B, n, std_, state);
+    if (rc != XVR_DRR_OK) return rc;
+    if (!grad_y || !grad_x) return sim_fail(XVR_DRR_E_ARG, "null pointer argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    TfState* st = static_cast<TfState*>(state);
+    const int groups = per_image ? B : 1;
+    const long long gn = per_image ? n : (long long)B * n;
+    double* partial = reinterpret_cast<double*>(st + B);
+    const unsigned rblocks = (unsigned)((gn + TB * 8 - 1) / (TB * 8) < TF_BLOCKS ? (gn + TB * 8 - 1) / (TB * 8) : TF_BLOCKS);
+    const unsigned ablocks = per_image ? (rblocks < 64 ? rblocks : 64) : (unsigned)((gn + TB * 4 - 1) / (TB * 4) < 4096 ? (gn + TB * 4 - 1) / (TB * 4) : 4096);
+    hipLaunchKernelGGL(k_tf_bwd_reduce, dim3(rblocks, groups), dim3(TB), 0, stream, x, grad_y, gn, eps, st, partial);
+    hipLaunchKernelGGL(k_tf_apply<true>, dim3(ablocks, groups), dim3(TB), 0, stream, x, grad_y, gn, mean, std_, eps, st, grad_x);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? XVR_DRR_OK : sim_fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
 }

@@ -194,6 +194,41 @@ class Equalize(torch.nn.Module):
         return torch.cat(out)
 
 
+class _StandardizeNormalize(torch.autograd.Function):
+    """Standardize (min / max over the tensor, or per image) -> Normalize as two HIP calls (xvr_sim_transform_forward /
+    _backward, include/xvr_sim.h): the same float32 values as the torch lines of XrayTransforms.forward; the backward
+    carries the gradient through the min and the max as torch's does."""
+
+    @staticmethod
+    def forward(ctx, x, per_image, mean, std):
+        from . import _lib
+        from .renderers import _ptr, _stream
+
+        lib = _lib.load()
+        B, n = x.shape[0], x[0].numel()
+        xc = x.contiguous()
+        y = torch.empty_like(xc)
+        state = torch.empty(lib.xvr_sim_transform_state_bytes(B), dtype=torch.uint8, device=x.device)
+        _lib.check(lib.xvr_sim_transform_forward(_ptr(xc), B, n, int(per_image), float(mean), float(std), 1e-6, _ptr(y), _ptr(state),
+                                                 _stream()), "xvr_sim_transform_forward")
+        ctx.save_for_backward(xc, state)
+        ctx.cfg = (B, n, int(per_image), float(mean), float(std))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        from .renderers import _ptr, _stream
+
+        xc, state = ctx.saved_tensors
+        B, n, per_image, mean, std = ctx.cfg
+        gc = g.contiguous()
+        gx = torch.empty_like(xc)
+        _lib.check(_lib.load().xvr_sim_transform_backward(_ptr(xc), _ptr(gc), B, n, per_image, mean, std, 1e-6, _ptr(gx), _ptr(state),
+                                                          _stream()), "xvr_sim_transform_backward")
+        return gx, None, None, None
+
+
 class XrayTransforms(torch.nn.Module):
     """Standardize (global min-max) -> [Equalize] -> Resize((h, w)) -> Normalize(mean, std), applied to
     every rendered DRR each iteration (/root/reference/src/xvr/utils/preprocess.py:5-31; call sites
@@ -210,7 +245,13 @@ class XrayTransforms(torch.nn.Module):
         # needs the images of a batch to be independent problems
         self.per_image = per_image
 
+    FUSED = True   # float32 CUDA images, no Equalize, no Resize: two HIP calls (_StandardizeNormalize); False: the torch lines
+
     def forward(self, x):
+        if (self.FUSED and self.equalize is None and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.numel() > 0
+                and tuple(x.shape[-2:]) == (self.height, self.width) and x.data_ptr() % 16 == 0
+                and (not self.per_image or x[0].numel() % 4 == 0) and x.shape[0] <= 65535):
+            return _StandardizeNormalize.apply(x, self.per_image, self.mean, self.std)
         if self.per_image:
             lo, hi = x.amin(dim=(1, 2, 3), keepdim=True), x.amax(dim=(1, 2, 3), keepdim=True)
             x = (x - lo) / (hi - lo + 1e-6)
