@@ -200,8 +200,10 @@ struct PatchJobs {
 };
 
 // one thread = one patch.  fimg / yimg: [B][nch][H][W] with channel `ch` selected.  maps: [4][B][Hp][Wp].
+// tpb = tile rows per workgroup (blockIdx.y covers tile rows blockIdx.y * tpb ...): 1 for a registration iteration (as many
+// workgroups as possible), 4 for batches -- a quarter of the deterministic grid reductions, which are most of a workgroup's time
 __global__ __launch_bounds__(TB) void k_sim_patch(PatchJobs jobs, int B, int H, int W, float eps, double* acc,
-                                                  double* partial, unsigned* tickets) {
+                                                  double* partial, unsigned* tickets, int tpb) {
     __shared__ float sf[(TILE + MAXP - 1) * (TILE + MAXP - 1)];
     __shared__ float sy[(TILE + MAXP - 1) * (TILE + MAXP - 1)];
     __shared__ double hs[5][(TILE + MAXP - 1) * TILE];
@@ -212,9 +214,14 @@ __global__ __launch_bounds__(TB) void k_sim_patch(PatchJobs jobs, int B, int H, 
     float* __restrict__ maps = J.maps;
     const int nch = J.nch, ch = J.ch, p = J.p, acc_slot = J.acc_slot;
     const int Hp = H - p + 1, Wp = W - p + 1;
-    const int oy0 = blockIdx.y * TILE, ox0 = blockIdx.x * TILE;
-    if (oy0 >= Hp || ox0 >= Wp) return;   // the grid is sized for the job with the smallest patch
+    const int ox0 = blockIdx.x * TILE;
+    if ((int)blockIdx.y * tpb * TILE >= Hp || ox0 >= Wp) return;   // the grid is sized for the job with the smallest patch
     const int E = TILE + p - 1;
+    double ncc_d = 0.0;
+    for (int row = 0; row < tpb; ++row) {
+    const int oy0 = ((int)blockIdx.y * tpb + row) * TILE;
+    if (oy0 >= Hp) break;
+    if (row) __syncthreads();   // the previous tile's shared arrays have been read
     const float* F = fimg + ((size_t)b * nch + ch) * H * W;
     const float* Y = yimg + ((size_t)b * nch + ch) * H * W;
     for (int t = threadIdx.x; t < E * E; t += TB) {
@@ -246,7 +253,6 @@ __global__ __launch_bounds__(TB) void k_sim_patch(PatchJobs jobs, int B, int H, 
     __syncthreads();
     const int ty = threadIdx.x / TILE, tx = threadIdx.x % TILE;
     const int oy = oy0 + ty, ox = ox0 + tx;
-    double ncc_d = 0.0;
     if (oy < Hp && ox < Wp) {
         const double inv = 1.0 / (double)(p * p);
         double s1f = 0.0, s1y = 0.0, s2f = 0.0, s2y = 0.0, sfy = 0.0;
@@ -265,10 +271,11 @@ __global__ __launch_bounds__(TB) void k_sim_patch(PatchJobs jobs, int B, int H, 
         maps[st + o] = mf / s;
         maps[2 * st + o] = cv / (vy * s);
         maps[3 * st + o] = cv * my / (vy * s);
-        ncc_d = ncc;
+        ncc_d += ncc;
     }
+    }   // next tile row
     double v1[1] = {ncc_d};
-    const int ntx = (Wp + TILE - 1) / TILE, nty = (Hp + TILE - 1) / TILE;   // the tiles of THIS job
+    const int ntx = (Wp + TILE - 1) / TILE, nty = ((Hp + TILE - 1) / TILE + tpb - 1) / tpb;   // the workgroups of THIS job
     grid_add_det<1>(v1, partial + (size_t)blockIdx.z * gridDim.x * gridDim.y, blockIdx.y * ntx + blockIdx.x, ntx * nty,
                     tickets + blockIdx.z, acc + (size_t)b * N_ACC + acc_slot);
 }
@@ -912,8 +919,11 @@ int xvr_sim_ncc_forward_backward(const float* fixed, const float* fixed_sobel, c
     if (sp->beta >= 1.f) { njobs = 1; pmin = p1; }
     else if (sp->beta <= 0.f) { jobs.j[0] = jobs.j[1]; jobs.j[1] = jobs.j[2]; njobs = 2; pmin = p2; }
     auto tiles = [&](int hh, int ww) { return dim3((ww + TILE - 1) / TILE, (hh + TILE - 1) / TILE, njobs * B); };
-    hipLaunchKernelGGL(k_sim_patch, tiles(H - pmin + 1, W - pmin + 1), dim3(TB), 0, stream, jobs, B, H, W, sp->ncc_eps, acc,
-                       reinterpret_cast<double*>(ws + L.part_patch), tickets + B);
+    const int tpb = B >= 16 ? 4 : 1;
+    dim3 pgrid = tiles(H - pmin + 1, W - pmin + 1);
+    pgrid.y = (pgrid.y + tpb - 1) / tpb;
+    hipLaunchKernelGGL(k_sim_patch, pgrid, dim3(TB), 0, stream, jobs, B, H, W, sp->ncc_eps, acc,
+                       reinterpret_cast<double*>(ws + L.part_patch), tickets + B, tpb);
     hipLaunchKernelGGL(k_sim_patch_grad, tiles(H, W), dim3(TB), 0, stream, jobs, B, H, W);
     hipLaunchKernelGGL(k_sim_final, dim3((hw + TB - 1) / TB, B), dim3(TB), 0, stream, moving, fixed, y, Gy, Gg, H, W, hd, acc,
                        *sp, grad_moving, reinterpret_cast<double*>(ws + L.part_final), tickets + 4 * B);
