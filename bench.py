@@ -52,11 +52,11 @@ BINDING = {
         # tools/microbench/gather.hip: a 64-lane gather costs ~15 clk per CU on one 128-B line and 10-14 more per further line;
         # two 16-byte gathers per sample (y-pair copy), ~3 lines by that estimate (the L1 miss path behind it: DESIGN 4.4)
         ("texture_address", 2, 36.0, CUS, "profiles/r01_microbench_gather_lines.txt"),
-        ("valu_issue", 3.239e9 / (1.809e9 / 64), VALU_CLK, 4 * CUS, "profiles/r03_microbench_valu_issue.txt x SQ_INSTS_VALU"),
+        ("valu_issue", 2.416e9 / (1.809e9 / 64), VALU_CLK, 4 * CUS, "profiles/r03_microbench_valu_issue.txt x SQ_INSTS_VALU"),
     ],
     "trilinear_forward": [
         ("texture_address", 2, 36.0, CUS, "profiles/r01_microbench_gather_lines.txt"),
-        ("valu_issue", 2.207e9 / (1.809e9 / 64), VALU_CLK, 4 * CUS, "profiles/r03_microbench_valu_issue.txt x SQ_INSTS_VALU"),
+        ("valu_issue", 1.751e9 / (1.809e9 / 64), VALU_CLK, 4 * CUS, "profiles/r03_microbench_valu_issue.txt x SQ_INSTS_VALU"),
     ],
     "siddon_backward": [
         ("valu_issue", 7.75e9 / (5.576e9 / 64), VALU_CLK, 4 * CUS, "profiles/r03_microbench_valu_issue.txt x SQ_INSTS_VALU"),
