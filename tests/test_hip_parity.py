@@ -1402,6 +1402,19 @@ def test_fuzz_random_configurations_against_the_oracle(seed):
         assert int(bad.sum()) <= 2, f"grad_target: {int(bad.sum())} rays disagree [{what}]"
         hs, rs = (t.detach().double().cpu() for t in named.pop("grad_source"))
         assert (hs - rs).abs().max() <= 5 * GRAD_TOL * rs.abs().max() + 2.0 * (per_ray * bad).sum(), f"grad_source [{what}]"
+    elif not masked:
+        # Trilinear: a sample that sits ON a voxel boundary (to the last bit) makes its ray's d/d target one-sided, and the
+        # two implementations may take different sides.  One ray in ~100 cases (tools/fuzz_soak.py over 800 fresh seeds found
+        # 4, each with exactly one such ray at 0.6-4 % of the largest gradient and every other ray within 3e-6): at most ONE
+        # ray may differ, by at most a tenth of the largest gradient; grad_source, the sum over rays, is compared with that
+        # ray's share taken out.
+        h, r = (t.detach().double().cpu() for t in named.pop("grad_target"))
+        per_ray = (h - r).abs().amax(dim=-1)
+        top = r.abs().max()
+        bad = per_ray > GRAD_TOL * top
+        assert int(bad.sum()) <= 1 and float(per_ray.max()) <= 0.1 * float(top), f"grad_target: {int(bad.sum())} rays disagree, worst {float(per_ray.max() / top):.2e} [{what}]"
+        hs, rs = (t.detach().double().cpu() for t in named.pop("grad_source"))
+        assert (hs - rs).abs().max() <= GRAD_TOL * rs.abs().max() + 2.0 * (per_ray * bad).sum(), f"grad_source [{what}]"
     if masked:
         # A sample within an ulp of the midpoint between two voxels can take its label from either (the oracle's
         # coordinate goes through grid_sample's normalise / denormalise round trip): the channel SUM is compared
