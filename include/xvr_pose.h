@@ -35,9 +35,11 @@
 extern "C" {
 #endif
 
+#define XVR_POSE_MAX_PARAMS 13     /* 10 rotation numbers (quaternion adjugate) + 3 of the translation */
+
 /* Per-pose optimiser state, resident in device memory (one element per pose of the batch). */
 typedef struct xvr_pose_opt_state {
-    float m[6], v[6];    /* Adam first / second moments of (r0, r1, r2, tx, ty, tz)                     */
+    float m[XVR_POSE_MAX_PARAMS], v[XVR_POSE_MAX_PARAMS];   /* Adam first / second moments of (rotation parameters, tx, ty, tz) */
     float lr[2];         /* current learning rates (rotation, translation)                               */
     float seen_lr;       /* smallest rotation lr counted so far (the reference's `current_lr`)           */
     int   step;          /* Adam step count                                                              */
@@ -60,7 +62,8 @@ typedef struct xvr_pose_opt_spec {
     int   max_iters;          /* rows per pose in `history`                                              */
 } xvr_pose_opt_spec;
 
-#define XVR_POSE_HISTORY_COLS 9   /* r0 r1 r2 tx ty tz (after the update), loss (before it), lr_rot, lr_xyz (after) */
+#define XVR_POSE_HISTORY_COLS 9   /* Euler: r0 r1 r2 tx ty tz (after the update), loss (before it), lr_rot, lr_xyz (after);
+                                     a parameterisation of k rotation numbers: k + 6 columns, same order                  */
 
 /* rot [B][3], xyz [B][3], G [24][12], c [24] -> cam [B][24] */
 int xvr_pose_camera_forward(const float* rot, const float* xyz, int B, const int axes[3], const float* G,
@@ -70,7 +73,7 @@ int xvr_pose_camera_forward(const float* rot, const float* xyz, int B, const int
 int xvr_pose_camera_backward(const float* rot, const float* xyz, int B, const int axes[3], const float* G,
                              const float* grad_cam, float* grad_rot, float* grad_xyz, void* stream);
 
-/* sizeof(xvr_pose_opt_state) as the library was compiled (88): lets a binding verify its own layout */
+/* sizeof(xvr_pose_opt_state) as the library was compiled (144): lets a binding verify its own layout */
 size_t xvr_pose_opt_state_bytes(void);
 
 /* reset the state of B poses: zero moments, step 0, lr = (lr_rot, lr_xyz), best = -inf */
@@ -86,6 +89,20 @@ int xvr_pose_opt_init(xvr_pose_opt_state* state, int B, float lr_rot, float lr_x
 int xvr_pose_opt_step(float* rot, float* xyz, int B, const xvr_pose_opt_spec* spec, const float* G,
                       float* grad_cam, const float* loss, xvr_pose_opt_state* state, float* history,
                       void* stream);
+
+/*
+ * The same two steps for ANY parameterisation xvr_pose_convert_forward knows (the reference's Registration takes them all,
+ * /root/reference/src/xvr/registrar/base.py:168-169,221-235): `kind` as there, rot [B][k].
+ *   xvr_pose_camera_forward_param   rot, xyz -> cam [B][24] in one launch, and the 12 x (k + 3) Jacobian of the pose matrix
+ *                                   (jac: xvr_pose_convert_jacobian_floats(B) floats) for the step below
+ *   xvr_pose_opt_step_param         g = J^T G^T grad_cam, Adam with lr_rot on the k rotation numbers and lr_xyz on the
+ *                                   translation, scheduler, stopping rule; history rows of k + 6 columns.  kind = 0 ignores jac
+ *                                   and is xvr_pose_opt_step.
+ */
+int xvr_pose_camera_forward_param(const float* rot, const float* xyz, int B, int kind, const int axes[3], const float* G,
+                                  const float* c, float* cam, float* jac, void* stream);
+int xvr_pose_opt_step_param(float* rot, float* xyz, int B, int kind, const xvr_pose_opt_spec* spec, const float* G, const float* jac,
+                            float* grad_cam, const float* loss, xvr_pose_opt_state* state, float* history, void* stream);
 
 /*
  * Pose terms of the training loss (/root/reference/src/xvr/model/loss.py:27-48), which the reference evaluates

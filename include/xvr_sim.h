@@ -72,15 +72,17 @@ int xvr_sim_gaussian_blur5(const float* in, float* out, float* scratch, int B, i
  * Equalize (/root/reference/src/xvr/utils/preprocess.py:34-66): the differentiable soft-histogram equalisation xvr's
  * XrayTransforms applies between Standardize and Normalize when `equalize` is set -- forward and exact backward, per image,
  * without the reference's [pixels x bins] weight matrix, sums in fixed order.
- *   x, y, S, grad_y, grad_x  [B][n]   (x in [0, 1]: the standardised image; S = per-pixel weight sums the backward reuses)
+ *   x, y, S, grad_out, grad_x  [B][n]   (x in [0, 1]: the standardised image; S = per-pixel weight sums the backward reuses)
  *   n_bins in [2, 1024] (256), tau (0.01), eps (1e-10)
+ *   y_out (nullable) = (y - out_mean) / out_std: the Normalize that follows Equalize in XrayTransforms, written in the same
+ *   pass; the backward takes grad_out = the gradient w.r.t. y_out (out_std = 1: w.r.t. y itself)
  *   workspace  xvr_sim_equalize_workspace_bytes(B, n_bins); the backward needs it as the forward left it
  */
 size_t xvr_sim_equalize_workspace_bytes(int B, int n_bins);
-int xvr_sim_equalize_forward(const float* x, int B, int n, int n_bins, float tau, float eps, float* y, float* S,
-                             void* workspace, size_t workspace_bytes, void* stream);
-int xvr_sim_equalize_backward(const float* x, const float* y, const float* S, const float* grad_y, int B, int n, int n_bins,
-                              float tau, float eps, float* grad_x, void* workspace, size_t workspace_bytes, void* stream);
+int xvr_sim_equalize_forward(const float* x, int B, int n, int n_bins, float tau, float eps, float out_mean, float out_std, float* y,
+                             float* S, float* y_out, void* workspace, size_t workspace_bytes, void* stream);
+int xvr_sim_equalize_backward(const float* x, const float* y, const float* S, const float* grad_out, int B, int n, int n_bins,
+                              float tau, float eps, float out_std, float* grad_x, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * XrayTransforms without Equalize and without a Resize -- Standardize then Normalize,
@@ -88,7 +90,8 @@ int xvr_sim_equalize_backward(const float* x, const float* y, const float* S, co
  *   reference's transform, /root/reference/src/xvr/utils/preprocess.py:5-31) or over each image (per_image = 1)
  * -- and its backward, which includes the gradient through lo and hi (torch's rule: shared evenly by the pixels that attain
  * them).  The trainer applies it to both renders of every step (trainer.py:207,216).  `state`: xvr_sim_transform_state_bytes(B)
- * bytes, written by the forward and needed, unchanged, by the backward.  y is bit-identical to the torch expression; the
+ * bytes, written by the forward and needed by the backward, which writes its two sums into it (the forward's min / max / tie
+ * counts stay; the backward may run any number of times over one forward).  y is bit-identical to the torch expression; the
  * backward's two sums are added in a fixed order (doubles).
  */
 size_t xvr_sim_transform_state_bytes(int B);

@@ -61,11 +61,38 @@ def gradient_ncc(x1, x2, patch_size=None, sigma=0.0, eps=1e-5):
     return ncc(sobel(x1), sobel(x2), patch_size, eps)
 
 
-def xray_transforms(x, height, width=None, mean=0.15, std=0.1):
-    """Standardize (global min-max over the whole tensor) -> Resize((h, w)) -> Normalize(mean, std)
-    (src/xvr/utils/preprocess.py:5-31; torchvision's Resize on tensors is antialiased bilinear)."""
+def equalize(x, n_bins=256, tau=0.01, eps=1e-10):
+    """Differentiable (soft-histogram) histogram equalisation of [B, 1, H, W] images in [0, 1], src/xvr/utils/preprocess.py:34-66:
+    Gaussian-kernel histogram over n_bins, its normalised CDF, every pixel mapped to the CDF averaged with its own bin weights.
+    (one image at a time: the [pixels, bins] weight matrix is H * W * n_bins floats)"""
+    B, _, H, W = x.shape
+    bins = torch.linspace(0, 1, n_bins, device=x.device, dtype=x.dtype)[None, None]
+    out = []
+    for b in range(B):
+        diff = x[b].reshape(1, -1, 1) - bins
+        weights = (-diff.square() / (2 * tau**2)).exp()
+        histogram = weights.sum(dim=1)
+        histogram = histogram / (histogram.sum(dim=1, keepdim=True) + eps)
+        cdf = torch.cumsum(histogram, dim=1)
+        cdf_min = cdf[:, 0:1]
+        cdf_normalized = (cdf - cdf_min) / (1 - cdf_min + eps)
+        weights_norm = weights / (weights.sum(dim=-1, keepdim=True) + eps)
+        out.append((weights_norm * cdf_normalized[:, None]).sum(dim=-1).view(1, 1, H, W))
+    return torch.cat(out)
+
+
+def xray_transforms(x, height, width=None, mean=0.15, std=0.1, equalize_=False, per_image=False):
+    """Standardize (global min-max over the whole tensor) -> [Equalize] -> Resize((h, w)) -> Normalize(mean, std)
+    (src/xvr/utils/preprocess.py:5-31; torchvision's Resize on tensors is antialiased bilinear).  per_image: every image by its
+    own min / max (this package's batched multi-start; the same thing for the single image the reference ever passes)."""
     width = height if width is None else width
-    x = (x - x.min()) / (x.max() - x.min() + 1e-6)
+    if per_image:
+        lo, hi = x.amin(dim=(1, 2, 3), keepdim=True), x.amax(dim=(1, 2, 3), keepdim=True)
+        x = (x - lo) / (hi - lo + 1e-6)
+    else:
+        x = (x - x.min()) / (x.max() - x.min() + 1e-6)
+    if equalize_:
+        x = equalize(x)
     if x.shape[-2:] != (height, width):
         x = torch.nn.functional.interpolate(x, size=(height, width), mode="bilinear", antialias=True, align_corners=False)
     return (x - mean) / std

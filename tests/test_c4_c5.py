@@ -19,15 +19,10 @@ pytestmark = pytest.mark.gpu
 
 
 def _reference_keep(img_channels, img_threshold=0.10, mask_threshold=0.05):
-    """The tail of Trainer.render_samples (/root/reference/src/xvr/model/trainer.py:292-302) on a [B,C,H,W] render."""
-    mask = img_channels > 0
-    img = img_channels.sum(dim=1, keepdim=True)
-    if mask.shape[1] == 1:
-        keep = mask.to(img).flatten(1).mean(1) > img_threshold
-    else:
-        keep = mask[:, 1:].sum(dim=1, keepdim=True)
-        keep = (keep > 0).to(img).flatten(1).mean(1) > mask_threshold
-    return img, mask, keep
+    """The tail of Trainer.render_samples (/root/reference/src/xvr/model/trainer.py:292-302): the oracle's restatement."""
+    from oracle.loss_restated import render_samples_tail
+
+    return render_samples_tail(img_channels, img_threshold, mask_threshold)
 
 
 def _c5_miniature():
@@ -244,8 +239,9 @@ def test_fused_foreground_tail_equals_the_reference_formulation(B, C, H, W):
 
 @pytest.mark.parametrize("B,C,hw", [(5, 4, (24, 20)), (3, 8, (64, 64)), (2, 3, (7, 9)), (1, 2, (1, 5))])
 def test_fused_boolean_dice_is_bit_identical_to_the_reference_formulation(B, C, hw):
-    """xvr_sim_dice_bool (integer counts) against the in-tree DiceMetric's float lines (loss.py:5-40): identical float32 values,
-    NaN where a structure is absent from both maps, and the same DiceLoss."""
+    """xvr_sim_dice_bool (integer counts) against the reference's float lines (src/xvr/model/loss.py:54-89, restated in
+    oracle/loss_restated.py): identical float32 values, NaN where a structure is absent from both maps, and the same DiceLoss."""
+    from oracle import loss_restated as oloss
     from xvr_amd.loss import DiceLoss, DiceMetric
 
     g = torch.Generator().manual_seed(B + 10 * C)
@@ -257,16 +253,15 @@ def test_fused_boolean_dice_is_bit_identical_to_the_reference_formulation(B, C, 
     a, b = a.cuda(), b.cuda()
     fused = DiceMetric()(a, b)
     loss_fused = DiceLoss()(a, b)
-    try:
-        DiceMetric.FUSED = False
-        ref = DiceMetric()(a, b)
-        loss_ref = DiceLoss()(a, b)
-    finally:
-        DiceMetric.FUSED = True
+    ref = oloss.dice_metric(a.float(), b.float())
+    loss_ref = oloss.dice_loss(a.float(), b.float())
     assert fused.shape == ref.shape == (B, C - 1)
     assert torch.equal(torch.isnan(fused), torch.isnan(ref)) and torch.isnan(ref).any()
     assert torch.equal(fused.nan_to_num(-1.0), ref.nan_to_num(-1.0))
     assert torch.equal(loss_fused, loss_ref)
     # a view that is not 16-byte aligned takes the byte loop
     assert torch.equal(DiceMetric()(a[:, :, :, 1:], b[:, :, :, 1:]).nan_to_num(-1.0),
-                       DiceMetric()(a[:, :, :, 1:].float(), b[:, :, :, 1:].float()).nan_to_num(-1.0))
+                       oloss.dice_metric(a[:, :, :, 1:].float(), b[:, :, :, 1:].float()).nan_to_num(-1.0))
+    # every sample dropped by `keep` (trainer.step): an empty batch gives an empty result, as the torch lines do
+    empty = DiceMetric()(a[:0], b[:0])
+    assert empty.shape == (0, C - 1) and DiceLoss()(a[:0], b[:0]).shape == (0,)

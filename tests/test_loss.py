@@ -1,35 +1,85 @@
+import pytest
 import torch
 
-from xvr_amd.loss import DiceLoss, DiceMetric, PoseRegressionLoss
+from oracle import loss_restated as oloss
 from xvr_amd.pose import convert
 
 
-def test_dice_metric_excludes_background_and_handles_empty_structures():
+def test_oracle_dice_excludes_background_and_handles_empty_structures():
+    """The checker itself (oracle/loss_restated.py, restating src/xvr/model/loss.py:54-89) on a hand-made case."""
     a = torch.zeros(2, 3, 4, 4)
     b = torch.zeros(2, 3, 4, 4)
     a[0, 1, :2] = 1
     b[0, 1, :2] = 1            # perfect overlap on structure 1, structure 2 empty in both -> nan -> ignored
     a[1, 2, :, :2] = 1
     b[1, 2, :, 1:3] = 1        # half overlap
-    d = DiceMetric()(a, b)
+    d = oloss.dice_metric(a, b)
     assert d.shape == (2, 2) and d[0, 0] == 1 and torch.isnan(d[0, 1])
     assert abs(d[1, 1].item() - 0.5) < 1e-6
-    loss = DiceLoss()(a, b)
+    loss = oloss.dice_loss(a, b)
     assert abs(loss[0].item()) < 1e-6 and abs(loss[1].item() - 0.5) < 1e-6
 
 
-def test_pose_regression_loss_is_zero_at_the_truth_and_differentiable():
+def _loss_case():
     g = torch.Generator().manual_seed(0)
     img = torch.rand(3, 1, 24, 24, generator=g)
     mask = (torch.rand(3, 3, 24, 24, generator=g) > 0.5)
     rot = (torch.rand(3, 3, generator=g) - 0.5)
     xyz = torch.tensor([[0.0, 700.0, 0.0]]).repeat(3, 1) + torch.rand(3, 3, generator=g) * 20
-    pose = convert(rot, xyz, parameterization="euler_angles", convention="ZXY")
-    lossfn = PoseRegressionLoss(1020.0)
-    loss, mncc, dgeo, *_ = lossfn(img, mask, pose, img, mask, pose)
+    noise = torch.rand(3, 1, 24, 24, generator=g)
+    return img, mask, rot, xyz, noise
+
+
+def test_oracle_pose_regression_loss_is_zero_at_the_truth_and_differentiable():
+    img, mask, rot, xyz, noise = _loss_case()
+    pose = convert(rot, xyz, parameterization="euler_angles", convention="ZXY").matrix
+    loss, mncc, dgeo, *_ = oloss.pose_regression_loss(img, mask.float(), pose, img, mask.float(), pose, 1020.0)
     assert torch.allclose(mncc, torch.ones(3), atol=1e-3) and loss.abs().max() < 2e-2
     r2 = (rot + 0.05).requires_grad_(True)
-    pred = convert(r2, xyz + 5.0, parameterization="euler_angles", convention="ZXY")
-    loss2, *_ = lossfn(img, mask, pose, img * 0.9 + 0.05 * torch.rand(3, 1, 24, 24, generator=g), mask, pred)
+    pred = convert(r2, xyz + 5.0, parameterization="euler_angles", convention="ZXY").matrix
+    loss2, *_ = oloss.pose_regression_loss(img, mask.float(), pose, img * 0.9 + 0.05 * noise, mask.float(), pred, 1020.0)
     loss2.mean().backward()
     assert (loss2 > loss).all() and torch.isfinite(r2.grad).all() and r2.grad.abs().sum() > 0
+
+
+def test_product_loss_has_no_cpu_path():
+    """DiceMetric / PoseRegressionLoss / Equalize / render_samples' tail are HIP entry points: CPU tensors raise."""
+    from xvr_amd.loss import DiceMetric, PoseRegressionLoss
+    from xvr_amd.metrics import Equalize
+
+    img, mask, rot, xyz, _ = _loss_case()
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        DiceMetric()(mask, mask)
+    pose = convert(rot, xyz, parameterization="euler_angles", convention="ZXY")
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        PoseRegressionLoss(1020.0)(img, mask, pose, img, mask, pose)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        Equalize()(img)
+
+
+@pytest.mark.gpu
+def test_pose_regression_loss_matches_the_oracle_value_and_gradient():
+    """xvr_amd.loss.PoseRegressionLoss (fused mNCC, boolean Dice, one launch each for the geodesics and the multiview term)
+    against the torch restatement of the reference's loss.py, value of every returned term and d loss / d (rot, xyz, image)."""
+    from xvr_amd.loss import PoseRegressionLoss
+
+    img, mask, rot, xyz, noise = _loss_case()
+    pose = convert(rot, xyz, parameterization="euler_angles", convention="ZXY")
+    pred_img = img * 0.9 + 0.05 * noise
+    pred_mask = mask.roll(1, dims=-1)
+    outs = {}
+    for dev in ("cuda", "cpu"):
+        r2 = (rot + 0.05).to(dev).requires_grad_(True)
+        pi = pred_img.to(dev).requires_grad_(True)
+        pred = convert(r2, (xyz + 5.0).to(dev), parameterization="euler_angles", convention="ZXY")
+        if dev == "cuda":
+            res = PoseRegressionLoss(1020.0)(img.cuda(), mask.cuda(), convert(rot.cuda(), xyz.cuda(), parameterization="euler_angles", convention="ZXY"),
+                                             pi, pred_mask.cuda(), pred)
+        else:
+            res = oloss.pose_regression_loss(img, mask.float(), pose.matrix, pi, pred_mask.float(), pred.matrix, 1020.0)
+        res[0].mean().backward()
+        outs[dev] = ([t.detach().cpu() for t in res], r2.grad.cpu(), pi.grad.cpu())
+    for a, b, name in zip(outs["cuda"][0], outs["cpu"][0], ("loss", "mncc", "dgeo", "rgeo", "tgeo", "dice", "mvc")):
+        assert torch.allclose(a, b, rtol=2e-4, atol=2e-4), (name, a, b)
+    assert torch.allclose(outs["cuda"][1], outs["cpu"][1], rtol=2e-3, atol=1e-4)
+    assert (outs["cuda"][2] - outs["cpu"][2]).abs().max() <= 2e-3 * outs["cpu"][2].abs().max()

@@ -45,13 +45,23 @@ def test_ncc_of_identical_images_is_one_and_of_negated_is_minus_one():
     assert torch.allclose(m(x1, 2.5 * x1 + 0.7), torch.ones(2), atol=1e-3)  # affine invariance
 
 
-def test_xray_transforms_match_reference_lines():
+@pytest.mark.gpu
+@pytest.mark.parametrize("equalize", [False, True])
+def test_xray_transforms_match_reference_lines(equalize):
+    """XrayTransforms (HIP Standardize / Equalize / Normalize around torch's Resize) against the oracle's torch lines."""
     g = torch.Generator().manual_seed(3)
     x = torch.rand(1, 1, 64, 64, generator=g) * 900
-    t = metrics.XrayTransforms(16)
-    assert torch.allclose(t(x), ref.xray_transforms(x, 16), atol=1e-6)
-    same = metrics.XrayTransforms(64)(x)
-    assert torch.allclose(same, ((x - x.min()) / (x.max() - x.min() + 1e-6) - 0.15) / 0.1)
+    t = metrics.XrayTransforms(16, equalize=equalize)
+    assert torch.allclose(t(x.cuda()).cpu(), ref.xray_transforms(x, 16, equalize_=equalize), atol=2e-5)
+    same = metrics.XrayTransforms(64, equalize=equalize)(x.cuda()).cpu()
+    assert torch.allclose(same, ref.xray_transforms(x, 64, equalize_=equalize), atol=2e-5)
+    if not equalize:
+        assert torch.equal(same, ((x - x.min()) / (x.max() - x.min() + 1e-6) - 0.15) / 0.1)
+
+
+def test_xray_transforms_have_no_cpu_path():
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        metrics.XrayTransforms(16)(torch.rand(1, 1, 16, 16))
 
 
 def test_double_geodesic():
@@ -65,14 +75,13 @@ def test_double_geodesic():
     assert abs(dbl.item() - (ang.item() ** 2 + tr.item() ** 2) ** 0.5) < 1e-3
 
 
-def test_equalize_matches_reference_lines_and_flattens_the_histogram():
-    """Line-by-line restatement of src/xvr/utils/preprocess.py:34-66, checked against its own definition."""
+def test_oracle_equalize_matches_its_definition_and_flattens_the_histogram():
+    """oracle/metrics_restated.py::equalize (src/xvr/utils/preprocess.py:34-66, one image at a time) against the same formula
+    vectorised over the batch; the HIP kernels are held to it in tests/test_pose_opt.py."""
     g = torch.Generator().manual_seed(5)
     x = torch.rand(2, 1, 24, 20, generator=g) ** 3  # skewed towards 0
-    eq = metrics.Equalize(n_bins=64, tau=0.02)
-    y = eq(x)
+    y = ref.equalize(x, n_bins=64, tau=0.02)
     assert y.shape == x.shape and y.min() >= -1e-6 and y.max() <= 1 + 1e-6
-    # reference formula, vectorised over the batch
     B = 2
     bins = torch.linspace(0, 1, 64)[None, None]
     diff = x.view(B, -1, 1) - bins
@@ -81,12 +90,11 @@ def test_equalize_matches_reference_lines_and_flattens_the_histogram():
     hist = hist / (hist.sum(dim=1, keepdim=True) + 1e-10)
     cdf = torch.cumsum(hist, dim=1)
     cdfn = (cdf - cdf[:, 0:1]) / (1 - cdf[:, 0:1] + 1e-10)
-    ref = ((w / (w.sum(dim=-1, keepdim=True) + 1e-10)) * cdfn[:, None]).sum(dim=-1).view(B, 1, 24, 20)
-    assert torch.allclose(y, ref, atol=1e-6)
+    want = ((w / (w.sum(dim=-1, keepdim=True) + 1e-10)) * cdfn[:, None]).sum(dim=-1).view(B, 1, 24, 20)
+    assert torch.allclose(y, want, atol=1e-6)
     # equalisation spreads the values: the median moves towards 0.5
     assert abs(y.median().item() - 0.5) < abs(x.median().item() - 0.5)
-    t = metrics.XrayTransforms(24, 20, equalize=True)
-    assert torch.isfinite(t(x * 100)).all()
+    assert torch.isfinite(ref.xray_transforms(x * 100, 24, 20, equalize_=True)).all()
 
 
 @pytest.mark.gpu
@@ -104,25 +112,44 @@ def test_fused_standardize_normalize_equals_the_torch_lines(shape, per_image):
     x[0, 0, 1, 1] = x[0, 0, 2, 2] = 9.0       # two tie for the batch's maximum
     w = torch.randn(*shape, generator=g)
     tf = XrayTransforms(shape[2], shape[3], per_image=per_image)
-    res = []
-    for fused in (True, False):
-        XrayTransforms.FUSED = fused
-        try:
-            xx = x.clone().cuda().requires_grad_()
-            y = tf(xx)
-            (y * w.cuda()).sum().backward()
-            res.append((y.detach().cpu(), xx.grad.cpu()))
-        finally:
-            XrayTransforms.FUSED = True
-    (y1, g1), (y0, g0) = res
+    xx = x.clone().cuda().requires_grad_()
+    y = tf(xx)
+    (y * w.cuda()).sum().backward()
+    y1, g1 = y.detach().cpu(), xx.grad.cpu()
+    xo = x.clone().cuda().requires_grad_()       # the oracle's torch lines on the same device
+    yo = ref.xray_transforms(xo, shape[2], shape[3], per_image=per_image)
+    (yo * w.cuda()).sum().backward()
+    y0, g0 = yo.detach().cpu(), xo.grad.cpu()
     assert torch.equal(y1, y0)
     scale = g0.abs().max()
     assert (g1 - g0).abs().max() <= 2e-5 * scale, ((g1 - g0).abs().max(), scale)
     # float64 autograd on the CPU: the fused backward is at least as close to it as the float32 torch chain
     xd = x.double().requires_grad_()
-    XrayTransforms.FUSED = False
-    try:
-        (tf(xd) * w.double()).sum().backward()
-    finally:
-        XrayTransforms.FUSED = True
+    (ref.xray_transforms(xd, shape[2], shape[3], per_image=per_image) * w.double()).sum().backward()
     assert (g1.double() - xd.grad).abs().max() <= 2.0 * (g0.double() - xd.grad).abs().max() + 1e-6 * scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("per_image", [False, True])
+def test_fused_standardize_normalize_backward_runs_twice(per_image):
+    """retain_graph / autograd.grad called twice: the second backward over the same forward state must give the gradient of ITS
+    grad_output (the deterministic reduction's ticket counter was only reset by the forward)."""
+    from xvr_amd.metrics import XrayTransforms
+
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(4, 1, 32, 28, generator=g) * 2.0 + 0.1
+    x[:, :, 0, :2] = 0.0
+    w1, w2 = torch.randn(4, 1, 32, 28, generator=g), torch.randn(4, 1, 32, 28, generator=g)
+    tf = XrayTransforms(32, 28, per_image=per_image)
+    res = {}
+    for fused in (True, False):
+        xx = x.clone().cuda().requires_grad_()
+        y = tf(xx) if fused else ref.xray_transforms(xx, 32, 28, per_image=per_image)
+        ga, = torch.autograd.grad(y, xx, w1.cuda(), retain_graph=True)
+        gb, = torch.autograd.grad(y, xx, w2.cuda(), retain_graph=True)
+        gc, = torch.autograd.grad(y, xx, w1.cuda())
+        res[fused] = (ga.cpu(), gb.cpu(), gc.cpu())
+    for a, b in zip(res[True], res[False]):
+        assert (a - b).abs().max() <= 2e-5 * b.abs().max()
+    assert torch.equal(res[True][0], res[True][2])      # the same grad_output twice: the same bits
+    assert (res[True][0] - res[True][1]).abs().max() > 1e-3

@@ -31,7 +31,7 @@ def test_camera_is_affine_in_the_pose_matrix():
 
 def test_state_layout_matches_header():
     from xvr_amd.pose_opt import STATE_DTYPE
-    assert ctypes.sizeof(_lib.CPoseOptState) == STATE_DTYPE.itemsize == 88
+    assert ctypes.sizeof(_lib.CPoseOptState) == STATE_DTYPE.itemsize == 144
     for name, _ in _lib.CPoseOptState._fields_:
         assert getattr(_lib.CPoseOptState, name).offset == STATE_DTYPE.fields[name][1], name
 
@@ -275,9 +275,10 @@ def test_fused_similarity_per_image_equals_one_image_at_a_time(shape):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("B", [2, 7, 40])
-def test_fused_pose_loss_terms_match_torch(B, monkeypatch):
+def test_fused_pose_loss_terms_match_torch(B):
     """Double geodesic and multiview consistency of the training loss (xvr_pose_geodesic, xvr_pose_multiview_*)
-    against the torch formulation in xvr_amd.metrics / xvr_amd.loss: values and gradients w.r.t. the predicted pose."""
+    against the torch restatement of the reference's loss (oracle/loss_restated.py): values and gradients w.r.t. the predicted pose."""
+    from oracle import loss_restated as oloss
     from xvr_amd import loss as loss_mod
     from xvr_amd.training import get_random_pose
 
@@ -286,14 +287,17 @@ def test_fused_pose_loss_terms_match_torch(B, monkeypatch):
     rot, xyz = true.convert("euler_angles", "ZXY")
     res = {}
     for fused in (True, False):
-        monkeypatch.setattr(loss_mod.PoseRegressionLoss, "FUSED", fused)
         r = (rot + 0.05 * torch.randn(B, 3, generator=torch.Generator().manual_seed(1)).cuda()).requires_grad_()
         t = (xyz + 4.0 * torch.randn(B, 3, generator=torch.Generator().manual_seed(2)).cuda()).requires_grad_()
         pred = convert(r, t, parameterization="euler_angles", convention="ZXY")
-        L = loss_mod.PoseRegressionLoss(1020.0, weight_mvc=0.5).cuda()
         img = torch.rand(B, 1, 32, 32, generator=torch.Generator().manual_seed(3)).cuda()
         mask = torch.rand(B, 3, 32, 32, generator=torch.Generator().manual_seed(4)).cuda() > 0.5
-        loss, mncc, dgeo, rgeo, tgeo, dice, mvc = L(img, mask, true, img * 0.9 + 0.01, mask, pred)
+        if fused:
+            L = loss_mod.PoseRegressionLoss(1020.0, weight_mvc=0.5).cuda()
+            loss, mncc, dgeo, rgeo, tgeo, dice, mvc = L(img, mask, true, img * 0.9 + 0.01, mask, pred)
+        else:
+            loss, mncc, dgeo, rgeo, tgeo, dice, mvc = oloss.pose_regression_loss(img, mask.float(), true.matrix, img * 0.9 + 0.01, mask.float(),
+                                                                                 pred.matrix, 1020.0, weight_mvc=0.5)
         loss.mean().backward()
         res[fused] = (loss.detach(), dgeo.detach(), rgeo.detach(), tgeo.detach(), mvc.detach(), r.grad.clone(), t.grad.clone())
     names = ("loss", "dgeo", "rgeo", "tgeo", "mvc", "d/drot", "d/dxyz")
@@ -303,7 +307,6 @@ def test_fused_pose_loss_terms_match_torch(B, monkeypatch):
     # identical poses: zero distance, finite (zero) gradient
     r = rot.clone().requires_grad_()
     pred = convert(r, xyz, parameterization="euler_angles", convention="ZXY")
-    monkeypatch.setattr(loss_mod.PoseRegressionLoss, "FUSED", True)
     L = loss_mod.PoseRegressionLoss(1020.0)
     mv = L.multiview_consistency(true, pred)
     mv.sum().backward()
@@ -565,10 +568,11 @@ def test_device_loop_and_run_batch_take_every_similarity_configuration(kw):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(1, 40, 36), (3, 64, 64), (2, 17, 129)])
-def test_equalize_hip_matches_the_torch_formulation_value_and_gradient(shape, monkeypatch):
+def test_equalize_hip_matches_the_torch_formulation_value_and_gradient(shape):
     """xvr_sim_equalize_forward / _backward against the line-by-line torch restatement of the reference's Equalize
     (/root/reference/src/xvr/utils/preprocess.py:34-66, [pixels x bins] weight matrix and autograd), incl. an image with
     large flat regions (many pixels on the same value, as a standardised DRR has)."""
+    from oracle import metrics_restated as mref
     from xvr_amd import metrics, renderers
 
     B, H, W = shape
@@ -584,9 +588,8 @@ def test_equalize_hip_matches_the_torch_formulation_value_and_gradient(shape, mo
     assert "equalize_forward" in {e[0] for e in renderers.PROFILER}
     renderers.PROFILER = None
     (out * w.cuda()).sum().backward()
-    monkeypatch.setattr(metrics.Equalize, "FUSED", False)
     xr = x.cuda().double().requires_grad_(True)      # the reference formulation in float64 on the same device
-    ref = eq(xr)
+    ref = mref.equalize(xr)
     (ref * w.cuda().double()).sum().backward()
     assert torch.allclose(out.double(), ref.detach(), atol=2e-5), (out.double() - ref).abs().max()
     err = (xh.grad.double() - xr.grad).abs().max() / xr.grad.abs().max()

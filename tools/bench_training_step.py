@@ -61,22 +61,17 @@ def step():
 
 import time  # noqa: E402
 
-import xvr_amd.training as _training  # noqa: E402
-
-for fused in (True, False):   # the tail of render_samples: one HIP pass (xvr_drr_foreground) | the reference's torch lines
-    _training.FUSED_FOREGROUND = fused
-    g.manual_seed(0)
-    for _ in range(3):
-        step()
-    marks.clear()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    n = 5
-    for _ in range(n):
-        step()
-    torch.cuda.synchronize()
-    total = (time.perf_counter() - t0) / n * 1e3
-    print(f"training step (render side), {size}^3 -> {H}^2, batch {B}, 8 labels, "
-          f"{'fused mask / sum / keep' if fused else 'torch mask / sum / keep'}: {total:.2f} ms")
-    for k, v in marks.items():
-        print(f"  {k:38s} {sum(a.elapsed_time(b) for a, b in v) / len(v):7.2f} ms")
+g.manual_seed(0)
+for _ in range(3):
+    step()
+marks.clear()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+n = 5
+for _ in range(n):
+    step()
+torch.cuda.synchronize()
+total = (time.perf_counter() - t0) / n * 1e3
+print(f"training step (render side), {size}^3 -> {H}^2, batch {B}, 8 labels: {total:.2f} ms")
+for k, v in marks.items():
+    print(f"  {k:38s} {sum(a.elapsed_time(b) for a, b in v) / len(v):7.2f} ms")

@@ -27,6 +27,14 @@ def one(mode):
     rot, xyz = (t.to(dev) for t in deepfluoro_poses(B, seed=0).convert("euler_angles", "ZXY"))
     if "samepose" in mode:
         rot, xyz = rot[:1].expand(B, 3).contiguous(), xyz[:1].expand(B, 3).contiguous()
+    if "sortyaw" in mode:     # poses ordered by view direction: neighbours in the launch look along neighbouring directions
+        order = torch.argsort(rot[:, 0])
+        rot, xyz = rot[order].contiguous(), xyz[order].contiguous()
+    if "sortdir" in mode:     # ... by yaw in 4 bands, by pitch within a band (a snake through the two angles)
+        band = torch.clamp(((rot[:, 0] - rot[:, 0].min()) / (rot[:, 0].max() - rot[:, 0].min() + 1e-6) * 4).long(), max=3)
+        key = band.double() * 10 + torch.where(band % 2 == 0, rot[:, 1], -rot[:, 1]).double()
+        order = torch.argsort(key)
+        rot, xyz = rot[order].contiguous(), xyz[order].contiguous()
     if "natural" in mode:
         renderers.YPAIR_LAYOUT = False
     vol, _ = make_phantom(512, n_ellipsoids=64, seed=0, device=dev)
@@ -53,6 +61,23 @@ def one(mode):
 if __name__ == "__main__":
     if sys.argv[1] == "one":
         one(sys.argv[2])
+    elif sys.argv[1] == "tiles":   # round 4: workgroup tile geometry (option tile_geom) and the order of the poses in the launch
+        for name, mode, env in [("16x16 tiles (default)", "default", {"XVR_DRR_TILE_GEOM": "0"}),
+                                ("8x32 tiles, long along z", "default", {"XVR_DRR_TILE_GEOM": "1"}),
+                                ("4x64 tiles, long along z", "default", {"XVR_DRR_TILE_GEOM": "2"}),
+                                ("16x16, poses sorted by yaw", "sortyaw", {"XVR_DRR_TILE_GEOM": "0"}),
+                                ("16x16, poses sorted yaw band / pitch", "sortdir", {"XVR_DRR_TILE_GEOM": "0"}),
+                                ("8x32, poses sorted by yaw", "sortyaw", {"XVR_DRR_TILE_GEOM": "1"}),
+                                ("8x32, natural layout", "natural", {"XVR_DRR_TILE_GEOM": "1"}),
+                                ("4x64, natural layout", "natural", {"XVR_DRR_TILE_GEOM": "2"}),
+                                ("8x32, no jacobian", "nojac", {"XVR_DRR_TILE_GEOM": "1"}),
+                                ("16x16, no jacobian", "nojac", {"XVR_DRR_TILE_GEOM": "0"})]:
+            out = subprocess.run([sys.executable, __file__, "one", mode], env=dict(os.environ, XVR_DRR_FWD_SLABS="0", **env), capture_output=True, text=True)
+            try:
+                d = json.loads(out.stdout.strip().splitlines()[-1])
+                print(f"{name:40s} forward {d['ms']:.3f} ms (min {d['min_ms']:.3f})  sha {d['sha']}", flush=True)
+            except (IndexError, ValueError):
+                print(f"{name}: FAILED\n{out.stderr[-2000:]}", flush=True)
     else:
         runs = [("one launch", "default", {"XVR_DRR_FWD_SLABS": "0"}), ("one launch, natural layout", "natural", {"XVR_DRR_FWD_SLABS": "0"}),
                 ("one launch, 116 x one pose", "samepose", {"XVR_DRR_FWD_SLABS": "0"}),

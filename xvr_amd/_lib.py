@@ -11,7 +11,7 @@ import warnings
 
 from .build import LIB, HipccMissing, build_library, is_stale
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 JAC_STRIDE = 8
 ALPHA_WINDOW_FLOATS = 16   # XVR_DRR_ALPHA_WINDOW_FLOATS
 
@@ -67,8 +67,8 @@ class CPoseOptSpec(ctypes.Structure):   # include/xvr_pose.h: xvr_pose_opt_spec
 
 class CPoseOptState(ctypes.Structure):  # include/xvr_pose.h: xvr_pose_opt_state (device resident)
     _fields_ = [
-        ("m", ctypes.c_float * 6),
-        ("v", ctypes.c_float * 6),
+        ("m", ctypes.c_float * 13),   # XVR_POSE_MAX_PARAMS
+        ("v", ctypes.c_float * 13),
         ("lr", ctypes.c_float * 2),
         ("seen_lr", ctypes.c_float),
         ("step", ctypes.c_int),
@@ -106,8 +106,10 @@ EXPORTS = {
     "xvr_sim_workspace_bytes": ([_I, _I, _I], ctypes.c_size_t),
     "xvr_sim_ncc_forward_backward": ([_P, _P, _P, _I, _I, _I, ctypes.POINTER(CSimSpec), _P, _P, _P, ctypes.c_size_t, _P], ctypes.c_int),
     "xvr_sim_equalize_workspace_bytes": ([_I, _I], ctypes.c_size_t),
-    "xvr_sim_equalize_forward": ([_P, _I, _I, _I, ctypes.c_float, ctypes.c_float, _P, _P, _P, ctypes.c_size_t, _P], ctypes.c_int),
-    "xvr_sim_equalize_backward": ([_P, _P, _P, _P, _I, _I, _I, ctypes.c_float, ctypes.c_float, _P, _P, ctypes.c_size_t, _P], ctypes.c_int),
+    "xvr_sim_equalize_forward": ([_P, _I, _I, _I, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _P, _P, _P, _P, ctypes.c_size_t, _P],
+                                 ctypes.c_int),
+    "xvr_sim_equalize_backward": ([_P, _P, _P, _P, _I, _I, _I, ctypes.c_float, ctypes.c_float, ctypes.c_float, _P, _P, ctypes.c_size_t, _P],
+                                  ctypes.c_int),
     "xvr_sim_transform_state_bytes": ([_I], ctypes.c_size_t),
     "xvr_sim_transform_forward": ([_P, _I, ctypes.c_longlong, _I, ctypes.c_float, ctypes.c_float, ctypes.c_float, _P, _P, _P], ctypes.c_int),
     "xvr_sim_transform_backward": ([_P, _P, _I, ctypes.c_longlong, _I, ctypes.c_float, ctypes.c_float, ctypes.c_float, _P, _P, _P], ctypes.c_int),
@@ -139,6 +141,8 @@ EXPORTS = {
     "xvr_pose_opt_state_bytes": ([], ctypes.c_size_t),
     "xvr_pose_opt_init": ([_P, _I, ctypes.c_float, ctypes.c_float, _P], ctypes.c_int),
     "xvr_pose_opt_step": ([_P, _P, _I, ctypes.POINTER(CPoseOptSpec), _P, _P, _P, _P, _P, _P], ctypes.c_int),
+    "xvr_pose_camera_forward_param": ([_P, _P, _I, _I, _AX, _P, _P, _P, _P, _P], ctypes.c_int),
+    "xvr_pose_opt_step_param": ([_P, _P, _I, _I, ctypes.POINTER(CPoseOptSpec), _P, _P, _P, _P, _P, _P, _P], ctypes.c_int),
 }
 
 _lib = None

@@ -133,7 +133,7 @@ __global__ void k_pose_opt_init(xvr_pose_opt_state* st, int B, float lr_rot, flo
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     xvr_pose_opt_state s;
-    for (int i = 0; i < 6; ++i) s.m[i] = s.v[i] = 0.f;
+    for (int i = 0; i < XVR_POSE_MAX_PARAMS; ++i) s.m[i] = s.v[i] = 0.f;
     s.lr[0] = lr_rot;
     s.lr[1] = lr_xyz;
     s.seen_lr = INFINITY;
@@ -142,18 +142,34 @@ __global__ void k_pose_opt_init(xvr_pose_opt_state* st, int B, float lr_rot, flo
     st[b] = s;
 }
 
-__global__ __launch_bounds__(64) void k_pose_opt_step(float* __restrict__ rot, float* __restrict__ xyz, int B, xvr_pose_opt_spec sp,
-                                const float* __restrict__ G, float* __restrict__ g_cam, const float* __restrict__ loss,
-                                xvr_pose_opt_state* __restrict__ state, float* __restrict__ history) {
+// KIND 0: Euler angles, chain rule in closed form (pose_chain).  Any other parameterisation (xvr_pose_convert_forward's kinds): the
+// 12 x (k + 3) Jacobian the forward of THIS iteration stored (k_pose_camera_param) -- g = J^T G^T g_cam; the first k parameters
+// are the rotation group (lr[0]), the last three the translation (lr[1]), as the reference's two Adam groups
+// (/root/reference/src/xvr/registrar/base.py:221-228).
+constexpr int CV_MAXN = XVR_POSE_MAX_PARAMS;
+__global__ __launch_bounds__(64) void k_pose_opt_step(float* __restrict__ rot, float* __restrict__ xyz, int B, xvr_pose_opt_spec sp, int kind, int k,
+                                const float* __restrict__ G, const float* __restrict__ jac, float* __restrict__ g_cam,
+                                const float* __restrict__ loss, xvr_pose_opt_state* __restrict__ state, float* __restrict__ history) {
     const int b = blockIdx.x;   // one wavefront per pose; every lane carries the scalars, lane 0 writes
     float gm[12];
     wave_gt_g(G, g_cam + (size_t)b * 24, true, gm);   // consumed: the next rays-backward accumulates from zero
     xvr_pose_opt_state s = state[b];
     if (s.done) return;
-    Axes ax = {{sp.axes[0], sp.axes[1], sp.axes[2]}};
-    float p[6] = {rot[b * 3], rot[b * 3 + 1], rot[b * 3 + 2], xyz[b * 3], xyz[b * 3 + 1], xyz[b * 3 + 2]};
-    float g[6];
-    pose_chain(ax, p, p + 3, gm, g, g + 3);
+    const int n = k + 3;
+    float p[CV_MAXN], g[CV_MAXN];
+    for (int i = 0; i < k; ++i) p[i] = rot[(size_t)b * k + i];
+    for (int i = 0; i < 3; ++i) p[k + i] = xyz[b * 3 + i];
+    if (kind == 0) {
+        Axes ax = {{sp.axes[0], sp.axes[1], sp.axes[2]}};
+        pose_chain(ax, p, p + 3, gm, g, g + 3);
+    } else {
+        const float* J = jac + (size_t)b * 12 * CV_MAXN;
+        for (int d = 0; d < n; ++d) {
+            float acc = 0.f;
+            for (int e = 0; e < 12; ++e) acc = fmaf(J[e * CV_MAXN + d], gm[e], acc);
+            g[d] = acc;
+        }
+    }
     if (threadIdx.x != 0) return;   // (after the loads above: every lane read the same, unmodified state)
 
     // Adam, in the operation order of torch.optim.Adam(capturable=True)
@@ -161,18 +177,16 @@ __global__ __launch_bounds__(64) void k_pose_opt_step(float* __restrict__ rot, f
     const float stepf = (float)s.step;
     const float bc1 = 1.f - powf(sp.beta1, stepf);
     const float bc2_sqrt = sqrtf(1.f - powf(sp.beta2, stepf));
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < n; ++i) {
         const float gi = sp.maximize ? -g[i] : g[i];
         s.m[i] = s.m[i] + (gi - s.m[i]) * (1.f - sp.beta1);                 // lerp_
         s.v[i] = fmaf(gi * gi, 1.f - sp.beta2, s.v[i] * sp.beta2);         // mul_().addcmul_()
-        const float step_size_neg = -(s.lr[i / 3] / bc1);
+        const float step_size_neg = -(s.lr[i < k ? 0 : 1] / bc1);
         const float denom = sqrtf(s.v[i]) / (bc2_sqrt * step_size_neg) + sp.eps / step_size_neg;
         p[i] += s.m[i] / denom;                                            // addcdiv_
     }
-    for (int i = 0; i < 3; ++i) {
-        rot[b * 3 + i] = p[i];
-        xyz[b * 3 + i] = p[3 + i];
-    }
+    for (int i = 0; i < k; ++i) rot[(size_t)b * k + i] = p[i];
+    for (int i = 0; i < 3; ++i) xyz[b * 3 + i] = p[k + i];
 
     // ReduceLROnPlateau(mode="max", threshold_mode="rel", cooldown=0, min_lr=0), in double like the host version
     const double cur = (double)loss[b];
@@ -183,10 +197,10 @@ __global__ __launch_bounds__(64) void k_pose_opt_step(float* __restrict__ rot, f
         s.n_bad += 1;
     }
     if (s.n_bad > sp.patience) {
-        for (int k = 0; k < 2; ++k) {
-            const double old_lr = (double)s.lr[k];
+        for (int q = 0; q < 2; ++q) {
+            const double old_lr = (double)s.lr[q];
             const double new_lr = fmax(old_lr * (double)sp.factor, 0.0);
-            if (old_lr - new_lr > sp.lr_eps) s.lr[k] = (float)new_lr;
+            if (old_lr - new_lr > sp.lr_eps) s.lr[q] = (float)new_lr;
         }
         s.n_bad = 0;
     }
@@ -197,11 +211,11 @@ __global__ __launch_bounds__(64) void k_pose_opt_step(float* __restrict__ rot, f
     }
     if (s.n_plateaus == sp.max_n_plateaus) s.done = 1;
     if (history && s.iter < sp.max_iters) {
-        float* h = history + ((size_t)b * sp.max_iters + s.iter) * XVR_POSE_HISTORY_COLS;
-        for (int i = 0; i < 6; ++i) h[i] = p[i];
-        h[6] = loss[b];
-        h[7] = s.lr[0];
-        h[8] = s.lr[1];
+        float* h = history + ((size_t)b * sp.max_iters + s.iter) * (n + 3);
+        for (int i = 0; i < n; ++i) h[i] = p[i];
+        h[n] = loss[b];
+        h[n + 1] = s.lr[0];
+        h[n + 2] = s.lr[1];
     }
     s.iter += 1;
     state[b] = s;
@@ -358,7 +372,6 @@ int launched(const char* what) {
 //        3 quaternion_adjugate (10 numbers)   4 rotation_6d   5 se3_log_map
 // The formulas are xvr_amd/pose.py's (the PyTorch3D heritage diffdrr shares), branch for branch.
 // ---------------------------------------------------------------------------------------------
-constexpr int CV_MAXN = 13;
 struct Dual {
     float v;
     float d[CV_MAXN];
@@ -413,12 +426,10 @@ __device__ inline void rodrigues(const Dual* w, const Dual& a, const Dual& b, Du
     R[6] = b * xz - a * y;       R[7] = b * yz + a * x;       R[8] = 1.f - b * (xx + yy);
 }
 
-__global__ __launch_bounds__(64) void k_pose_convert_fwd(const float* __restrict__ rot, const float* __restrict__ xyz, int B, int kind, int k,
-                                                         Axes ax, float* __restrict__ matrix, float* __restrict__ jac) {
-    const int p = blockIdx.x * 64 + threadIdx.x;
-    if (p >= B) return;
-    const int n = k + 3;
-    Dual r[10], t[3], R[9], T[3];
+// pose p of the batch: R (row-major 3x3) and T = the translation column of the 4x4, as dual numbers over the k + 3 parameters
+__device__ inline void convert_dual(const float* __restrict__ rot, const float* __restrict__ xyz, int p, int kind, int k, const Axes ax,
+                                    Dual* R, Dual* T) {
+    Dual r[10], t[3];
     for (int i = 0; i < k; ++i) r[i] = dvar(rot[(size_t)p * k + i], i);
     for (int i = 0; i < 3; ++i) t[i] = dvar(xyz[(size_t)p * 3 + i], k + i);
     bool rotate_t = true;
@@ -482,18 +493,41 @@ __global__ __launch_bounds__(64) void k_pose_convert_fwd(const float* __restrict
     }
     if (rotate_t)   // C-arm convention: x_world = R (x_cam + t)
         for (int i = 0; i < 3; ++i) T[i] = R[i * 3] * t[0] + R[i * 3 + 1] * t[1] + R[i * 3 + 2] * t[2];
-    float* M = matrix + (size_t)p * 16;
+}
+
+// matrix (nullable) [B][16], jac [B][12][CV_MAXN]; with G and c also cam [B][24] = G vec(M[:3,:4]) + c (the registration loop's
+// first step for any parameterisation: xvr_pose_camera_forward_param)
+__global__ __launch_bounds__(64) void k_pose_convert_fwd(const float* __restrict__ rot, const float* __restrict__ xyz, int B, int kind, int k,
+                                                         Axes ax, float* __restrict__ matrix, float* __restrict__ jac,
+                                                         const float* __restrict__ G, const float* __restrict__ c, float* __restrict__ cam) {
+    const int p = blockIdx.x * 64 + threadIdx.x;
+    if (p >= B) return;
+    const int n = k + 3;
+    Dual R[9], T[3];
+    convert_dual(rot, xyz, p, kind, k, ax, R, T);
     float* J = jac + (size_t)p * 12 * CV_MAXN;
+    float m12[12];
     for (int i = 0; i < 3; ++i) {
         for (int j = 0; j < 3; ++j) {
-            M[i * 4 + j] = R[i * 3 + j].v;
+            m12[i * 4 + j] = R[i * 3 + j].v;
             for (int d = 0; d < n; ++d) J[(i * 4 + j) * CV_MAXN + d] = R[i * 3 + j].d[d];
         }
-        M[i * 4 + 3] = T[i].v;
+        m12[i * 4 + 3] = T[i].v;
         for (int d = 0; d < n; ++d) J[(i * 4 + 3) * CV_MAXN + d] = T[i].d[d];
     }
-    M[12] = M[13] = M[14] = 0.f;
-    M[15] = 1.f;
+    if (matrix) {
+        float* M = matrix + (size_t)p * 16;
+        for (int e = 0; e < 12; ++e) M[e] = m12[e];
+        M[12] = M[13] = M[14] = 0.f;
+        M[15] = 1.f;
+    }
+    if (cam) {
+        for (int r = 0; r < 24; ++r) {
+            float sacc = c[r];
+            for (int q = 0; q < 12; ++q) sacc = fmaf(G[r * 12 + q], m12[q], sacc);
+            cam[(size_t)p * 24 + r] = sacc;
+        }
+    }
 }
 
 // grad_rot [B][k], grad_xyz [B][3] = J^T grad_matrix (rows 0..2 of the 4x4): one thread per (pose, parameter)
@@ -539,16 +573,26 @@ extern "C" int xvr_pose_opt_init(xvr_pose_opt_state* state, int B, float lr_rot,
     return launched("pose_opt_init");
 }
 
+static const int POSE_K[6] = {3, 3, 4, 10, 6, 3};
+
+extern "C" int xvr_pose_opt_step_param(float* rot, float* xyz, int B, int kind, const xvr_pose_opt_spec* spec, const float* G,
+                                       const float* jac, float* grad_cam, const float* loss, xvr_pose_opt_state* state, float* history,
+                                       void* stream) {
+    if (!rot || !xyz || !spec || !G || !grad_cam || !loss || !state || B <= 0) return pfail(XVR_DRR_E_ARG, "bad argument");
+    if (kind < 0 || kind > 5) return pfail(XVR_DRR_E_ARG, "bad parameterisation");
+    if (kind == 0 && !axes_ok(spec->axes)) return pfail(XVR_DRR_E_ARG, "axes must be in {0,1,2} with the middle one distinct from its neighbours");
+    if (kind != 0 && !jac) return pfail(XVR_DRR_E_ARG, "a non-Euler parameterisation needs the Jacobian xvr_pose_camera_forward_param stored");
+    if (spec->max_n_plateaus < 1 || spec->patience < 0 || (history && spec->max_iters < 1))
+        return pfail(XVR_DRR_E_ARG, "bad optimiser spec");
+    hipLaunchKernelGGL(k_pose_opt_step, dim3(B), dim3(64), 0, (hipStream_t)stream, rot, xyz, B, *spec, kind, POSE_K[kind], G, jac,
+                       grad_cam, loss, state, history);
+    return launched("pose_opt_step");
+}
+
 extern "C" int xvr_pose_opt_step(float* rot, float* xyz, int B, const xvr_pose_opt_spec* spec, const float* G,
                                  float* grad_cam, const float* loss, xvr_pose_opt_state* state, float* history,
                                  void* stream) {
-    if (!rot || !xyz || !spec || !G || !grad_cam || !loss || !state || B <= 0) return pfail(XVR_DRR_E_ARG, "bad argument");
-    if (!axes_ok(spec->axes)) return pfail(XVR_DRR_E_ARG, "axes must be in {0,1,2} with the middle one distinct from its neighbours");
-    if (spec->max_n_plateaus < 1 || spec->patience < 0 || (history && spec->max_iters < 1))
-        return pfail(XVR_DRR_E_ARG, "bad optimiser spec");
-    hipLaunchKernelGGL(k_pose_opt_step, dim3(B), dim3(64), 0, (hipStream_t)stream, rot, xyz, B, *spec, G,
-                       grad_cam, loss, state, history);
-    return launched("pose_opt_step");
+    return xvr_pose_opt_step_param(rot, xyz, B, 0, spec, G, nullptr, grad_cam, loss, state, history, stream);
 }
 
 extern "C" int xvr_pose_geodesic(const float* a, const float* b, int N, float sdd, float eps, float* out, float* grad_b,
@@ -576,31 +620,46 @@ extern "C" int xvr_pose_multiview_backward(const float* true_pose, const float* 
 
 extern "C" size_t xvr_pose_convert_jacobian_floats(int B) { return B > 0 ? (size_t)B * 12 * CV_MAXN : 0; }
 
-extern "C" int xvr_pose_convert_forward(const float* rot, const float* xyz, int B, int kind, const int axes[3], float* matrix,
-                                        float* jac, void* stream) {
-    static const int K[6] = {3, 3, 4, 10, 6, 3};
-    if (!rot || !xyz || !matrix || !jac) return pfail(XVR_DRR_E_ARG, "null pointer argument");
-    if (B <= 0 || kind < 0 || kind > 5) return pfail(XVR_DRR_E_ARG, "bad batch size or parameterisation");
-    Axes ax = {{0, 1, 2}};
+static int convert_axes(int kind, const int axes[3], Axes* ax) {
+    *ax = Axes{{0, 1, 2}};
     if (kind == 0) {
         if (!axes) return pfail(XVR_DRR_E_ARG, "euler angles need a convention");
         for (int i = 0; i < 3; ++i) {
             if (axes[i] < 0 || axes[i] > 2) return pfail(XVR_DRR_E_ARG, "axes must be 0, 1 or 2");
-            ax.a[i] = axes[i];
+            ax->a[i] = axes[i];
         }
     }
-    hipLaunchKernelGGL(k_pose_convert_fwd, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, (hipStream_t)stream, rot, xyz, B, kind, K[kind], ax,
-                       matrix, jac);
+    return XVR_DRR_OK;
+}
+
+extern "C" int xvr_pose_convert_forward(const float* rot, const float* xyz, int B, int kind, const int axes[3], float* matrix,
+                                        float* jac, void* stream) {
+    if (!rot || !xyz || !matrix || !jac) return pfail(XVR_DRR_E_ARG, "null pointer argument");
+    if (B <= 0 || kind < 0 || kind > 5) return pfail(XVR_DRR_E_ARG, "bad batch size or parameterisation");
+    Axes ax;
+    if (int rc = convert_axes(kind, axes, &ax)) return rc;
+    hipLaunchKernelGGL(k_pose_convert_fwd, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, (hipStream_t)stream, rot, xyz, B, kind, POSE_K[kind], ax,
+                       matrix, jac, (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
     return launched("xvr_pose_convert_forward");
+}
+
+extern "C" int xvr_pose_camera_forward_param(const float* rot, const float* xyz, int B, int kind, const int axes[3], const float* G,
+                                             const float* c, float* cam, float* jac, void* stream) {
+    if (!rot || !xyz || !G || !c || !cam || !jac) return pfail(XVR_DRR_E_ARG, "null pointer argument");
+    if (B <= 0 || kind < 0 || kind > 5) return pfail(XVR_DRR_E_ARG, "bad batch size or parameterisation");
+    Axes ax;
+    if (int rc = convert_axes(kind, axes, &ax)) return rc;
+    hipLaunchKernelGGL(k_pose_convert_fwd, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, (hipStream_t)stream, rot, xyz, B, kind, POSE_K[kind], ax,
+                       (float*)nullptr, jac, G, c, cam);
+    return launched("xvr_pose_camera_forward_param");
 }
 
 extern "C" int xvr_pose_convert_backward(const float* jac, const float* grad_matrix, int B, int kind, float* grad_rot, float* grad_xyz,
                                          void* stream) {
-    static const int K[6] = {3, 3, 4, 10, 6, 3};
     if (!jac || !grad_matrix || !grad_rot || !grad_xyz) return pfail(XVR_DRR_E_ARG, "null pointer argument");
     if (B <= 0 || kind < 0 || kind > 5) return pfail(XVR_DRR_E_ARG, "bad batch size or parameterisation");
-    const int n = B * (K[kind] + 3);
-    hipLaunchKernelGGL(k_pose_convert_bwd, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, (hipStream_t)stream, jac, grad_matrix, B, K[kind],
+    const int n = B * (POSE_K[kind] + 3);
+    hipLaunchKernelGGL(k_pose_convert_bwd, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, (hipStream_t)stream, jac, grad_matrix, B, POSE_K[kind],
                        grad_rot, grad_xyz);
     return launched("xvr_pose_convert_backward");
 }

@@ -80,6 +80,9 @@ __device__ __forceinline__ void grid_add_det(double (&v)[NV], double* partial, i
         last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nblk - 1);
     __syncthreads();
     if (!last) return;
+    // (every block has drawn its ticket: the counter goes back to 0, so that a second launch over the same state -- a backward
+    //  run twice, retain_graph -- draws a full set of tickets again instead of never seeing nblk - 1)
+    if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int q = threadIdx.x % NV, grp = threadIdx.x / NV;
     if (grp < NG) {
         double t = 0.0;
@@ -519,7 +522,7 @@ struct EqState {   // per image, in the workspace
 // h[b] (or, GRAD, dcn[b] = sum_i g_i w_ib / S_i): one block per (bin, image), pixels in a fixed order
 template <bool GRAD>
 __global__ __launch_bounds__(TB) void k_eq_bins(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ S,
-                                                int n, int K, float inv2tau2, float cut, float* __restrict__ out) {
+                                                int n, int K, float inv2tau2, float cut, float* __restrict__ out, float gscale) {
     const int b = blockIdx.x, img = blockIdx.y;
     const float beta = (float)b / (float)(K - 1);
     const float* xi = x + (size_t)img * n;
@@ -528,7 +531,7 @@ __global__ __launch_bounds__(TB) void k_eq_bins(const float* __restrict__ x, con
         const float d = xi[i] - beta;
         if (fabsf(d) <= cut) {
             const float w = __expf(-d * d * inv2tau2);
-            acc += GRAD ? g[(size_t)img * n + i] * w / S[(size_t)img * n + i] : w;
+            acc += GRAD ? (g[(size_t)img * n + i] * gscale) * w / S[(size_t)img * n + i] : w;
         }
     }
     __shared__ float red[TB];
@@ -584,10 +587,13 @@ __global__ void k_eq_cdf_bwd(const float* __restrict__ h, const float* __restric
 }
 
 // per pixel: forward y_i (and S_i kept for the backward); backward g_x,i
+// (forward: yn (nullable) = (y - out_mean) * out_inv_std, the Normalize that follows Equalize in XrayTransforms;
+//  backward: g is the gradient w.r.t. that normalised output, i.e. scaled by out_inv_std on the way in)
 template <bool BWD>
 __global__ __launch_bounds__(TB) void k_eq_pixels(const float* __restrict__ x, int n, int K, float tau, float eps, float cut,
                                                   const float* __restrict__ cn, float* __restrict__ y, float* __restrict__ S,
-                                                  const float* __restrict__ g, const float* __restrict__ dh, float* __restrict__ gx) {
+                                                  const float* __restrict__ g, const float* __restrict__ dh, float* __restrict__ gx,
+                                                  float* __restrict__ yn, float out_mean, float out_inv_std) {
     __shared__ float c_s[EQ_MAX_BINS], d_s[EQ_MAX_BINS];
     const int img = blockIdx.y;
     for (int b = threadIdx.x; b < K; b += TB) {
@@ -610,10 +616,12 @@ __global__ __launch_bounds__(TB) void k_eq_pixels(const float* __restrict__ x, i
             N = fmaf(w, c_s[b], N);
         }
         Ssum += eps;
-        y[e] = N / Ssum;
+        const float yi = N / Ssum;
+        y[e] = yi;
         S[e] = Ssum;
+        if (yn) yn[e] = (yi - out_mean) * out_inv_std;
     } else {
-        const float Si = S[e], yi = y[e], gi = g[e];
+        const float Si = S[e], yi = y[e], gi = g[e] * out_inv_std;
         float acc = 0.f;
         for (int b = blo; b <= bhi; ++b) {
             const float d = xi - (float)b / fk;
@@ -701,13 +709,14 @@ __global__ __launch_bounds__(TB) void k_tf_minmax(const float* __restrict__ m, l
     float lo = INFINITY, hi = -INFINITY;
     m += (size_t)blockIdx.y * n;
     st += blockIdx.y;
+    const bool vec = (reinterpret_cast<uintptr_t>(m) & 15u) == 0;   // (an image of a pixel count that is not a multiple of 4)
     for (long long i = ((long long)blockIdx.x * TB + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * TB * 4) {
-        if (i + 3 < n) {
+        if (i + 3 < n && vec) {
             const float4 v = *reinterpret_cast<const float4*>(m + i);
             lo = fminf(fminf(lo, v.x), fminf(fminf(v.y, v.z), v.w));
             hi = fmaxf(fmaxf(hi, v.x), fmaxf(fmaxf(v.y, v.z), v.w));
         } else {
-            for (long long j = i; j < n; ++j) { lo = fminf(lo, m[j]); hi = fmaxf(hi, m[j]); }
+            for (long long j = i; j < n && j < i + 4; ++j) { lo = fminf(lo, m[j]); hi = fmaxf(hi, m[j]); }
         }
     }
 #pragma unroll
@@ -794,10 +803,11 @@ size_t xvr_sim_equalize_workspace_bytes(int B, int n_bins) {
 }
 
 // workspace layout: [h][cdf][cn][dcn][dh] (B x K floats each) [EqState x B]
-int xvr_sim_equalize_forward(const float* x, int B, int n, int n_bins, float tau, float eps, float* y, float* S, void* workspace,
-                             size_t workspace_bytes, void* stream_) {
+int xvr_sim_equalize_forward(const float* x, int B, int n, int n_bins, float tau, float eps, float out_mean, float out_std, float* y,
+                             float* S, float* y_out, void* workspace, size_t workspace_bytes, void* stream_) {
     if (!x || !y || !S || !workspace) return sim_fail(XVR_DRR_E_ARG, "null pointer argument");
     if (B <= 0 || n <= 0 || n_bins < 2 || n_bins > EQ_MAX_BINS || !(tau > 0.f)) return sim_fail(XVR_DRR_E_ARG, "bad size / bins / tau");
+    if (y_out && !(out_std != 0.f)) return sim_fail(XVR_DRR_E_ARG, "out_std must not be zero");
     if (workspace_bytes < xvr_sim_equalize_workspace_bytes(B, n_bins)) return sim_fail(XVR_DRR_E_ARG, "workspace too small");
     hipStream_t stream = (hipStream_t)stream_;
     float* h = static_cast<float*>(workspace);
@@ -806,19 +816,20 @@ int xvr_sim_equalize_forward(const float* x, int B, int n, int n_bins, float tau
     EqState* st = reinterpret_cast<EqState*>(h + (size_t)B * n_bins * 5);
     const float cut = EQ_CUT * tau;
     hipLaunchKernelGGL(k_eq_bins<false>, dim3(n_bins, B), dim3(TB), 0, stream, x, (const float*)nullptr, (const float*)nullptr, n, n_bins,
-                       1.f / (2.f * tau * tau), cut, h);
+                       1.f / (2.f * tau * tau), cut, h, 1.f);
     hipLaunchKernelGGL(k_eq_cdf, dim3(B), dim3(64), 0, stream, (const float*)h, n_bins, eps, cn, cdf, st);
     hipLaunchKernelGGL(k_eq_pixels<false>, dim3((n + TB - 1) / TB, B), dim3(TB), 0, stream, x, n, n_bins, tau, eps, cut, (const float*)cn, y, S,
-                       (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
+                       (const float*)nullptr, (const float*)nullptr, (float*)nullptr, y_out, out_mean, y_out ? 1.f / out_std : 1.f);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? XVR_DRR_OK : sim_fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
 }
 
 // needs the workspace exactly as the forward left it (h, cdf, cn, state), and the forward's y and S
-int xvr_sim_equalize_backward(const float* x, const float* y, const float* S, const float* grad_y, int B, int n, int n_bins, float tau,
-                              float eps, float* grad_x, void* workspace, size_t workspace_bytes, void* stream_) {
-    if (!x || !y || !S || !grad_y || !grad_x || !workspace) return sim_fail(XVR_DRR_E_ARG, "null pointer argument");
+int xvr_sim_equalize_backward(const float* x, const float* y, const float* S, const float* grad_out, int B, int n, int n_bins, float tau,
+                              float eps, float out_std, float* grad_x, void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!x || !y || !S || !grad_out || !grad_x || !workspace) return sim_fail(XVR_DRR_E_ARG, "null pointer argument");
     if (B <= 0 || n <= 0 || n_bins < 2 || n_bins > EQ_MAX_BINS || !(tau > 0.f)) return sim_fail(XVR_DRR_E_ARG, "bad size / bins / tau");
+    if (!(out_std != 0.f)) return sim_fail(XVR_DRR_E_ARG, "out_std must not be zero (1 for a gradient w.r.t. y itself)");
     if (workspace_bytes < xvr_sim_equalize_workspace_bytes(B, n_bins)) return sim_fail(XVR_DRR_E_ARG, "workspace too small");
     hipStream_t stream = (hipStream_t)stream_;
     float* h = static_cast<float*>(workspace);
@@ -827,12 +838,12 @@ int xvr_sim_equalize_backward(const float* x, const float* y, const float* S, co
     float* dcn = cn + (size_t)B * n_bins;
     float* dh = dcn + (size_t)B * n_bins;
     EqState* st = reinterpret_cast<EqState*>(h + (size_t)B * n_bins * 5);
-    const float cut = EQ_CUT * tau;
-    hipLaunchKernelGGL(k_eq_bins<true>, dim3(n_bins, B), dim3(TB), 0, stream, x, grad_y, S, n, n_bins, 1.f / (2.f * tau * tau), cut, dcn);
+    const float cut = EQ_CUT * tau, gs = 1.f / out_std;
+    hipLaunchKernelGGL(k_eq_bins<true>, dim3(n_bins, B), dim3(TB), 0, stream, x, grad_out, S, n, n_bins, 1.f / (2.f * tau * tau), cut, dcn, gs);
     hipLaunchKernelGGL(k_eq_cdf_bwd, dim3(B), dim3(64), 0, stream, (const float*)h, (const float*)cdf, (const float*)dcn, n_bins, eps,
                        (const EqState*)st, dh);
     hipLaunchKernelGGL(k_eq_pixels<true>, dim3((n + TB - 1) / TB, B), dim3(TB), 0, stream, x, n, n_bins, tau, eps, cut, (const float*)cn,
-                       const_cast<float*>(y), const_cast<float*>(S), grad_y, (const float*)dh, grad_x);
+                       const_cast<float*>(y), const_cast<float*>(S), grad_out, (const float*)dh, grad_x, (float*)nullptr, 0.f, gs);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? XVR_DRR_OK : sim_fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
 }
@@ -961,7 +972,6 @@ int xvr_sim_transform_forward(const float* x, int B, long long n, int per_image,
     const int rc = tf_check(x, B, n, std_, state);
     if (rc != XVR_DRR_OK) return rc;
     if (!y) return sim_fail(XVR_DRR_E_ARG, "null pointer argument");
-    if (per_image && (n & 3)) return sim_fail(XVR_DRR_E_UNSUPPORTED, "per-image statistics need a pixel count that is a multiple of 4");
     hipStream_t stream = (hipStream_t)stream_;
     TfState* st = static_cast<TfState*>(state);
     const int groups = per_image ? B : 1;

@@ -229,44 +229,3 @@ def make_phantom(size=64, n_ellipsoids=12, n_labels=0, seed=0, noise=0.02, devic
     q = sum((((ax[i] - (D[i] - 1) / 2) / (0.45 * D[i])) ** 2).reshape([-1 if j == i else 1 for j in range(3)]) for i in range(3))
     vol += 0.15 * (q <= 1.0)
     return vol.clamp_(0, 1), lab
-
-
-def center_crop(img: torch.Tensor, size) -> torch.Tensor:
-    """torchvision.transforms.functional.center_crop for sizes not larger than the image (the only case
-    /root/reference/src/xvr/io/xray.py:99 produces): top = round((H - h) / 2), left = round((W - w) / 2)."""
-    h, w = (size, size) if isinstance(size, int) else size
-    *_, H, W = img.shape
-    if h > H or w > W:
-        raise ValueError("center_crop: the crop is larger than the image")
-    top, left = int(round((H - h) / 2.0)), int(round((W - w) / 2.0))
-    return img[..., top:top + h, left:left + w]
-
-
-def preprocess_xray(img: torch.Tensor, crop: int = 0, subtract_background: bool = False, linearize: bool = True,
-                    reducefn="max") -> torch.Tensor:
-    """The X-ray side of the registration loop: what ``read_xray`` does to the pixel array after DICOM parsing
-    (/root/reference/src/xvr/io/xray.py:93-129) -- collimator crop, rescale to [0, 1], optional background (mode)
-    subtraction, exponential -> linear (log) form, and the reduction of a multi-frame acquisition.  ``img`` is
-    [B, 1, H, W] or [B, 1, T, H, W]; returns a new tensor."""
-    if crop != 0:
-        *_, height, width = img.shape
-        img = center_crop(img, (height - crop, width - crop))
-    img = (img - img.min()) / (img.max() - img.min() + 1e-6)
-    if subtract_background:
-        background = img.flatten().mode().values.item()
-        img = torch.clamp(img - background, -1, 0) + 1
-    if linearize:
-        img = img + 1
-        img = img.max().log() - img.log()
-    if img.ndim == 5:
-        if reducefn == "max":
-            img = img.max(dim=2).values
-        elif reducefn == "sum":
-            img = img.sum(dim=2)
-        elif isinstance(reducefn, int):
-            img = img[:, :, reducefn]
-        elif callable(reducefn):
-            img = reducefn(img)
-        elif reducefn is not None:
-            raise ValueError(f"Unrecognized reducefn: {reducefn}")
-    return img

@@ -86,25 +86,27 @@ class _Multiview(torch.autograd.Function):
 
 
 class DiceMetric(torch.nn.Module):
-    """2D Dice between two multi-channel label maps, background (channel 0) excluded; reduction none."""
-
-    FUSED = True   # two boolean CUDA maps: integer counts in one HIP launch (xvr_sim_dice_bool), the same float32 values
+    """2D Dice between two multi-channel BOOLEAN label maps [B, C, ...] (what the trainer passes: ``mask = img > 0``,
+    /root/reference/src/xvr/model/trainer.py:292), background (channel 0) excluded, no reduction: [B, C - 1], NaN where a
+    structure is absent from both maps.  One HIP launch of integer counts (xvr_sim_dice_bool) -- the float32 values of the
+    reference's float formulation (/root/reference/src/xvr/model/loss.py:63-89; oracle/loss_restated.py is the checker)."""
 
     def forward(self, y_pred, y_true):
-        if (self.FUSED and y_pred.is_cuda and y_pred.dtype == torch.bool and y_true.dtype == torch.bool and y_pred.shape == y_true.shape
-                and y_pred.dim() >= 3 and y_pred[0, 0].numel() <= 2 ** 24):
+        if not (y_pred.is_cuda and y_true.is_cuda and y_pred.dtype == torch.bool and y_true.dtype == torch.bool):
+            raise RuntimeError("DiceMetric: boolean CUDA label maps only (HIP kernel, no CPU path)")
+        if y_pred.shape != y_true.shape or y_pred.dim() < 3:
+            raise ValueError(f"DiceMetric: label maps {tuple(y_pred.shape)} and {tuple(y_true.shape)} must be equal [B, C, ...] shapes")
+        B, C = y_pred.shape[:2]
+        n = y_pred.shape[2:].numel()
+        dice = torch.empty(B, C, device=y_pred.device, dtype=torch.float32)
+        if B > 0 and C > 0 and n > 0:   # (every sample dropped by `keep`: an empty [0, C - 1] result, as the torch lines give)
             from . import _lib
             from .renderers import _ptr, _stream
 
-            B, C = y_pred.shape[:2]
             a, b = y_pred.contiguous(), y_true.contiguous()
-            dice = torch.empty(B, C, device=a.device, dtype=torch.float32)
-            _lib.check(_lib.load().xvr_sim_dice_bool(_ptr(a), _ptr(b), B, C, a[0, 0].numel(), _ptr(dice), _stream()), "xvr_sim_dice_bool")
-            return dice[:, 1:]
-        y_pred = y_pred.reshape(y_pred.shape[0], y_pred.shape[1], -1).to(torch.float32)
-        y_true = y_true.reshape(y_true.shape[0], y_true.shape[1], -1).to(torch.float32)
-        intersection = (y_pred * y_true).sum(dim=2)
-        dice = (2.0 * intersection) / (y_pred.sum(dim=2) + y_true.sum(dim=2))
+            _lib.check(_lib.load().xvr_sim_dice_bool(_ptr(a), _ptr(b), B, C, n, _ptr(dice), _stream()), "xvr_sim_dice_bool")
+        else:
+            dice.fill_(float("nan"))
         return dice[:, 1:]
 
 
@@ -118,9 +120,8 @@ class DiceLoss(torch.nn.Module):
 
 
 class PoseRegressionLoss(torch.nn.Module):
-    # the pose terms (double geodesic, multiview consistency over all pairs) as one HIP launch each on CUDA poses
-    # instead of ~200 tiny torch launches; False keeps the torch formulation (the cross-check in tests)
-    FUSED = True
+    # the pose terms (double geodesic, multiview consistency over all pairs) are one HIP launch each instead of ~200 tiny torch
+    # launches; the torch formulation they are checked against lives in oracle/loss_restated.py
 
     def __init__(self, sdd: float, weight_ncc: float = 1e0, weight_geo: float = 1e-2, weight_dice: float = 1e0,
                  weight_mvc: float = 1e-3):
@@ -132,25 +133,26 @@ class PoseRegressionLoss(torch.nn.Module):
         self.weight_dice, self.weight_mvc = weight_dice, weight_mvc
 
     def forward(self, img, mask, pose, pred_img, pred_mask, pred_pose):
+        """-> (loss [B], mncc, dgeo, rgeo, tgeo, dice, mvc), the reference's tuple (loss.py:25-42).  Every term is a HIP call:
+        fused mNCC, boolean Dice, one launch for the geodesics, one for the multiview term (true poses carry no gradient)."""
+        if not _hip_poses(pose, pred_pose) or pose.matrix.requires_grad:
+            raise RuntimeError("PoseRegressionLoss: float32 CUDA poses, the true pose without a gradient (HIP kernels, no CPU path)")
         mncc = self.imagesim(img, pred_img)
         dice = self.diceloss(mask, pred_mask)
-        if self.FUSED and _hip_poses(pose, pred_pose) and len(pose) > 0 and not pose.matrix.requires_grad:
-            rgeo, tgeo, dgeo = _Geodesic.apply(pose.matrix, pred_pose.matrix, self.geodesic.sdd, self.geodesic.eps)
-        else:
-            rgeo, tgeo, dgeo = self.geodesic(pose, pred_pose)
-        loss = self.weight_ncc * (1 - mncc) + self.weight_dice * dice + self.weight_geo * dgeo
+        rgeo, tgeo, dgeo = _Geodesic.apply(pose.matrix, pred_pose.matrix, self.geodesic.sdd, self.geodesic.eps)
         mvc = self.multiview_consistency(pose, pred_pose)
+        terms = (self.weight_ncc * (1 - mncc), self.weight_dice * dice, self.weight_geo * dgeo)
+        loss = terms[0] + terms[1] + terms[2]
         if self.weight_mvc > 0:
             loss = loss + self.weight_mvc * mvc.mean()
         return loss, mncc, dgeo, rgeo, tgeo, dice, mvc
 
     def multiview_consistency(self, true_pose, pred_pose):
-        assert (B := len(true_pose)) == len(pred_pose)
-        if self.FUSED and B >= 2 and _hip_poses(true_pose, pred_pose) and not true_pose.matrix.requires_grad:
-            return _Multiview.apply(true_pose.matrix, pred_pose.matrix, self.geodesic.sdd, self.geodesic.eps)
-        idx, jdx = torch.triu_indices(B, B, offset=1)
-        if len(idx) == 0:
+        """Double geodesic between the relative poses of every pair (i < j), true against predicted: [B (B - 1) / 2]."""
+        if len(true_pose) != len(pred_pose):
+            raise ValueError("multiview_consistency: the two batches of poses differ in length")
+        if not _hip_poses(true_pose, pred_pose) or true_pose.matrix.requires_grad:
+            raise RuntimeError("multiview_consistency: float32 CUDA poses, the true pose without a gradient (HIP kernels, no CPU path)")
+        if len(true_pose) < 2:
             return torch.zeros(1, device=true_pose.matrix.device)
-        _, _, dgeo_relative = self.geodesic(true_pose[jdx] @ true_pose[idx].inverse(),
-                                            pred_pose[jdx] @ pred_pose[idx].inverse())
-        return dgeo_relative
+        return _Multiview.apply(true_pose.matrix, pred_pose.matrix, self.geodesic.sdd, self.geodesic.eps)

@@ -170,28 +170,18 @@ class Equalize(torch.nn.Module):
         super().__init__()
         self.n_bins, self.tau, self.eps = n_bins, tau, eps
 
-    FUSED = True   # float32 CUDA images of one channel: HIP kernels (xvr_sim_equalize_*), no [pixels x bins] matrix
-
     def forward(self, x):
-        if self.FUSED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 1 and 2 <= self.n_bins <= 1024 \
-                and x.shape[0] > 0:
-            from .similarity import equalize_hip
+        """float32 CUDA images [B, 1, H, W]: HIP kernels (xvr_sim_equalize_forward / _backward), no [pixels x bins] matrix.  The
+        line-by-line torch restatement they are checked against is oracle/metrics_restated.py::equalize."""
+        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 1):
+            raise RuntimeError("Equalize: float32 CUDA images of shape [B, 1, H, W] only (HIP kernels, no CPU path)")
+        if not 2 <= self.n_bins <= 1024:
+            raise ValueError("Equalize: n_bins must be in [2, 1024]")
+        if x.shape[0] == 0:
+            return x.clone()
+        from .similarity import equalize_hip
 
-            return equalize_hip(x, self.n_bins, self.tau, self.eps)
-        B, _, H, W = x.shape
-        bins = torch.linspace(0, 1, self.n_bins, device=x.device, dtype=x.dtype)[None, None]
-        out = []
-        for b in range(B):  # one image at a time: the [pixels, bins] weight matrix is H*W*n_bins floats
-            diff = x[b].reshape(1, -1, 1) - bins
-            weights = (-diff.square() / (2 * self.tau**2)).exp()
-            histogram = weights.sum(dim=1)
-            histogram = histogram / (histogram.sum(dim=1, keepdim=True) + self.eps)
-            cdf = torch.cumsum(histogram, dim=1)
-            cdf_min = cdf[:, 0:1]
-            cdf_normalized = (cdf - cdf_min) / (1 - cdf_min + self.eps)
-            weights_norm = weights / (weights.sum(dim=-1, keepdim=True) + self.eps)
-            out.append((weights_norm * cdf_normalized[:, None]).sum(dim=-1).view(1, 1, H, W))
-        return torch.cat(out)
+        return equalize_hip(x, self.n_bins, self.tau, self.eps)
 
 
 class _StandardizeNormalize(torch.autograd.Function):
@@ -207,6 +197,8 @@ class _StandardizeNormalize(torch.autograd.Function):
         lib = _lib.load()
         B, n = x.shape[0], x[0].numel()
         xc = x.contiguous()
+        if xc.data_ptr() % 16:   # (a contiguous view at an odd offset: the kernels want 16-byte aligned images)
+            xc = xc.clone()
         y = torch.empty_like(xc)
         state = torch.empty(lib.xvr_sim_transform_state_bytes(B), dtype=torch.uint8, device=x.device)
         _lib.check(lib.xvr_sim_transform_forward(_ptr(xc), B, n, int(per_image), float(mean), float(std), 1e-6, _ptr(y), _ptr(state),
@@ -245,20 +237,29 @@ class XrayTransforms(torch.nn.Module):
         # needs the images of a batch to be independent problems
         self.per_image = per_image
 
-    FUSED = True   # float32 CUDA images, no Equalize, no Resize: two HIP calls (_StandardizeNormalize); False: the torch lines
-
     def forward(self, x):
-        if (self.FUSED and self.equalize is None and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.numel() > 0
-                and tuple(x.shape[-2:]) == (self.height, self.width) and x.data_ptr() % 16 == 0
-                and (not self.per_image or x[0].numel() % 4 == 0) and x.shape[0] <= 65535):
+        """float32 CUDA images [B, C, H, W].  Standardize -> Normalize is one pair of HIP calls (_StandardizeNormalize) when nothing
+        sits between them; with ``equalize`` the chain is Standardize (HIP) -> Equalize + Normalize (HIP, one pass).  A Resize -- the
+        full-resolution X-ray once per pyramid stage, never a DRR rendered at the stage's size -- is torch's antialiased bilinear
+        interpolation between the HIP steps.  oracle/metrics_restated.py::xray_transforms holds the torch lines all of this is
+        checked against."""
+        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
+            raise RuntimeError("XrayTransforms: float32 CUDA images of shape [B, C, H, W] only (HIP kernels, no CPU path)")
+        if x.numel() == 0:
+            return x.clone()
+        if x.shape[0] > 65535:
+            raise ValueError("XrayTransforms: at most 65535 images per call")
+        resize = tuple(x.shape[-2:]) != (self.height, self.width)
+        if self.equalize is None and not resize:
             return _StandardizeNormalize.apply(x, self.per_image, self.mean, self.std)
-        if self.per_image:
-            lo, hi = x.amin(dim=(1, 2, 3), keepdim=True), x.amax(dim=(1, 2, 3), keepdim=True)
-            x = (x - lo) / (hi - lo + 1e-6)
-        else:
-            x = (x - x.min()) / (x.max() - x.min() + 1e-6)
+        x = _StandardizeNormalize.apply(x, self.per_image, 0.0, 1.0)          # Standardize alone: ((x - lo) / r - 0) * 1, the same bits
         if self.equalize is not None:
+            from .similarity import equalize_hip
+
+            if x.shape[1] != 1:
+                raise RuntimeError("XrayTransforms(equalize=True): one-channel images only")
+            if not resize:
+                return equalize_hip(x, self.equalize.n_bins, self.equalize.tau, self.equalize.eps, self.mean, self.std)
             x = self.equalize(x)
-        if tuple(x.shape[-2:]) != (self.height, self.width):
-            x = F.interpolate(x, size=(self.height, self.width), mode="bilinear", antialias=True, align_corners=False)
+        x = F.interpolate(x, size=(self.height, self.width), mode="bilinear", antialias=True, align_corners=False)
         return (x - self.mean) / self.std

@@ -30,8 +30,14 @@ from .renderers import _ptr, _stream, _timed, make_cspec
 
 __all__ = ["PoseCamera", "pose_camera", "RegistrationStage", "axes_of"]
 
-STATE_DTYPE = np.dtype([("m", "f4", 6), ("v", "f4", 6), ("lr", "f4", 2), ("seen_lr", "f4"), ("step", "i4"),
+MAX_PARAMS = 13   # XVR_POSE_MAX_PARAMS
+STATE_DTYPE = np.dtype([("m", "f4", MAX_PARAMS), ("v", "f4", MAX_PARAMS), ("lr", "f4", 2), ("seen_lr", "f4"), ("step", "i4"),
                         ("n_bad", "i4"), ("n_plateaus", "i4"), ("done", "i4"), ("iter", "i4"), ("best", "f8")], align=True)
+
+
+# parameterisations the device loop knows (xvr_pose_convert_forward's kinds) and their number of rotation parameters
+PARAM_KINDS = {"euler_angles": (0, 3), "axis_angle": (1, 3), "quaternion": (2, 4), "quaternion_adjugate": (3, 10), "rotation_6d": (4, 6),
+               "se3_log_map": (5, 3)}
 
 
 def axes_of(convention: str):
@@ -83,26 +89,34 @@ class RegistrationStage:
     tensors, updated IN PLACE."""
 
     def __init__(self, drr, sim, rot, xyz, convention="ZXY", lr_rot=1e-2, lr_xyz=1.0, patience=10, threshold=1e-4,
-                 max_n_plateaus=3, max_iters=500, factor=0.1, betas=(0.9, 0.999), eps=1e-8, maximize=True):
+                 max_n_plateaus=3, max_iters=500, factor=0.1, betas=(0.9, 0.999), eps=1e-8, maximize=True,
+                 parameterization="euler_angles"):
         self.lib = _lib.load()
         if self.lib.xvr_pose_opt_state_bytes() != STATE_DTYPE.itemsize or ctypes.sizeof(_lib.CPoseOptState) != STATE_DTYPE.itemsize:
             raise _lib.HipLibraryError("xvr_pose_opt_state layout mismatch between the library and the binding")
+        if parameterization not in PARAM_KINDS:
+            raise ValueError(f"the device-resident loop knows {sorted(PARAM_KINDS)}, not {parameterization!r}")
+        # any parameterisation the reference's Registration takes (/root/reference/src/xvr/registrar/base.py:168-169): Euler angles
+        # through the closed-form pose -> camera pair, the others through xvr_pose_camera_forward_param / xvr_pose_opt_step_param
+        self.kind, self.k = PARAM_KINDS[parameterization]
         dev = drr.density.device
-        for name, t in (("rot", rot), ("xyz", xyz)):
-            if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous() or t.dim() != 2 or t.shape[1] != 3:
-                raise RuntimeError(f"{name} must be a contiguous float32 CUDA tensor [B, 3] (HIP kernels, no CPU path)")
+        for name, t, cols in (("rot", rot, self.k), ("xyz", xyz, 3)):
+            if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous() or t.dim() != 2 or t.shape[1] != cols:
+                raise RuntimeError(f"{name} must be a contiguous float32 CUDA tensor [B, {cols}] (HIP kernels, no CPU path)")
         self.drr, self.sim, self.rot, self.xyz = drr, sim, rot, xyz
         self.B = B = rot.shape[0]
         self.H, self.W = drr.detector.height, drr.detector.width
         # `sim`: a FusedSimilarity (one C-ABI call per iteration), or any callable raw DRRs [B,1,H,W] -> similarity [B]
         # built from differentiable torch ops (a GeneralSimilarity: Equalize, sigma > 0, patches > 15 ...), which is then
         # differentiated by autograd between the render and the optimiser step -- still no host sync, still capturable
-        self.sim_is_fused = hasattr(sim, "fixed_sobel")
+        # ... or an EqualizedSimilarity: a chain of five HIP calls (`evaluate`), no tape either
+        self.sim_kind = "chain" if hasattr(sim, "evaluate") else ("fused" if hasattr(sim, "fixed_sobel") else "general")
         if tuple(sim.fixed.shape) != (B, 1, self.H, self.W):
             raise ValueError(f"similarity target {tuple(sim.fixed.shape)} does not match {B} poses at {self.H}x{self.W}")
         n = self.n = self.H * self.W
         self.G, self.c = drr.camera_affine()
-        self.axes = axes_of(convention)
+        self.axes = axes_of(convention if self.kind == 0 else "ZXY")
+        self.hist_cols = self.k + 6
         self.spec = _lib.CPoseOptSpec(self.axes, betas[0], betas[1], eps, int(bool(maximize)), factor, int(patience),
                                       float(threshold), 1e-8, int(max_n_plateaus), int(max_iters))
         self.max_iters = int(max_iters)
@@ -117,7 +131,8 @@ class RegistrationStage:
         self.img, self.g_img = torch.empty(B, 1, self.H, self.W, **f), torch.empty(B, 1, self.H, self.W, **f)
         self.jac = torch.empty(B, n, _lib.JAC_STRIDE, **f)
         self.loss = torch.empty(B, **f)
-        self.history = torch.zeros(B, self.max_iters, _lib.POSE_HISTORY_COLS, **f)
+        self.history = torch.zeros(B, self.max_iters, self.hist_cols, **f)
+        self.pose_jac = torch.empty(self.lib.xvr_pose_convert_jacobian_floats(B), **f) if self.kind else None
         self.state = torch.zeros(B * STATE_DTYPE.itemsize, device=dev, dtype=torch.uint8)
         _lib.check(self.lib.xvr_pose_opt_init(_ptr(self.state), B, float(lr_rot), float(lr_xyz), _stream()),
                    "xvr_pose_opt_init")
@@ -127,8 +142,12 @@ class RegistrationStage:
     def render(self):
         lib, B, H, W, n, s = self.lib, self.B, self.H, self.W, self.n, _stream()
         vol = self.drr.density
-        _lib.check(_timed("pose_camera_forward", lib.xvr_pose_camera_forward, _ptr(self.rot), _ptr(self.xyz), B, self.axes,
-                          _ptr(self.G), _ptr(self.c), _ptr(self.cam), s), "xvr_pose_camera_forward")
+        if self.kind == 0:
+            _lib.check(_timed("pose_camera_forward", lib.xvr_pose_camera_forward, _ptr(self.rot), _ptr(self.xyz), B, self.axes,
+                              _ptr(self.G), _ptr(self.c), _ptr(self.cam), s), "xvr_pose_camera_forward")
+        else:
+            _lib.check(_timed("pose_camera_forward", lib.xvr_pose_camera_forward_param, _ptr(self.rot), _ptr(self.xyz), B, self.kind, self.axes,
+                              _ptr(self.G), _ptr(self.c), _ptr(self.cam), _ptr(self.pose_jac), s), "xvr_pose_camera_forward_param")
         _lib.check(_timed(f"{self.rspec.renderer}_forward+jac", self.render_fn, _ptr(vol), None, *vol.shape, 1, _ptr(self.cam), B, H, W,
                           ctypes.byref(self.cspec), _ptr(self.img), _ptr(self.jac), None, s),
                    f"xvr_drr_{self.rspec.renderer}_forward_camera")
@@ -137,7 +156,9 @@ class RegistrationStage:
         lib, B, H, W, n = self.lib, self.B, self.H, self.W, self.n
         self.render()
         s, sim = _stream(), self.sim
-        if self.sim_is_fused:
+        if self.sim_kind == "chain":
+            sim.evaluate(self.img, self.loss, self.g_img)
+        elif self.sim_kind == "fused":
             _lib.check(_timed("ncc_forward_backward", lib.xvr_sim_ncc_forward_backward, _ptr(sim.fixed), _ptr(sim.fixed_sobel),
                               _ptr(self.img), B, H, W, ctypes.byref(sim.spec), _ptr(self.loss), _ptr(self.g_img),
                               _ptr(sim.workspace), sim.workspace.numel() * 4, s), "xvr_sim_ncc_forward_backward")
@@ -151,9 +172,9 @@ class RegistrationStage:
         _lib.check(_timed("jac_to_camera_backward", lib.xvr_drr_jac_to_camera_backward, _ptr(self.jac), _ptr(self.g_img),
                           _ptr(self.cam), B, H, W, _ptr(self.g_cam), _ptr(self.j2c_ws), self.j2c_ws.numel() * 4, s),
                    "xvr_drr_jac_to_camera_backward")
-        _lib.check(_timed("pose_opt_step", lib.xvr_pose_opt_step, _ptr(self.rot), _ptr(self.xyz), B,
-                          ctypes.byref(self.spec), _ptr(self.G), _ptr(self.g_cam), _ptr(self.loss), _ptr(self.state),
-                          _ptr(self.history), s), "xvr_pose_opt_step")
+        _lib.check(_timed("pose_opt_step", lib.xvr_pose_opt_step_param, _ptr(self.rot), _ptr(self.xyz), B, self.kind,
+                          ctypes.byref(self.spec), _ptr(self.G), _ptr(self.pose_jac), _ptr(self.g_cam), _ptr(self.loss), _ptr(self.state),
+                          _ptr(self.history), s), "xvr_pose_opt_step_param")
 
     # -- host control --------------------------------------------------------------------------------
     def read_state(self) -> np.ndarray:
@@ -179,10 +200,16 @@ class RegistrationStage:
             if use_graph and self.graph is None and taken >= 2:
                 try:
                     self.capture()   # capture enqueues nothing: the k replays below are the iterations
-                except Exception:    # capture is an optimisation, never a requirement (the general similarity path runs
-                    # autograd and torch transforms inside it): carry on eagerly, as registrar.py's torch-optimiser loop does
-                    if self.sim_is_fused:
+                except RuntimeError as e:
+                    # capture is an optimisation, never a requirement -- but only for the general similarity path (autograd and
+                    # torch ops inside it may refuse a capture); the all-HIP iteration must capture, and anything that is not a
+                    # capture error is a bug to be seen.  iteration() keeps no host-side state, so a discarded capture has
+                    # advanced nothing.
+                    if self.sim_kind != "general":
                         raise
+                    import warnings
+
+                    warnings.warn(f"RegistrationStage: HIP-graph capture failed ({e}); continuing eagerly", RuntimeWarning, stacklevel=2)
                     self.graph, use_graph = None, False
                     torch.cuda.synchronize()
             for _ in range(k if (self.graph is not None or not use_graph) else min(k, 2 - taken)):
@@ -199,7 +226,8 @@ class RegistrationStage:
         return st, times
 
     def results(self):
-        """history rows of every pose that were actually written: list over poses of arrays [iters, 9]."""
+        """history rows of every pose that were actually written: list over poses of arrays [iters, k + 6] = (the k rotation
+        parameters and the translation after the update, the similarity before it, lr_rot, lr_xyz)."""
         st = self.read_state()
         h = self.history.cpu().numpy()
         return [h[b, : int(st["iter"][b])] for b in range(self.B)]

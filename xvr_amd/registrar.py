@@ -32,7 +32,8 @@ from .metrics import (GradientNormalizedCrossCorrelation2d, MultiscaleNormalized
 from .pose import RigidTransform, convert
 from .pose_opt import RegistrationStage
 from .registration import Registration
-from .similarity import FusedSimilarity, GeneralSimilarity
+from .pose_opt import PARAM_KINDS
+from .similarity import EqualizedSimilarity, FusedSimilarity, GeneralSimilarity
 
 
 def parse_scales(scales, crop: int, height: int):
@@ -67,7 +68,7 @@ class Registrar:
         self.fused = fused
         # pose -> camera, its chain rule, Adam, the plateau scheduler and the stopping rule on the device too
         # (xvr_amd/pose_opt.py): eight launches per iteration, one host sync every `check_every` iterations.
-        # Needs the fused similarity and Euler angles; None = use it whenever possible.
+        # Any parameterisation xvr_pose_convert_forward knows (pose_opt.PARAM_KINDS); None = use it whenever possible.
         self.device_loop, self.check_every = device_loop, check_every
         self.sim1 = MultiscaleNormalizedCrossCorrelation2d([None, mncc_patch_size], [0.5, 0.5])
         self.sim2 = GradientNormalizedCrossCorrelation2d(gncc_patch_size, sigma)
@@ -107,18 +108,18 @@ class Registrar:
             lr_rot = self.lr_rot / step_size_scalar
             lr_xyz = self.lr_xyz / step_size_scalar
             device_loop = (self.device_loop if self.device_loop is not None else True) and device.type == "cuda" and n_itr > 0 \
-                and self.parameterization == "euler_angles" and (self.fused if self.fused is not None else True)
+                and self.parameterization in PARAM_KINDS and (self.fused if self.fused is not None else True)
             if device_loop:
-                sim_obj = fused_sim if use_fused else GeneralSimilarity(img, transform, self.mncc_patch_size, self.gncc_patch_size,
-                                                                       self.sigma, self.beta)
+                sim_obj = self._stage_similarity(img, transform, h, w, fused_sim, per_image=False)
                 stage_run = RegistrationStage(reg.drr, sim_obj, reg.rotation.data, reg.translation.data, self.convention,
                                               lr_rot, lr_xyz, self.patience, self.threshold, self.max_n_plateaus,
-                                              max_iters=n_itr)
+                                              max_iters=n_itr, parameterization=self.parameterization)
                 _, stage_times = stage_run.run(n_itr, self.check_every, use_graph=graphed)
                 rows = stage_run.results()[0]
-                nccs += rows[:, 6].tolist()
-                traj += rows[:, :6].tolist()
-                lrs += rows[:, 7:9].tolist()
+                np_ = rows.shape[1] - 3            # the k rotation parameters + the translation
+                nccs += rows[:, np_].tolist()
+                traj += rows[:, :np_].tolist()
+                lrs += rows[:, np_ + 1:np_ + 3].tolist()
                 times += stage_times
                 if self.verbose:
                     print(f"stage {stage}: {len(rows)} iterations on the device, ncc = {nccs[-1]:.4f}")
@@ -190,6 +191,19 @@ class Registrar:
         return dict(final_pose=RigidTransform(reg.pose.matrix.detach()), init_pose=init_pose, nccs=nccs, times=times,
                     lrs=lrs, trajectory=self._rows_as_euler_zxy(traj), runtime=sum(times), drr=reg.drr)
 
+    def _stage_similarity(self, img, transform, h, w, fused_sim=None, per_image=False):
+        """The similarity object of one pyramid stage for the device-resident loop: the single fused call, the tape-free chain for
+        ``equalize``, or -- sigma > 0, patches beyond 15 -- HIP kernels strung together by autograd."""
+        cfg = (h, w, self.mncc_patch_size, self.gncc_patch_size, self.sigma, self.equalize)
+        if fused_sim is not None:
+            return fused_sim
+        if FusedSimilarity.supported(*cfg):
+            return FusedSimilarity(img, self.mncc_patch_size, self.gncc_patch_size, self.beta, per_image=per_image)
+        if EqualizedSimilarity.supported(*cfg):
+            return EqualizedSimilarity(img, self.mncc_patch_size, self.gncc_patch_size, self.beta, per_image=per_image)
+        tf = transform if not per_image else XrayTransforms(h, w, equalize=self.equalize, per_image=True)
+        return GeneralSimilarity(img, tf, self.mncc_patch_size, self.gncc_patch_size, self.sigma, self.beta)
+
     def _rows_as_euler_zxy(self, rows):
         """Trajectory rows (rotation parameters + translation in THIS registrar's parameterisation, one row per
         iteration) -> the reference's logging convention: ``pose.convert("euler_angles", "ZXY")`` whatever the
@@ -211,14 +225,14 @@ class Registrar:
         standardises every rendered image by its own min/max (``per_image``), and a stage ends when all poses
         have met the stopping rule (finished poses are left untouched).  One launch then renders B poses, which
         fills the GPU where a single 256^2 pose is one wavefront per SIMD.  Same schedule per pose as ``run``;
-        needs Euler angles and the fused similarity.  Returns one result dict per pose."""
+        needs a parameterisation of pose_opt.PARAM_KINDS.  Returns one result dict per pose."""
         device = self.drr.density.device
         *_, height, width = gt.shape
         B = len(init_poses)
         if gt.shape[0] not in (1, B):
             raise ValueError(f"gt holds {gt.shape[0]} images for {B} poses: pass one target, or one per pose")
-        if self.parameterization != "euler_angles" or device.type != "cuda":
-            raise RuntimeError("run_batch needs the device-resident loop: Euler angles on a GPU")
+        if self.parameterization not in PARAM_KINDS or device.type != "cuda":
+            raise RuntimeError(f"run_batch needs the device-resident loop: a GPU and one of {sorted(PARAM_KINDS)}")
         drr = deepcopy(self.drr)
         if intrinsics is not None:
             drr.set_intrinsics_(**{**intrinsics, "height": height, "width": width})
@@ -237,22 +251,19 @@ class Registrar:
             transform = XrayTransforms(h, w, equalize=self.equalize)
             img = torch.cat([transform(gt[b:b + 1]) for b in range(gt.shape[0])])   # every target standardised on its own
             fixed = img.expand(B, -1, -1, -1) if img.shape[0] == 1 else img   # one target for all starts, or one per pose
-            if FusedSimilarity.supported(h, w, self.mncc_patch_size, self.gncc_patch_size, self.sigma, self.equalize):
-                sim = FusedSimilarity(fixed.contiguous(), self.mncc_patch_size, self.gncc_patch_size, self.beta, per_image=True)
-            else:   # Equalize / sigma > 0 / large patches: the same loop, the similarity composed of HIP NCC kernels + torch ops
-                sim = GeneralSimilarity(fixed.contiguous(), XrayTransforms(h, w, equalize=self.equalize, per_image=True),
-                                        self.mncc_patch_size, self.gncc_patch_size, self.sigma, self.beta)
+            sim = self._stage_similarity(fixed.contiguous(), transform, h, w, per_image=True)
             step_size_scalar *= 2 ** (stage - 1)
             if n_itr <= 0:
                 continue
             stage_run = RegistrationStage(drr, sim, rot, xyz, self.convention, self.lr_rot / step_size_scalar,
                                           self.lr_xyz / step_size_scalar, self.patience, self.threshold, self.max_n_plateaus,
-                                          max_iters=n_itr)
+                                          max_iters=n_itr, parameterization=self.parameterization)
             _, stage_times = stage_run.run(n_itr, self.check_every, use_graph=self.use_graph)
             for b, rows in enumerate(stage_run.results()):
-                per[b]["nccs"] += rows[:, 6].tolist()
-                per[b]["traj"] += rows[:, :6].tolist()
-                per[b]["lrs"] += rows[:, 7:9].tolist()
+                np_ = rows.shape[1] - 3
+                per[b]["nccs"] += rows[:, np_].tolist()
+                per[b]["traj"] += rows[:, :np_].tolist()
+                per[b]["lrs"] += rows[:, np_ + 1:np_ + 3].tolist()
                 per[b]["times"] += stage_times[: len(rows)]
             if self.verbose:
                 print(f"stage {stage}: iterations per pose {[len(r) for r in stage_run.results()]}")

@@ -13,26 +13,15 @@ import torch
 from .pose import convert
 
 
-def _uniform(low, high, n, circle_shift=False, generator=None):
-    x = (high - low) * torch.rand(n, 1, generator=generator) + low
-    if circle_shift:
-        x = ((x + 180) % 360) - 180
-    return x
-
-
 def get_random_pose(alphamin, alphamax, betamin, betamax, gammamin, gammamax, txmin, txmax, tymin, tymax,
                     tzmin, tzmax, batch_size, generator=None):
-    """A batch of random poses: uniform Euler-ZXY angles (degrees) and translations (mm)."""
-    rot = torch.concat([_uniform(alphamin, alphamax, batch_size, True, generator),
-                        _uniform(betamin, betamax, batch_size, True, generator),
-                        _uniform(gammamin, gammamax, batch_size, True, generator)], dim=1)
-    xyz = torch.concat([_uniform(txmin, txmax, batch_size, generator=generator),
-                        _uniform(tymin, tymax, batch_size, generator=generator),
-                        _uniform(tzmin, tzmax, batch_size, generator=generator)], dim=1)
-    return convert(rot, xyz, parameterization="euler_angles", convention="ZXY", degrees=True)
-
-
-FUSED_FOREGROUND = True   # A/B switch (tools/bench_training_step.py): False = the reference's torch lines
+    """A batch of random poses: uniform Euler-ZXY angles (degrees, wrapped to [-180, 180)) and translations (mm); the six columns
+    are drawn one after the other, alpha first, so that a seeded generator reproduces the reference's draws
+    (/root/reference/src/xvr/model/sampler.py:5-38; tests/test_reference_goldens.py holds it to the reference's output)."""
+    bounds = ((alphamin, alphamax), (betamin, betamax), (gammamin, gammamax), (txmin, txmax), (tymin, tymax), (tzmin, tzmax))
+    cols = [lo + torch.rand(batch_size, 1, generator=generator) * (hi - lo) for lo, hi in bounds]
+    rot = torch.remainder(torch.cat(cols[:3], dim=1) + 180, 360) - 180
+    return convert(rot, torch.cat(cols[3:], dim=1), parameterization="euler_angles", convention="ZXY", degrees=True)
 
 
 class _Foreground(torch.autograd.Function):
@@ -80,16 +69,9 @@ def render_samples(drr, volume, seg, affinv, pose, img_threshold=0.10, mask_thre
         source, target = affinv(source), affinv(target)
     img = drr.renderer(volume, source, target, img, mask=seg)
     img = drr.reshape_transform(img, batch_size=len(pose))
-    if FUSED_FOREGROUND and img.is_cuda and img.dtype == torch.float32:
-        return _Foreground.apply(img, img_threshold if img.shape[1] == 1 else mask_threshold)
-    mask = img > 0
-    img = img.sum(dim=1, keepdim=True)
-    if mask.shape[1] == 1:
-        keep = mask.to(img).flatten(1).mean(1) > img_threshold
-    else:
-        keep = mask[:, 1:].sum(dim=1, keepdim=True)
-        keep = (keep > 0).to(img).flatten(1).mean(1) > mask_threshold
-    return img, mask, keep
+    if not (img.is_cuda and img.dtype == torch.float32):
+        raise RuntimeError("render_samples: the foreground / keep pass is a HIP kernel (float32 CUDA renders, no CPU path)")
+    return _Foreground.apply(img, img_threshold if img.shape[1] == 1 else mask_threshold)
 
 
 # ---------------------------------------------------------------------------------------------------------------
