@@ -127,6 +127,156 @@ def deepfluoro_poses(batch, seed):
                            batch, generator=g)
 
 
+class Exchange:
+    """The exchange step of the path for N > 1 (and --force-dist): every rank ends up with every rendered DRR -- one
+    all_gather_into_tensor over RCCL, issued async right after the forward and waited for after the backward.  The unequal
+    shares of a ragged strong-scaling split are padded to the largest share (no backend gathers uneven tensors in one call)."""
+
+    def __init__(self, world, B, Bmax, H, dev):
+        self.B = B
+        self.gathered = torch.empty(world * Bmax, 1, H, H, device=dev)
+        self.send = torch.zeros(Bmax, 1, H, H, device=dev) if Bmax != B else None
+        self.handle = None
+
+    def post_forward(self, img):
+        if self.send is not None:
+            self.send[:self.B].copy_(img.detach())
+        self.handle = dist.all_gather_into_tensor(self.gathered, img.detach() if self.send is None else self.send, async_op=True)
+
+    def wait(self):
+        if self.handle is not None:
+            self.handle.wait()
+            self.handle = None
+
+
+def render_leg(dev, subject, renderer, voxel_grad, rot0, xyz0, H, delx, n_points, steps, warmup, exchange=None, update_volume=False,
+               drr_kwargs=None, B_total=None):
+    """One benchmark leg: `steps` timed passes of DRR.forward of the poses + backward of a weighted sum to (rot, xyz) and, with
+    voxel_grad, to the voxels.  Returns the timings, the per-kernel HIP-event table and the roofline object of the leg."""
+    from xvr_amd import renderers
+    from xvr_amd.drr import DRR
+    from xvr_amd.pose import convert
+
+    B = rot0.shape[0]
+    kw = {"n_points": n_points} if renderer == "trilinear" else {}
+    drr = DRR(subject, 1020.0, H, delx, renderer=renderer, reverse_x_axis=False, **(drr_kwargs or {})).to(dev)
+    density = drr.density.clone().requires_grad_(voxel_grad)
+    rot = rot0.detach().clone().to(dev).requires_grad_(True)
+    xyz = xyz0.detach().clone().to(dev).requires_grad_(True)
+    w = torch.rand(B, 1, H, H, device=dev, generator=torch.Generator(device=dev).manual_seed(1234))
+
+    def step(module=None, update=update_volume):
+        density.grad = None
+        rot.grad = None
+        xyz.grad = None
+        if update:   # an optimiser that USES dL/dvoxel writes the volume every step
+            with torch.no_grad():
+                density.add_(0.0)
+        # DRR.forward from the pose parameters (Euler ZXY, xvr's registration parameterisation): pose -> camera is
+        # one HIP launch, then rays -> render, [B,1,H,H]
+        img = (module or drr)(rot, xyz, parameterization="euler_angles", convention="ZXY", density=density, **kw)
+        if exchange is not None:
+            exchange.post_forward(img)
+        (img * w).sum().backward()
+        if exchange is not None:
+            exchange.wait()
+        return img
+
+    # algorithmic work of one step, counted by the kernel itself (samples that touch the volume / voxel segments traversed)
+    with torch.no_grad():
+        work = torch.zeros(1, dtype=torch.int64, device=dev)
+        pose = convert(rot, xyz, parameterization="euler_angles", convention="ZXY")
+        s, t = drr.detector(pose, None)
+        L = (t - s).norm(dim=-1).unsqueeze(1)
+        spec = drr.renderer._spec(**kw)
+        renderers.render(density.detach(), drr.affine_inverse(s), drr.affine_inverse(t), L, spec, ray_grid_w=H, work=work)
+        units = int(work.item())
+        del s, t, L
+    # Resident data: the renderer keeps a render-ready copy of a STATIC volume next to it (y-pair interleaved for the
+    # trilinear march, bricked for Siddon; xvr_amd/renderers.py builds it on the third render of a volume version, 0.7 ms).
+    # It belongs to the inputs that are in HBM when the timed region starts, whatever --warmup says.
+    with torch.no_grad():
+        for _ in range(3):
+            drr(rot, xyz, parameterization="euler_angles", convention="ZXY", density=density, **kw)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if exchange is not None:
+        dist.barrier()
+    renderers.PROFILER = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if exchange is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    events, renderers.PROFILER = renderers.PROFILER, None
+
+    # per-kernel launch durations from the HIP events recorded on the launch stream
+    per_kernel = {}
+    for name, e0, e1 in events:
+        per_kernel.setdefault(name, []).append(e0.elapsed_time(e1))
+    kernels = {k: {"launches": len(v), "avg_ms": sum(v) / len(v)} for k, v in per_kernel.items()}
+    # the roofline is priced on the dominant RENDER kernel (forward / backward of the chosen renderer); the
+    # elementwise helpers (ray generation, from-jacobian) do no taps and are listed under "kernels" only
+    render_kernels = [k for k in kernels if k.startswith(renderer)] or list(kernels)
+    dominant = max(render_kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"])
+    bytes_per_unit = TAP_BYTES_PER_SAMPLE if renderer == "trilinear" else 4
+    for k, v in kernels.items():
+        tapk = k.startswith(renderer)  # the elementwise from-jacobian kernel does no taps
+        v["algorithmic_GBps"] = (units * bytes_per_unit / (v["avg_ms"] * 1e-3) / 1e9) if tapk else None
+    dom = kernels[dominant]
+    nominal_units = B * H * H * (n_points if renderer == "trilinear" else 0)
+    for k, v in kernels.items():
+        bf = binding_floor(k, units, v["avg_ms"])
+        if bf:
+            v["binding"] = bf
+    roofline = {
+        # (`frac` prices SURVEY 8d's algorithmic tap bytes against the HBM peak -- the survey's metric.  The taps are served
+        #  on-chip: what the memory side moved is `hbm_physical`, and the unit that really binds the kernel is `binding`.)
+        "bound": "hbm", "bound_detail": "algorithmic tap bandwidth (cache-served); binding unit under `binding`", "kernel": dominant,
+        "achieved": dom["algorithmic_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": (dom["algorithmic_GBps"] or 0.0) / HBM_PEAK_GBS,
+        "frac_of_measured_copy_peak": (dom["algorithmic_GBps"] or 0.0) / HBM_COPY_GBS,
+        "traffic": pmc_traffic(dominant),
+        "units_per_launch": units, "unit_name": "volume-touching samples" if renderer == "trilinear" else "voxel segments",
+        "bytes_per_unit": bytes_per_unit, "avg_launch_ms": dom["avg_ms"],
+        "nominal_units_per_launch": nominal_units or None,
+    }
+    if "binding" in dom:
+        roofline["binding"] = dom["binding"]
+    # Three ways to price the same launch, side by side (VERDICT r1): `frac` = counted algorithmic taps (the kernel
+    # skips, exactly, the samples that only read padding); `nominal_frac` = SURVEY 8d's nominal B*H*W*N samples -- it can
+    # exceed 1 because more than half of them lie outside the volume; `hbm_physical` = what the memory side actually
+    # moved (FETCH_SIZE + WRITE_SIZE of the committed rocprofv3 PMC passes; calibrated in round 4,
+    # profiles/r04_fetch_calibration.txt: one L2 miss is one 128-byte line tallied at 64 bytes, for 16-byte gathers as for
+    # coalesced streams -- `frac_corrected` doubles the fetch side accordingly)
+    if nominal_units:
+        roofline["nominal_frac"] = nominal_units * bytes_per_unit / (dom["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+    if roofline["traffic"]:
+        phys = roofline["traffic"] / (dom["avg_ms"] * 1e-3) / 1e9
+        roofline["hbm_physical"] = {"GBps": phys, "frac": phys / HBM_PEAK_GBS, "frac_if_fetch_undercounts_2x": 2 * phys / HBM_PEAK_GBS,
+                                    "source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; separate passes)"}
+    # the forward+backward PAIR priced as one unit (SURVEY.md 8d: 64 B per sample with the voxel gradient,
+    # 32 B without), over the summed HIP-event time of every kernel of a step
+    kernel_ms = sum(v["avg_ms"] * v["launches"] for v in kernels.values()) / steps
+    pair_bytes = units * bytes_per_unit * (2 if voxel_grad else 1)
+    roofline["forward_backward_pair"] = {
+        "achieved": pair_bytes / (kernel_ms * 1e-3) / 1e9, "unit": "GB/s", "frac": pair_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "kernel_ms_per_step": kernel_ms, "bytes_per_unit": bytes_per_unit * (2 if voxel_grad else 1),
+    }
+    return {"elapsed": elapsed, "ms_per_step": 1e3 * elapsed / steps, "kernels": kernels, "roofline": roofline, "units": units,
+            "step": step, "drr": drr, "spec": spec, "rot": rot, "xyz": xyz, "B": B}
+
+
+def leg_summary(leg, B):
+    """What a secondary leg contributes to the JSON line: ms per step, DRRs/s, its kernel table and roofline."""
+    return {"ms_per_step": leg["ms_per_step"], "DRRs_per_s": B / (leg["ms_per_step"] * 1e-3), "kernels": leg["kernels"],
+            "roofline": leg["roofline"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -149,14 +299,24 @@ def main():
                          "layout survives) -- the scenario the voxel gradient exists for")
     ap.add_argument("--force-dist", action="store_true",
                     help="with --gpus 1: initialise the process group (RCCL for --backend nccl) and run the all-gather on one rank")
-    ap.add_argument("--no-variants", action="store_true", help="skip the short secondary loops (volume changing, clip_to_volume)")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="skip the secondary legs (volume changing, clip_to_volume, Siddon, pose-only, registration iteration, training step)")
     ap.add_argument("--single-device", action="store_true",
                     help="testing hook: every rank uses cuda:0 (with --backend gloo), to exercise the N > 1 code path on a 1-GPU box")
+    ap.add_argument("--check-gather", action="store_true",
+                    help="with N > 1 (or --force-dist): rank 0 re-renders EVERY rank's poses itself through the HIP path and compares "
+                         "the all-gathered tensor with it value by value (`gather_check` in the JSON line)")
+    ap.add_argument("--dry-run-collectives", action="store_true",
+                    help="allocate the exact tensors of the N-rank step (--gpus N names N; this process is ONE rank), run the rank-local "
+                         "part once with the all-gather on a one-rank group of the chosen backend, check the gathered block against "
+                         "the render, print a JSON report and exit: the first 8-GPU run then measures instead of debugging")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry_run_collectives:
+        return dry_run_collectives(args)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run for N>1")
     if args.single_device:
@@ -165,22 +325,10 @@ def main():
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
-        kw_pg = {}
-        if world == 1 and "RANK" not in os.environ:   # --force-dist outside a launcher: a one-rank group on the loopback
-            import socket
-            with socket.socket() as sk:
-                sk.bind(("127.0.0.1", 0))
-                port = sk.getsockname()[1]
-            kw_pg = dict(init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev, **kw_pg)
-        else:
-            dist.init_process_group(args.backend, **kw_pg)
+        init_group(args.backend, dev, world)
 
-    from xvr_amd import renderers
     from xvr_amd.data import make_phantom, read
     from xvr_amd.drr import DRR
-    from xvr_amd.pose import convert
 
     B, H = args.batch, args.det
     if args.scaling == "strong":   # the same B poses whatever the number of ranks: contiguous shares (distributed.shard_bounds)
@@ -194,133 +342,20 @@ def main():
     vol, _ = make_phantom(args.size, n_ellipsoids=64, seed=0, device=dev)
     subject = read(vol, orientation="AP")
     delx = 1.08821875 * 256 / H  # scripts/v1-submission/pelvis/train/patient_specific.sh:31-33
-    kw = {"n_points": args.n_points} if args.renderer == "trilinear" else {}
-    drr = DRR(subject, 1020.0, H, delx, renderer=args.renderer, reverse_x_axis=False).to(dev)
-    density = drr.density.clone().requires_grad_(not args.no_voxel_grad)
     if args.scaling == "strong":
         rot, xyz = (t[lo:lo + B] for t in deepfluoro_poses(B_total, seed=0).convert("euler_angles", "ZXY"))
     else:
         rot, xyz = deepfluoro_poses(B, seed=rank).convert("euler_angles", "ZXY")
-    rot = rot.to(dev).requires_grad_(True)
-    xyz = xyz.to(dev).requires_grad_(True)
-    w = torch.rand(B, 1, H, H, device=dev)
-    # the exchange step: every rank ends up with every DRR (one all_gather_into_tensor).  The unequal shares of a ragged
-    # strong-scaling split are padded to the largest share: no backend gathers uneven tensors in one collective
     Bmax = B if args.scaling == "weak" else -(-B_total // world)
-    gathered = torch.empty(world * Bmax, 1, H, H, device=dev) if use_dist else None
-    send = torch.zeros(Bmax, 1, H, H, device=dev) if use_dist and Bmax != B else None
+    exchange = Exchange(world, B, Bmax, H, dev) if use_dist else None
 
-    def step(module=None, update_volume=args.update_volume):
-        density.grad = None
-        rot.grad = None
-        xyz.grad = None
-        if update_volume:   # an optimiser that USES dL/dvoxel writes the volume every step
-            with torch.no_grad():
-                density.add_(0.0)
-        # DRR.forward from the pose parameters (Euler ZXY, xvr's registration parameterisation): pose -> camera is
-        # one HIP launch, then rays -> render, [B,1,H,H]
-        img = (module or drr)(rot, xyz, parameterization="euler_angles", convention="ZXY", density=density, **kw)
-        handle = None
-        if use_dist:  # the exchange step of the path: every rank gets every rendered DRR (RCCL over xGMI)
-            if send is not None:
-                send[:B].copy_(img.detach())
-            handle = dist.all_gather_into_tensor(gathered, img.detach() if send is None else send, async_op=True)
-        (img * w).sum().backward()
-        if handle is not None:
-            handle.wait()
-        return img
-
-    # algorithmic work of one step, counted by the kernel itself (samples that touch the volume /
-    # voxel segments traversed)
-    with torch.no_grad():
-        work = torch.zeros(1, dtype=torch.int64, device=dev)
-        pose = convert(rot, xyz, parameterization="euler_angles", convention="ZXY")
-        s, t = drr.detector(pose, None)
-        L = (t - s).norm(dim=-1).unsqueeze(1)
-        spec = drr.renderer._spec(**kw)
-        renderers.render(density.detach(), drr.affine_inverse(s), drr.affine_inverse(t), L, spec,
-                         ray_grid_w=H, work=work)
-        units = int(work.item())
-
-    # Resident data: the renderer keeps a render-ready copy of a STATIC volume next to it (y-pair interleaved for the
-    # trilinear march, bricked for Siddon; xvr_amd/renderers.py builds it on the third render of a volume version, 0.7 ms).
-    # It belongs to the inputs that are in HBM when the timed region starts, whatever --warmup says.
-    with torch.no_grad():
-        for _ in range(3):
-            drr(rot, xyz, parameterization="euler_angles", convention="ZXY", density=density, **kw)
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    renderers.PROFILER = []
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    events, renderers.PROFILER = renderers.PROFILER, None
+    leg = render_leg(dev, subject, args.renderer, not args.no_voxel_grad, rot, xyz, H, delx, args.n_points, args.steps, args.warmup,
+                     exchange=exchange, update_volume=args.update_volume)
+    elapsed = leg["elapsed"]
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = tmax.item()
-
-    # per-kernel launch durations from the HIP events recorded on the launch stream
-    per_kernel = {}
-    for name, e0, e1 in events:
-        per_kernel.setdefault(name, []).append(e0.elapsed_time(e1))
-    kernels = {k: {"launches": len(v), "avg_ms": sum(v) / len(v)} for k, v in per_kernel.items()}
-    # the roofline is priced on the dominant RENDER kernel (forward / backward of the chosen renderer); the
-    # elementwise helpers (ray generation, from-jacobian) do no taps and are listed under "kernels" only
-    render_kernels = [k for k in kernels if k.startswith(args.renderer)] or list(kernels)
-    dominant = max(render_kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"])
-    bytes_per_unit = TAP_BYTES_PER_SAMPLE if args.renderer == "trilinear" else 4
-    for k, v in kernels.items():
-        tapk = k.startswith(args.renderer)  # the elementwise from-jacobian kernel does no taps
-        v["algorithmic_GBps"] = (units * bytes_per_unit / (v["avg_ms"] * 1e-3) / 1e9) if tapk else None
-    dom = kernels[dominant]
-    nominal_units = B * H * H * (args.n_points if args.renderer == "trilinear" else 0)
-    for k, v in kernels.items():
-        bf = binding_floor(k, units, v["avg_ms"])
-        if bf:
-            v["binding"] = bf
-    roofline = {
-        # (`frac` prices SURVEY 8d's algorithmic tap bytes against the HBM peak -- the survey's metric.  The taps are served
-        #  on-chip: what the memory side moved is `hbm_physical`, and the unit that really binds the kernel is `binding`.)
-        "bound": "hbm", "bound_detail": "algorithmic tap bandwidth (cache-served); binding unit under `binding`", "kernel": dominant,
-        "achieved": dom["algorithmic_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": (dom["algorithmic_GBps"] or 0.0) / HBM_PEAK_GBS,
-        "frac_of_measured_copy_peak": (dom["algorithmic_GBps"] or 0.0) / HBM_COPY_GBS,
-        "traffic": pmc_traffic(dominant),
-        "units_per_launch": units, "unit_name": "volume-touching samples" if args.renderer == "trilinear" else "voxel segments",
-        "bytes_per_unit": bytes_per_unit, "avg_launch_ms": dom["avg_ms"],
-        "nominal_units_per_launch": nominal_units or None,
-    }
-    if "binding" in dom:
-        roofline["binding"] = dom["binding"]
-    # Three ways to price the same launch, side by side: `frac` = counted algorithmic taps (the kernel
-    # skips, exactly, the samples that only read padding); `nominal_frac` = SURVEY 8d's nominal B*H*W*N samples -- it can
-    # exceed 1 because more than half of them lie outside the volume; `hbm_physical` = what the memory side actually
-    # moved (FETCH_SIZE + WRITE_SIZE of the committed rocprofv3 PMC passes; FETCH_SIZE under-counts wide coalesced reads
-    # by 2x on gfx950 and is uncalibrated for 4-16 B gathers: the x2 figure is the upper bound)
-    if nominal_units:
-        roofline["nominal_frac"] = nominal_units * bytes_per_unit / (dom["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
-    if roofline["traffic"]:
-        phys = roofline["traffic"] / (dom["avg_ms"] * 1e-3) / 1e9
-        roofline["hbm_physical"] = {"GBps": phys, "frac": phys / HBM_PEAK_GBS, "frac_if_fetch_undercounts_2x": 2 * phys / HBM_PEAK_GBS,
-                                    "source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; separate passes)"}
-
-    # the forward+backward PAIR priced as one unit (64 B per sample with the voxel gradient,
-    # 32 B without), over the summed HIP-event time of every kernel of a step
-    kernel_ms = sum(v["avg_ms"] * v["launches"] for v in kernels.values()) / args.steps
-    pair_bytes = units * bytes_per_unit * (1 if args.no_voxel_grad else 2)
-    roofline["forward_backward_pair"] = {
-        "achieved": pair_bytes / (kernel_ms * 1e-3) / 1e9, "unit": "GB/s", "frac": pair_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-        "kernel_ms_per_step": kernel_ms, "bytes_per_unit": bytes_per_unit * (1 if args.no_voxel_grad else 2),
-    }
 
     result = {
         "metric": "DRRs/sec (fwd+bwd) 512³ CT→256² detector; achieved HBM GB/s vs peak",
@@ -335,14 +370,40 @@ def main():
             "global_batch": B_total, "parallelism": f"pose-sharded x{world}, replicated volume, all-gather of DRRs"
             if world > 1 else "single GPU",
         },
-        "roofline": roofline, "kernels": kernels,
+        "roofline": leg["roofline"], "kernels": leg["kernels"],
     }
 
-    # The headline is conditional on two things the driver's record should show next to it: (i) the benchmark
-    # never changes the volume, so the renderer's cached y-pair copy serves every step -- an optimiser that uses dL/dvoxel
-    # does, and falls back to the natural layout; (ii) `clip_to_volume` is an unpinned semantic knob of the reference's
-    # trilinear renderer, and the other setting has 2.1 x the volume-touching samples.  Two short secondary loops.
-    if world == 1 and not args.no_variants and args.renderer == "trilinear" and not args.no_voxel_grad:
+    if args.check_gather and use_dist:
+        # the exchange moved the right numbers to the right place: every rank's block of the gathered tensor against a render of
+        # that rank's poses done HERE, by this rank alone (the forward is deterministic and independent of the batch's make-up)
+        if rank == 0:
+            kwr = {"n_points": args.n_points} if args.renderer == "trilinear" else {}
+            worst, equal, pad_zero = 0.0, True, True
+            for r in range(world):
+                if args.scaling == "strong":
+                    from xvr_amd.distributed import shard_bounds
+                    l, h = shard_bounds(B_total, r, world)
+                    rr, xx = (t[l:h] for t in deepfluoro_poses(B_total, seed=0).convert("euler_angles", "ZXY"))
+                else:
+                    rr, xx = deepfluoro_poses(args.batch, seed=r).convert("euler_angles", "ZXY")
+                with torch.no_grad():
+                    ref_img = leg["drr"](rr.to(dev), xx.to(dev), parameterization="euler_angles", convention="ZXY", **kwr)
+                blk = exchange.gathered[r * Bmax:r * Bmax + rr.shape[0]]
+                equal = equal and bool(torch.equal(blk, ref_img))
+                worst = max(worst, float((blk - ref_img).abs().max()))
+                pad_zero = pad_zero and bool((exchange.gathered[r * Bmax + rr.shape[0]:(r + 1) * Bmax] == 0).all())
+            result["gather_check"] = {"equal": equal, "max_abs_diff": worst, "padding_zero": pad_zero, "ranks": world}
+        dist.barrier()
+
+    # Secondary legs of the default single-GPU run (every single-GPU configuration of BASELINE.json in the
+    # driver's own line, not in builder-side files).  (i) the headline is conditional on a static volume (cached y-pair copy) and
+    # on the unpinned `clip_to_volume` knob: two short loops; (ii) C3 = the same step through the Siddon renderer; (iii) the
+    # pose-only backward -- the only backward xvr itself requests (registrar/base.py:252, trainer.py:223) -- for both renderers;
+    # (iv) C4 = one registration iteration at 256^2 and 512^2, single and 8 starts batched; (v) C5 = the render side of one
+    # training step.  Each leg carries its own kernel table.
+    if world == 1 and not args.no_variants and args.renderer == "trilinear" and not args.no_voxel_grad and not use_dist:
+        step = leg["step"]
+
         def timed_loop(n, **kws):
             step(**kws)
             torch.cuda.synchronize()
@@ -352,20 +413,109 @@ def main():
             torch.cuda.synchronize()
             return 1e3 * (time.perf_counter() - t) / n
 
-        variants = {"ms_per_step_volume_changing": timed_loop(5, update_volume=True)}
+        variants = {"ms_per_step_volume_changing": timed_loop(5, update=True)}
         drr_clip = DRR(subject, 1020.0, H, delx, renderer="trilinear", reverse_x_axis=False, clip_to_volume=True).to(dev)
-        variants["clip_to_volume_ms_per_step"] = timed_loop(3, module=drr_clip, update_volume=False)
-        del drr_clip
+        variants["clip_to_volume_ms_per_step"] = timed_loop(3, module=drr_clip, update=False)
+        del drr_clip, step
+        leg.pop("step")
+        nsec = max(3, min(args.steps, 10))
+        variants["trilinear_pose_only"] = leg_summary(render_leg(dev, subject, "trilinear", False, rot, xyz, H, delx, args.n_points, nsec, 1), B)
+        torch.cuda.empty_cache()
+        variants["siddon"] = leg_summary(render_leg(dev, subject, "siddon", True, rot, xyz, H, delx, args.n_points, nsec, 1), B)
+        variants["siddon_pose_only"] = leg_summary(render_leg(dev, subject, "siddon", False, rot, xyz, H, delx, args.n_points, nsec, 1), B)
+        for v in ("trilinear_pose_only", "siddon", "siddon_pose_only"):
+            variants[v].pop("step", None)
+        variants["siddon_ms_per_step"] = variants["siddon"]["ms_per_step"]
+        variants["pose_only_ms_per_step"] = {"trilinear": variants["trilinear_pose_only"]["ms_per_step"],
+                                             "siddon": variants["siddon_pose_only"]["ms_per_step"]}
+        torch.cuda.empty_cache()
+        sys.path.insert(0, str(ROOT / "tools"))
+        import benchlib
+
+        # (2048^2 X-ray at 0.136 mm, scales "8,4": 256^2 then 512^2, registrar/base.py:402-407; scaled with --det for the tiny test runs)
+        c4_delx = 0.1360 * 8 * 256 / H
+        variants["c4_register_ms_per_pose_iteration"] = benchlib.c4_register(dev, subject, sizes=((H, c4_delx), (2 * H, c4_delx / 2)))
+        torch.cuda.empty_cache()
+        if args.size == 512 and H == 256:
+            c5 = benchlib.c5_train_step(dev, size=args.size, B=B, H=H)
+            variants["c5_train_step_ms"] = c5["ms_per_step"]
+            variants["c5_train_step"] = c5
         result["variants"] = variants
         result["ms_per_step_volume_changing"] = variants["ms_per_step_volume_changing"]
         result["clip_to_volume_ms_per_step"] = variants["clip_to_volume_ms_per_step"]
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(vol, drr, rot, xyz, spec, args)
+        result["cpu_baseline"] = cpu_baseline(vol, leg["drr"], leg["rot"], leg["xyz"], leg["spec"], args)
     if rank == 0:
         print(json.dumps(result))
     if use_dist:
         dist.destroy_process_group()
+
+
+def init_group(backend, dev, world):
+    kw_pg = {}
+    if world == 1 and "RANK" not in os.environ:   # --force-dist outside a launcher: a one-rank group on the loopback
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        kw_pg = dict(init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev, **kw_pg)
+    else:
+        dist.init_process_group(backend, **kw_pg)
+
+
+def dry_run_collectives(args):
+    """`--gpus N --dry-run-collectives` on ONE GPU: this process plays rank 0 of N.  It allocates the tensors of the N-rank step
+    exactly as a rank would (its share of the poses, the [N * Bmax, 1, H, H] gather buffer, the padded send buffer of a ragged
+    strong split), initialises a one-rank group of --backend (nccl = RCCL), runs the step -- the async all_gather_into_tensor
+    between forward and backward included -- and checks that the block the gather wrote equals this rank's render and that
+    nothing else of the buffer was touched.  What it cannot check is more than one rank over xGMI."""
+    N = max(args.gpus, 1)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    init_group(args.backend, dev, 1)
+    from xvr_amd.data import make_phantom, read
+    from xvr_amd.distributed import shard_bounds
+
+    B, H = args.batch, args.det
+    report = {"dry_run_collectives": True, "as_world_size": N, "backend": args.backend, "scaling": args.scaling, "legs": []}
+    vol, _ = make_phantom(args.size, n_ellipsoids=64, seed=0, device=dev)
+    subject = read(vol, orientation="AP")
+    delx = 1.08821875 * 256 / H
+    for rank in sorted({0, N - 1}):      # the first rank and the last (the ragged share of a strong split)
+        if args.scaling == "strong":
+            lo, hi = shard_bounds(B, rank, N)
+            Bl, B_total = hi - lo, B
+            rot, xyz = (t[lo:hi] for t in deepfluoro_poses(B_total, seed=0).convert("euler_angles", "ZXY"))
+        else:
+            Bl, B_total = B, N * B
+            rot, xyz = deepfluoro_poses(B, seed=rank).convert("euler_angles", "ZXY")
+        Bmax = Bl if args.scaling == "weak" else -(-B_total // N)
+        # a one-rank group gathers into a buffer of ONE share; the N-rank buffer is allocated as well (same bytes a rank holds)
+        full = torch.full((N * Bmax, 1, H, H), float("nan"), device=dev)
+        ex = Exchange(1, Bl, Bmax, H, dev)
+        leg = render_leg(dev, subject, args.renderer, not args.no_voxel_grad, rot, xyz, H, delx, args.n_points, 1, 0, exchange=ex)
+        with torch.no_grad():
+            img = leg["drr"](leg["rot"], leg["xyz"], parameterization="euler_angles", convention="ZXY",
+                             **({"n_points": args.n_points} if args.renderer == "trilinear" else {}))
+        full[rank * Bmax:rank * Bmax + Bmax].copy_(ex.gathered)
+        ok_block = bool(torch.equal(ex.gathered[:Bl], img))
+        ok_pad = bool((ex.gathered[Bl:] == 0).all()) if Bmax > Bl else True
+        ok_rest = bool(torch.isnan(full[:rank * Bmax]).all() and torch.isnan(full[(rank + 1) * Bmax:]).all())
+        report["legs"].append({"as_rank": rank, "poses": Bl, "share_padded_to": Bmax, "gather_buffer_MB": full.numel() * 4 / 1e6,
+                               "send_MB": Bmax * H * H * 4 / 1e6, "gathered_block_equals_render": ok_block, "padding_is_zero": ok_pad,
+                               "rest_untouched": ok_rest, "ms_step": leg["ms_per_step"]})
+        del full, ex, leg
+        torch.cuda.empty_cache()
+    report["ok"] = all(l["gathered_block_equals_render"] and l["padding_is_zero"] and l["rest_untouched"] for l in report["legs"])
+    print(json.dumps(report))
+    dist.destroy_process_group()
+    if not report["ok"]:
+        raise SystemExit(1)
 
 
 def host_cpu():

@@ -42,6 +42,15 @@ def test_bench_json_contract(renderer):
         assert abs(r["binding"]["frac"] - r["binding"]["floor_ms"] / r["avg_launch_ms"]) < 1e-9
         # the knob- and scenario-conditional figures next to the headline
         assert d["ms_per_step_volume_changing"] > 0 and d["clip_to_volume_ms_per_step"] > 0
+        # every single-GPU configuration of BASELINE.json in the driver's line: C3, the pose-only steps, the
+        # C4 iteration at both pyramid levels (single and batched), each with its kernel table (C5 runs at the full size only)
+        v = d["variants"]
+        assert v["siddon_ms_per_step"] > 0 and v["siddon"]["roofline"]["unit_name"] == "voxel segments" and v["siddon"]["kernels"]
+        assert v["pose_only_ms_per_step"]["trilinear"] > 0 and v["pose_only_ms_per_step"]["siddon"] > 0
+        assert "trilinear_forward+jac" in v["trilinear_pose_only"]["kernels"] and v["trilinear_pose_only"]["roofline"]["forward_backward_pair"]["bytes_per_unit"] == 32
+        c4 = v["c4_register_ms_per_pose_iteration"]
+        assert set(c4) == {"32", "64"} and all(c4[k]["single"] > 0 and c4[k]["batched8"] > 0 and c4[k]["kernels"] for k in c4)
+        assert all(c4[k]["ncc"][1] > c4[k]["ncc"][0] for k in c4)
         assert r["nominal_frac"] >= r["frac"]            # nominal samples >= volume-touching samples
         p1 = c["c1_plumbing"]                            # BASELINE.json configs[0], whole DRRs, on the CPU
         assert p1["value"] > 0 and p1["reps"] >= 3 and "128x128" in p1["config"] and "batch_size 4" in p1["config"]
@@ -59,6 +68,24 @@ def test_bench_one_rank_over_rccl():
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["global_batch"] == 4
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--scaling", "strong"], ["--renderer", "siddon"]], ids=["weak", "strong-ragged", "siddon"])
+def test_bench_dry_run_collectives_as_rank_of_eight(extra):
+    """--gpus 8 --dry-run-collectives on ONE GPU: the tensors of the 8-rank step (gather buffer, padded ragged share) allocated as a
+    rank would, the step run with its async all_gather_into_tensor on a one-rank RCCL group, the gathered block compared with the
+    render.  The first 8-GPU run is then the measurement, not the debugging."""
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--dry-run-collectives", "--size", "64", "--det", "32", "--batch", "13",
+           "--n-points", "80", "--backend", "nccl", *extra]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["ok"] and d["as_world_size"] == 8 and [l["as_rank"] for l in d["legs"]] == [0, 7]
+    if "strong" in extra:   # 13 poses over 8 ranks: shares of 2 and 1, padded to 2
+        assert [l["poses"] for l in d["legs"]] == [2, 1] and all(l["share_padded_to"] == 2 for l in d["legs"])
+    else:
+        assert all(l["poses"] == 13 and abs(l["gather_buffer_MB"] - 8 * 13 * 32 * 32 * 4 / 1e6) < 1e-9 for l in d["legs"])
+
+
 def _torchrun_bench(extra, port):
     """bench.py's N > 1 branch on ONE GPU: two ranks, gloo rendezvous, both on cuda:0 (--single-device)."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
@@ -73,8 +100,10 @@ def _torchrun_bench(extra, port):
 
 @pytest.mark.gpu
 def test_bench_two_ranks_weak_scaling_contract():
-    d = _torchrun_bench(["--batch", "4"], 29611)
+    d = _torchrun_bench(["--batch", "4", "--check-gather"], 29611)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8
+    # the gathered tensor, value by value, against a single-process render of both ranks' poses through the HIP path
+    assert d["gather_check"] == {"equal": True, "max_abs_diff": 0.0, "padding_zero": True, "ranks": 2}
     assert abs(d["value"] - 8 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
     assert "cpu_baseline" not in d and "pose-sharded x2" in d["config"]["parallelism"]
     assert d["roofline"]["units_per_launch"] > 0
@@ -83,8 +112,9 @@ def test_bench_two_ranks_weak_scaling_contract():
 @pytest.mark.gpu
 @pytest.mark.parametrize("batch", [6, 5], ids=["even-split", "ragged-split"])
 def test_bench_two_ranks_strong_scaling_contract(batch):
-    d = _torchrun_bench(["--batch", str(batch), "--scaling", "strong"], 29612 + batch)
+    d = _torchrun_bench(["--batch", str(batch), "--scaling", "strong", "--check-gather"], 29612 + batch)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["global_batch"] == batch
+    assert d["gather_check"] == {"equal": True, "max_abs_diff": 0.0, "padding_zero": True, "ranks": 2}   # (ragged: 3 + 2 poses, padded to 3)
     assert abs(d["value"] - batch * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
 
 

@@ -594,3 +594,138 @@ def test_equalize_hip_matches_the_torch_formulation_value_and_gradient(shape):
     assert torch.allclose(out.double(), ref.detach(), atol=2e-5), (out.double() - ref).abs().max()
     err = (xh.grad.double() - xr.grad).abs().max() / xr.grad.abs().max()
     assert err <= 2e-3, err
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# round 4: the device-resident loop for every parameterisation (/root/reference/src/xvr/registrar/base.py:168-169)
+# ---------------------------------------------------------------------------------------------------------------
+NON_EULER = ["axis_angle", "quaternion", "quaternion_adjugate", "rotation_6d", "se3_log_map"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("param", NON_EULER)
+def test_param_camera_and_opt_step_match_torch_adam(param):
+    """xvr_pose_camera_forward_param = drr.camera(convert(rot, xyz, param)); xvr_pose_opt_step_param = the chain rule through
+    convert (forward-mode Jacobian) + torch.optim.Adam(maximize) with the reference's two parameter groups, over several steps."""
+    from xvr_amd.pose_opt import PARAM_KINDS, STATE_DTYPE, axes_of
+    lib = _lib.load()
+    drr = _drr("cuda")
+    G, c = drr.camera_affine()
+    kind, k = PARAM_KINDS[param]
+    B, T = 3, 12
+    g = torch.Generator().manual_seed(21)
+    start = convert((torch.rand(B, 3, generator=g) - 0.5), (torch.rand(B, 3, generator=g) - 0.5) * 50 + torch.tensor([0.0, 800.0, 0.0]),
+                    parameterization="euler_angles", convention="ZXY")
+    rot0, xyz0 = start.convert(param)
+    assert rot0.shape == (B, k)
+    gcams = torch.randn(T, B, 24, generator=g) * torch.logspace(-3, 0, 24)
+    losses = (torch.arange(T).float()[:, None] * 0.01 + torch.zeros(T, B)).contiguous()
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    # torch
+    rot, xyz = rot0.clone().cuda().requires_grad_(), xyz0.clone().cuda().requires_grad_()
+    opt = torch.optim.Adam([{"params": [rot], "lr": 1e-2}, {"params": [xyz], "lr": 1.0}], maximize=True)
+    want_cam, rows = None, []
+    for t in range(T):
+        opt.zero_grad()
+        cam = drr.camera(convert(rot, xyz, parameterization=param))
+        if t == 0:
+            want_cam = cam.detach().clone()
+        (cam * gcams[t].cuda()).sum().backward()
+        opt.step()
+        rows.append(torch.cat([rot.detach(), xyz.detach()], 1).cpu())
+    # HIP
+    r, x = rot0.clone().cuda().contiguous(), xyz0.clone().cuda().contiguous()
+    cam = torch.empty(B, 24, device="cuda")
+    jac = torch.empty(lib.xvr_pose_convert_jacobian_floats(B), device="cuda")
+    spec = _lib.CPoseOptSpec(axes_of("ZXY"), 0.9, 0.999, 1e-8, 1, 0.1, 100, 1e-4, 1e-8, 3, T)
+    state = torch.zeros(B * STATE_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    hist = torch.zeros(B, T, k + 6, device="cuda")
+    assert lib.xvr_pose_opt_init(P(state), B, 1e-2, 1.0, None) == 0
+    for t in range(T):
+        assert lib.xvr_pose_camera_forward_param(P(r), P(x), B, kind, axes_of("ZXY"), P(G), P(c), P(cam), P(jac), None) == 0, lib.xvr_drr_last_error()
+        if t == 0:
+            assert torch.allclose(cam, want_cam, rtol=1e-5, atol=1e-4 * float(want_cam.abs().max()))
+        gc = gcams[t].clone().cuda()
+        assert lib.xvr_pose_opt_step_param(P(r), P(x), B, kind, ctypes.byref(spec), P(G), P(jac), P(gc), P(losses[t].cuda()), P(state), P(hist),
+                                           None) == 0, lib.xvr_drr_last_error()
+        assert float(gc.abs().max()) == 0.0
+        got = torch.cat([r, x], 1).cpu()
+        np.testing.assert_allclose(got[:, :k].numpy(), rows[t][:, :k].numpy(), rtol=0, atol=3e-4)    # steps of 1e-2
+        np.testing.assert_allclose(got[:, k:].numpy(), rows[t][:, k:].numpy(), rtol=0, atol=3e-2)    # steps of 1 mm
+    h = hist.cpu().numpy()
+    np.testing.assert_allclose(h[:, -1, :k + 3], torch.cat([r, x], 1).cpu().numpy())
+    np.testing.assert_allclose(h[:, :, k + 3], losses.T.numpy(), rtol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("param", NON_EULER)
+def test_device_loop_follows_autograd_loop_for_every_parameterisation(param):
+    """Registrar(parameterization=...) on the device (pose -> camera with its Jacobian, Adam on k + 3 parameters) vs the
+    autograd + torch.optim loop over the same kernels: same first iterations, same optimum, and bit-reproducible."""
+    from xvr_amd.metrics import DoubleGeodesicSE3
+    from xvr_amd.registrar import Registrar
+    vol, _ = make_phantom(48, n_ellipsoids=8, seed=8, device="cuda")
+    drr = DRR(read(vol, spacing=(2.5,) * 3, orientation="AP"), 1020.0, 96, 1.8, renderer="trilinear", reverse_x_axis=False,
+              voxel_shift=0.0).cuda()
+    true = convert(torch.tensor([[3.10, 0.05, -0.03]]), torch.tensor([[4.0, 700.0, -6.0]]), parameterization="euler_angles", convention="ZXY")
+    init = convert(torch.tensor([[3.16, 0.01, 0.01]]), torch.tensor([[-4.0, 712.0, 3.0]]), parameterization="euler_angles", convention="ZXY")
+    with torch.no_grad():
+        gt = drr(true.cuda())
+    kw = dict(scales="2,1", n_itrs="40,30", patience=5, max_n_plateaus=2, parameterization=param, lr_rot=5e-3)
+    a = Registrar(drr, device_loop=True, check_every=5, **kw).run(gt, init)
+    a2 = Registrar(drr, device_loop=True, check_every=8, **kw).run(gt, init)
+    b = Registrar(drr, device_loop=False, use_graph=False, **kw).run(gt, init)
+    assert a["trajectory"] == a2["trajectory"] and torch.equal(a["final_pose"].matrix, a2["final_pose"].matrix)
+    ta, tb = np.array(a["trajectory"]), np.array(b["trajectory"])      # logged as Euler ZXY whatever the parameterisation
+    assert ta.shape[1] == 6 and tb.shape[1] == 6
+    k = min(8, len(ta), len(tb))
+    np.testing.assert_allclose(ta[:k, :3], tb[:k, :3], atol=3e-3)
+    np.testing.assert_allclose(ta[:k, 3:], tb[:k, 3:], atol=0.3)
+    np.testing.assert_allclose(a["nccs"][:k], b["nccs"][:k], atol=3e-3)
+    geo = DoubleGeodesicSE3(1020.0)
+    ea, eb, e0 = geo(true, a["final_pose"].cpu())[2].item(), geo(true, b["final_pose"].cpu())[2].item(), geo(true, init)[2].item()
+    assert ea < 0.3 * e0 and eb < 0.3 * e0, (e0, ea, eb)
+    assert len(a["trajectory"]) + 1 == len(a["nccs"]) and len(a["times"]) == len(a["nccs"]) == len(a["lrs"])
+    # the batched multi-start takes the parameterisation too
+    batch = Registrar(drr, device_loop=True, **kw).run_batch(gt, convert(torch.tensor([[3.16, 0.01, 0.01], [3.05, 0.08, -0.05]]),
+                                                                          torch.tensor([[-4.0, 712.0, 3.0], [8.0, 690.0, -10.0]]),
+                                                                          parameterization="euler_angles", convention="ZXY"))
+    assert len(batch) == 2 and all(r["nccs"][-1] > r["nccs"][0] for r in batch)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("per_image", [False, True])
+@pytest.mark.parametrize("beta", [0.5, 1.0])
+def test_equalized_similarity_matches_the_oracle_value_and_gradient(per_image, beta):
+    """EqualizedSimilarity (Standardize -> Equalize + Normalize -> NCC and back, five HIP calls, no tape) against float64
+    autograd through the oracle's torch lines (XrayTransforms with Equalize, unfold NCC)."""
+    from oracle import metrics_restated as mref
+    from xvr_amd.similarity import EqualizedSimilarity
+
+    B, H, W = 2, 40, 36
+    g = torch.Generator().manual_seed(13)
+    base = torch.rand(B, 1, H, W, generator=g)
+    base[:, :, : H // 4] = 0.0                                       # a flat background, as a DRR has
+    fixed_raw = base * 3.0
+    moving = (base.roll(2, dims=-1) * 2.5 + 0.2 * torch.rand(B, 1, H, W, generator=g)) * (base.roll(2, dims=-1) > 0)
+    tf = lambda x: torch.cat([mref.xray_transforms(x[b:b + 1], H, W, equalize_=True) for b in range(x.shape[0])]) if per_image \
+        else mref.xray_transforms(x, H, W, equalize_=True)          # noqa: E731
+    fixed = tf(fixed_raw.double()).float()
+    sim = EqualizedSimilarity(fixed.cuda(), 9, 11, beta, per_image=per_image)
+    m = moving.cuda().requires_grad_()
+    w = torch.tensor([1.0, 1.0]) if not per_image else torch.tensor([0.7, 1.3])
+    loss = sim(m)
+    (loss * w.cuda()).sum().backward()
+    mo = moving.double().requires_grad_()
+    yo = tf(mo)
+    oref = beta * mref.multiscale_ncc(fixed.double(), yo) + (1 - beta) * mref.gradient_ncc(fixed.double(), yo, 11, 0.0)
+    (oref * w.double()).sum().backward()
+    assert torch.allclose(loss.detach().cpu().double(), oref.detach(), atol=3e-4), (loss, oref)
+    err = (m.grad.cpu().double() - mo.grad).abs().max() / mo.grad.abs().max()
+    assert err < 2e-2, err
+    # evaluate() twice over the same buffers: the same bits (fixed-order sums, re-entrant tickets)
+    l2, g2 = torch.empty(B, device="cuda"), torch.empty(B, 1, H, W, device="cuda")
+    l3, g3 = torch.empty(B, device="cuda"), torch.empty(B, 1, H, W, device="cuda")
+    sim.evaluate(m.detach().contiguous(), l2, g2)
+    sim.evaluate(m.detach().contiguous(), l3, g3)
+    assert torch.equal(l2, l3) and torch.equal(g2, g3) and torch.equal(l2, loss.detach())
