@@ -41,7 +41,8 @@ def _c5_miniature():
 def test_c5_miniature_renders_keep_and_pose_gradient_match_the_oracle_pipeline():
     from oracle.diffdrr_restated import drr_from_pose
     from oracle.metrics_restated import multiscale_ncc, xray_transforms
-    from xvr_amd.loss import DiceLoss, PoseRegressionLoss
+    from oracle import loss_restated as oloss
+    from xvr_amd.loss import PoseRegressionLoss
     from xvr_amd.metrics import DoubleGeodesicSE3, XrayTransforms
     from xvr_amd.pose import convert
     from xvr_amd.training import get_random_pose, render_samples
@@ -86,7 +87,7 @@ def test_c5_miniature_renders_keep_and_pose_gradient_match_the_oracle_pipeline()
     o_pred = convert(o_rot, o_xyz, parameterization="euler_angles", convention="ZXY")
     o_p_img, o_p_mask, _ = _reference_keep(oracle_render(o_pred))
     o_mncc = multiscale_ncc(xray_transforms(o_img, H), xray_transforms(o_p_img, H), (None, 9), (0.5, 0.5))
-    o_dice = DiceLoss()(o_mask, o_p_mask)
+    o_dice = oloss.dice_loss(o_mask.float(), o_p_mask.float())
     geo = DoubleGeodesicSE3(1020.0)
     _, _, o_dgeo = geo(pose, o_pred)
     idx, jdx = torch.triu_indices(B, B, offset=1)

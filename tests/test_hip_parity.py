@@ -1013,7 +1013,7 @@ def test_fused_similarity_matches_torch_metrics_and_the_unfold_oracle(shape, bet
     fixed_raw = torch.rand(B, 1, H, W, generator=g) * 40
     moving = (0.7 * fixed_raw + 12 * torch.rand(B, 1, H, W, generator=g)).clamp_min(6.0) - 6.0  # many exact zeros
     moving[:, :, :6, :6] = 0.0
-    tf = XrayTransforms(H, W)
+    tf = lambda x: mref.xray_transforms(x, H, W)   # noqa: E731  (the torch lines, on the CPU)
     fixed = tf(fixed_raw)
     sim = FusedSimilarity(fixed.cuda(), 9, 11, beta)
     mv = moving.cuda().requires_grad_(True)

@@ -480,7 +480,7 @@ def test_fused_similarity_gradient_matches_autograd_through_the_oracle(shape, be
     fixed_raw = torch.rand(B, 1, H, W, generator=g) * 40
     # (a unique minimum and maximum: the oracle's x.min() / x.max() then have one sub-gradient, like the kernels')
     moving = 0.7 * fixed_raw + 12 * torch.rand(B, 1, H, W, generator=g)
-    fixed = XrayTransforms(H, W)(fixed_raw)
+    fixed = mref.xray_transforms(fixed_raw, H, W)
     sim = FusedSimilarity(fixed.cuda(), 9, 11, beta)
     mv = moving.cuda().requires_grad_(True)
     loss = sim(mv)
@@ -519,7 +519,7 @@ def test_fused_similarity_on_drr_like_images_with_a_flat_background(beta):
     fixed_raw, moving = blobs(0.0), blobs(1.5)
     assert (fixed_raw == 0).float().mean() > 0.4 and (moving == 0).float().mean() > 0.4      # mostly exactly-flat background
     moving[:, :, 3, 5] += 31.0   # (a unique maximum, see the test above)
-    fixed = XrayTransforms(H, W)(fixed_raw)
+    fixed = mref.xray_transforms(fixed_raw, H, W)
     sim = FusedSimilarity(fixed.cuda(), 9, 11, beta)
     mv = moving.cuda().requires_grad_(True)
     loss = sim(mv)

@@ -1,0 +1,191 @@
+"""The dominant-axis slab march of the Siddon forward (k_siddon_slab, round 4) against the merge walk it replaces (option
+siddon_slab = 0), the torch oracle and analytic answers -- incl. the tie-breaking cases a fixed three-segment body must get
+right: rays exactly along voxel planes, exactly through voxel corners (45 degrees), a source inside the volume, rays that miss."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import make_case, to_oracle_spec
+
+pytestmark = pytest.mark.gpu
+FWD_TOL, GRAD_TOL = 1e-4, 2e-3
+
+
+def _close(a, b, tol, what=""):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    scale = max(b.abs().max().item(), 1e-12)
+    err = (a - b).abs().max().item() / scale
+    assert err <= tol, f"{what}: rel err {err:.3e} > {tol:.1e} (scale {scale:.3e})"
+
+
+def _render(case, spec, slab, w=None, grid_w=0, count=False):
+    """The UNSPLIT forward (+ jacobian-borne pose gradients) through the slab march (slab = 1) or the merge walk (0)."""
+    from xvr_amd import _lib
+    from xvr_amd.renderers import render
+
+    vol, src, tgt, img = (case[k].cuda() for k in ("volume", "source", "target", "img"))
+    work = torch.zeros(1, dtype=torch.int64, device="cuda") if count else None
+    if w is not None:
+        for t in (src, tgt, img):
+            t.requires_grad_(True)
+    with _lib.option("fwd_split", 1), _lib.option("siddon_slab", slab):
+        out = render(vol, src, tgt, img, spec, None, ray_grid_w=grid_w, **({"work": work} if count else {}))
+        if w is not None:
+            (out * w.cuda()).sum().backward()
+    if count:
+        return out, int(work.item())
+    return (out, src.grad, tgt.grad, img.grad) if w is not None else out
+
+
+@pytest.mark.parametrize("shift", [0.5, 0.0])
+@pytest.mark.parametrize("seed", range(6))
+def test_slab_march_matches_merge_walk_and_oracle(seed, shift):
+    from oracle.diffdrr_restated import render as oracle_render
+    from xvr_amd.spec import RenderSpec
+
+    rng = np.random.default_rng(100 + seed)
+    shape = tuple(int(x) for x in rng.integers(17, 40, size=3))
+    rot = tuple((float(rng.uniform(135, 225)), float(rng.uniform(-45, 45)), float(rng.uniform(-15, 15))) for _ in range(2))
+    xyz = tuple((float(rng.uniform(-8, 8)), float(rng.uniform(150, 320)), float(rng.uniform(-8, 8))) for _ in range(2))
+    case = make_case(shape=shape, height=18, width=26, seed=seed, rot=rot, xyz=xyz, delx=float(rng.uniform(2.0, 7.0)))
+    spec = RenderSpec(renderer="siddon", voxel_shift=shift)
+    w = torch.rand(2, 1, 18 * 26, generator=torch.Generator().manual_seed(seed))
+    new = _render(case, spec, 1, w, grid_w=26)
+    old = _render(case, spec, 0, w, grid_w=26)
+    vol, src, tgt, img = (case[k].clone() for k in ("volume", "source", "target", "img"))
+    for t in (src, tgt, img):
+        t.requires_grad_(True)
+    ref = oracle_render(vol, src, tgt, img, to_oracle_spec(spec), None)
+    (ref * w).sum().backward()
+    _close(new[0], ref, FWD_TOL, "slab forward vs oracle")
+    _close(new[0], old[0], 2e-5, "slab forward vs merge walk")
+    for n, o, r, name in zip(new[1:], old[1:], (src.grad, tgt.grad, img.grad), ("grad_source", "grad_target", "grad_img")):
+        _close(n, r, GRAD_TOL, f"{name} vs oracle")
+        _close(n, o, GRAD_TOL, f"{name} vs merge walk")
+    # linear ray order (no detector lattice) takes the same kernel
+    _close(_render(case, spec, 1), new[0], 1e-6, "linear vs tiled ray order")
+    # the kernels' own segment counts agree (ties aside)
+    _, c_new = _render(case, spec, 1, count=True)
+    _, c_old = _render(case, spec, 0, count=True)
+    assert abs(c_new - c_old) <= 0.01 * c_old + 8, (c_new, c_old)
+
+
+def _rays(src, tgts):
+    s = torch.tensor([[src]], dtype=torch.float32)
+    t = torch.tensor([tgts], dtype=torch.float32)
+    return dict(source=s, target=t, img=(t - s).norm(dim=-1).unsqueeze(1))
+
+
+@pytest.mark.parametrize("shift", [0.5, 0.0])
+def test_slab_march_known_answers_axis_aligned_and_on_planes(shift):
+    """Uniform box: the integral is density x chord, whatever plane or corner the ray runs along.  Rays exactly ALONG voxel planes
+    (both minor coordinates on plane positions) and through the volume's corner columns are the ties of a Siddon walk."""
+    from xvr_amd.spec import RenderSpec
+
+    spec = RenderSpec(renderer="siddon", voxel_shift=shift)
+    D = (10, 12, 14)
+    vol = torch.full(D, 0.75)
+    p0 = -shift                     # plane p of an axis sits at p + plane0, plane0 = -shift
+    for axis in range(3):
+        u, v = [a for a in range(3) if a != axis]
+        tg = []
+        for cu, cv in ((3.3, 4.1), (3.0 + p0, 4.1), (3.0 + p0, 5.0 + p0), (0.0 + p0 + 1e-3, 0.0 + p0 + 1e-3), (D[u] + p0 - 1e-3, 2.5)):
+            s = [0.0, 0.0, 0.0]
+            s[u], s[v] = cu, cv
+            tg.append(s)
+        for sign in (1.0, -1.0):
+            outs = []
+            for s in tg:
+                a, b = list(s), list(s)
+                a[axis], b[axis] = (-50.0, 150.0) if sign > 0 else (150.0, -50.0)
+                case = dict(volume=vol, **_rays(a, [b]))
+                outs.append(_render(case, spec, 1).item())
+            assert all(abs(o - 0.75 * D[axis]) < 2e-3 for o in outs), (shift, axis, sign, outs)
+
+
+@pytest.mark.parametrize("shift", [0.5, 0.0])
+def test_slab_march_known_answers_diagonals(shift):
+    """45-degree rays: |d_u| = |d_m| exactly, every slab has a minor crossing, and a ray aimed through voxel corners crosses two
+    planes at the same alpha in every slab.  Uniform box => density x chord (L x fraction of alpha inside)."""
+    from xvr_amd.spec import RenderSpec
+
+    spec = RenderSpec(renderer="siddon", voxel_shift=shift)
+    D = 12
+    vol = torch.full((D, D, D), 0.5)
+    lo, hi = -shift, D - shift               # the box in index coordinates
+    cases = []
+    for off in (0.0, 0.3, 0.5):              # through the corners / off the corners
+        cases.append(([lo - 20.0, lo - 20.0 + off, 5.3], [hi + 20.0, hi + 20.0 + off, 5.3]))          # x-y diagonal
+        cases.append(([5.3, hi + 20.0 + off, lo - 20.0], [5.3, lo - 20.0 + off, hi + 20.0]))          # y-z anti-diagonal
+        cases.append(([lo - 20.0, lo - 20.0 + off, lo - 20.0 + off], [hi + 20.0, hi + 20.0 + off, hi + 20.0 + off]))   # space diagonal
+    for s, t in cases:
+        case = dict(volume=vol, **_rays(s, [t]))
+        got = _render(case, spec, 1).item()
+        d = np.array(t, dtype=np.float64) - np.array(s, dtype=np.float64)
+        a0 = np.where(d > 0, (lo - np.array(s)) / d, (hi - np.array(s)) / d)
+        a1 = np.where(d > 0, (hi - np.array(s)) / d, (lo - np.array(s)) / d)
+        mask = np.abs(d) > 1e-9
+        span = max(0.0, min(a1[mask].min(), 1.0) - max(a0[mask].max(), 0.0))
+        want = 0.5 * span * np.linalg.norm(d)
+        assert abs(got - want) < 2e-3 * max(want, 1.0), (shift, s, t, got, want)
+        old = _render(case, spec, 0).item()
+        assert abs(got - old) < 2e-3 * max(want, 1.0), (shift, s, t, got, old)
+
+
+def test_slab_march_source_inside_miss_and_hot_voxel():
+    from oracle.diffdrr_restated import render as oracle_render
+    from xvr_amd.spec import RenderSpec
+
+    spec = RenderSpec(renderer="siddon", voxel_shift=0.0)
+    vol = torch.full((10, 10, 10), 0.5)
+    # source inside the volume: integration clamped to alpha >= 0; a target inside as well; a ray that misses
+    case = dict(volume=vol, **_rays([2.25, 5.0, 5.0], [[30.0, 5.0, 5.0], [7.5, 6.0, 4.0], [2.25, 5.0, 40.0]]))
+    out = _render(case, spec, 1)[0, 0]
+    assert abs(out[0].item() - 0.5 * (10 - 2.25)) < 1e-4
+    assert abs(out[1].item() - 0.5 * math.dist([2.25, 5.0, 5.0], [7.5, 6.0, 4.0])) < 1e-4
+    case = dict(volume=vol, **_rays([-20.0, 30.0, 5.0], [[40.0, 31.0, 5.0], [-20.0, 5.0, 5.0]]))
+    assert float(_render(case, spec, 1).abs().max()) == 0.0
+    # one hot voxel: exactly the path length inside it, against the oracle for oblique rays
+    spec = RenderSpec(renderer="siddon", voxel_shift=0.5)
+    vol = torch.zeros(9, 9, 9)
+    vol[4, 5, 3] = 2.0
+    case = dict(volume=vol, **_rays([-50.0, 5.2, 2.9], [[150.0, 5.2, 2.9], [150.0, 5.2, 3.6], [150.0, 9.0, 2.0], [150.0, 1.0, 4.0]]))
+    got = _render(case, spec, 1)
+    assert abs(got[0, 0, 0].item() - 2.0) < 1e-4
+    ref = oracle_render(case["volume"], case["source"], case["target"], case["img"], to_oracle_spec(spec), None)
+    _close(got, ref, FWD_TOL, "hot voxel")
+
+
+def test_slab_march_is_the_default_for_large_one_channel_launches_and_deterministic():
+    """A launch of >= 2048 wavefronts with the exact index map takes the slab march by itself (no option), on the natural layout;
+    two runs give the same bits; DRR.forward's pose gradient follows central differences of the render."""
+    from xvr_amd import renderers
+    from xvr_amd.data import make_phantom, read
+    from xvr_amd.drr import DRR
+    from xvr_amd.pose import convert
+
+    vol, _ = make_phantom(64, n_ellipsoids=10, seed=3, device="cuda")
+    drr = DRR(read(vol, spacing=(2.0,) * 3, orientation="AP"), 1020.0, 128, 2.2, renderer="siddon", reverse_x_axis=False).cuda()
+    B = 10                                                              # 10 x 256 wavefronts
+    g = torch.Generator().manual_seed(1)
+    rot = (torch.tensor([[3.14, 0.0, 0.0]]) + (torch.rand(B, 3, generator=g) - 0.5) * 0.8).cuda().requires_grad_()
+    xyz = (torch.tensor([[0.0, 700.0, 0.0]]) + (torch.rand(B, 3, generator=g) - 0.5) * 30).cuda().requires_grad_()
+    renderers.PROFILER = []
+    a = drr(rot, xyz, parameterization="euler_angles", convention="ZXY")
+    names = {e[0] for e in renderers.PROFILER}
+    renderers.PROFILER = None
+    assert "pack_bricks" not in names, names
+    b = drr(rot, xyz, parameterization="euler_angles", convention="ZXY")
+    assert torch.equal(a, b)
+    w = torch.rand(a.shape, generator=g).cuda()
+    (a * w).sum().backward()
+    with torch.no_grad():
+        for col, h in ((1, 2e-3), (2, 2e-3)):
+            e = torch.zeros(B, 3, device="cuda")
+            e[:, col] = h
+            num = ((drr(rot + e, xyz, parameterization="euler_angles", convention="ZXY") * w).sum((1, 2, 3))
+                   - (drr(rot - e, xyz, parameterization="euler_angles", convention="ZXY") * w).sum((1, 2, 3))) / (2 * h)
+            rel = (rot.grad[:, col] - num).abs() / num.abs().clamp_min(1e-3 * num.abs().max())
+            assert rel.median() < 0.05 and rel.max() < 0.5, (col, rel)

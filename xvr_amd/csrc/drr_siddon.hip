@@ -271,6 +271,147 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAX : WG) __attribute__((amdgpu_
 }
 
 
+// =============================================================================================
+// Siddon forward (+ jacobian) as a march over the unit slabs of every ray's DOMINANT axis (round 4).
+//
+// The merge walk above spends ~77 vector instructions per voxel segment: three plane alphas recomputed per segment, a four-way
+// minimum, three compares and selects for the axis, bounds tests, a cvt chain per axis -- and it is vector-issue bound (0.93 of
+// the launch, profiles/r03_bench_final_siddon.json).  Here a trip of the loop is one unit slab between two consecutive planes of
+// the axis m along which the ray moves fastest.  Inside a slab the ray advances by at most one voxel along either of the other
+// two axes (|d_u|, |d_v| <= |d_m|), so the slab holds at most three voxel segments, in a FIXED body:
+//
+//     [ac, lo] in voxel (iu, iv) . [lo, hi] behind the first minor crossing . [hi, a_end] behind both,   lo <= hi the two minor
+//     crossing alphas clamped into the slab (med3): a crossing that is not in this slab gives a zero-length segment.
+//
+// No minimum search, no axis select chain, no per-segment bounds test: the voxel offset moves by constants (+-stride of the
+// crossed axis), the walk starts inside the volume and can only cross INTERIOR planes, because the far boundary plane of every
+// axis bounds a_hi by the very arithmetic the loop evaluates plane alphas with (alpha(p) = ((float)p + (plane0 - s)) / d is a pure
+// function of the plane index: monotone along the ray, the same bits inside and outside the loop).  The three loads of a slab are
+// independent and predicated on their segment's length; values of zero-length segments repeat their predecessor's, which makes
+// the jumps the jacobian sums (U_i = sum dW alpha, M_i = sum dW per axis, as in the merge walk) vanish where nothing is crossed.
+// ~50 vector instructions per slab for 1.8 segments.  The roles (m, u, v) are per-lane data, not template parameters: strides,
+// reciprocals and plane counters live in registers either way, so a wavefront whose rays disagree on the dominant axis costs
+// nothing extra.  Serves the unsplit one-channel forward with the exact index map on the natural layout (option siddon_slab,
+// default 1); masks, non-exact maps, the alpha-split small launches and the re-marching backward keep the merge walk.
+// =============================================================================================
+#ifndef XVR_SLAB_WAVES
+#define XVR_SLAB_WAVES 8
+#endif
+__device__ __forceinline__ float sel3f(int k, float a, float b, float c) { return k == 0 ? a : (k == 1 ? b : c); }
+__device__ __forceinline__ int sel3i(int k, int a, int b, int c) { return k == 0 ? a : (k == 1 ? b : c); }
+__device__ __forceinline__ float med3f(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+
+template <bool JAC>
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, XVR_SLAB_WAVES))) void k_siddon_slab(RenderArgs A) {
+    int b, r;
+    const bool valid = map_ray(A, b, r, threadIdx.x);
+    Ray R;
+    ray_setup(A, b, r, valid, R);
+    const float* __restrict__ vol = A.volume;
+    const int D[3] = {A.D0, A.D1, A.D2};
+    const int strd[3] = {A.D1 * A.D2 * 4, A.D2 * 4, 4};   // (byte offsets: the buffer loads take them as they are)
+    const unsigned vol_bytes = (unsigned)A.D0 * (unsigned)A.D1 * (unsigned)A.D2 * 4u;
+    const bool live = valid && (R.amax > R.amin);
+    const float alo = live ? R.amin : 0.f;
+
+    // per axis: the voxel the ray enters, the next plane in travel direction and the far boundary plane (as floats: exact small
+    // integers), plane0 - s, 1 / d, the signed stride
+    float fp[3], fpfar[3], ps[3], inv_d[3], stpf[3];
+    int sstr[3], off = 0;
+    float ahi = live ? R.amax : 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        inv_d[i] = 1.f / R.d[i];
+        ps[i] = A.sp.plane0[i] - R.s[i];
+        const float f = fmaf(alo, R.d[i], R.s[i]) - A.sp.plane0[i];   // entry position in plane-index units
+        const int i0 = min(max((int)floorf(f), 0), D[i] - 1);
+        const bool fwd = R.d[i] > 0.f;
+        fp[i] = (float)(i0 + (fwd ? 1 : 0));
+        fpfar[i] = fwd ? (float)D[i] : 0.f;
+        stpf[i] = fwd ? 1.f : -1.f;
+        sstr[i] = fwd ? strd[i] : -strd[i];
+        off += i0 * strd[i];
+        ahi = fminf(ahi, (fpfar[i] + ps[i]) * inv_d[i]);   // the loop's own plane arithmetic: no far plane is ever crossed
+    }
+    const float ad0 = fabsf(R.d[0]), ad1 = fabsf(R.d[1]), ad2 = fabsf(R.d[2]);
+    const int m = (ad0 >= ad1 && ad0 >= ad2) ? 0 : (ad1 >= ad2 ? 1 : 2);
+    const int u = m == 2 ? 0 : m + 1, v = 3 - m - u;
+    float fpm = sel3f(m, fp[0], fp[1], fp[2]), fpu = sel3f(u, fp[0], fp[1], fp[2]), fpv = sel3f(v, fp[0], fp[1], fp[2]);
+    const float psm = sel3f(m, ps[0], ps[1], ps[2]), psu = sel3f(u, ps[0], ps[1], ps[2]), psv = sel3f(v, ps[0], ps[1], ps[2]);
+    const float ivm = sel3f(m, inv_d[0], inv_d[1], inv_d[2]), ivu = sel3f(u, inv_d[0], inv_d[1], inv_d[2]), ivv = sel3f(v, inv_d[0], inv_d[1], inv_d[2]);
+    const float stm = sel3f(m, stpf[0], stpf[1], stpf[2]), stu = sel3f(u, stpf[0], stpf[1], stpf[2]), stv = sel3f(v, stpf[0], stpf[1], stpf[2]);
+    const int sm = sel3i(m, sstr[0], sstr[1], sstr[2]), su = sel3i(u, sstr[0], sstr[1], sstr[2]), sv = sel3i(v, sstr[0], sstr[1], sstr[2]);
+
+    float ac = alo, acc = 0.f;
+    float Um = 0.f, Uu = 0.f, Uv = 0.f, Mm = 0.f, Mu = 0.f, Mv = 0.f;
+    // Loads go through a buffer resource over the volume: a lane whose segment has zero length hands the hardware an offset
+    // beyond the buffer and gets 0 back WITHOUT a memory request -- predication with no exec-mask branch, so the three loads of a
+    // slab are issued back to back (with branches the compiler chains each load behind its predecessor's select).
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vol), (short)0, vol_bytes, 0x00020000);
+    auto ld = [&](bool p, int o) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, p ? o : -1, 0, 0)); };
+    // the first voxel's value opens the walk: the entry crossing (on axis ax_in, when the ray enters through a real plane) is
+    // added after the loop, the loop's first "dominant-axis crossing" then sees no jump
+    const bool walks = live && ahi > alo;
+    const float vfirst = ld(walks, off);
+    float Wprev = vfirst;
+    unsigned cnt = 0;
+    // (terminates: the dominant plane counter moves every trip, so its alpha passes a_hi after at most D_m trips; a NaN alpha
+    //  clamps to the slab's start and the next trip's differs)
+    while (__builtin_amdgcn_ballot_w64(ac < ahi)) {             // wave-uniform: until every ray of the wavefront has left the volume
+        const float am = (fpm + psm) * ivm;
+        const float aend = med3f(am, ac, ahi);
+        const float aur = (fpu + psu) * ivu, avr = (fpv + psv) * ivv;
+        const bool cu = aur < aend, cv = avr < aend;            // the minor planes crossed inside this slab
+        const float au = med3f(aur, ac, aend), av = med3f(avr, ac, aend);
+        const bool uf = au <= av;                               // u is crossed first
+        const float lo = uf ? au : av, hi = uf ? av : au;
+        const float l1 = lo - ac, l2 = hi - lo, l3 = aend - hi;
+        const int du = cu ? su : 0, dv = cv ? sv : 0;
+        const int off2 = off + (uf ? du : dv), off3 = off + du + dv;
+        const bool p1 = l1 > 0.f, p2 = l2 > 0.f, p3 = l3 > 0.f;
+        const float t1 = ld(p1, off), t2 = ld(p2, off2), t3 = ld(p3, off3);
+        if (A.work) cnt += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(p1)) + (unsigned)__popcll(__builtin_amdgcn_ballot_w64(p2)) +
+                           (unsigned)__popcll(__builtin_amdgcn_ballot_w64(p3));
+        acc = fmaf(t1, l1, acc);                                // (a masked load returns 0 and its length is 0)
+        acc = fmaf(t2, l2, acc);
+        acc = fmaf(t3, l3, acc);
+        if (JAC) {
+            const float v1 = p1 ? t1 : Wprev, v2 = p2 ? t2 : v1, v3 = p3 ? t3 : v2;
+            const float Jm = Wprev - v1, J1 = v1 - v2, J2 = v2 - v3;   // jumps at the slab's entry plane, at lo, at hi
+            const float Ju = uf ? J1 : J2, Jv = uf ? J2 : J1;
+            Um = fmaf(Jm, ac, Um); Mm += Jm;
+            Uu = fmaf(Ju, au, Uu); Mu += Ju;
+            Uv = fmaf(Jv, av, Uv); Mv += Jv;
+            Wprev = v3;
+        }
+        fpu += cu ? stu : 0.f;
+        fpv += cv ? stv : 0.f;
+        fpm += stm;
+        off = off3 + sm;
+        ac = aend;
+    }
+
+    if (valid) {
+        A.out[(size_t)b * A.n + r] = acc * R.L;
+        if (JAC) {
+            float U[3], M[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                U[i] = m == i ? Um : (u == i ? Uu : Uv);
+                M[i] = m == i ? Mm : (u == i ? Mu : Mv);
+                if (walks) {
+                    if (R.ax_in == i) { U[i] = fmaf(-vfirst, alo, U[i]); M[i] -= vfirst; }      // entry: 0 -> first voxel
+                    if (R.ax_out == i) { U[i] = fmaf(Wprev, ahi, U[i]); M[i] += Wprev; }         // exit: last voxel -> 0
+                }
+            }
+            float4* jp = reinterpret_cast<float4*>(A.jac + ((size_t)b * A.n + r) * XVR_DRR_JAC_STRIDE);
+            jp[0] = make_float4(acc, R.L * inv_d[0] * (U[0] - M[0]), R.L * inv_d[1] * (U[1] - M[1]), R.L * inv_d[2] * (U[2] - M[2]));
+            jp[1] = make_float4(-R.L * inv_d[0] * U[0], -R.L * inv_d[1] * U[1], -R.L * inv_d[2] * U[2], 0.f);
+        }
+    }
+    if (A.work && (threadIdx.x & 63) == 0 && cnt) atomicAdd(A.work, (unsigned long long)cnt);
+}
+
 }  // namespace
 
 extern "C" {
@@ -298,6 +439,11 @@ static int siddon_forward_impl(const float* volume, const float* mask, int D0, i
     if (mask && jac) return (ex ? launch(k_siddon<1, true, false, false, true>, A, lds, stream) : launch(k_siddon<1, true, false, false, false>, A, lds, stream));
     if (mask) return (ex ? launch(k_siddon<0, true, false, false, true>, A, lds, stream) : launch(k_siddon<0, true, false, false, false>, A, lds, stream));
     bool tile16 = false;
+    if (sp->volume_layout == 0 && ex && xvr_detail::option(xvr_detail::OPT_SIDDON_SLAB) && (long long)D0 * D1 * D2 < (1LL << 29) &&
+        split_factor(B, n, (long long)D0 * D1 * D2, true, &tile16) == 1) {   // the dominant-axis slab march (round 4)
+        if (jac) return launch(k_siddon_slab<true>, A, 0, stream);
+        return launch(k_siddon_slab<false>, A, 0, stream);
+    }
     if (sp->volume_layout == 2) {
         if (jac) return launch(k_siddon<1, false, false, false, true, 0, true>, A, 0, stream);
         return launch(k_siddon<0, false, false, false, true, 0, true>, A, 0, stream);
