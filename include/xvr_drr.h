@@ -89,7 +89,7 @@ const char* xvr_drr_last_error(void);
  *   "gather_splat"  1 | 0 | 2  trilinear voxel gradient: brick-local fixed-point splat | fp32 voxel-driven gathers | the ray-major
  *                              splat (clip_to_volume = 1 and per-channel masks always use it) for every render (A/B) [1]
  *   "fwd_slabs"     0 | -1 | n  slab-major trilinear forward (one launch per slab of the volume, all poses; measured SLOWER,
- *                              DESIGN.md 4.4): never | by size | n slabs                                         [0]
+ *                              HISTORY.md 4.4): never | by size | n slabs                                         [0]
  *   "fwd_slab_axis" 0-2        volume axis the slabs are cut along                                               [1]
  * Returns XVR_DRR_E_ARG for an unknown name or a value outside the option's range.
  */
@@ -253,7 +253,7 @@ int xvr_drr_pack_labels(const float* volume, const float* mask, long long n, flo
  *     pairs[x][yp][z] = (V[x][yp - 1][z], V[x][yp][z]),  yp = 0 .. D1, zero outside the volume
  * i.e. [D0][D1 + 1][D2][2] floats = xvr_drr_ypairs_bytes().  One 16-byte load at (x, floor(y) + 1, z) then returns the
  * four taps (y, z), (y + 1, z), (y, z + 1), (y + 1, z + 1): a sample costs two gather instructions instead of four, and
- * the march is bound by the texture-address rate per instruction.  Twice the memory of the
+ * the march is bound by the texture-address rate per instruction (HISTORY.md section 4.2).  Twice the memory of the
  * volume; built in one streaming pass; the forward's arithmetic is unchanged (identical output bits).
  */
 size_t xvr_drr_ypairs_bytes(int D0, int D1, int D2);

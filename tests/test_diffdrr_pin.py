@@ -12,13 +12,14 @@ import torch
 
 PIN = Path(__file__).resolve().parent / "golden" / "diffdrr_pin.npz"
 needs_pin = pytest.mark.skipif(not PIN.exists(), reason="tests/golden/diffdrr_pin.npz absent: run tools/pin_against_diffdrr.py where diffdrr is installed")
+PIN_FILE = {"path": PIN}      # (the rehearsal below points the consumers at the file the tool wrote against a planted renderer)
 
 TAGS = [(r, s) for r in ("trilinear", "siddon") for s in (0.5, 0.0)]
 CASES = ["case11", "case12", "c1"]
 
 
 def _load():
-    z = np.load(PIN, allow_pickle=False)
+    z = np.load(PIN_FILE["path"], allow_pickle=False)
     return {k: z[k] for k in z.files}
 
 
@@ -42,13 +43,8 @@ def test_pin_tool_is_importable_and_refuses_to_run_without_diffdrr():
     c1 = mod.c1_case()
     assert c1["target"].shape == (1, 128 * 128, 3) and c1["img"].shape == (1, 1, 128 * 128)
     if importlib.util.find_spec("diffdrr") is None:
-        old = sys.argv
-        sys.argv = ["pin_against_diffdrr.py"]
-        try:
-            with pytest.raises(SystemExit, match="diffdrr is not importable"):
-                mod.main()
-        finally:
-            sys.argv = old
+        with pytest.raises(SystemExit, match="diffdrr is not importable"):
+            mod.main([])
 
 
 @needs_pin
@@ -86,7 +82,7 @@ def test_hip_reproduces_the_real_diffdrr(renderer, shift):
     for name in CASES:
         c = {k: v.cuda() for k, v in _case(z, name).items()}
         v, s, t = (c[k].clone().requires_grad_(True) for k in ("volume", "source", "target"))
-        gw = 128 if name == "c1" else 10
+        gw = int(round(c["img"].shape[-1] ** 0.5)) if name == "c1" else 10
         out = render(v, s, t, c["img"], spec, ray_grid_w=gw)
         (out * torch.from_numpy(z[f"{tag}_{name}_w"]).cuda()).sum().backward()
         assert _rel(out.cpu(), torch.from_numpy(z[f"{tag}_{name}_out"])) <= 1e-4
@@ -94,3 +90,86 @@ def test_hip_reproduces_the_real_diffdrr(renderer, shift):
             assert _rel(g.cpu(), torch.from_numpy(z[f"{tag}_{name}_{key}"])) <= 2e-3, key
         outm = render(c["volume"], c["source"], c["target"], c["img"], spec, c["mask"], ray_grid_w=gw)
         assert _rel(outm.cpu(), torch.from_numpy(z[f"{tag}_{name}_mask_out"])) <= 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Rehearsal of the pin's first contact: a fake ``diffdrr.renderers`` whose Siddon / Trilinear are the oracle
+# with PLANTED, non-default knobs (different per renderer and per voxel_shift).  The tool must run end to end against it, its grid
+# search must recover exactly the planted knobs, and the consumers above, pointed at the file it wrote, must go green.  On the
+# day someone has the real package the recipe then works first time.  (This proves the RECIPE; parity itself stays unpinned.)
+# ---------------------------------------------------------------------------------------------------------------
+PLANTED = {
+    ("trilinear", 0.5): dict(norm_dims_offset=-1, align_corners=False, step_mode="n_minus_1", clip_to_volume=True),
+    ("trilinear", 0.0): dict(norm_dims_offset=0, align_corners=True, step_mode="n_points", clip_to_volume="batch"),
+    ("siddon", 0.5): dict(norm_dims_offset=+1, align_corners=False),
+    ("siddon", 0.0): dict(norm_dims_offset=0, align_corners=True),
+}
+
+
+def _install_planted_diffdrr(monkeypatch):
+    import sys
+    import types
+
+    from oracle.diffdrr_restated import RenderSpec, render as oracle_render
+
+    def make(renderer):
+        class _Renderer(torch.nn.Module):
+            def __init__(self, voxel_shift=0.5):
+                super().__init__()
+                self.voxel_shift = voxel_shift
+
+            def forward(self, volume, source, target, img, mask=None, n_points=500):
+                spec = RenderSpec(renderer=renderer, voxel_shift=self.voxel_shift, n_points=n_points, **PLANTED[(renderer, self.voxel_shift)])
+                return oracle_render(volume, source, target, img, spec, mask)
+        _Renderer.__name__ = renderer.capitalize()
+        return _Renderer
+
+    pkg = types.ModuleType("diffdrr")
+    pkg.__doc__, pkg.__version__, pkg.__file__, pkg.__path__ = "planted stand-in for the rehearsal", "0.0-planted", str(PIN), []
+    ren = types.ModuleType("diffdrr.renderers")
+    ren.Siddon, ren.Trilinear = make("siddon"), make("trilinear")
+    pkg.renderers = ren
+    monkeypatch.setitem(sys.modules, "diffdrr", pkg)
+    monkeypatch.setitem(sys.modules, "diffdrr.renderers", ren)
+
+
+@pytest.fixture(scope="module")
+def planted_pin(tmp_path_factory):
+    """tools/pin_against_diffdrr.py --quick run end to end against the planted renderers; -> path of the file it wrote."""
+    import importlib.util
+
+    mp = pytest.MonkeyPatch()
+    try:
+        _install_planted_diffdrr(mp)
+        spec = importlib.util.spec_from_file_location("pin_against_diffdrr_rehearsal", PIN.parents[2] / "tools" / "pin_against_diffdrr.py")
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        out = tmp_path_factory.mktemp("pin") / "diffdrr_pin.npz"
+        rc = mod.main(["--out", str(out), "--quick"])
+        assert rc == 0 and out.exists()          # "PINNED": some knob set reproduces every vector to 1e-4
+    finally:
+        mp.undo()
+    return out
+
+
+def test_pin_recipe_recovers_planted_knobs(planted_pin):
+    z = np.load(planted_pin, allow_pickle=False)
+    for (renderer, shift), planted in PLANTED.items():
+        tag = f"{renderer}_shift{shift}"
+        found = json.loads(str(z[tag + "_knobs"]))
+        assert float(z[tag + "_err"]) <= 1e-6, (tag, float(z[tag + "_err"]))
+        for k, v in planted.items():      # (eps_in_xyz, per_ray_clamp and the Siddon filter are numerically neutral on these cases)
+            assert found[k] == v, (tag, k, found[k], v)
+
+
+@pytest.mark.parametrize("renderer,shift", TAGS)
+def test_pin_consumers_go_green_on_the_rehearsal_file(planted_pin, renderer, shift, monkeypatch):
+    monkeypatch.setitem(PIN_FILE, "path", planted_pin)
+    test_oracle_reproduces_the_real_diffdrr(renderer, shift)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("renderer,shift", TAGS)
+def test_hip_consumer_goes_green_on_the_rehearsal_file(planted_pin, renderer, shift, monkeypatch):
+    monkeypatch.setitem(PIN_FILE, "path", planted_pin)
+    test_hip_reproduces_the_real_diffdrr(renderer, shift)

@@ -55,8 +55,9 @@ def test_xray_transforms_match_reference_lines(equalize):
     assert torch.allclose(t(x.cuda()).cpu(), ref.xray_transforms(x, 16, equalize_=equalize), atol=2e-5)
     same = metrics.XrayTransforms(64, equalize=equalize)(x.cuda()).cpu()
     assert torch.allclose(same, ref.xray_transforms(x, 64, equalize_=equalize), atol=2e-5)
-    if not equalize:
-        assert torch.equal(same, ((x - x.min()) / (x.max() - x.min() + 1e-6) - 0.15) / 0.1)
+    if not equalize:   # the torch expression evaluated on the same device: the same bits
+        xg = x.cuda()
+        assert torch.equal(same, (((xg - xg.min()) / (xg.max() - xg.min() + 1e-6) - 0.15) / 0.1).cpu())
 
 
 def test_xray_transforms_have_no_cpu_path():

@@ -16,15 +16,17 @@ def test_multistart_registration_two_ranks():
            "--starts", "3"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("rank ")]
-    assert len(lines) == 2, out.stdout
-    found = [re.search(r"refined (\d+) starts; best ncc ([\d.]+) from rank (\d); pose error ([\d.]+) mm", l) for l in lines]
-    assert all(found)
+    # (two processes write to one pipe: a report can land behind another line's text instead of on a line of its own)
+    found = list(re.finditer(r"rank \d/2: refined (\d+) starts; best ncc ([\d.]+) from rank (\d); pose error ([\d.]+) mm = ([\d.]+) deg, "
+                             r"([\d.]+) mm across / ([\d.]+) mm along", out.stdout))
+    assert len(found) == 2, out.stdout
     assert sorted(int(m.group(1)) for m in found) == [1, 2]                      # 3 starts split 2 + 1
     assert len({(m.group(2), m.group(3), m.group(4)) for m in found}) == 1          # every rank agrees on the winner
-    # starts are 100+ mm off; the end point moves by a few mm from run to run (atomic-order noise, amplified by
-    # Adam's sign-like first steps, mostly along the poorly conditioned source-detector axis)
-    assert float(found[0].group(2)) > 0.9 and float(found[0].group(4)) < 20.0
+    # starts are 100+ mm off (+-10 degrees, +-20 mm).  The device-resident loop is bit-reproducible, so the bound is what a
+    # registration should deliver (the full-size C4 test's bar): under a degree, under 2 mm across the view; a single view fixes
+    # the depth poorly (1 % of magnification per 7 mm at 700 mm), hence the looser bound along it
+    ncc, rot_deg, across, along = (float(found[0].group(k)) for k in (2, 5, 6, 7))
+    assert ncc > 0.99 and rot_deg < 1.0 and across < 2.0 and along < 12.0, (ncc, rot_deg, across, along)
 
 
 @pytest.mark.gpu

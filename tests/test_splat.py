@@ -1,5 +1,5 @@
 """The default voxel gradient of the trilinear renderer: the brick-local fixed-point splat (k_trilinear_splat_b16,
-DESIGN.md section 4.1) against the fp32 table gather (option gather_splat = 0), the atomic scatter and the oracle -- on
+HISTORY.md section 4.1) against the fp32 table gather (option gather_splat = 0), the atomic scatter and the oracle -- on
 the paths the small parity cases do not reach (list overflow and more steps than a list holds -> "safe mode", a pose with
 an all-zero or a non-finite upstream gradient, volumes smaller than a brick) and bit-for-bit repeatability."""
 import pytest

@@ -2,7 +2,7 @@
 instead of loaded; results are WRONG by construction -- separate libraries, never the product's).  CAUTION when reading
 the numbers (round 2 learnt this the hard way): with constant candidates the compiler hoists their arithmetic out of the
 trip, so "ablated = 8.7 ms, half the loads = 10.6 ms" is an UPPER bound on what memory costs, not the cost -- a variant
-that really loaded a quarter of the bytes was slower.  python tools/ablate_gather.py build | run"""
+that really loaded a quarter of the bytes was slower (HISTORY.md section 4.1).  python tools/ablate_gather.py build | run"""
 import json
 import os
 import subprocess

@@ -1,5 +1,5 @@
 """Trilinear forward (+ jacobian) at the benchmark's size (512^3 -> 256^2, 116 poses, n_points 500) under the launch options of
-the slab-major march, with two diagnostics.  Run on the GPU box:   run | one <mode>
+the slab-major march (HISTORY.md section 4.4), with two diagnostics.  Run on the GPU box:   run | one <mode>
 
 Diagnostics with the one-launch march: the natural layout, and 116 copies of ONE pose (the whole launch's footprint fits the
 256 MiB Infinity Cache: what the same kernel costs when no tap ever comes from HBM).

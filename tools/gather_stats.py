@@ -1,4 +1,4 @@
-"""Loop-trip statistics of the trilinear voxel gather at the benchmark's size: how many
+"""Loop-trip statistics of the trilinear voxel gather at the benchmark's size (HISTORY.md section 9): how many
 (lane, pose) visits, steps, detector rows (and how many of them empty), candidates and wavefront-level inner trips one
 backward takes.  Builds a diagnostic copy of the library (-DXVR_GATHER_STATS) next to the product one and loads it
 through XVR_DRR_LIBRARY.  Run on the GPU box:  python tools/gather_stats.py [siddon]"""

@@ -70,12 +70,24 @@ def real_render(renderer, volume, source, target, img, voxel_shift, n_points, ma
     return res
 
 
-def c1_case():
-    """One pose at C1's geometry (scripts/deepfluoro/train/de_novo.sh:24-32) over a small seeded phantom."""
+def c1_case(quick=False):
+    """One pose at C1's geometry (scripts/deepfluoro/train/de_novo.sh:24-32) over a small seeded phantom.  ``quick``: a quarter
+    of the detector and of the volume per axis -- the rehearsal of tests/test_diffdrr_pin.py, not the pin."""
     from oracle.diffdrr_restated import _apply, rays_from_pose
     from xvr_amd.data import make_phantom
     from xvr_amd.pose import convert
 
+    if quick:
+        vol, lab = make_phantom((22, 20, 24), n_ellipsoids=6, n_labels=4, seed=7)
+        affine = torch.diag(torch.tensor([12.8, 14.4, 12.0, 1.0]))
+        affine[:3, 3] = -(affine[:3, :3] @ ((torch.tensor(vol.shape, dtype=torch.float32) - 1) / 2))
+        pose = convert(torch.tensor([[175.0, 12.0, -6.0]]), torch.tensor([[20.0, 760.0, -35.0]]), parameterization="euler_angles",
+                       convention="ZXY", degrees=True)
+        src, tgt = rays_from_pose(pose.matrix, 32, 32, 1020.0, 2.1764375 * 4, 2.1764375 * 4, 0.0, 0.0, "AP", True)
+        img = (tgt - src).norm(dim=-1).unsqueeze(1)
+        affinv = torch.linalg.inv(affine)[None]
+        return dict(volume=vol, mask=lab, source=_apply(affinv, src), target=_apply(affinv, tgt), img=img, affine=affine,
+                    pose=pose.matrix, height=32, width=32, sdd=1020.0, delx=2.1764375 * 4)
     vol, lab = make_phantom((88, 80, 96), n_ellipsoids=12, n_labels=4, seed=7)
     affine = torch.diag(torch.tensor([3.2, 3.6, 3.0, 1.0]))
     affine[:3, 3] = -(affine[:3, :3] @ ((torch.tensor(vol.shape, dtype=torch.float32) - 1) / 2))
@@ -121,10 +133,11 @@ def knob_grid(renderer):
         yield dict(zip(keys, values))
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=str(OUT))
-    args = ap.parse_args()
+    ap.add_argument("--quick", action="store_true", help="small C1 stand-in (the rehearsal against a planted renderer in the test suite)")
+    args = ap.parse_args(argv)
     try:
         import diffdrr
     except ImportError:
@@ -136,7 +149,7 @@ def main():
     from oracle.diffdrr_restated import RenderSpec, drr_from_pose, render as oracle_render
 
     store, report = {}, []
-    cases = {"case11": make_case(seed=11), "case12": make_case(seed=12), "c1": c1_case()}
+    cases = {"case11": make_case(seed=11), "case12": make_case(seed=12), "c1": c1_case(args.quick)}
     for renderer in ("trilinear", "siddon"):
         for shift in (0.5, 0.0):
             n_points = 60
@@ -179,7 +192,7 @@ def main():
                 store[tag + "_c1_drr_module"] = img.numpy()
                 spec = RenderSpec(renderer=renderer, voxel_shift=shift, **best[0])
                 c = cases["c1"]
-                mine = drr_from_pose(c["volume"], c["affine"], c["pose"], 128, 128, c["sdd"], c["delx"], c["delx"], 0.0, 0.0, spec,
+                mine = drr_from_pose(c["volume"], c["affine"], c["pose"], c["height"], c["width"], c["sdd"], c["delx"], c["delx"], 0.0, 0.0, spec,
                                      orientation="AP", reverse_x_axis=True)
                 err = ((mine - img).abs().max() / img.abs().max()).item()
                 print(f"  DRR module (n_points = 500 default) vs oracle with the winning knobs: {err:.3e}")

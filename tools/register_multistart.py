@@ -51,10 +51,16 @@ score, pose, best_rank, local = register_multistart(reg, gt, inits, batched=args
 torch.cuda.synchronize()
 wall = time.perf_counter() - t0
 geo = DoubleGeodesicSE3(1020.0)
-err = geo(true_pose, RigidTransform(pose.cpu()[None]))[2].item()
+best = RigidTransform(pose.cpu()[None])
+ang, _, dbl = geo(true_pose, best)
+err = dbl.item()
+rot_deg = ang.item() / (0.5 * 1020.0) * 57.29578                      # the angular part is sdd / 2 x angle
+dt = best.convert("euler_angles", "ZXY")[1][0] - true_xyz[0]         # camera frame: y runs along the view, x and z across it
+across, along = float((dt[0] ** 2 + dt[2] ** 2).sqrt()), float(dt[1].abs())
 errs0 = [geo(true_pose, inits[i])[2].item() for i in range(args.starts)]
 print(f"rank {rank}/{world}: refined {len(local)} starts; best ncc {score.item():.4f} from rank {best_rank}; "
-      f"pose error {err:.2f} mm (starts were {min(errs0):.1f}-{max(errs0):.1f} mm off); "
+      f"pose error {err:.2f} mm = {rot_deg:.3f} deg, {across:.2f} mm across / {along:.2f} mm along the view "
+      f"(starts were {min(errs0):.1f}-{max(errs0):.1f} mm off); "
       f"{sum(len(r['trajectory']) for r in local)} iterations in {wall:.2f} s{' (batched)' if args.batched else ''}", flush=True)
 # per-rank timeline: what this rank spent on each of its starts (no communication until the final 68-byte all-gather)
 for n, r in enumerate(local):

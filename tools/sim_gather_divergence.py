@@ -6,7 +6,7 @@ It replays, in numpy, the integer loop bounds every lane derives (step range, ro
 interval per row) for a random sample of 8^3 bricks over the benchmark's 116 poses, and prices a few
 candidate organisations of the same work with per-section instruction counts read off the ISA
 (`hipcc -S`).  Only geometry: no volume, no weights.  Used to choose the round-2 kernel structure
-(DESIGN.md section 4.1); the numbers it prints for the round-1 structure agree with the instrumented
+(HISTORY.md section 4.1); the numbers it prints for the round-1 structure agree with the instrumented
 build of tools/gather_stats.py (2.19 steps per visit, 3.4 rows per step, 3.3 candidates per row).
 """
 import argparse

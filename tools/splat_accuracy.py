@@ -1,5 +1,5 @@
 """Per-magnitude accuracy of the fixed-point voxel gradient (k_trilinear_splat_b16) against the float64 oracle, next to the
-fp32 table gather: the table of DESIGN.md section 4.1 / include/xvr_drr.h.  Run on the GPU box.
+fp32 table gather: the table of HISTORY.md section 4.1 / include/xvr_drr.h.  Run on the GPU box.
 
     python tools/splat_accuracy.py [--full]      (--full adds the benchmark size: 512^3 -> 256^2, two poses, ~1 min of CPU)
 """

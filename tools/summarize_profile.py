@@ -21,13 +21,15 @@ for f in glob.glob(f"{root}/pmc_*/*/*_counter_collection.csv"):
         if not any(t in k for t in ("k_trilinear", "k_siddon", "k_gather", "k_backward")):
             continue
         pm[k][r["Counter_Name"]] += float(r["Counter_Value"])
-        if (k, r["Dispatch_Id"]) not in seen and r["Counter_Name"] in ("SQ_WAVES", "FETCH_SIZE", "WRITE_SIZE"):
+        if (k, r["Dispatch_Id"]) not in seen and r["Counter_Name"] in ("SQ_WAVES", "FETCH_SIZE", "WRITE_SIZE", "TCC_EA0_RDREQ_sum"):
             seen.add((k, r["Dispatch_Id"]))
             calls[(k, r["Counter_Name"])] += 1
 if pm:
     print("\n## PMC (separate passes; totals over the dispatches of one bench step + the work-count launch)\n")
-    print("FETCH_SIZE / WRITE_SIZE are in KiB as reported; per MI355X_MICROARCH.md FETCH_SIZE under-counts wide\n"
-          "coalesced reads by 2x on gfx950 and is uncalibrated for 4-16 B gathers: read as indicative.\n")
+    print("FETCH_SIZE / WRITE_SIZE are in KiB as reported.  Calibrated in round 4 (profiles/r04_fetch_calibration.txt): one L2 miss\n"
+          "is ONE fabric request for a whole 128-byte line, whatever part of it the gather uses (16-byte gathers and coalesced\n"
+          "streams alike), and FETCH_SIZE tallies it at 64 bytes: bytes moved = 2 x FETCH_SIZE = 128 x TCC_EA0_RDREQ;\n"
+          "TCP_TCC_READ_REQ counts L1 misses in 128-byte lines too.\n")
     for k, v in pm.items():
         n = max(calls[(k, "SQ_WAVES")], calls[(k, "FETCH_SIZE")], calls[(k, "WRITE_SIZE")], 1)
         print(f"### `{k[:100]}`  ({n} dispatches)")
@@ -38,7 +40,14 @@ if pm:
         if "TCC_HIT_sum" in v:
             print(f"- derived: L2 hit rate = {v['TCC_HIT_sum']/(v['TCC_HIT_sum']+v['TCC_MISS_sum']):.3f}")
         if "FETCH_SIZE" in v:
-            print(f"- derived: FETCH_SIZE per dispatch = {v['FETCH_SIZE']*1024/n/1e9:.3f} GB (x2 if the wide-read correction applies)")
+            print(f"- derived: FETCH_SIZE per dispatch = {v['FETCH_SIZE']*1024/n/1e9:.3f} GB as reported = {2*v['FETCH_SIZE']*1024/n/1e9:.3f} GB moved (128-byte lines)")
+        if "TCC_EA0_RDREQ_sum" in v:
+            nn = max(calls[(k, "SQ_WAVES")], calls[(k, "FETCH_SIZE")], 1)
+            print(f"- derived: fabric read lines per dispatch = {v['TCC_EA0_RDREQ_sum']/nn:.4g} = {v['TCC_EA0_RDREQ_sum']*128/nn/1e9:.2f} GB")
+        if "TCP_TCC_READ_REQ_sum" in v:
+            nn = max(calls[(k, "SQ_WAVES")], calls[(k, "FETCH_SIZE")], 1)
+            print(f"- derived: L1-miss lines per dispatch = {v['TCP_TCC_READ_REQ_sum']/nn:.4g} = {v['TCP_TCC_READ_REQ_sum']*128/nn/1e9:.2f} GB"
+                  + (f", mean latency {v['TCP_TCC_READ_REQ_LATENCY_sum']/v['TCP_TCC_READ_REQ_sum']:.0f} clk" if "TCP_TCC_READ_REQ_LATENCY_sum" in v else ""))
         if "WRITE_SIZE" in v:
             print(f"- derived: WRITE_SIZE per dispatch = {v['WRITE_SIZE']*1024/n/1e9:.3f} GB")
         print()

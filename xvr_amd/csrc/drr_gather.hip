@@ -1,5 +1,5 @@
 // MI355X (gfx950) differentiable-DRR kernels: the voxel gradient as an atomic-free, voxel-driven gather
-// (trilinear and Siddon), its per-pose preparation and per-brick cull.  DESIGN.md section 4.1.
+// (trilinear and Siddon), its per-pose preparation and per-brick cull.  HISTORY.md section 4.1.
 #include "drr_common.hiph"
 
 #ifdef XVR_GATHER_STATS
@@ -316,7 +316,7 @@ __device__ __forceinline__ float linspace_sel(int k, int N, float near_, float f
 
 
 // ---------------------------------------------------------------------------------------------
-// The same gather with the loop nest FLATTENED per lane (round 2; DESIGN.md section 4.1, tools/sim_gather_divergence.py).
+// The same gather with the loop nest FLATTENED per lane (round 2; HISTORY.md section 4.1, tools/sim_gather_divergence.py).
 //
 // In the round-1 kernel (one nest of step -> row -> pixel loops per lane; retired in round 3) the 64 lanes of a wavefront walk step -> row -> pixel loops whose trip counts differ per
 // lane: at the benchmark geometry a wavefront's inner trip fills 47 of its 128 candidate slots and a (wavefront, pose)

@@ -775,7 +775,7 @@ static int trilinear_forward_impl(const float* volume, const float* mask, int D0
     if (mask) return clip ? launch(k_trilinear_fwd<false, 1, true>, A, lds, stream)
                           : launch(k_trilinear_fwd<false, 1, false>, A, lds, stream);
     // LDS-staged bricks are opt-in (option "fwd_lds"; natural layout only): measured 2.25x SLOWER than the direct kernel at C2 (19.8 vs 8.8 ms;
-    // with ~4 taps per voxel the L1/L2 already capture the reuse)
+    // with ~4 taps per voxel the L1/L2 already capture the reuse, HISTORY.md section 4.2)
     const bool use_lds = xvr_detail::option(xvr_detail::OPT_FWD_LDS) == 1 && sp->volume_layout == 0 && !sp->alpha_window;
     if (use_lds && !clip && A.grid_w > 0) {
         const size_t bytes = (size_t)(LDS_HDR + LDS_BRICK_CAP) * sizeof(float);
