@@ -312,10 +312,7 @@ def test_layout_copies_follow_the_volume_through_deepcopy_data_writes_and_invali
     from xvr_amd.spec import RenderSpec
 
     spec = RenderSpec(renderer=renderer, n_points=90) if renderer == "trilinear" else RenderSpec(renderer="siddon")
-    if renderer == "siddon":   # the bricked copy belongs to the merge walk (the slab march of round 4 walks the natural layout)
-        ctx = _lib.option("siddon_slab", 0)
-        ctx.__enter__()
-        request.addfinalizer(lambda: ctx.__exit__(None, None, None))
+
     monkeypatch.setattr(renderers, "YPAIR_MIN_WAVEFRONTS", 1)
     # (a launch this small would take the sample-split kernels on the natural layout -- another summation order; unsplit, the
     #  layouts are bit-identical, which makes "not stale" an equality)
@@ -1637,16 +1634,17 @@ def test_voxel_gather_with_more_than_one_cull_word(renderer, B):
     _close(grads[0], ref, GRAD_TOL, "gather vs oracle")
 
 
+@pytest.mark.parametrize("slab", [1, 0], ids=["slab-march", "merge-walk"])
 @pytest.mark.parametrize("kw", [dict(), dict(voxel_shift=0.0)], ids=_id)
 @pytest.mark.parametrize("shape", [(40, 44, 48), (33, 31, 29)], ids=["even", "odd"])
-def test_bricked_volume_layout_is_bit_identical_for_siddon(kw, shape, monkeypatch, request):
-    """Large launches of the Siddon MERGE walk (option siddon_slab = 0; the default slab march of round 4 walks the natural
-    layout) take a 4 x 2 x 4-bricked copy of the volume (xvr_drr_pack_bricks, one brick per cache line).
+def test_bricked_volume_layout_is_bit_identical_for_siddon(kw, shape, slab, monkeypatch, request):
+    """Large Siddon launches -- the slab march (default) and the merge walk (option siddon_slab = 0) alike -- take a
+    4 x 2 x 4-bricked copy of the volume (xvr_drr_pack_bricks, one brick per cache line).
     Same traversal, same voxels: image and jacobian-borne pose gradients must be IDENTICAL to the natural layout's, bit for
     bit, also for sizes that do not fill the last bricks and with the labels packed into the taps."""
     from xvr_amd import _lib, renderers
 
-    ctx = _lib.option("siddon_slab", 0)
+    ctx = _lib.option("siddon_slab", slab)
     ctx.__enter__()
     request.addfinalizer(lambda: ctx.__exit__(None, None, None))
     from xvr_amd.renderers import render

@@ -159,8 +159,8 @@ def test_slab_march_source_inside_miss_and_hot_voxel():
 
 
 def test_slab_march_is_the_default_for_large_one_channel_launches_and_deterministic():
-    """A launch of >= 2048 wavefronts with the exact index map takes the slab march by itself (no option), on the natural layout;
-    two runs give the same bits; DRR.forward's pose gradient follows central differences of the render."""
+    """A launch of >= 2048 wavefronts with the exact index map takes the slab march by itself (no option), on the bricked copy
+    (built at first sight); two runs give the same bits; image and pose gradient of DRR.forward agree with the merge walk's."""
     from xvr_amd import renderers
     from xvr_amd.data import make_phantom, read
     from xvr_amd.drr import DRR
@@ -176,7 +176,7 @@ def test_slab_march_is_the_default_for_large_one_channel_launches_and_determinis
     a = drr(rot, xyz, parameterization="euler_angles", convention="ZXY")
     names = {e[0] for e in renderers.PROFILER}
     renderers.PROFILER = None
-    assert "pack_bricks" not in names, names
+    assert "pack_bricks" in names and "siddon_forward+jac" in names, names
     b = drr(rot, xyz, parameterization="euler_angles", convention="ZXY")
     assert torch.equal(a, b)
     w = torch.rand(a.shape, generator=g).cuda()

@@ -301,23 +301,43 @@ __device__ __forceinline__ float sel3f(int k, float a, float b, float c) { retur
 __device__ __forceinline__ int sel3i(int k, int a, int b, int c) { return k == 0 ? a : (k == 1 ? b : c); }
 __device__ __forceinline__ float med3f(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
 
-template <bool JAC>
+// BRICK: the volume is the 4 x 2 x 4-bricked copy (xvr_drr_pack_bricks, one brick per 128-byte line).  On [x][y][z] rows a
+// wavefront's 64 voxels of one slab sit in ~6 rows of which it uses a fifth, and the next slab (the usual dominant axis is y) is
+// another set of rows: 5.3e8 L1-miss lines per C3 launch (67 GB), 25 GB from the fabric.  A brick holds two slabs of a 4 x 4 patch.
+// The brick offset is separable, offset = fx(ix) + fy(iy) + fz(iz), so every axis keeps its own partial offset and replaces it
+// when its plane is crossed; the partial offsets come from three small tables in LDS (built by the workgroup at the start) -- a
+// ds_read per axis and slab, issued one slab ahead, instead of ~5 vector instructions of shifts and multiplies each.
+template <bool JAC, bool BRICK>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, XVR_SLAB_WAVES))) void k_siddon_slab(RenderArgs A) {
+    extern __shared__ unsigned slab_tab[];   // BRICK: byte offsets fx[-1 .. D0], fy[-1 .. D1], fz[-1 .. D2] (indices clamped)
     int b, r;
     const bool valid = map_ray(A, b, r, threadIdx.x);
     Ray R;
     ray_setup(A, b, r, valid, R);
     const float* __restrict__ vol = A.volume;
     const int D[3] = {A.D0, A.D1, A.D2};
-    const int strd[3] = {A.D1 * A.D2 * 4, A.D2 * 4, 4};   // (byte offsets: the buffer loads take them as they are)
-    const unsigned vol_bytes = (unsigned)A.D0 * (unsigned)A.D1 * (unsigned)A.D2 * 4u;
+    const int nby = (A.D1 + 1) >> 1, nbz = (A.D2 + 3) >> 2;
+    const int tbase[3] = {1, A.D0 + 3, A.D0 + A.D1 + 5};                     // entry of index 0 of every axis' table
+    if (BRICK) {
+        const int total = A.D0 + A.D1 + A.D2 + 6;
+        for (int e = threadIdx.x; e < total; e += WG) {
+            const int ax = e < A.D0 + 2 ? 0 : (e < A.D0 + A.D1 + 4 ? 1 : 2);
+            const int ic = min(max(e - tbase[ax], 0), D[ax] - 1);
+            const int f = ax == 0 ? (((ic >> 2) * nby * nbz) << 5) + ((ic & 3) << 3) : (ax == 1 ? (((ic >> 1) * nbz) << 5) + ((ic & 1) << 2) : ((ic >> 2) << 5) + (ic & 3));
+            slab_tab[e] = (unsigned)f * 4u;
+        }
+        __syncthreads();
+    }
+    const int strd[3] = {A.D1 * A.D2 * 4, A.D2 * 4, 4};   // (natural layout; byte offsets: the buffer loads take them as they are)
+    const unsigned vol_bytes = BRICK ? (unsigned)((A.D0 + 3) >> 2) * (unsigned)nby * (unsigned)nbz * 128u
+                                     : (unsigned)A.D0 * (unsigned)A.D1 * (unsigned)A.D2 * 4u;
     const bool live = valid && (R.amax > R.amin);
     const float alo = live ? R.amin : 0.f;
 
     // per axis: the voxel the ray enters, the next plane in travel direction and the far boundary plane (as floats: exact small
     // integers), plane0 - s, 1 / d, the signed stride
     float fp[3], fpfar[3], ps[3], inv_d[3], stpf[3];
-    int sstr[3], off = 0;
+    int sstr[3], off = 0, i0s[3];
     float ahi = live ? R.amax : 0.f;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -326,6 +346,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, XVR_SLAB_
         const float f = fmaf(alo, R.d[i], R.s[i]) - A.sp.plane0[i];   // entry position in plane-index units
         const int i0 = min(max((int)floorf(f), 0), D[i] - 1);
         const bool fwd = R.d[i] > 0.f;
+        i0s[i] = i0;
         fp[i] = (float)(i0 + (fwd ? 1 : 0));
         fpfar[i] = fwd ? (float)D[i] : 0.f;
         stpf[i] = fwd ? 1.f : -1.f;
@@ -341,6 +362,19 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, XVR_SLAB_
     const float ivm = sel3f(m, inv_d[0], inv_d[1], inv_d[2]), ivu = sel3f(u, inv_d[0], inv_d[1], inv_d[2]), ivv = sel3f(v, inv_d[0], inv_d[1], inv_d[2]);
     const float stm = sel3f(m, stpf[0], stpf[1], stpf[2]), stu = sel3f(u, stpf[0], stpf[1], stpf[2]), stv = sel3f(v, stpf[0], stpf[1], stpf[2]);
     const int sm = sel3i(m, sstr[0], sstr[1], sstr[2]), su = sel3i(u, sstr[0], sstr[1], sstr[2]), sv = sel3i(v, sstr[0], sstr[1], sstr[2]);
+    // BRICK: LDS byte address of the table entry of the NEXT index along every role's axis, its step, and the current partial offsets
+    int am_a = 0, au_a = 0, av_a = 0, st4m = 0, st4u = 0, st4v = 0;
+    unsigned fm = 0, fu = 0, fv = 0, fm_n = 0, fu_n = 0, fv_n = 0;
+    auto tabrd = [&](int byte_addr) { return *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(slab_tab) + byte_addr); };
+    if (BRICK) {
+        const int im = sel3i(m, i0s[0], i0s[1], i0s[2]), iu = sel3i(u, i0s[0], i0s[1], i0s[2]), iv = sel3i(v, i0s[0], i0s[1], i0s[2]);
+        const int bm = sel3i(m, tbase[0], tbase[1], tbase[2]), bu = sel3i(u, tbase[0], tbase[1], tbase[2]), bv = sel3i(v, tbase[0], tbase[1], tbase[2]);
+        st4m = stm > 0.f ? 4 : -4; st4u = stu > 0.f ? 4 : -4; st4v = stv > 0.f ? 4 : -4;
+        fm = tabrd((bm + im) * 4); fu = tabrd((bu + iu) * 4); fv = tabrd((bv + iv) * 4);
+        am_a = (bm + im) * 4 + st4m; au_a = (bu + iu) * 4 + st4u; av_a = (bv + iv) * 4 + st4v;
+        fm_n = tabrd(am_a); fu_n = tabrd(au_a); fv_n = tabrd(av_a);
+        off = (int)(fm + fu + fv);
+    }
 
     float ac = alo, acc = 0.f;
     float Um = 0.f, Uu = 0.f, Uv = 0.f, Mm = 0.f, Mu = 0.f, Mv = 0.f;
@@ -355,9 +389,11 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, XVR_SLAB_
     const float vfirst = ld(walks, off);
     float Wprev = vfirst;
     unsigned cnt = 0;
+
     // (terminates: the dominant plane counter moves every trip, so its alpha passes a_hi after at most D_m trips; a NaN alpha
     //  clamps to the slab's start and the next trip's differs)
-    while (__builtin_amdgcn_ballot_w64(ac < ahi)) {             // wave-uniform: until every ray of the wavefront has left the volume
+    const int tab_last = (A.D0 + A.D1 + A.D2 + 5) * 4;
+    if (__builtin_amdgcn_ballot_w64(ac < ahi)) do {             // wave-uniform: until every ray of the wavefront has left the volume
         const float am = (fpm + psm) * ivm;
         const float aend = med3f(am, ac, ahi);
         const float aur = (fpu + psu) * ivu, avr = (fpv + psv) * ivv;
@@ -366,8 +402,24 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, XVR_SLAB_
         const bool uf = au <= av;                               // u is crossed first
         const float lo = uf ? au : av, hi = uf ? av : au;
         const float l1 = lo - ac, l2 = hi - lo, l3 = aend - hi;
-        const int du = cu ? su : 0, dv = cv ? sv : 0;
-        const int off2 = off + (uf ? du : dv), off3 = off + du + dv;
+        int off2, off3, off_next;
+        if (BRICK) {
+            const unsigned fu2 = cu ? fu_n : fu, fv2 = cv ? fv_n : fv;      // partial offsets behind the minor crossings
+            off2 = (int)(fm + (uf ? fu2 + fv : fu + fv2));
+            off3 = (int)(fm + fu2 + fv2);
+            off_next = (int)(fm_n + fu2 + fv2);
+            fu = fu2; fv = fv2; fm = fm_n;
+            au_a += cu ? st4u : 0; av_a += cv ? st4v : 0; am_a += st4m;
+            // (the minor axes only ever cross interior planes: their next index stays in [-1, D], inside the padded tables; the
+            //  dominant axis' address runs on while the wavefront's other rays finish -- those trips' loads are masked -- and is
+            //  clamped into the table)
+            fu_n = tabrd(au_a); fv_n = tabrd(av_a); fm_n = tabrd(min(max(am_a, 0), tab_last));
+        } else {
+            const int du = cu ? su : 0, dv = cv ? sv : 0;
+            off2 = off + (uf ? du : dv);
+            off3 = off + du + dv;
+            off_next = off3 + sm;
+        }
         const bool p1 = l1 > 0.f, p2 = l2 > 0.f, p3 = l3 > 0.f;
         const float t1 = ld(p1, off), t2 = ld(p2, off2), t3 = ld(p3, off3);
         if (A.work) cnt += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(p1)) + (unsigned)__popcll(__builtin_amdgcn_ballot_w64(p2)) +
@@ -387,9 +439,9 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, XVR_SLAB_
         fpu += cu ? stu : 0.f;
         fpv += cv ? stv : 0.f;
         fpm += stm;
-        off = off3 + sm;
+        off = off_next;
         ac = aend;
-    }
+    } while (__builtin_amdgcn_ballot_w64(ac < ahi));
 
     if (valid) {
         A.out[(size_t)b * A.n + r] = acc * R.L;
@@ -439,10 +491,16 @@ static int siddon_forward_impl(const float* volume, const float* mask, int D0, i
     if (mask && jac) return (ex ? launch(k_siddon<1, true, false, false, true>, A, lds, stream) : launch(k_siddon<1, true, false, false, false>, A, lds, stream));
     if (mask) return (ex ? launch(k_siddon<0, true, false, false, true>, A, lds, stream) : launch(k_siddon<0, true, false, false, false>, A, lds, stream));
     bool tile16 = false;
-    if (sp->volume_layout == 0 && ex && xvr_detail::option(xvr_detail::OPT_SIDDON_SLAB) && (long long)D0 * D1 * D2 < (1LL << 29) &&
+    if ((sp->volume_layout == 0 || sp->volume_layout == 2) && ex && xvr_detail::option(xvr_detail::OPT_SIDDON_SLAB) &&
+        (long long)D0 * D1 * D2 < (1LL << 29) && (size_t)(D0 + D1 + D2 + 6) * 4 <= 48 * 1024 &&
         split_factor(B, n, (long long)D0 * D1 * D2, true, &tile16) == 1) {   // the dominant-axis slab march (round 4)
-        if (jac) return launch(k_siddon_slab<true>, A, 0, stream);
-        return launch(k_siddon_slab<false>, A, 0, stream);
+        if (sp->volume_layout == 2) {
+            const size_t tab = (size_t)(D0 + D1 + D2 + 6) * 4;
+            if (jac) return launch(k_siddon_slab<true, true>, A, tab, stream);
+            return launch(k_siddon_slab<false, true>, A, tab, stream);
+        }
+        if (jac) return launch(k_siddon_slab<true, false>, A, 0, stream);
+        return launch(k_siddon_slab<false, false>, A, 0, stream);
     }
     if (sp->volume_layout == 2) {
         if (jac) return launch(k_siddon<1, false, false, false, true, 0, true>, A, 0, stream);

@@ -245,8 +245,6 @@ def _use_bricks(spec, volume, B, n, C=1):
     """(large one-channel Siddon launches with the exact index map: 10.3 -> 9.7 ms at C3.  Measured SLOWER, by 0.2 / 0.7 ms,
     for non-exact maps and for labels packed into the taps -- their walks are bound by arithmetic the brick address adds to.)"""
     D0, D1, D2 = volume.shape
-    if _lib.get_option("siddon_slab"):   # the slab march (round 4) walks the natural layout: lanes of a wavefront share a slab
-        return False
     return (BRICK_LAYOUT and spec.renderer == "siddon" and C == 1 and spec.norm_dims_offset == 0 and not spec.align_corners
             and B * ((n + 63) // 64) >= YPAIR_MIN_WAVEFRONTS
             and ((D0 + 3) // 4) * ((D1 + 1) // 2) * ((D2 + 3) // 4) * 32 < 2 ** 31 and min(D0, D1, D2) >= 2)
