@@ -91,6 +91,10 @@ const char* xvr_drr_last_error(void);
  *   "fwd_slabs"     0 | -1 | n  slab-major trilinear forward (one launch per slab of the volume, all poses; measured SLOWER,
  *                              HISTORY.md 4.4): never | by size | n slabs                                         [0]
  *   "fwd_slab_axis" 0-2        volume axis the slabs are cut along                                               [1]
+ *   "tile_geom"     1 | 0 | 2  pixels a workgroup takes of a detector that is a multiple of 64: 8 x 32 | 16 x 16 | 4 x 64, long side
+ *                              along the detector axis that runs along the volume's contiguous axis (per pose)     [1]
+ *   "siddon_slab"   1 | 0      unsplit one-channel Siddon forward with the exact index map: dominant-axis slab march
+ *                              (k_siddon_slab, both volume layouts) | the merge walk (k_siddon)                    [1]
  * Returns XVR_DRR_E_ARG for an unknown name or a value outside the option's range.
  */
 int xvr_drr_set_option(const char* name, int value);

@@ -519,20 +519,23 @@ struct EqState {   // per image, in the workspace
     float T, D, dh_scale_pad0, pad1;
 };
 
-// h[b] (or, GRAD, dcn[b] = sum_i g_i w_ib / S_i): one block per (bin, image), pixels in a fixed order
+// h[b] (or, GRAD, dcn[b] = sum_i g_i w_ib / S_i), as EQ_CHUNKS partial sums per (bin, image): one block per (bin, chunk of the
+// pixels, image), pixels in a fixed order; the consumer (k_eq_cdf / k_eq_cdf_bwd) adds a bin's partials in chunk order.
+// (Round 3 gave a bin ONE block that walked all the pixels: 256 blocks of four wavefronts each, 1024 dependent trips at
+// 512^2 -- 163 / 195 us per call, most of an iteration with `equalize`.)
+constexpr int EQ_CHUNKS = 32;
 template <bool GRAD>
 __global__ __launch_bounds__(TB) void k_eq_bins(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ S,
-                                                int n, int K, float inv2tau2, float cut, float* __restrict__ out, float gscale) {
-    const int b = blockIdx.x, img = blockIdx.y;
+                                                int n, int K, float inv2tau2, float cut, float* __restrict__ part, float gscale) {
+    const int b = blockIdx.x, ch = blockIdx.y, img = blockIdx.z;
     const float beta = (float)b / (float)(K - 1);
+    const int per = (n + EQ_CHUNKS - 1) / EQ_CHUNKS, lo = ch * per, hi = min(lo + per, n);
     const float* xi = x + (size_t)img * n;
     float acc = 0.f;
-    for (int i = threadIdx.x; i < n; i += TB) {
+    for (int i = lo + (int)threadIdx.x; i < hi; i += TB) {
         const float d = xi[i] - beta;
-        if (fabsf(d) <= cut) {
-            const float w = __expf(-d * d * inv2tau2);
-            acc += GRAD ? (g[(size_t)img * n + i] * gscale) * w / S[(size_t)img * n + i] : w;
-        }
+        const float w = fabsf(d) <= cut ? __expf(-d * d * inv2tau2) : 0.f;
+        acc += GRAD ? (g[(size_t)img * n + i] * gscale) * w / S[(size_t)img * n + i] : w;
     }
     __shared__ float red[TB];
     red[threadIdx.x] = acc;
@@ -541,49 +544,111 @@ __global__ __launch_bounds__(TB) void k_eq_bins(const float* __restrict__ x, con
         if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[(size_t)img * K + b] = red[0];
+    if (threadIdx.x == 0) part[((size_t)img * K + b) * EQ_CHUNKS + ch] = red[0];
 }
 
-// histogram -> normalised cdf (forward) ; d cn -> d h (backward).  One block per image, serial scans by thread 0 (K <= 1024)
-__global__ void k_eq_cdf(const float* __restrict__ h, int K, float eps, float* __restrict__ cn, float* __restrict__ cdf, EqState* st) {
-    const int img = blockIdx.x;
-    if (threadIdx.x != 0) return;
-    const float* hb = h + (size_t)img * K;
-    float T = 0.f;
-    for (int b = 0; b < K; ++b) T += hb[b];
-    float run = 0.f, c0 = 0.f;
-    for (int b = 0; b < K; ++b) {
-        run += hb[b] / (T + eps);
-        if (b == 0) c0 = run;
-        cdf[(size_t)img * K + b] = run;
+// a bin's value from its partial sums, added in chunk order
+__device__ __forceinline__ float eq_bin_sum(const float* __restrict__ part, int img, int K, int b) {
+    const float* p = part + ((size_t)img * K + b) * EQ_CHUNKS;
+    float s = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < EQ_CHUNKS; ++c) s += p[c];
+    return s;
+}
+
+// histogram -> normalised cdf (forward) ; d cn -> d h (backward).  One block of TB threads per image; thread t owns the
+// EQ_PER = 4 consecutive bins 4t .. 4t + 3 (K <= 1024) and the block combines the threads' sums with a fixed tree in LDS
+// (deterministic; round 3 scanned the bins serially in one thread: 256 dependent global round trips, two thirds of the call).
+constexpr int EQ_PER = EQ_MAX_BINS / TB;
+static_assert(EQ_PER * TB == EQ_MAX_BINS, "bins per thread");
+
+// inclusive prefix sums of one value per thread over the block (REVERSE: suffix sums), and the block's total, through LDS
+template <bool REVERSE>
+__device__ __forceinline__ float block_scan(float v, float* sh, float& total) {
+    const int t = REVERSE ? TB - 1 - (int)threadIdx.x : (int)threadIdx.x;
+    sh[t] = v;
+    __syncthreads();
+    for (int o = 1; o < TB; o <<= 1) {                 // Hillis-Steele: a fixed order of additions
+        const float add = t >= o ? sh[t - o] : 0.f;
+        __syncthreads();
+        sh[t] += add;
+        __syncthreads();
     }
-    const float D = 1.f - c0 + eps;
-    for (int b = 0; b < K; ++b) cn[(size_t)img * K + b] = (cdf[(size_t)img * K + b] - c0) / D;
-    st[img].T = T;
-    st[img].D = D;
+    const float r = sh[t];
+    total = sh[TB - 1];
+    __syncthreads();
+    return r;
 }
 
-__global__ void k_eq_cdf_bwd(const float* __restrict__ h, const float* __restrict__ cdf, const float* __restrict__ dcn, int K, float eps,
-                             const EqState* st, float* __restrict__ dh) {
-    const int img = blockIdx.x;
-    if (threadIdx.x != 0) return;
+__global__ __launch_bounds__(TB) void k_eq_cdf(const float* __restrict__ part, float* __restrict__ h, int K, float eps, float* __restrict__ cn,
+                                               float* __restrict__ cdf, EqState* st) {
+    __shared__ float sh[TB];
+    const int img = blockIdx.x, b0 = threadIdx.x * EQ_PER;
+    float v[EQ_PER], mine = 0.f;
+#pragma unroll
+    for (int e = 0; e < EQ_PER; ++e) {
+        v[e] = b0 + e < K ? eq_bin_sum(part, img, K, b0 + e) : 0.f;
+        if (b0 + e < K) h[(size_t)img * K + b0 + e] = v[e];      // the histogram itself: the backward reads it
+        mine += v[e];
+    }
+    float T;
+    block_scan<false>(mine, sh, T);
+    const float it = 1.f / (T + eps);
+    float run = 0.f, loc[EQ_PER];
+#pragma unroll
+    for (int e = 0; e < EQ_PER; ++e) { run += v[e] * it; loc[e] = run; }      // normalised histogram, prefix sums within the thread
+    float all;
+    const float incl = block_scan<false>(run, sh, all);
+    const float before = incl - run;
+    if (threadIdx.x == 0) sh[0] = loc[0];                                      // cdf_0
+    __syncthreads();
+    const float c0 = sh[0], D = 1.f - c0 + eps;
+#pragma unroll
+    for (int e = 0; e < EQ_PER; ++e) {
+        if (b0 + e < K) {
+            const float c = before + loc[e];
+            cdf[(size_t)img * K + b0 + e] = c;
+            cn[(size_t)img * K + b0 + e] = (c - c0) / D;
+        }
+    }
+    if (threadIdx.x == 0) { st[img].T = T; st[img].D = D; }
+}
+
+__global__ __launch_bounds__(TB) void k_eq_cdf_bwd(const float* __restrict__ h, const float* __restrict__ cdf, const float* __restrict__ dcn_part, int K, float eps,
+                                                   const EqState* st, float* __restrict__ dh) {
+    __shared__ float sh[TB];
+    const int img = blockIdx.x, b0 = threadIdx.x * EQ_PER;
     const float T = st[img].T, D = st[img].D;
     const float* hb = h + (size_t)img * K;
     const float* cb = cdf + (size_t)img * K;
-    const float* gb = dcn + (size_t)img * K;
     float* out = dh + (size_t)img * K;
     // d cdf_b = d cn_b / D, and through cdf_0's second role: d cdf_0 += sum_b d cn_b (cdf_b - 1 - eps) / D^2
-    float extra = 0.f;
-    for (int b = 0; b < K; ++b) extra += gb[b] * (cb[b] - 1.f - eps) / (D * D);
-    // d H_b = sum_{b' >= b} d cdf_b'   (reverse cumulative sum);  d h_b = d H_b / (T + eps) - (sum_b' d H_b' h_b') / (T + eps)^2
-    float run = 0.f, dot = 0.f;
-    for (int b = K - 1; b >= 0; --b) {
-        run += gb[b] / D + (b == 0 ? extra : 0.f);
-        out[b] = run;
-        dot += run * hb[b];
+    float g[EQ_PER], hv[EQ_PER], ex = 0.f;
+#pragma unroll
+    for (int e = 0; e < EQ_PER; ++e) {
+        const bool in = b0 + e < K;
+        g[e] = in ? eq_bin_sum(dcn_part, img, K, b0 + e) : 0.f;
+        hv[e] = in ? hb[b0 + e] : 0.f;
+        if (in) ex += g[e] * (cb[b0 + e] - 1.f - eps) / (D * D);
     }
+    float extra;
+    block_scan<false>(ex, sh, extra);
+    // d H_b = sum_{b' >= b} d cdf_b' (suffix sums);  d h_b = d H_b / (T + eps) - (sum_b' d H_b' h_b') / (T + eps)^2
+    float suf[EQ_PER], run = 0.f;
+#pragma unroll
+    for (int e = EQ_PER - 1; e >= 0; --e) { run += g[e] / D + (b0 + e == 0 ? extra : 0.f); suf[e] = run; }
+    float all;
+    const float incl = block_scan<true>(run, sh, all);
+    const float after = incl - run;                  // the bins of the threads behind this one
+    float dotp = 0.f;
+#pragma unroll
+    for (int e = 0; e < EQ_PER; ++e) { suf[e] += after; dotp += suf[e] * hv[e]; }
+    float dot;
+    block_scan<false>(dotp, sh, dot);
     const float it = 1.f / (T + eps);
-    for (int b = 0; b < K; ++b) out[b] = out[b] * it - dot * it * it;
+#pragma unroll
+    for (int e = 0; e < EQ_PER; ++e)
+        if (b0 + e < K) out[b0 + e] = suf[e] * it - dot * it * it;
 }
 
 // per pixel: forward y_i (and S_i kept for the backward); backward g_x,i
@@ -799,10 +864,10 @@ extern "C" {
 
 size_t xvr_sim_equalize_workspace_bytes(int B, int n_bins) {
     if (B <= 0 || n_bins < 2 || n_bins > EQ_MAX_BINS) return 0;
-    return (size_t)B * ((size_t)n_bins * 5 * sizeof(float) + sizeof(EqState)) + 256;
+    return (size_t)B * ((size_t)n_bins * (4 + EQ_CHUNKS) * sizeof(float) + sizeof(EqState)) + 256;
 }
 
-// workspace layout: [h][cdf][cn][dcn][dh] (B x K floats each) [EqState x B]
+// workspace layout: [h][cdf][cn][dh] (B x K floats each) [partial sums of h, then of dcn: B x K x EQ_CHUNKS] [EqState x B]
 int xvr_sim_equalize_forward(const float* x, int B, int n, int n_bins, float tau, float eps, float out_mean, float out_std, float* y,
                              float* S, float* y_out, void* workspace, size_t workspace_bytes, void* stream_) {
     if (!x || !y || !S || !workspace) return sim_fail(XVR_DRR_E_ARG, "null pointer argument");
@@ -813,11 +878,12 @@ int xvr_sim_equalize_forward(const float* x, int B, int n, int n_bins, float tau
     float* h = static_cast<float*>(workspace);
     float* cdf = h + (size_t)B * n_bins;
     float* cn = cdf + (size_t)B * n_bins;
-    EqState* st = reinterpret_cast<EqState*>(h + (size_t)B * n_bins * 5);
+    float* part = h + (size_t)B * n_bins * 4;
+    EqState* st = reinterpret_cast<EqState*>(h + (size_t)B * n_bins * (4 + EQ_CHUNKS));
     const float cut = EQ_CUT * tau;
-    hipLaunchKernelGGL(k_eq_bins<false>, dim3(n_bins, B), dim3(TB), 0, stream, x, (const float*)nullptr, (const float*)nullptr, n, n_bins,
-                       1.f / (2.f * tau * tau), cut, h, 1.f);
-    hipLaunchKernelGGL(k_eq_cdf, dim3(B), dim3(64), 0, stream, (const float*)h, n_bins, eps, cn, cdf, st);
+    hipLaunchKernelGGL(k_eq_bins<false>, dim3(n_bins, EQ_CHUNKS, B), dim3(TB), 0, stream, x, (const float*)nullptr, (const float*)nullptr, n, n_bins,
+                       1.f / (2.f * tau * tau), cut, part, 1.f);
+    hipLaunchKernelGGL(k_eq_cdf, dim3(B), dim3(TB), 0, stream, (const float*)part, h, n_bins, eps, cn, cdf, st);
     hipLaunchKernelGGL(k_eq_pixels<false>, dim3((n + TB - 1) / TB, B), dim3(TB), 0, stream, x, n, n_bins, tau, eps, cut, (const float*)cn, y, S,
                        (const float*)nullptr, (const float*)nullptr, (float*)nullptr, y_out, out_mean, y_out ? 1.f / out_std : 1.f);
     hipError_t e = hipGetLastError();
@@ -835,12 +901,12 @@ int xvr_sim_equalize_backward(const float* x, const float* y, const float* S, co
     float* h = static_cast<float*>(workspace);
     float* cdf = h + (size_t)B * n_bins;
     float* cn = cdf + (size_t)B * n_bins;
-    float* dcn = cn + (size_t)B * n_bins;
-    float* dh = dcn + (size_t)B * n_bins;
-    EqState* st = reinterpret_cast<EqState*>(h + (size_t)B * n_bins * 5);
+    float* dh = cn + (size_t)B * n_bins;
+    float* part = h + (size_t)B * n_bins * 4;      // (the forward's partials are spent: the histogram is in h)
+    EqState* st = reinterpret_cast<EqState*>(h + (size_t)B * n_bins * (4 + EQ_CHUNKS));
     const float cut = EQ_CUT * tau, gs = 1.f / out_std;
-    hipLaunchKernelGGL(k_eq_bins<true>, dim3(n_bins, B), dim3(TB), 0, stream, x, grad_out, S, n, n_bins, 1.f / (2.f * tau * tau), cut, dcn, gs);
-    hipLaunchKernelGGL(k_eq_cdf_bwd, dim3(B), dim3(64), 0, stream, (const float*)h, (const float*)cdf, (const float*)dcn, n_bins, eps,
+    hipLaunchKernelGGL(k_eq_bins<true>, dim3(n_bins, EQ_CHUNKS, B), dim3(TB), 0, stream, x, grad_out, S, n, n_bins, 1.f / (2.f * tau * tau), cut, part, gs);
+    hipLaunchKernelGGL(k_eq_cdf_bwd, dim3(B), dim3(TB), 0, stream, (const float*)h, (const float*)cdf, (const float*)part, n_bins, eps,
                        (const EqState*)st, dh);
     hipLaunchKernelGGL(k_eq_pixels<true>, dim3((n + TB - 1) / TB, B), dim3(TB), 0, stream, x, n, n_bins, tau, eps, cut, (const float*)cn,
                        const_cast<float*>(y), const_cast<float*>(S), grad_out, (const float*)dh, grad_x, (float*)nullptr, 0.f, gs);

@@ -17,6 +17,13 @@ matrix is ``B.matrix @ A.matrix``; xvr relies on this in ``pose.compose(offset)`
 (src/xvr/model/trainer.py:189-193).
 
 This is B x 4 x 4 scalar math -- it is on the autograd chain of the renderer but is not a kernel.
+
+Provenance: the rotation-conversion helpers (``euler_angles_to_matrix`` / ``matrix_to_euler_angles`` with ``_angle_from_tan``,
+``quaternion_to_matrix`` / ``matrix_to_quaternion`` with ``_sqrt_positive_part``, ``axis_angle_to_matrix``,
+``rotation_6d_to_matrix`` / ``matrix_to_rotation_6d``, the se(3) exp / log maps) keep the names, signatures and formulas of
+PyTorch3D's ``pytorch3d.transforms`` (BSD 3-Clause, Copyright (c) Meta Platforms, Inc. and affiliates), which diffdrr.pose itself
+re-exports and xvr's call sites therefore assume; they were written here from those public definitions (neither package is in
+this tree) and the HIP ``xvr_pose_convert_*`` kernels evaluate the same formulas branch for branch.
 """
 
 from __future__ import annotations
