@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define XVR_DRR_ABI_VERSION 8   /* 8: xvr_pose_camera_forward_param / xvr_pose_opt_step_param (device-resident registration for every parameterisation; xvr_pose_opt_state holds 13 parameters), xvr_sim_equalize_* write / take the normalised output, option tile_geom; 7: xvr_drr_foreground, xvr_drr_pack_labels_ypairs, xvr_sim_dice_bool, xvr_sim_transform_* (xvr_sim.h), xvr_pose_convert_* (xvr_pose.h); 6: xvr_drr_spec.alpha_window + xvr_drr_alpha_window (clip_to_volume = 2); 5: xvr_drr_set_option / xvr_drr_get_option (the A/B switches are no longer getenv calls per launch); 4: volume_layout 2 + xvr_drr_pack_bricks (siddon forward); 3: xvr_drr_spec.volume_layout + xvr_drr_pack_ypairs; 2: xvr_sim_spec grew, camera-driven forwards, packed labels, xvr_pose.h */
+#define XVR_DRR_ABI_VERSION 8   /* 8: volume_layout 3 + xvr_drr_pack_ytiles / _labels_ytiles (tiled y-pair copy), xvr_pose_camera_forward_param / xvr_pose_opt_step_param (device-resident registration for every parameterisation; xvr_pose_opt_state holds 13 parameters), xvr_sim_equalize_* write / take the normalised output, option tile_geom; 7: xvr_drr_foreground, xvr_drr_pack_labels_ypairs, xvr_sim_dice_bool, xvr_sim_transform_* (xvr_sim.h), xvr_pose_convert_* (xvr_pose.h); 6: xvr_drr_spec.alpha_window + xvr_drr_alpha_window (clip_to_volume = 2); 5: xvr_drr_set_option / xvr_drr_get_option (the A/B switches are no longer getenv calls per launch); 4: volume_layout 2 + xvr_drr_pack_bricks (siddon forward); 3: xvr_drr_spec.volume_layout + xvr_drr_pack_ypairs; 2: xvr_sim_spec grew, camera-driven forwards, packed labels, xvr_pose.h */
 
 #define XVR_DRR_OK 0
 #define XVR_DRR_E_ARG (-1)     /* bad argument (null pointer, non-positive size, unsupported combo) */
@@ -65,7 +65,8 @@ typedef struct xvr_drr_spec {
                               lanes are mapped to 8x8 pixel tiles; 0: rays are mapped linearly             */
     int32_t volume_layout; /* forward only: 0 = `volume` is [D0][D1][D2]; 1 (trilinear) = it is the y-pair interleaved
                               copy written by xvr_drr_pack_ypairs; 2 (siddon) = the 4 x 2 x 4 bricks written by
-                              xvr_drr_pack_bricks (same results, bit for bit)                               */
+                              xvr_drr_pack_bricks; 3 (trilinear) = the y-pair copy in 4 x 4 tiles written by
+                              xvr_drr_pack_ytiles (same results, bit for bit)                               */
     const float* alpha_window; /* clip_to_volume == 2: device buffer of xvr_drr_alpha_window_bytes(B) bytes, 16-byte aligned, written by
                               xvr_drr_alpha_window() on the same stream before the render (the kernels read the call's
                               near / far / scale from it: no host round trip); NULL otherwise                  */
@@ -265,6 +266,14 @@ int xvr_drr_pack_ypairs(const float* volume, int D0, int D1, int D2, float* pair
 /* The y-pair copy of the LABEL-CARRYING volume (xvr_drr_pack_labels then xvr_drr_pack_ypairs) in one pass over volume and mask:
  * for masked renders of large launches whose volume is new every call (xvr's training step, trainer.py:185-230). */
 int xvr_drr_pack_labels_ypairs(const float* volume, const float* mask, int D0, int D1, int D2, float* pairs, void* stream);
+/* The same y-pairs cut into 128-byte lines of 4 x-rows x 4 z-entries, tiles [ceil(D0 / 4)][D1 + 1][(D2 - 2) / 3 + 1][4][4][2] that
+ * OVERLAP by one entry along z (tile b holds z = 3 b .. 3 b + 3: the 16 bytes of any (z, z + 1) pair lie in one tile), for
+ * volume_layout = 3 (round 4).  The forward is bound by fabric bandwidth, one 128-byte line per L2 miss whatever part is used
+ * (profiles/r04_fetch_calibration.txt); an oblique view cuts a z-run of 16 entries after ~2 voxels, a 4 x 4 tile is used two to
+ * three times as densely.  4/3 of the row copy's memory; same results, bit for bit. */
+size_t xvr_drr_ytiles_bytes(int D0, int D1, int D2);
+int xvr_drr_pack_ytiles(const float* volume, int D0, int D1, int D2, float* tiles, void* stream);
+int xvr_drr_pack_labels_ytiles(const float* volume, const float* mask, int D0, int D1, int D2, float* tiles, void* stream);
 
 /*
  * Bricked copy of a volume for the Siddon forward (spec.volume_layout = 2):

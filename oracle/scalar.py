@@ -64,6 +64,8 @@ def _c_spec(shape, spec: RenderSpec) -> _Spec:
         c.a[i], c.b[i] = float(a[i]), float(b[i])
     c.n_points, c.near, c.far = spec.n_points, spec.near, spec.far
     c.denom = float(spec.n_points if spec.step_mode == "n_points" else spec.n_points - 1)
+    if spec.clip_to_volume == "batch":
+        raise NotImplementedError("the scalar oracle has no clip_to_volume = 'batch' (the torch restatement does)")
     c.clip = int(spec.clip_to_volume)
     c.per_ray_clamp = int(spec.per_ray_clamp)
     return c

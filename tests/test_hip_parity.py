@@ -124,13 +124,17 @@ def test_sample_split_forward_and_jacobian(ns, kw, grid, monkeypatch):
 @pytest.mark.parametrize("kw", [dict(n_points=120), dict(n_points=90, voxel_shift=0.0, step_mode="n_minus_1"),
                                 dict(n_points=100, norm_dims_offset=-1), dict(n_points=80, near=0.2, far=0.9),
                                 dict(n_points=70, clip_to_volume=True)], ids=_id)
-@pytest.mark.parametrize("shape", [(40, 44, 48), (33, 31, 29)], ids=["even", "odd"])
-def test_ypair_volume_layout_is_bit_identical(kw, shape, monkeypatch):
-    """Large one-channel trilinear launches march the y-pair interleaved copy of the volume (xvr_drr_pack_ypairs: two
-    16-byte gathers per sample instead of four 8-byte ones).  Same taps, same arithmetic: the image and the jacobian-borne
-    pose gradients must be IDENTICAL to the natural layout's, bit for bit -- also where rays leave the volume (the copy's
-    zero rows) and for odd sizes."""
+@pytest.mark.parametrize("tiles", [True, False], ids=["tiles", "rows"])
+@pytest.mark.parametrize("shape", [(40, 44, 48), (33, 31, 29), (9, 10, 5)], ids=["even", "odd", "tiny"])
+def test_ypair_volume_layout_is_bit_identical(kw, shape, tiles, monkeypatch):
+    """Large one-channel trilinear launches march a y-pair interleaved copy of the volume -- rows (xvr_drr_pack_ypairs) or 4 x 4
+    tiles overlapping along z (xvr_drr_pack_ytiles, the default since round 4) --: two 16-byte gathers per sample instead of
+    four 8-byte ones.  Same taps, same arithmetic: the image and the jacobian-borne pose gradients must be IDENTICAL to the
+    natural layout's, bit for bit -- also where rays leave the volume (the copy's zero rows), for sizes that do not fill the last
+    tiles, and for a z extent that ends inside a tile."""
     from xvr_amd import renderers
+
+    monkeypatch.setattr(renderers, "YPAIR_TILES", tiles)
     from xvr_amd.renderers import render
     from xvr_amd.spec import RenderSpec
 
@@ -201,6 +205,7 @@ def test_slab_major_forward_partitions_the_samples_exactly(kw, nslabs, axis, ypa
     spec = RenderSpec(renderer="trilinear", **kw)
     monkeypatch.setattr(renderers, "YPAIR_MIN_WAVEFRONTS", 1)
     monkeypatch.setattr(renderers, "YPAIR_LAYOUT", ypairs)
+    monkeypatch.setattr(renderers, "YPAIR_TILES", False)     # (the opt-in slab-major march knows the row copy only)
     case = make_case(seed=17, shape=(44, 40, 36), height=40, width=48, delx=1.4,
                      rot=((170.0, 25.0, 5.0), (200.0, -30.0, -8.0), (150.0, 5.0, 12.0)), xyz=((5.0, 300.0, -4.0), (-3.0, 250.0, 6.0), (0.0, 280.0, 0.0)))
     w = torch.rand(3, 1, 40 * 48, generator=torch.Generator().manual_seed(4))

@@ -126,6 +126,9 @@ EXPORTS = {
     "xvr_drr_ypairs_bytes": ([_I, _I, _I], ctypes.c_size_t),
     "xvr_drr_pack_ypairs": ([_P, _I, _I, _I, _P, _P], ctypes.c_int),
     "xvr_drr_pack_labels_ypairs": ([_P, _P, _I, _I, _I, _P, _P], ctypes.c_int),
+    "xvr_drr_ytiles_bytes": ([_I, _I, _I], ctypes.c_size_t),
+    "xvr_drr_pack_ytiles": ([_P, _I, _I, _I, _P, _P], ctypes.c_int),
+    "xvr_drr_pack_labels_ytiles": ([_P, _P, _I, _I, _I, _P, _P], ctypes.c_int),
     "xvr_drr_bricks_bytes": ([_I, _I, _I], ctypes.c_size_t),
     "xvr_drr_pack_bricks": ([_P, _I, _I, _I, _P, _P], ctypes.c_int),
     "xvr_drr_jac_to_camera_workspace_bytes": ([_I, _I, _I], ctypes.c_size_t),

@@ -47,7 +47,7 @@ struct SlabRange {
 
 // WIN (clip_to_volume == 2, with the jacobian): also E1 = sum (alpha_k - A) (a d . grad V) -- d out / d (window width) needs it
 // directly; rebuilt from G and H it is a difference of two large sums and loses 2 % in float32
-template <bool JAC, int MASK, bool CLIP, bool YP = false, bool SLAB = false, bool WIN = false, int SYNC = 0>
+template <bool JAC, int MASK, bool CLIP, int YP = 0, bool SLAB = false, bool WIN = false, int SYNC = 0>
 __device__ __forceinline__ void tri_march(const RenderArgs& A, const Ray& R, const KRange K, const int kbeg, const int kend,
                                           const float step, const SpecWin Wn, float* lds, const int tid, TriAcc& acc,
                                           const SlabRange slab = SlabRange{0, 0.f, 0.f}) {
@@ -103,7 +103,7 @@ __device__ __forceinline__ void tri_march(const RenderArgs& A, const Ray& R, con
                     T[h].base[0] = T[h].base[1] = T[h].base[2] = T[h].base[3] = 0;
                 }
             }
-            else if (YP) make_taps_yp(pxs[h], pys[h], pzs[h], D0, D1, D2, T[h], yoff[h]);
+            else if (YP) make_taps_yp<YP>(pxs[h], pys[h], pzs[h], D0, D1, D2, T[h], yoff[h]);
             else make_taps(pxs[h], pys[h], pzs[h], D0, D1, D2, T[h]);  // offsets are clamped: always loadable
         }
         // unconditional (offsets are clamped into the volume): a branch here would split the loads into
@@ -237,7 +237,7 @@ constexpr double SLAB_TARGET_BYTES = 150e6, SLAB_MIN_VOLUME_BYTES = 192.0 * (1 <
 #ifndef XVR_FWD_WAVES   // (overridable for tuning builds)
 #define XVR_FWD_WAVES 4
 #endif
-template <bool JAC, int MASK, bool CLIP, bool YP = false, bool WIN = false>
+template <bool JAC, int MASK, bool CLIP, int YP = 0, bool WIN = false>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, XVR_FWD_WAVES))) void k_trilinear_fwd(RenderArgs A) {
     extern __shared__ float lds[];  // MASK: per-lane channel accumulators [C][WG]
     int b, r;
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, XVR_FWD_W
     acc.S = 0.f; acc.cnt = 0; acc.E0 = acc.E1 = 0.f;
 #pragma unroll
     for (int i = 0; i < 3; ++i) acc.G[i] = acc.H[i] = 0.f;
-    if (active) tri_march<JAC, 0, false, YP, true>(A, R, K, kbeg, kend, step, Wn, nullptr, tid, acc, S);
+    if (active) tri_march<JAC, 0, false, YP ? 1 : 0, true>(A, R, K, kbeg, kend, step, Wn, nullptr, tid, acc, S);
     if (valid) {
         float4* jp = JAC ? reinterpret_cast<float4*>(A.jac + ((size_t)b * A.n + r) * XVR_DRR_JAC_STRIDE) : nullptr;
         float* op = A.out + (size_t)b * A.n + r;
@@ -748,10 +748,13 @@ static int trilinear_forward_impl(const float* volume, const float* mask, int D0
     if (packed && C > (1 << LABEL_BITS)) return fail(XVR_DRR_E_ARG, "packed labels hold at most 16 channels");
     if (sp->alpha_window && jac && (mask || packed))
         return fail(XVR_DRR_E_UNSUPPORTED, "clip_to_volume == 2: the jacobian is implemented for one channel");
-    if (sp->volume_layout != 0 && sp->volume_layout != 1) return fail(XVR_DRR_E_ARG, "unknown volume_layout");
-    if (sp->volume_layout == 1 && mask) return fail(XVR_DRR_E_UNSUPPORTED, "the y-pair layout takes labels packed into the volume, not a mask volume");
+    if (sp->volume_layout != 0 && sp->volume_layout != 1 && sp->volume_layout != 3) return fail(XVR_DRR_E_ARG, "unknown volume_layout");
+    const bool ypl = sp->volume_layout == 1 || sp->volume_layout == 3;   // a y-pair copy: rows (1) or 4 x 4 tiles (3)
+    if (ypl && mask) return fail(XVR_DRR_E_UNSUPPORTED, "the y-pair layouts take labels packed into the volume, not a mask volume");
     if (sp->volume_layout == 1 && (long long)D0 * (D1 + 1) * D2 * 2 >= (1LL << 31))
         return fail(XVR_DRR_E_UNSUPPORTED, "y-pair copy has >= 2^31 elements");
+    if (sp->volume_layout == 3 && ((long long)((D0 + 3) / 4) * (D1 + 1) * ((D2 - 2) / 3 + 1) * 32 >= (1LL << 31) || D2 >= 98304))
+        return fail(XVR_DRR_E_UNSUPPORTED, "tiled y-pair copy has >= 2^31 elements");
     RenderArgs A;
     fill_args(A, volume, mask, D0, D1, D2, C, source, target, raylen, B, n, sp, cam);
     A.out = out; A.jac = jac; A.work = work;
@@ -760,12 +763,13 @@ static int trilinear_forward_impl(const float* volume, const float* mask, int D0
         return fail(XVR_DRR_E_ARG, "clip_to_volume == 2 needs spec.alpha_window (xvr_drr_alpha_window), and only it");
     const bool clip = sp->clip_to_volume == 1;
     const size_t lds = C > 1 || mask ? (size_t)C * WG * sizeof(float) : 0;
-    if (packed && sp->volume_layout == 1) {   // the y-pair copy of the label-carrying volume
-        if (jac) return clip ? launch(k_trilinear_fwd<true, 2, true, true>, A, lds, stream)
-                             : launch(k_trilinear_fwd<true, 2, false, true>, A, lds, stream);
-        return clip ? launch(k_trilinear_fwd<false, 2, true, true>, A, lds, stream)
-                    : launch(k_trilinear_fwd<false, 2, false, true>, A, lds, stream);
-    }
+#define XVR_YP_LAUNCH(M, Y, L)                                                                                           \
+    do {                                                                                                                \
+        if (jac) return clip ? launch(k_trilinear_fwd<true, M, true, Y>, A, L, stream) : launch(k_trilinear_fwd<true, M, false, Y>, A, L, stream); \
+        return clip ? launch(k_trilinear_fwd<false, M, true, Y>, A, L, stream) : launch(k_trilinear_fwd<false, M, false, Y>, A, L, stream);        \
+    } while (0)
+    if (packed && sp->volume_layout == 1) XVR_YP_LAUNCH(2, 1, lds);   // the y-pair copy of the label-carrying volume
+    if (packed && sp->volume_layout == 3) XVR_YP_LAUNCH(2, 2, lds);
     if (packed && jac) return clip ? launch(k_trilinear_fwd<true, 2, true>, A, lds, stream)
                                    : launch(k_trilinear_fwd<true, 2, false>, A, lds, stream);
     if (packed) return clip ? launch(k_trilinear_fwd<false, 2, true>, A, lds, stream)
@@ -783,22 +787,23 @@ static int trilinear_forward_impl(const float* volume, const float* mask, int D0
     }
     if (sp->alpha_window && jac) {   // the jacobian of a windowed render also carries d out / d (window width): unsplit kernel
         RenderArgs Aw = A;
-        return sp->volume_layout == 1 ? launch(k_trilinear_fwd<true, 0, false, true, true>, Aw, 0, stream)
-                                      : launch(k_trilinear_fwd<true, 0, false, false, true>, Aw, 0, stream);
+        return sp->volume_layout == 1 ? launch(k_trilinear_fwd<true, 0, false, 1, true>, Aw, 0, stream)
+                                      : (sp->volume_layout == 3 ? launch(k_trilinear_fwd<true, 0, false, 2, true>, Aw, 0, stream)
+                                                                : launch(k_trilinear_fwd<true, 0, false, 0, true>, Aw, 0, stream));
     }
     // Large batches over a volume the Infinity Cache cannot hold: the slab-major march (k_trilinear_fwd_slab).  Option
     // "fwd_slabs": 0 = never, n >= 2 = always n slabs, -1 (default) = as many slabs as keep a slab's bytes under
     // SLAB_TARGET_BYTES, for launches of >= 8192 workgroups over a volume copy of > 192 MiB.  "fwd_slab_axis": 0-2.
     {
         const int want = xvr_detail::option(xvr_detail::OPT_FWD_SLABS);
-        const double layout_bytes = (sp->volume_layout == 1 ? 2.0 * D0 * (D1 + 1) * D2 : 1.0 * D0 * D1 * D2) * sizeof(float);
+        const double layout_bytes = (ypl ? 2.0 * D0 * (D1 + 1) * D2 : 1.0 * D0 * D1 * D2) * sizeof(float);
         const long long nblocks = (long long)B * A.blocks_per_pose;
         int nslabs = want;
         if (want < 0) nslabs = (nblocks >= 8192 && layout_bytes > SLAB_MIN_VOLUME_BYTES) ? (int)ceil(layout_bytes / SLAB_TARGET_BYTES) : 0;
         const int axis = xvr_detail::option(xvr_detail::OPT_FWD_SLAB_AXIS);
         const int Daxis = axis == 0 ? D0 : (axis == 1 ? D1 : D2);
         if (nslabs > Daxis / 4) nslabs = Daxis / 4;
-        if (nslabs >= 2 && !clip && A.grid_w > 0) {
+        if (nslabs >= 2 && !clip && A.grid_w > 0 && sp->volume_layout != 3) {
             for (int s = 0; s < nslabs; ++s) {
                 SlabRange S;
                 S.axis = axis;
@@ -818,12 +823,9 @@ static int trilinear_forward_impl(const float* volume, const float* mask, int D0
             return XVR_DRR_OK;
         }
     }
-    if (sp->volume_layout == 1) {   // `volume` is the y-pair interleaved copy: the unsplit kernel, whatever the launch size
-        if (jac) return clip ? launch(k_trilinear_fwd<true, 0, true, true>, A, 0, stream)
-                             : launch(k_trilinear_fwd<true, 0, false, true>, A, 0, stream);
-        return clip ? launch(k_trilinear_fwd<false, 0, true, true>, A, 0, stream)
-                    : launch(k_trilinear_fwd<false, 0, false, true>, A, 0, stream);
-    }
+    if (sp->volume_layout == 1) XVR_YP_LAUNCH(0, 1, 0);   // `volume` is a y-pair copy: the unsplit kernel, whatever the launch size
+    if (sp->volume_layout == 3) XVR_YP_LAUNCH(0, 2, 0);
+#undef XVR_YP_LAUNCH
     bool tile16 = false;
     const int ns = split_factor(B, n, (long long)D0 * D1 * D2, false, &tile16);
     if (ns > 1) {

@@ -179,11 +179,14 @@ def _packed_ypair_volume(lib, volume, mask):
     D0, D1, D2 = volume.shape
     key = (mask.data_ptr(), mask._version, volume._version)
     slot = _cache_slot(volume)
+    key = key + (YPAIR_TILES,)
     hit = slot.get("packed_ypairs")
     if hit is not None and hit[0] == key and hit[2]() is mask:
         return hit[1]
-    buf = torch.empty(lib.xvr_drr_ypairs_bytes(D0, D1, D2) // 4, device=volume.device, dtype=torch.float32)
-    rc = _timed("pack_labels_ypairs", lib.xvr_drr_pack_labels_ypairs, _ptr(volume), _ptr(mask), D0, D1, D2, _ptr(buf), _stream())
+    nbytes, pack = ((lib.xvr_drr_ytiles_bytes, lib.xvr_drr_pack_labels_ytiles) if YPAIR_TILES
+                    else (lib.xvr_drr_ypairs_bytes, lib.xvr_drr_pack_labels_ypairs))
+    buf = torch.empty(nbytes(D0, D1, D2) // 4, device=volume.device, dtype=torch.float32)
+    rc = _timed("pack_labels_ypairs", pack, _ptr(volume), _ptr(mask), D0, D1, D2, _ptr(buf), _stream())
     _lib.check(rc, "xvr_drr_pack_labels_ypairs")
     slot["packed_ypairs"] = (key, buf, weakref.ref(mask))
     return buf
@@ -195,6 +198,13 @@ def _packed_ypair_volume(lib, volume, mask):
 # its version counter, built the third time a version is rendered: see _ypair_volume).  False (or XVR_DRR_YPAIRS=0):
 # natural layout.
 YPAIR_LAYOUT = _os.environ.get("XVR_DRR_YPAIRS", "1") != "0"
+# ... and that copy is cut into 4 x 4 tiles overlapping along z (xvr_drr_pack_ytiles, volume_layout 3; round 4): the forward is
+# bound by fabric bandwidth and a tile's 128 bytes are used two to three times as densely as a z-run's.  XVR_DRR_YTILES=0: rows.
+YPAIR_TILES = _os.environ.get("XVR_DRR_YTILES", "1") != "0"
+
+
+def _ypair_layout_code() -> int:
+    return 3 if YPAIR_TILES else 1
 YPAIR_MIN_WAVEFRONTS = 2048     # smaller launches take the sample-split kernels on the natural layout
 # Siddon's counterpart: 4 x 2 x 4-voxel bricks, one per cache line (xvr_drr_pack_bricks); same caching rule.  XVR_DRR_BRICKS=0: off.
 BRICK_LAYOUT = _os.environ.get("XVR_DRR_BRICKS", "1") != "0"
@@ -212,7 +222,7 @@ def _layout_copy(lib, volume, kind):
     training step, rendered exactly twice with a mask (trainer.py:185-230), gets labels and y-pairs in one pass at first
     sight (_packed_ypair_volume).  The bricked copy for Siddon saves 1.3 ms per render and is built at first sight."""
     D0, D1, D2 = volume.shape
-    key = volume._version
+    key = (volume._version, YPAIR_TILES)
     slot = _cache_slot(volume)
     hit = slot.get(kind)      # (version, copy or None, buffer kept for reuse, renders seen)
     if hit is not None and hit[0] == key and hit[1] is not None:
@@ -222,8 +232,13 @@ def _layout_copy(lib, volume, kind):
     if seen <= LAYOUT_COPY_AFTER[kind]:
         slot[kind] = (key, None, buf, seen)
         return None
-    nbytes, pack, name = ((lib.xvr_drr_ypairs_bytes, lib.xvr_drr_pack_ypairs, "pack_ypairs") if kind == "ypairs"
-                          else (lib.xvr_drr_bricks_bytes, lib.xvr_drr_pack_bricks, "pack_bricks"))
+    if kind == "ypairs":
+        nbytes, pack, name = ((lib.xvr_drr_ytiles_bytes, lib.xvr_drr_pack_ytiles, "pack_ypairs") if YPAIR_TILES
+                              else (lib.xvr_drr_ypairs_bytes, lib.xvr_drr_pack_ypairs, "pack_ypairs"))
+    else:
+        nbytes, pack, name = lib.xvr_drr_bricks_bytes, lib.xvr_drr_pack_bricks, "pack_bricks"
+    if buf is not None and buf.numel() * 4 != nbytes(D0, D1, D2):
+        buf = None
     if buf is None:
         buf = torch.empty(nbytes(D0, D1, D2) // 4, device=volume.device, dtype=torch.float32)
     rc = _timed(name, pack, _ptr(volume), D0, D1, D2, _ptr(buf), _stream())
@@ -253,8 +268,9 @@ def _use_bricks(spec, volume, B, n, C=1):
 def _use_ypairs(spec, volume, B, n):
     """(one channel, or labels packed into the volume's mantissa bits -- never with a separate mask volume)"""
     D0, D1, D2 = volume.shape
+    elements = ((D0 + 3) // 4) * (D1 + 1) * ((D2 - 2) // 3 + 1) * 32 if YPAIR_TILES else D0 * (D1 + 1) * D2 * 2
     return (YPAIR_LAYOUT and spec.renderer == "trilinear" and B * ((n + 63) // 64) >= YPAIR_MIN_WAVEFRONTS
-            and D0 * (D1 + 1) * D2 * 2 < 2 ** 31 and min(D0, D1, D2) >= 2)
+            and elements < 2 ** 31 and min(D0, D1, D2) >= 2)
 
 
 class _Render(torch.autograd.Function):
@@ -290,7 +306,7 @@ class _Render(torch.autograd.Function):
             vol_f = pairs                                              # (of the label-carrying copy when there is one)
         if bricks is not None:
             vol_f = bricks
-        cs = make_cspec((D0, D1, D2), spec, ray_grid_w, volume_layout=1 if pairs is not None else (2 if bricks is not None else 0))
+        cs = make_cspec((D0, D1, D2), spec, ray_grid_w, volume_layout=_ypair_layout_code() if pairs is not None else (2 if bricks is not None else 0))
         window = None
         if spec.renderer == "trilinear" and spec.clip_to_volume == "batch":
             # ONE alpha window for the whole call, reduced on the device from its rays (no host round trip): the kernels read
@@ -393,7 +409,7 @@ class _RenderFromCamera(torch.autograd.Function):
         pairs = _ypair_volume(lib, vol_c) if _use_ypairs(spec, vol_c, B, n) else None
         if pairs is None and _use_bricks(spec, vol_c, B, n):
             pairs = _brick_volume(lib, vol_c)                          # (siddon: the bricked copy takes the same seat)
-        layout = 0 if pairs is None else (1 if spec.renderer == "trilinear" else 2)
+        layout = 0 if pairs is None else (_ypair_layout_code() if spec.renderer == "trilinear" else 2)
         cs = make_cspec(tuple(vol_c.shape), spec, W, volume_layout=layout)
         need = ctx.needs_input_grad[0]
         out = torch.empty(B, 1, n, device=cam.device, dtype=torch.float32)
