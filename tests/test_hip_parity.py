@@ -135,6 +135,7 @@ def test_ypair_volume_layout_is_bit_identical(kw, shape, tiles, monkeypatch):
     from xvr_amd import renderers
 
     monkeypatch.setattr(renderers, "YPAIR_TILES", tiles)
+    monkeypatch.setattr(renderers, "YPAIR_TILES_PACKED", tiles)     # (the label-carrying copy is tiled on request only)
     from xvr_amd.renderers import render
     from xvr_amd.spec import RenderSpec
 

@@ -197,30 +197,29 @@ __global__ __launch_bounds__(TB) void k_pack_ypairs(const float* __restrict__ vo
 template <bool LABELS>
 __global__ __launch_bounds__(TB) void k_pack_ytiles(const float* __restrict__ vol, const float* __restrict__ mask, int D0, int D1, int D2,
                                                     float* __restrict__ tiles) {
+    // one thread per 16 bytes of the copy (two z-entries of one tile row): consecutive threads write consecutive 16 bytes
     const int nbx = (D0 + 3) >> 2, nbz = (D2 - 2) / 3 + 1;
-    const long long total = (long long)nbx * (D1 + 1) * nbz * 4;
+    const long long total = (long long)nbx * (D1 + 1) * nbz * 8;
     auto pk = [](const float d, const float l) {
         const unsigned lab = (unsigned)min(max((int)l, 0), 15);
         return __uint_as_float((__float_as_uint(d) & ~15u) | lab);
     };
     for (long long t = (long long)blockIdx.x * TB + threadIdx.x; t < total; t += (long long)gridDim.x * TB) {
-        const int xr = (int)(t & 3);
-        const long long tile = t >> 2;
+        const int piece = (int)(t & 7), xr = piece >> 1, half = piece & 1;
+        const long long tile = t >> 3;
         const int bz = (int)(tile % nbz);
         const long long row = tile / nbz;
         const int yp = (int)(row % (D1 + 1)), x = (int)(row / (D1 + 1)) * 4 + xr;
-        float v[8];
+        float v[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int z = 3 * bz + r;
+        for (int r = 0; r < 2; ++r) {
+            const int z = 3 * bz + 2 * half + r;
             const bool in = x < D0 && z < D2;
             const long long olo = ((long long)x * D1 + (yp - 1)) * D2 + z, ohi = ((long long)x * D1 + yp) * D2 + z;
             v[2 * r] = in && yp >= 1 ? (LABELS ? pk(vol[olo], mask[olo]) : vol[olo]) : 0.f;
             v[2 * r + 1] = in && yp <= D1 - 1 ? (LABELS ? pk(vol[ohi], mask[ohi]) : vol[ohi]) : 0.f;
         }
-        float4* dst = reinterpret_cast<float4*>(tiles + (tile * 16 + xr * 4) * 2);
-        dst[0] = make_float4(v[0], v[1], v[2], v[3]);
-        dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+        reinterpret_cast<float4*>(tiles)[t] = make_float4(v[0], v[1], v[2], v[3]);
     }
 }
 
@@ -305,10 +304,10 @@ size_t xvr_drr_ytiles_bytes(int D0, int D1, int D2) {
 static int pack_ytiles_impl(const float* volume, const float* mask, int D0, int D1, int D2, float* tiles, void* stream_) {
     if (!volume || !tiles || D0 < 2 || D1 < 2 || D2 < 2) return vfail(XVR_DRR_E_ARG, "bad argument");
     if (reinterpret_cast<uintptr_t>(tiles) & 15u) return vfail(XVR_DRR_E_ARG, "the tiled copy must be 16-byte aligned");
-    const long long total = (long long)((D0 + 3) / 4) * (D1 + 1) * ((D2 - 2) / 3 + 1) * 4;
-    if (total * 8 >= (1LL << 31)) return vfail(XVR_DRR_E_UNSUPPORTED, "tiled y-pair copy has >= 2^31 elements");
+    const long long total = (long long)((D0 + 3) / 4) * (D1 + 1) * ((D2 - 2) / 3 + 1) * 8;   // 16-byte pieces
+    if (total * 4 >= (1LL << 31)) return vfail(XVR_DRR_E_UNSUPPORTED, "tiled y-pair copy has >= 2^31 elements");
     const long long blocks = (total + TB - 1) / TB;
-    const dim3 grid((unsigned)(blocks < 32768 ? blocks : 32768));
+    const dim3 grid((unsigned)(blocks < 65536 ? blocks : 65536));
     if (mask) hipLaunchKernelGGL(k_pack_ytiles<true>, grid, dim3(TB), 0, (hipStream_t)stream_, volume, mask, D0, D1, D2, tiles);
     else hipLaunchKernelGGL(k_pack_ytiles<false>, grid, dim3(TB), 0, (hipStream_t)stream_, volume, mask, D0, D1, D2, tiles);
     hipError_t e = hipGetLastError();

@@ -179,17 +179,18 @@ def _packed_ypair_volume(lib, volume, mask):
     D0, D1, D2 = volume.shape
     key = (mask.data_ptr(), mask._version, volume._version)
     slot = _cache_slot(volume)
-    key = key + (YPAIR_TILES,)
+    tiles = YPAIR_TILES and YPAIR_TILES_PACKED
+    key = key + (tiles,)
     hit = slot.get("packed_ypairs")
     if hit is not None and hit[0] == key and hit[2]() is mask:
-        return hit[1]
-    nbytes, pack = ((lib.xvr_drr_ytiles_bytes, lib.xvr_drr_pack_labels_ytiles) if YPAIR_TILES
+        return hit[1], (3 if tiles else 1)
+    nbytes, pack = ((lib.xvr_drr_ytiles_bytes, lib.xvr_drr_pack_labels_ytiles) if tiles
                     else (lib.xvr_drr_ypairs_bytes, lib.xvr_drr_pack_labels_ypairs))
     buf = torch.empty(nbytes(D0, D1, D2) // 4, device=volume.device, dtype=torch.float32)
     rc = _timed("pack_labels_ypairs", pack, _ptr(volume), _ptr(mask), D0, D1, D2, _ptr(buf), _stream())
     _lib.check(rc, "xvr_drr_pack_labels_ypairs")
     slot["packed_ypairs"] = (key, buf, weakref.ref(mask))
-    return buf
+    return buf, (3 if tiles else 1)
 
 
 # One-channel trilinear renders of LARGE launches march a y-pair interleaved copy of the volume (xvr_drr_pack_ypairs): two
@@ -200,11 +201,11 @@ def _packed_ypair_volume(lib, volume, mask):
 YPAIR_LAYOUT = _os.environ.get("XVR_DRR_YPAIRS", "1") != "0"
 # ... and that copy is cut into 4 x 4 tiles overlapping along z (xvr_drr_pack_ytiles, volume_layout 3; round 4): the forward is
 # bound by fabric bandwidth and a tile's 128 bytes are used two to three times as densely as a z-run's.  XVR_DRR_YTILES=0: rows.
+# The label-carrying copy of a training step is packed EVERY step (a fresh HU -> density map, rendered twice): there the tiled
+# copy's larger write (0.96 against 0.53 ms at 512^3) costs more than its two renders save (C5: 15.98 against 15.76 ms per step),
+# so it stays on rows unless XVR_DRR_YTILES_PACKED=1.
 YPAIR_TILES = _os.environ.get("XVR_DRR_YTILES", "1") != "0"
-
-
-def _ypair_layout_code() -> int:
-    return 3 if YPAIR_TILES else 1
+YPAIR_TILES_PACKED = _os.environ.get("XVR_DRR_YTILES_PACKED", "0") != "0"
 YPAIR_MIN_WAVEFRONTS = 2048     # smaller launches take the sample-split kernels on the natural layout
 # Siddon's counterpart: 4 x 2 x 4-voxel bricks, one per cache line (xvr_drr_pack_bricks); same caching rule.  XVR_DRR_BRICKS=0: off.
 BRICK_LAYOUT = _os.environ.get("XVR_DRR_BRICKS", "1") != "0"
@@ -248,7 +249,8 @@ def _layout_copy(lib, volume, kind):
 
 
 def _ypair_volume(lib, volume):
-    return _layout_copy(lib, volume, "ypairs")
+    """-> (copy or None, its volume_layout code: 3 = 4 x 4 tiles, 1 = rows)"""
+    return _layout_copy(lib, volume, "ypairs"), (3 if YPAIR_TILES else 1)
 
 
 def _brick_volume(lib, volume):
@@ -293,20 +295,20 @@ class _Render(torch.autograd.Function):
         jac = torch.empty(B, n, _lib.JAC_STRIDE, device=volume.device, dtype=torch.float32) if use_jac else None
         fn = lib.xvr_drr_trilinear_forward if spec.renderer == "trilinear" else lib.xvr_drr_siddon_forward
         vol_f, msk_f = vol_c, msk_c
-        pairs = None
+        pairs, pairs_layout = None, 1
         if msk_c is not None and PACK_LABELS and 2 <= C <= 16 and vol_c.data_ptr() % 16 == 0 and msk_c.data_ptr() % 16 == 0:
             if _use_ypairs(spec, vol_c, B, n):
-                pairs, msk_f = _packed_ypair_volume(lib, vol_c, msk_c), None   # labels in the taps AND the y-pair layout, one pass
+                (pairs, pairs_layout), msk_f = _packed_ypair_volume(lib, vol_c, msk_c), None   # labels in the taps AND the y-pair layout, one pass
             else:
                 vol_f, msk_f = _packed_volume(lib, vol_c, msk_c), None     # labels ride in the taps
-        if pairs is None:
-            pairs = _ypair_volume(lib, vol_f) if msk_f is None and _use_ypairs(spec, vol_c, B, n) else None
+        if pairs is None and msk_f is None and _use_ypairs(spec, vol_c, B, n):
+            pairs, pairs_layout = _ypair_volume(lib, vol_f)
         bricks = _brick_volume(lib, vol_f) if msk_f is None and _use_bricks(spec, vol_c, B, n, C) else None
         if pairs is not None:
             vol_f = pairs                                              # (of the label-carrying copy when there is one)
         if bricks is not None:
             vol_f = bricks
-        cs = make_cspec((D0, D1, D2), spec, ray_grid_w, volume_layout=_ypair_layout_code() if pairs is not None else (2 if bricks is not None else 0))
+        cs = make_cspec((D0, D1, D2), spec, ray_grid_w, volume_layout=pairs_layout if pairs is not None else (2 if bricks is not None else 0))
         window = None
         if spec.renderer == "trilinear" and spec.clip_to_volume == "batch":
             # ONE alpha window for the whole call, reduced on the device from its rays (no host round trip): the kernels read
@@ -406,10 +408,11 @@ class _RenderFromCamera(torch.autograd.Function):
         lib = _lib.load()
         cam_c, vol_c = cam.contiguous(), volume.contiguous()
         B, n = cam_c.shape[0], H * W
-        pairs = _ypair_volume(lib, vol_c) if _use_ypairs(spec, vol_c, B, n) else None
+        pairs, layout = _ypair_volume(lib, vol_c) if _use_ypairs(spec, vol_c, B, n) else (None, 0)
         if pairs is None and _use_bricks(spec, vol_c, B, n):
-            pairs = _brick_volume(lib, vol_c)                          # (siddon: the bricked copy takes the same seat)
-        layout = 0 if pairs is None else (_ypair_layout_code() if spec.renderer == "trilinear" else 2)
+            pairs, layout = _brick_volume(lib, vol_c), 2               # (siddon: the bricked copy takes the same seat)
+        if pairs is None:
+            layout = 0
         cs = make_cspec(tuple(vol_c.shape), spec, W, volume_layout=layout)
         need = ctx.needs_input_grad[0]
         out = torch.empty(B, 1, n, device=cam.device, dtype=torch.float32)
