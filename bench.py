@@ -41,35 +41,48 @@ VALU_CLK = 3.0   # clocks a plain wave64 vector instruction occupies its SIMD (2
 # candidate units per timed call: (unit, wavefront instructions per 64 units of work, clocks each on the unit's 256 CU-wide or
 # 1024 SIMD-wide resource, source).  Vector-instruction counts per 64 units are SQ_INSTS_VALU of the committed PMC passes
 # (profiles/r03_*_rocprof_summary.md) over the kernels' own unit counts.
+# fabric_bandwidth: an L2 miss moves one whole 128-byte line (tools/microbench/fetch_calib.hip, profiles/r04_fetch_calibration.txt);
+# random lines of a working set far beyond the Infinity Cache arrive at 43-46 G lines/s (5.5-5.9 TB/s) -- 0.054 clocks per line for
+# the chip.  Lines per 64 units are TCC_EA0_RDREQ of the committed PMC passes over the kernels' own unit counts.
+LINE_CLK = CLK_GHZ / 44.5
 BINDING = {
     "trilinear_backward": [
         # tools/microbench/lds_atomics.hip: a ds_add_u32 wavefront instruction costs >= 4.4 LDS clocks however few lanes are
-        # live; 8 per sample; 53.9 of 64 lanes live
-        ("lds_atomic_issue", 8 / (53.9 / 64), 4.4, CUS, "profiles/r02_microbench_lds_atomics.txt"),
-        ("valu_issue", 3.767e9 / (1.809e9 / 64), VALU_CLK, 4 * CUS, "profiles/r03_microbench_valu_issue.txt x SQ_INSTS_VALU"),
+        # live; 8 per sample; 54.3 of 64 lanes live
+        ("lds_atomic_issue", 8 / (54.3 / 64), 4.4, CUS, "profiles/r02_microbench_lds_atomics.txt"),
+        ("valu_issue", 3.767e9 / (1.809e9 / 64), VALU_CLK, 4 * CUS, "profiles/r03_microbench_valu_issue.txt x SQ_INSTS_VALU (profiles/r04_trilinear_rocprof_summary.md)"),
+        ("fabric_bandwidth", 6.038e7 / (1.809e9 / 64), LINE_CLK, 1, "profiles/r04_fetch_calibration.txt x TCC_EA0_RDREQ"),
     ],
     "trilinear_forward+jac": [
         # tools/microbench/gather.hip: a 64-lane gather costs ~15 clk per CU on one 128-B line and 10-14 more per further line;
-        # two 16-byte gathers per sample (y-pair copy), ~3 lines by that estimate (the L1 miss path behind it: DESIGN 4.4)
+        # two 16-byte gathers per sample (y-pair copy), ~3 lines by that estimate
         ("texture_address", 2, 36.0, CUS, "profiles/r01_microbench_gather_lines.txt"),
-        ("valu_issue", 2.416e9 / (1.809e9 / 64), VALU_CLK, 4 * CUS, "profiles/r03_microbench_valu_issue.txt x SQ_INSTS_VALU"),
+        ("valu_issue", 2.769e9 / (1.809e9 / 64), VALU_CLK, 4 * CUS, "profiles/r03_microbench_valu_issue.txt x SQ_INSTS_VALU (profiles/r04_trilinear_rocprof_summary.md)"),
+        ("fabric_bandwidth", 2.298e8 / (1.809e9 / 64), LINE_CLK, 1, "profiles/r04_fetch_calibration.txt x TCC_EA0_RDREQ"),
     ],
     "trilinear_forward": [
         ("texture_address", 2, 36.0, CUS, "profiles/r01_microbench_gather_lines.txt"),
-        ("valu_issue", 1.751e9 / (1.809e9 / 64), VALU_CLK, 4 * CUS, "profiles/r03_microbench_valu_issue.txt x SQ_INSTS_VALU"),
+        ("valu_issue", 2.103e9 / (1.809e9 / 64), VALU_CLK, 4 * CUS, "profiles/r03_microbench_valu_issue.txt x SQ_INSTS_VALU (profiles/r04_trilinear_rocprof_summary.md)"),
+        ("fabric_bandwidth", 2.156e8 / (1.809e9 / 64), LINE_CLK, 1, "profiles/r04_fetch_calibration.txt x TCC_EA0_RDREQ"),
     ],
     "siddon_backward": [
-        ("valu_issue", 7.75e9 / (5.576e9 / 64), VALU_CLK, 4 * CUS, "profiles/r03_microbench_valu_issue.txt x SQ_INSTS_VALU"),
+        ("valu_issue", 7.755e9 / (5.576e9 / 64), VALU_CLK, 4 * CUS, "profiles/r03_microbench_valu_issue.txt x SQ_INSTS_VALU (profiles/r04_siddon_rocprof_summary.md)"),
+        ("fabric_bandwidth", 1.772e8 / (5.576e9 / 64), LINE_CLK, 1, "profiles/r04_fetch_calibration.txt x TCC_EA0_RDREQ"),
     ],
     "siddon_forward+jac": [
-        ("valu_issue", 6.656e9 / (5.576e9 / 64), VALU_CLK, 4 * CUS, "profiles/r03_microbench_valu_issue.txt x SQ_INSTS_VALU"),
+        ("valu_issue", 3.401e9 / (5.576e9 / 64), VALU_CLK, 4 * CUS, "profiles/r03_microbench_valu_issue.txt x SQ_INSTS_VALU (profiles/r04_siddon_rocprof_summary.md)"),
+        ("fabric_bandwidth", 1.09e8 / (5.576e9 / 64), LINE_CLK, 1, "profiles/r04_fetch_calibration.txt x TCC_EA0_RDREQ"),
+    ],
+    "siddon_forward": [
+        ("valu_issue", 2.75e9 / (5.576e9 / 64), VALU_CLK, 4 * CUS, "profiles/r03_microbench_valu_issue.txt x SQ_INSTS_VALU (profiles/r04_siddon_rocprof_summary.md)"),
+        ("fabric_bandwidth", 1.108e8 / (5.576e9 / 64), LINE_CLK, 1, "profiles/r04_fetch_calibration.txt x TCC_EA0_RDREQ"),
     ],
 }
 
 
 def binding_floor(tag, units, avg_ms):
     """The unit with the largest floor for one timed call, and every candidate's floor next to it."""
-    cands = BINDING.get(tag.split("[")[0]) or BINDING.get(tag.split("[")[0].split("+")[0])
+    cands = BINDING.get(tag.split("[")[0])
     if not cands or not units:
         return None
     floors = {}
@@ -85,7 +98,7 @@ def binding_floor(tag, units, avg_ms):
 TRAFFIC_KERNELS = {
     "trilinear_forward": ["k_trilinear_fwd"],
     "trilinear_backward": ["k_trilinear_splat_b16", "k_trilinear_gather_tab", "k_gather_prep", "k_gather_cull", "k_trilinear_bwd"],
-    "siddon_forward": ["k_siddon<"],
+    "siddon_forward": ["k_siddon<", "k_siddon_slab"],
     "siddon_backward": ["k_siddon_gather_vol", "k_gather_prep", "k_gather_cull", "k_siddon<"],
     "backward_from_jac": ["k_backward_from_jac"],
 }
@@ -94,7 +107,8 @@ TRAFFIC_KERNELS = {
 def pmc_traffic(tag):
     """HBM-side bytes per launch of the kernels behind one timed call, from the committed rocprofv3 PMC
     passes (profiles/traffic.json, written by tools/summarize_profile.py: FETCH_SIZE + WRITE_SIZE, in
-    bytes, un-corrected -- see the gfx950 caveats in profiles/*_summary.md).  None when not profiled."""
+    bytes MOVED: the fetch side is the reported FETCH_SIZE doubled, as calibrated in profiles/r04_fetch_calibration.txt).
+    None when not profiled."""
     path = ROOT / "profiles" / "traffic.json"
     if not path.exists():
         return None
@@ -112,6 +126,8 @@ def pmc_traffic(tag):
             mode = "2" if base == "siddon_backward" else ("1" if "+jac" in tag else "0")
             if f"k_siddon<{mode}," not in name:
                 continue
+        if "k_siddon_slab<" in name and (("k_siddon_slab<true" in name) != ("+jac" in tag) or base != "siddon_forward"):
+            continue
         if any(k in name for k in keys) and (("fwd<true" in name) == ("+jac" in tag) or "fwd<" not in name):
             fam.setdefault(name.split("<")[0], []).append(v.get("fetch_bytes", 0.0) + v.get("write_bytes", 0.0))
     # different kernels of one call add up; instantiations of one kernel (volume layouts) are alternatives: their mean
@@ -257,8 +273,8 @@ def render_leg(dev, subject, renderer, voxel_grad, rot0, xyz0, H, delx, n_points
         roofline["nominal_frac"] = nominal_units * bytes_per_unit / (dom["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
     if roofline["traffic"]:
         phys = roofline["traffic"] / (dom["avg_ms"] * 1e-3) / 1e9
-        roofline["hbm_physical"] = {"GBps": phys, "frac": phys / HBM_PEAK_GBS, "frac_if_fetch_undercounts_2x": 2 * phys / HBM_PEAK_GBS,
-                                    "source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; separate passes)"}
+        roofline["hbm_physical"] = {"GBps": phys, "frac": phys / HBM_PEAK_GBS, "frac_of_measured_copy_peak": phys / HBM_COPY_GBS,
+                                    "source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE x 2 as calibrated, WRITE_SIZE; separate passes)"}
     # the forward+backward PAIR priced as one unit (64 B per sample with the voxel gradient,
     # 32 B without), over the summed HIP-event time of every kernel of a step
     kernel_ms = sum(v["avg_ms"] * v["launches"] for v in kernels.values()) / steps

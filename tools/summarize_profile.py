@@ -6,7 +6,8 @@ import sys
 
 root = sys.argv[1]
 print(f"# rocprofv3 summary ({root.rstrip('/').split('/')[-1]})\n")
-stats = glob.glob(f"{root}/trace/*/*_kernel_stats.csv")
+import os
+stats = sorted(glob.glob(f"{root}/trace/*/*_kernel_stats.csv"), key=os.path.getmtime, reverse=True)   # (a re-used tag: the latest run)
 if stats:
     print("## kernel trace (--kernel-trace --stats), whole run incl. warm-up\n")
     print("| kernel | calls | avg ms | total ms | % |\n|---|---|---|---|---|")
@@ -14,7 +15,12 @@ if stats:
         print(f"| `{r['Name'][:90]}` | {r['Calls']} | {float(r['AverageNs'])/1e6:.3f} | {float(r['TotalDurationNs'])/1e6:.2f} | {r['Percentage']} |")
 pm = collections.defaultdict(lambda: collections.defaultdict(float))
 calls = collections.Counter()
+_latest = {}
 for f in glob.glob(f"{root}/pmc_*/*/*_counter_collection.csv"):
+    d = f.split("/")[-3]
+    if d not in _latest or os.path.getmtime(f) > os.path.getmtime(_latest[d]):
+        _latest[d] = f
+for f in _latest.values():
     seen = set()
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
@@ -47,7 +53,7 @@ if pm:
         if "TCP_TCC_READ_REQ_sum" in v:
             nn = max(calls[(k, "SQ_WAVES")], calls[(k, "FETCH_SIZE")], 1)
             print(f"- derived: L1-miss lines per dispatch = {v['TCP_TCC_READ_REQ_sum']/nn:.4g} = {v['TCP_TCC_READ_REQ_sum']*128/nn/1e9:.2f} GB"
-                  + (f", mean latency {v['TCP_TCC_READ_REQ_LATENCY_sum']/v['TCP_TCC_READ_REQ_sum']:.0f} clk" if "TCP_TCC_READ_REQ_LATENCY_sum" in v else ""))
+                  + (f", mean latency {v['TCP_TCC_READ_REQ_LATENCY_sum']/v['TCP_TCC_READ_REQ_sum']:.0f} clk" if "TCP_TCC_READ_REQ_LATENCY_sum" in v and v["TCP_TCC_READ_REQ_sum"] else ""))
         if "WRITE_SIZE" in v:
             print(f"- derived: WRITE_SIZE per dispatch = {v['WRITE_SIZE']*1024/n/1e9:.3f} GB")
         print()
@@ -56,7 +62,8 @@ traffic = {}
 for k, v in pm.items():
     n = max(calls[(k, "FETCH_SIZE")], calls[(k, "WRITE_SIZE")], 1)
     if "FETCH_SIZE" in v or "WRITE_SIZE" in v:
-        traffic[k] = {"fetch_bytes": v.get("FETCH_SIZE", 0.0) * 1024 / n, "write_bytes": v.get("WRITE_SIZE", 0.0) * 1024 / n,
-                      "dispatches": n}
+        # fetch_bytes: the bytes MOVED -- twice the reported FETCH_SIZE (128-byte lines tallied at 64: profiles/r04_fetch_calibration.txt)
+        traffic[k] = {"fetch_bytes": 2.0 * v.get("FETCH_SIZE", 0.0) * 1024 / n, "fetch_bytes_reported": v.get("FETCH_SIZE", 0.0) * 1024 / n,
+                      "write_bytes": v.get("WRITE_SIZE", 0.0) * 1024 / n, "dispatches": n}
 with open(f"{root}/traffic.json", "w") as f:
     json.dump(traffic, f, indent=1)

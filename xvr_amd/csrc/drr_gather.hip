@@ -944,24 +944,31 @@ __global__ __launch_bounds__(WG) void k_siddon_cells_to_voxels(GatherArgs G) {
 // (Round 2 measured the per-lane FLATTENED window loop here too -- lane-private (row, column) cursor, same arithmetic:
 //  13.5 ms against 12.2 ms.  Fewer trips, but the lanes of a wavefront drift onto different detector rows, and the four
 //  loads of a trip then touch that many more cache lines; the nested loops keep the wavefront on one row at a time.)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_siddon_gather_vol2(GatherArgs G) {
+// VZ: voxels per lane along z -- 2 (a 2 x 2 x 2 block, 8^3 bricks) or 4 (2 x 2 x 4, 8 x 8 x 16 bricks; round 4): the plane alphas, the
+// window and the loads of a candidate ray are shared by twice the voxels, and the window grows in one direction only.
+template <int VZ>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VZ == 2 ? 6 : 4, VZ == 2 ? 6 : 4))) void k_siddon_gather_vol2(GatherArgs G) {
     if (*G.flag > __float_as_uint(GATHER_DEV_TOL)) return;
     int bx, by, bz;
     brick_coords(blockIdx.x, G.D1, G.D2, G.bd, bx, by, bz);
     const int tid = threadIdx.x;
-    const int vx = (bx * 4 + (tid >> 4)) * 2, vy = (by * 4 + ((tid >> 2) & 3)) * 2, vz = (bz * 4 + (tid & 3)) * 2;
+    const int vx = (bx * 4 + (tid >> 4)) * 2, vy = (by * 4 + ((tid >> 2) & 3)) * 2, vz = (bz * 4 + (tid & 3)) * VZ;
     const bool inb = vx < G.D0 && vy < G.D1 && vz < G.D2;
     // the three planes per axis that bound the block's voxels, and the block centre, in x coordinates
-    float px[3], py[3], pz[3];
+    float px[3], py[3], pz[VZ + 1];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         px[k] = (float)(vx + k) + G.sp.plane0[0];
         py[k] = (float)(vy + k) + G.sp.plane0[1];
-        pz[k] = (float)(vz + k) + G.sp.plane0[2];
     }
-    const float cx = px[1], cy = py[1], cz = pz[1];
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const float ea0 = 1.f / G.sp.a[0], ea1 = 1.f / G.sp.a[1], ea2 = 1.f / G.sp.a[2];   // half a block, in x coordinates
+#pragma unroll
+    for (int k = 0; k <= VZ; ++k) pz[k] = (float)(vz + k) + G.sp.plane0[2];
+    const float cx = px[1], cy = py[1], cz = pz[VZ / 2];
+    constexpr int NV = 4 * VZ;
+    float acc[NV];
+#pragma unroll
+    for (int e = 0; e < NV; ++e) acc[e] = 0.f;
+    const float ea0 = 1.f / G.sp.a[0], ea1 = 1.f / G.sp.a[1], ea2 = (float)(VZ / 2) / G.sp.a[2];   // half a block, in x coordinates
     for (int wd = 0; wd < G.words; ++wd) {
         unsigned bits = G.cull[(size_t)blockIdx.x * G.words + wd];
         while (bits) {
@@ -974,7 +981,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
             const float s0 = P.s[0], s1 = P.s[1], s2 = P.s[2];
             const float w0 = cx - s0, w1 = cy - s1, w2 = cz - s2;
             const float av = P.nh[0] * w0 + P.nh[1] * w1 + P.nh[2] * w2;
-            const float da = P.dalpha;                        // half-range of alpha over the 2-voxel block
+            const float da = P.dalpha + (VZ == 2 ? 0.f : fabsf(P.nh[2]) * (ea2 - 1.f / G.sp.a[2]));   // half-range of alpha over the block
             const float amin = av - da, amax = av + da;
             const float nj = P.gc[0] * w0 + P.gc[1] * w1 + P.gc[2] * w2;
             const float ni = P.gr[0] * w0 + P.gr[1] * w1 + P.gr[2] * w2;
@@ -1005,9 +1012,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
                 jhi = G.W - 1;   // the block reaches the source plane: no perspective bound -- visit every ray
                 ihi = G.H - 1;
             }
-            float lx[3], ly[3], lz[3];
+            float lx[3], ly[3], lz[VZ + 1];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { lx[k] = px[k] - s0; ly[k] = py[k] - s1; lz[k] = pz[k] - s2; }
+            for (int k = 0; k < 3; ++k) { lx[k] = px[k] - s0; ly[k] = py[k] - s1; }
+#pragma unroll
+            for (int k = 0; k <= VZ; ++k) lz[k] = pz[k] - s2;
             const float4* __restrict__ q = G.q + (size_t)p * G.n;
             const float2* __restrict__ q2 = G.q2 + (size_t)p * G.n;
             for (int i = ilo; i <= ihi; ++i) {
@@ -1028,14 +1037,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
                         // intervals; the ray's own [alpha_lo, alpha_hi] is folded into the x intervals once
                         const float x0 = lx[0] * t.x, x1 = lx[1] * t.x, x2 = lx[2] * t.x;
                         const float y0 = ly[0] * t.y, y1 = ly[1] * t.y, y2 = ly[2] * t.y;
-                        const float z0 = lz[0] * t.z, z1 = lz[1] * t.z, z2 = lz[2] * t.z;
+                        float zz[VZ + 1];
+#pragma unroll
+                        for (int k = 0; k <= VZ; ++k) zz[k] = lz[k] * t.z;
                         const float xl[2] = {fmaxf(fminf(x0, x1), ab.x), fmaxf(fminf(x1, x2), ab.x)};
                         const float xh[2] = {fminf(fmaxf(x0, x1), ab.y), fminf(fmaxf(x1, x2), ab.y)};
                         const float yl[2] = {fminf(y0, y1), fminf(y1, y2)}, yh[2] = {fmaxf(y0, y1), fmaxf(y1, y2)};
-                        const float zl[2] = {fminf(z0, z1), fminf(z1, z2)}, zh[2] = {fmaxf(z0, z1), fmaxf(z1, z2)};
+                        float zl[VZ], zh[VZ];
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const int a = e >> 2, b = (e >> 1) & 1, c = e & 1;
+                        for (int k = 0; k < VZ; ++k) { zl[k] = fminf(zz[k], zz[k + 1]); zh[k] = fmaxf(zz[k], zz[k + 1]); }
+#pragma unroll
+                        for (int e = 0; e < NV; ++e) {
+                            const int a = e / (2 * VZ), b = (e / VZ) & 1, c = e % VZ;
                             const float en = fmaxf(fmaxf(xl[a], yl[b]), zl[c]);
                             const float ex = fminf(fminf(xh[a], yh[b]), zh[c]);
                             // (alphas live in [0, 1]: the [0, 1] clamp is the max with 0, folded into the subtract)
@@ -1047,8 +1060,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
         }
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int x = vx + (e >> 2), y = vy + ((e >> 1) & 1), z = vz + (e & 1);
+    for (int e = 0; e < NV; ++e) {
+        const int x = vx + e / (2 * VZ), y = vy + ((e / VZ) & 1), z = vz + e % VZ;
         if (x < G.D0 && y < G.D1 && z < G.D2 && acc[e] != 0.f) G.gvol[((size_t)x * G.D1 + y) * G.D2 + z] += acc[e];
     }
 }
@@ -1102,7 +1115,7 @@ int xvr_detail::launch_gather(bool siddon, const float* source, const float* tar
     const bool use_splat = splat_mode != 0;
     const bool splat = !siddon && splat_mode == 1 && sp->clip_to_volume != 1 && !mask;
     if (siddon && (G.cells || G.mask)) { G.bd[0] = 4; G.bd[1] = 8; G.bd[2] = 8; }
-    else if (siddon) { G.bd[0] = G.bd[1] = G.bd[2] = 8; }
+    else if (siddon) { G.bd[0] = G.bd[1] = 8; G.bd[2] = xvr_detail::option(xvr_detail::OPT_SIDDON_GATHER_VZ) == 4 ? 16 : 8; }
     else {
         if (G.clip || G.mask) G.V = 2;   // (the pixel-major kernel is written for 2x2x2 blocks)
         G.bd[0] = G.bd[1] = G.bd[2] = 4 * G.V;
@@ -1139,7 +1152,8 @@ int xvr_detail::launch_gather(bool siddon, const float* source, const float* tar
         hipLaunchKernelGGL(k_siddon_cells_to_voxels, dim3((unsigned)((nvox + WG - 1) / WG)), dim3(WG), 0, (hipStream_t)stream, G);
     }
     else if (siddon && G.mask) hipLaunchKernelGGL(k_siddon_gather_mask, dim3((unsigned)bricks), dim3(WG), 0, (hipStream_t)stream, G);
-    else if (siddon) hipLaunchKernelGGL(k_siddon_gather_vol2, dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
+    else if (siddon && G.bd[2] == 16) hipLaunchKernelGGL(k_siddon_gather_vol2<4>, dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
+    else if (siddon) hipLaunchKernelGGL(k_siddon_gather_vol2<2>, dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
     else if (psplat) {
         const void* kern = G.clip ? (G.mask ? (const void*)k_trilinear_splat_px<true, true> : (const void*)k_trilinear_splat_px<true, false>)
                                   : (G.mask ? (const void*)k_trilinear_splat_px<false, true> : (const void*)k_trilinear_splat_px<false, false>);
