@@ -131,6 +131,10 @@ def test_pmc_traffic_reads_the_committed_counter_table():
     assert bench.pmc_traffic("trilinear_backward[vol]") == pytest.approx(splat)
     fwd = [v["fetch_bytes"] + v["write_bytes"] for k, v in table.items() if "k_trilinear_fwd<true" in k]
     assert len(fwd) >= 1 and bench.pmc_traffic("trilinear_forward+jac") == pytest.approx(sum(fwd) / len(fwd))
-    jac = [v["fetch_bytes"] + v["write_bytes"] for k, v in table.items() if "k_siddon<1," in k]
+    # the Siddon forward of the default path is the slab march: <true, ...> carries the jacobian, <false, ...> does not
+    jac = [v["fetch_bytes"] + v["write_bytes"] for k, v in table.items() if "k_siddon_slab<true" in k]
+    plain = [v["fetch_bytes"] + v["write_bytes"] for k, v in table.items() if "k_siddon_slab<false" in k]
+    assert jac and plain
     assert bench.pmc_traffic("siddon_forward+jac") == pytest.approx(sum(jac) / len(jac))
+    assert bench.pmc_traffic("siddon_forward") == pytest.approx(sum(plain) / len(plain))
     assert bench.pmc_traffic("no_such_call") is None
