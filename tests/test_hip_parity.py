@@ -576,6 +576,34 @@ def test_siddon_voxel_gather_with_source_inside_the_volume():
     _close(hip[1], ref[1], GRAD_TOL, "grad_volume")
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_siddon_gather_one_projection_window_equals_the_projected_corners_window(seed):
+    """k_siddon_gather_vol2<true> (default) bounds a voxel block's pixel window from ONE projection of its centre,
+    |j - jc| <= sum_k |ec_k - jc en_k| / alpha_min; option siddon_gather_fast = 0 keeps the bounding box of the eight projected
+    corners.  Extra candidates contribute exact zeros and the sums run in the same order, so the two must agree BIT FOR BIT
+    -- on oblique poses, magnified / minified detectors and a source inside the volume alike."""
+    from xvr_amd import _lib
+    from xvr_amd.spec import RenderSpec
+
+    rng = np.random.default_rng(700 + seed)
+    shape = tuple(int(x) for x in rng.integers(14, 44, size=3))
+    h, wd = int(rng.integers(9, 40)), int(rng.integers(9, 40))
+    rot = tuple((float(rng.uniform(100, 260)), float(rng.uniform(-60, 60)), float(rng.uniform(-30, 30))) for _ in range(3))
+    # the last pose's source sits inside the volume on odd seeds (its rays are cut at alpha = 0)
+    depth = [float(rng.uniform(120, 400)), float(rng.uniform(120, 400)), 5.0 if seed % 2 else float(rng.uniform(120, 400))]
+    xyz = tuple((float(rng.uniform(-10, 10)), d, float(rng.uniform(-10, 10))) for d in depth)
+    case = make_case(shape=shape, height=h, width=wd, seed=seed, rot=rot, xyz=xyz, delx=float(rng.uniform(0.4, 6.0)))
+    spec = RenderSpec(renderer="siddon", voxel_shift=0.5 if seed % 3 else 0.0)
+    w = torch.randn(3, 1, h * wd, generator=torch.Generator().manual_seed(seed))
+    with _lib.option("siddon_gather_fast", 1):
+        fast = _hip_render(case, spec, grid_w=wd, grads=True, w=w)[1]
+    with _lib.option("siddon_gather_fast", 0):
+        corners = _hip_render(case, spec, grid_w=wd, grads=True, w=w)[1]
+    assert fast.abs().max() > 0
+    assert torch.equal(fast, corners), f"max diff {(fast - corners).abs().max().item():.3e}"
+    _close(fast, _oracle_render(case, spec, grads=True, w=w)[1], GRAD_TOL, "grad_volume vs oracle")
+
+
 def test_voxel_gather_declines_non_lattice_rays_on_device():
     """Targets that are not a planar lattice (here: shuffled) must take the scatter fallback, decided
     on the device, and still give the right gradient."""

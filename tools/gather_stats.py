@@ -21,9 +21,10 @@ from xvr_amd.data import make_phantom, read  # noqa: E402
 from xvr_amd.drr import DRR  # noqa: E402
 from xvr_amd.training import get_random_pose  # noqa: E402
 
+SIDDON = len(sys.argv) > 1 and sys.argv[1] == "siddon"
 dev = torch.device("cuda")
 vol, _ = make_phantom(512, n_ellipsoids=64, seed=0, device=dev)
-drr = DRR(read(vol, orientation="AP"), 1020.0, 256, 1.08821875, renderer="trilinear", reverse_x_axis=False).to(dev)
+drr = DRR(read(vol, orientation="AP"), 1020.0, 256, 1.08821875, renderer="siddon" if SIDDON else "trilinear", reverse_x_axis=False).to(dev)
 pose = get_random_pose(135.0, 225.0, -45.0, 45.0, -15.0, 15.0, -150.0, 150.0, 450.0, 1000.0, -150.0, 150.0, 116,
                        generator=torch.Generator().manual_seed(0)).to(dev)
 density = drr.density.clone().requires_grad_()
@@ -36,6 +37,11 @@ drr(pose, density=density).sum().backward()
 torch.cuda.synchronize()
 raw.xvr_drr_debug_gather_stats(out, 0)
 v = [float(x) for x in out]
+if SIDDON:   # k_siddon_gather_vol2: one lane = one 2 x 2 x 2 block, one wavefront = one 8^3 brick
+    print(f"(lane, pose) visits with a window {v[0]:.4g} | candidates {v[4]:.4g} ({v[4] / max(v[0], 1):.2f} per visit) | wavefront visits {v[7]:.4g} | "
+          f"wavefront rows {v[2]:.4g} ({v[2] / max(v[7], 1):.2f} per visit) | wavefront trips {v[6]:.4g} ({v[6] / max(v[7], 1):.2f} per visit, "
+          f"{v[4] / max(v[6], 1):.1f} of 128 candidate slots filled per trip)")
+    sys.exit(0)
 print(f"(lane, pose) visits {v[0]:.4g} | steps {v[1]:.4g} | rows {v[2]:.4g} (empty {v[3]:.4g}) | candidates {v[4]:.4g} | "
       f"wavefront inner trips {v[6]:.4g} | wavefront pose iterations {v[7]:.4g}")
 print(f"steps per visit {v[1] / v[0]:.2f} | rows per step {v[2] / v[1]:.2f} | empty rows {100 * v[3] / v[2]:.1f} % | "

@@ -31,7 +31,7 @@ const OptionDef OPTIONS[] = {
     {"fwd_slab_axis", "XVR_DRR_FWD_SLAB_AXIS", 1, 0, 2},
     {"tile_geom", "XVR_DRR_TILE_GEOM", 1, 0, 2},
     {"siddon_slab", "XVR_DRR_SIDDON_SLAB", 1, 0, 1},
-    {"siddon_gather_vz", "XVR_DRR_SIDDON_GATHER_VZ", 2, 2, 4},
+    {"siddon_gather_fast", "XVR_DRR_SIDDON_GATHER_FAST", 1, 0, 1},
 };
 constexpr int N_OPTIONS = sizeof(OPTIONS) / sizeof(OPTIONS[0]);
 std::atomic<int> g_opt[N_OPTIONS];

@@ -1,6 +1,7 @@
 // MI355X (gfx950) differentiable-DRR kernels: the voxel gradient as an atomic-free, voxel-driven gather
 // (trilinear and Siddon), its per-pose preparation and per-brick cull.  HISTORY.md section 4.1.
 #include "drr_common.hiph"
+#include <type_traits>
 
 #ifdef XVR_GATHER_STATS
 // Diagnostic build only (tools/gather_stats.py compiles it into a separate library): loop-trip counters of the
@@ -739,8 +740,6 @@ __global__ __launch_bounds__(64) void k_trilinear_gather_px(GatherArgs G) {
     }
 }
 
-
-
 // ---------------------------------------------------------------------------------------------
 // Siddon voxel gradient under a mask whose upstream gradient DIFFERS between channels (round 3; exact-geometry index map).
 // Siddon credits a segment to ONE voxel -- in exact geometry the voxel whose box holds it -- so the channel of everything a
@@ -940,37 +939,75 @@ __global__ __launch_bounds__(WG) void k_siddon_cells_to_voxels(GatherArgs G) {
 // Same gather with a 2 x 2 x 2 voxel block per lane (one wavefront per 8^3 brick, as the trilinear gather):
 // the per-pose window and the candidate's loads are paid once for eight voxels, the three planes per axis give
 // nine crossing alphas per candidate (the forward's expression, plane by plane), from which every voxel's
-// entry / exit are one max3 / min3.  A candidate costs ~57 VALU for 8 voxels instead of 8 x 19.
+// entry / exit are one max3 / min3.
 // (Round 2 measured the per-lane FLATTENED window loop here too -- lane-private (row, column) cursor, same arithmetic:
 //  13.5 ms against 12.2 ms.  Fewer trips, but the lanes of a wavefront drift onto different detector rows, and the four
 //  loads of a trip then touch that many more cache lines; the nested loops keep the wavefront on one row at a time.)
-// VZ: voxels per lane along z -- 2 (a 2 x 2 x 2 block, 8^3 bricks) or 4 (2 x 2 x 4, 8 x 8 x 16 bricks; round 4): the plane alphas, the
-// window and the loads of a candidate ray are shared by twice the voxels, and the window grows in one direction only.
-template <int VZ>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VZ == 2 ? 6 : 4, VZ == 2 ? 6 : 4))) void k_siddon_gather_vol2(GatherArgs G) {
+// Round 4, second pass.  The kernel is vector-issue bound and a (lane, pose) visit sees only ~5 candidate rays, so the
+// visit's set-up weighs as much as its candidates.  Counted in the ISA: 236 vector instructions per visit (80 of them the
+// eight IEEE divisions of the projected corners) and 143 per trip of two candidates.  Now:
+//   * the pixel window from ONE projection: j(w + sum s_k e_k) - jc = (A - jc B) / (av + B) with A = sum s_k ec_k,
+//     B = sum s_k en_k over the corner signs s_k, so |j - jc| <= sum_k |ec_k - jc en_k| / (av - da) -- rigorous, two
+//     v_rcp_f32 (1 ulp: 3e-5 pixel, the window has GATHER_WIN_MARGIN) and wider than the corners' bounding box by da / av
+//     ~ 1e-3 of itself;
+//   * a candidate's eight entries / exits as v_max3_f32 / v_min3_f32 of the per-axis interval ends (the compiler shares
+//     max(xl, yl) between two voxels instead: 24 two-operand instructions where 16 three-operand ones do); plain fp32
+//     throughout -- a packed pair (v_pk_*_f32) occupies the SIMD for 1.3 x two plain instructions on this chip;
+//   * the loop body exists twice: poses none of whose rays is cut at alpha = 0 / 1 neither load nor apply (lo, hi).
+// ~53 vector instructions per candidate (57 with the cut) and ~110 per visit.
+__device__ __forceinline__ float max3_raw(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float min3_raw(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float max_raw(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float min_raw(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+//   * FAST: a workgroup is four wavefronts on four bricks IN A ROW ALONG THE VIEWING DIRECTION (the volume axis the first
+//     pose's detector normal is closest to: every workgroup derives the same axis).  Their pixel footprints overlap, they
+//     run on one CU, and a q line fetched for one brick is in the L1 for the other three: on its own a wavefront finds
+//     almost nothing of its ~40 lines per visit in the L1 (1.15e9 L1-miss lines, 148 GB from L2 per C3 launch).
+template <bool FAST>
+__global__ __launch_bounds__(FAST ? 256 : 64) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_siddon_gather_vol2(GatherArgs G) {
     if (*G.flag > __float_as_uint(GATHER_DEV_TOL)) return;
     int bx, by, bz;
-    brick_coords(blockIdx.x, G.D1, G.D2, G.bd, bx, by, bz);
-    const int tid = threadIdx.x;
-    const int vx = (bx * 4 + (tid >> 4)) * 2, vy = (by * 4 + ((tid >> 2) & 3)) * 2, vz = (bz * 4 + (tid & 3)) * VZ;
+    int brick = blockIdx.x;   // the brick's number in the cull array's order (brick_coords)
+    if (FAST) {
+        const int nb[3] = {(G.D0 + G.bd[0] - 1) / G.bd[0], (G.D1 + G.bd[1] - 1) / G.bd[1], (G.D2 + G.bd[2] - 1) / G.bd[2]};
+        const float n0 = fabsf(G.poses[0].nh[0] / G.sp.a[0]), n1 = fabsf(G.poses[0].nh[1] / G.sp.a[1]), n2 = fabsf(G.poses[0].nh[2] / G.sp.a[2]);
+        const int ax = (n0 >= n1 && n0 >= n2) ? 0 : (n1 >= n2 ? 1 : 2);            // (uniform: scalar loads, the same in every workgroup)
+        const int u = ax == 0 ? 1 : 0, v = ax == 2 ? 1 : 2;                        // the other two axes, v the faster one
+        const int groups = (nb[ax] + 3) >> 2;                                      // runs of four bricks along ax
+        int g = blockIdx.x;
+        const int cv = g % nb[v]; g /= nb[v];
+        const int ga = g % groups, cu = g / groups;
+        const int ca = ga * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (scalar: everything per brick and pose below is uniform)
+        if (ca >= nb[ax] || cu >= nb[u]) return;   // (no barrier below)
+        int c[3];
+        c[ax] = ca; c[u] = cu; c[v] = cv;
+        bx = c[0]; by = c[1]; bz = c[2];
+        brick = (bx * nb[1] + by) * nb[2] + bz;
+    } else {
+        brick_coords(blockIdx.x, G.D1, G.D2, G.bd, bx, by, bz);
+    }
+    const int tid = threadIdx.x & 63;
+    const int vx = (bx * 4 + (tid >> 4)) * 2, vy = (by * 4 + ((tid >> 2) & 3)) * 2, vz = (bz * 4 + (tid & 3)) * 2;
     const bool inb = vx < G.D0 && vy < G.D1 && vz < G.D2;
     // the three planes per axis that bound the block's voxels, and the block centre, in x coordinates
-    float px[3], py[3], pz[VZ + 1];
+    float px[3], py[3], pz[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         px[k] = (float)(vx + k) + G.sp.plane0[0];
         py[k] = (float)(vy + k) + G.sp.plane0[1];
+        pz[k] = (float)(vz + k) + G.sp.plane0[2];
     }
+    const float cx = px[1], cy = py[1], cz = pz[1];
+    float acc[8];   // voxels (a, b, c)
 #pragma unroll
-    for (int k = 0; k <= VZ; ++k) pz[k] = (float)(vz + k) + G.sp.plane0[2];
-    const float cx = px[1], cy = py[1], cz = pz[VZ / 2];
-    constexpr int NV = 4 * VZ;
-    float acc[NV];
-#pragma unroll
-    for (int e = 0; e < NV; ++e) acc[e] = 0.f;
-    const float ea0 = 1.f / G.sp.a[0], ea1 = 1.f / G.sp.a[1], ea2 = (float)(VZ / 2) / G.sp.a[2];   // half a block, in x coordinates
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#ifdef XVR_GATHER_STATS   // 0 (lane, pose) visits with a window . 2 wavefront rows . 4 candidates . 6 wavefront trips . 7 wavefront visits
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    const float ea0 = 1.f / G.sp.a[0], ea1 = 1.f / G.sp.a[1], ea2 = 1.f / G.sp.a[2];   // half a block, in x coordinates
     for (int wd = 0; wd < G.words; ++wd) {
-        unsigned bits = G.cull[(size_t)blockIdx.x * G.words + wd];
+        unsigned bits = G.cull[(size_t)brick * G.words + wd];
         while (bits) {
             const int p = wd * 32 + __builtin_ctz(bits);
             bits &= bits - 1;
@@ -981,26 +1018,34 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VZ == 2 ? 6 
             const float s0 = P.s[0], s1 = P.s[1], s2 = P.s[2];
             const float w0 = cx - s0, w1 = cy - s1, w2 = cz - s2;
             const float av = P.nh[0] * w0 + P.nh[1] * w1 + P.nh[2] * w2;
-            const float da = P.dalpha + (VZ == 2 ? 0.f : fabsf(P.nh[2]) * (ea2 - 1.f / G.sp.a[2]));   // half-range of alpha over the block
+            const float da = P.dalpha;   // half-range of alpha over the block
             const float amin = av - da, amax = av + da;
             const float nj = P.gc[0] * w0 + P.gc[1] * w1 + P.gc[2] * w2;
             const float ni = P.gr[0] * w0 + P.gr[1] * w1 + P.gr[2] * w2;
             int jlo = 0, jhi = -1, ilo = 0, ihi = -1;
             if (inb && amin > 1e-6f && amax >= 0.f && amin <= 1.f) {
-                // the block is convex and in front of the source: its projection is the hull of its 8 projected
-                // corners, whose bounding box is the exact pixel window (the (n +- dn) / alpha box over the alpha range
-                // pairs extremes that no single point attains)
                 const float en0 = P.nh[0] * ea0, en1 = P.nh[1] * ea1, en2 = P.nh[2] * ea2;
                 const float ec0 = P.gc[0] * ea0, ec1 = P.gc[1] * ea1, ec2 = P.gc[2] * ea2;
                 const float er0 = P.gr[0] * ea0, er1 = P.gr[1] * ea1, er2 = P.gr[2] * ea2;
-                float jmn = INFINITY, jmx = -INFINITY, imn = INFINITY, imx = -INFINITY;
+                float jmn, jmx, imn, imx;
+                if (FAST) {
+                    const float iav = __builtin_amdgcn_rcpf(av), iam = __builtin_amdgcn_rcpf(amin);
+                    const float jc = nj * iav, ic = ni * iav;
+                    const float hj = (fabsf(fmaf(-jc, en0, ec0)) + fabsf(fmaf(-jc, en1, ec1)) + fabsf(fmaf(-jc, en2, ec2))) * iam;
+                    const float hi = (fabsf(fmaf(-ic, en0, er0)) + fabsf(fmaf(-ic, en1, er1)) + fabsf(fmaf(-ic, en2, er2))) * iam;
+                    jmn = jc - hj; jmx = jc + hj; imn = ic - hi; imx = ic + hi;
+                } else {
+                    // the block is convex and in front of the source: its projection is the hull of its 8 projected
+                    // corners, whose bounding box is the exact pixel window
+                    jmn = INFINITY; jmx = -INFINITY; imn = INFINITY; imx = -INFINITY;
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const float sx = (c & 4) ? 1.f : -1.f, sy = (c & 2) ? 1.f : -1.f, sz = (c & 1) ? 1.f : -1.f;
-                    const float inv = 1.f / (av + sx * en0 + sy * en1 + sz * en2);
-                    const float jv = (nj + sx * ec0 + sy * ec1 + sz * ec2) * inv, iv = (ni + sx * er0 + sy * er1 + sz * er2) * inv;
-                    jmn = fminf(jmn, jv); jmx = fmaxf(jmx, jv);
-                    imn = fminf(imn, iv); imx = fmaxf(imx, iv);
+                    for (int c = 0; c < 8; ++c) {
+                        const float sx = (c & 4) ? 1.f : -1.f, sy = (c & 2) ? 1.f : -1.f, sz = (c & 1) ? 1.f : -1.f;
+                        const float inv = 1.f / (av + sx * en0 + sy * en1 + sz * en2);
+                        const float jv = (nj + sx * ec0 + sy * ec1 + sz * ec2) * inv, iv = (ni + sx * er0 + sy * er1 + sz * er2) * inv;
+                        jmn = fminf(jmn, jv); jmx = fmaxf(jmx, jv);
+                        imn = fminf(imn, iv); imx = fmaxf(imx, iv);
+                    }
                 }
                 jmn += P.gc0 - GATHER_WIN_MARGIN; jmx += P.gc0 + GATHER_WIN_MARGIN;
                 imn += P.gr0 - GATHER_WIN_MARGIN; imx += P.gr0 + GATHER_WIN_MARGIN;
@@ -1012,61 +1057,66 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VZ == 2 ? 6 
                 jhi = G.W - 1;   // the block reaches the source plane: no perspective bound -- visit every ray
                 ihi = G.H - 1;
             }
-            float lx[3], ly[3], lz[VZ + 1];
+            float lx[3], ly[3], lz[3];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { lx[k] = px[k] - s0; ly[k] = py[k] - s1; }
-#pragma unroll
-            for (int k = 0; k <= VZ; ++k) lz[k] = pz[k] - s2;
+            for (int k = 0; k < 3; ++k) { lx[k] = px[k] - s0; ly[k] = py[k] - s1; lz[k] = pz[k] - s2; }
             const float4* __restrict__ q = G.q + (size_t)p * G.n;
             const float2* __restrict__ q2 = G.q2 + (size_t)p * G.n;
-            for (int i = ilo; i <= ihi; ++i) {
-                const float4* __restrict__ row = q + (size_t)i * G.W;
-                const float2* __restrict__ row2 = q2 + (size_t)i * G.W;
-                // two candidates per trip: the four loads are issued before either candidate is evaluated
-                for (int j = jlo; j <= jhi; j += 2) {
-                    const int j1 = j < jhi ? j + 1 : j;
-                    float4 tt[2] = {row[j], row[j1]};
-                    float2 aa[2] = {make_float2(-INFINITY, INFINITY), make_float2(-INFINITY, INFINITY)};
-                    if (cut_rays) { aa[0] = row2[j]; aa[1] = row2[j1]; }
-                    if (j1 == j) tt[1].w = 0.f;
+            // one candidate ray into the eight sums: crossing alphas of the planes (forward's expression), per axis the two voxel
+            // intervals (the ray's own [alpha_lo, alpha_hi] folded into the x intervals once), per voxel entry, exit, chord
+            auto candidate = [&](const float4 t, const float2 ab, auto cut) {
+                const float x0 = lx[0] * t.x, x1 = lx[1] * t.x, x2 = lx[2] * t.x;
+                const float y0 = ly[0] * t.y, y1 = ly[1] * t.y, y2 = ly[2] * t.y;
+                const float z0 = lz[0] * t.z, z1 = lz[1] * t.z, z2 = lz[2] * t.z;
+                float xl[2] = {min_raw(x0, x1), min_raw(x1, x2)}, xh[2] = {max_raw(x0, x1), max_raw(x1, x2)};
+                if (decltype(cut)::value) {
+                    xl[0] = max_raw(xl[0], ab.x); xl[1] = max_raw(xl[1], ab.x);
+                    xh[0] = min_raw(xh[0], ab.y); xh[1] = min_raw(xh[1], ab.y);
+                }
+                const float yl[2] = {min_raw(y0, y1), min_raw(y1, y2)}, yh[2] = {max_raw(y0, y1), max_raw(y1, y2)};
+                const float zl[2] = {min_raw(z0, z1), min_raw(z1, z2)}, zh[2] = {max_raw(z0, z1), max_raw(z1, z2)};
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const float4 t = tt[h];
-                        const float2 ab = aa[h];
-                        // crossing alphas of the planes (forward's expression), then per axis the two voxel
-                        // intervals; the ray's own [alpha_lo, alpha_hi] is folded into the x intervals once
-                        const float x0 = lx[0] * t.x, x1 = lx[1] * t.x, x2 = lx[2] * t.x;
-                        const float y0 = ly[0] * t.y, y1 = ly[1] * t.y, y2 = ly[2] * t.y;
-                        float zz[VZ + 1];
-#pragma unroll
-                        for (int k = 0; k <= VZ; ++k) zz[k] = lz[k] * t.z;
-                        const float xl[2] = {fmaxf(fminf(x0, x1), ab.x), fmaxf(fminf(x1, x2), ab.x)};
-                        const float xh[2] = {fminf(fmaxf(x0, x1), ab.y), fminf(fmaxf(x1, x2), ab.y)};
-                        const float yl[2] = {fminf(y0, y1), fminf(y1, y2)}, yh[2] = {fmaxf(y0, y1), fmaxf(y1, y2)};
-                        float zl[VZ], zh[VZ];
-#pragma unroll
-                        for (int k = 0; k < VZ; ++k) { zl[k] = fminf(zz[k], zz[k + 1]); zh[k] = fmaxf(zz[k], zz[k + 1]); }
-#pragma unroll
-                        for (int e = 0; e < NV; ++e) {
-                            const int a = e / (2 * VZ), b = (e / VZ) & 1, c = e % VZ;
-                            const float en = fmaxf(fmaxf(xl[a], yl[b]), zl[c]);
-                            const float ex = fminf(fminf(xh[a], yh[b]), zh[c]);
-                            // (alphas live in [0, 1]: the [0, 1] clamp is the max with 0, folded into the subtract)
-                            acc[e] = fmaf(__builtin_amdgcn_fmed3f(ex - en, 0.f, 1.f), t.w, acc[e]);
-                        }
+                for (int e = 0; e < 8; ++e) {
+                    const int a = e >> 2, b = (e >> 1) & 1, c = e & 1;
+                    const float en = max3_raw(xl[a], yl[b], zl[c]), ex = min3_raw(xh[a], yh[b], zh[c]);
+                    // (alphas live in [0, 1]: the [0, 1] clamp is the max with 0, folded into the subtract)
+                    acc[e] = fmaf(__builtin_amdgcn_fmed3f(ex - en, 0.f, 1.f), t.w, acc[e]);
+                }
+            };
+            XVR_STAT(0, (ihi >= ilo && jhi >= jlo) ? 1 : 0);
+            XVR_STAT(4, (ihi >= ilo && jhi >= jlo) ? (ihi - ilo + 1) * (jhi - jlo + 1) : 0);
+            XVR_STAT_WAVE(7);
+            auto rows = [&](auto cut) {
+                for (int i = ilo; i <= ihi; ++i) {
+                    const float4* __restrict__ row = q + (size_t)i * G.W;
+                    const float2* __restrict__ row2 = q2 + (size_t)i * G.W;
+                    XVR_STAT_WAVE(2);
+                    // two candidates per trip: the loads are issued before either candidate is evaluated
+                    for (int j = jlo; j <= jhi; j += 2) {
+                        XVR_STAT_WAVE(6);
+                        const int j1 = j < jhi ? j + 1 : j;
+                        float4 ta = row[j], tb = row[j1];
+                        float2 aa = make_float2(0.f, 1.f), ab = make_float2(0.f, 1.f);
+                        if (decltype(cut)::value) { aa = row2[j]; ab = row2[j1]; }
+                        if (j1 == j) tb.w = 0.f;
+                        candidate(ta, aa, cut);
+                        candidate(tb, ab, cut);
                     }
                 }
-            }
+            };
+            if (cut_rays) rows(std::true_type{}); else rows(std::false_type{});
         }
     }
 #pragma unroll
-    for (int e = 0; e < NV; ++e) {
-        const int x = vx + e / (2 * VZ), y = vy + ((e / VZ) & 1), z = vz + e % VZ;
+    for (int e = 0; e < 8; ++e) {
+        const int x = vx + (e >> 2), y = vy + ((e >> 1) & 1), z = vz + (e & 1);
         if (x < G.D0 && y < G.D1 && z < G.D2 && acc[e] != 0.f) G.gvol[((size_t)x * G.D1 + y) * G.D2 + z] += acc[e];
     }
+#ifdef XVR_GATHER_STATS
+    for (int i = 0; i < 8; ++i)
+        if (st[i]) atomicAdd(&g_gather_stats[i], st[i]);
+#endif
 }
-
-
 
 // (Round 2 also built the RAY-driven counterpart of the trilinear splat for Siddon -- per (16^3 brick, pose) visit the rays
 //  of the brick's pixel footprint walk its voxels with the forward's plane arithmetic and add segment * g * L to fixed-point
@@ -1115,7 +1165,7 @@ int xvr_detail::launch_gather(bool siddon, const float* source, const float* tar
     const bool use_splat = splat_mode != 0;
     const bool splat = !siddon && splat_mode == 1 && sp->clip_to_volume != 1 && !mask;
     if (siddon && (G.cells || G.mask)) { G.bd[0] = 4; G.bd[1] = 8; G.bd[2] = 8; }
-    else if (siddon) { G.bd[0] = G.bd[1] = 8; G.bd[2] = xvr_detail::option(xvr_detail::OPT_SIDDON_GATHER_VZ) == 4 ? 16 : 8; }
+    else if (siddon) G.bd[0] = G.bd[1] = G.bd[2] = 8;
     else {
         if (G.clip || G.mask) G.V = 2;   // (the pixel-major kernel is written for 2x2x2 blocks)
         G.bd[0] = G.bd[1] = G.bd[2] = 4 * G.V;
@@ -1152,8 +1202,14 @@ int xvr_detail::launch_gather(bool siddon, const float* source, const float* tar
         hipLaunchKernelGGL(k_siddon_cells_to_voxels, dim3((unsigned)((nvox + WG - 1) / WG)), dim3(WG), 0, (hipStream_t)stream, G);
     }
     else if (siddon && G.mask) hipLaunchKernelGGL(k_siddon_gather_mask, dim3((unsigned)bricks), dim3(WG), 0, (hipStream_t)stream, G);
-    else if (siddon && G.bd[2] == 16) hipLaunchKernelGGL(k_siddon_gather_vol2<4>, dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
-    else if (siddon) hipLaunchKernelGGL(k_siddon_gather_vol2<2>, dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
+    else if (siddon && xvr_detail::option(xvr_detail::OPT_SIDDON_GATHER_FAST)) {
+        // four bricks in a row per workgroup, whichever axis the kernel picks for the rows: enough workgroups for the worst case
+        const long long nb0 = (D0 + 7) / 8, nb1 = (D1 + 7) / 8, nb2 = (D2 + 7) / 8;
+        const long long g0 = ((nb0 + 3) / 4) * nb1 * nb2, g1 = nb0 * ((nb1 + 3) / 4) * nb2, g2 = nb0 * nb1 * ((nb2 + 3) / 4);
+        const long long groups = g0 > g1 ? (g0 > g2 ? g0 : g2) : (g1 > g2 ? g1 : g2);
+        hipLaunchKernelGGL(k_siddon_gather_vol2<true>, dim3((unsigned)groups), dim3(256), 0, (hipStream_t)stream, G);
+    }
+    else if (siddon) hipLaunchKernelGGL(k_siddon_gather_vol2<false>, dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
     else if (psplat) {
         const void* kern = G.clip ? (G.mask ? (const void*)k_trilinear_splat_px<true, true> : (const void*)k_trilinear_splat_px<true, false>)
                                   : (G.mask ? (const void*)k_trilinear_splat_px<false, true> : (const void*)k_trilinear_splat_px<false, false>);
