@@ -286,7 +286,10 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAX : WG) __attribute__((amdgpu_
 // No minimum search, no axis select chain, no per-segment bounds test: the voxel offset moves by constants (+-stride of the
 // crossed axis), the walk starts inside the volume and can only cross INTERIOR planes, because the far boundary plane of every
 // axis bounds a_hi by the very arithmetic the loop evaluates plane alphas with (alpha(p) = ((float)p + (plane0 - s)) / d is a pure
-// function of the plane index: monotone along the ray, the same bits inside and outside the loop).  The three loads of a slab are
+// function of the plane index: monotone along the ray, the same bits inside and outside the loop).
+// (Round 4, measured and not kept: alpha(p) as one fma(p, 1 / d, (plane0 - s) / d) -- three vector instructions fewer per slab of
+//  ~70, 5.86 against 5.89 ms, and the image then differs from the merge walk's by 2.8e-5 instead of 1e-6: the march does not
+//  wait on the vector ALU alone.)  The three loads of a slab are
 // independent and predicated on their segment's length; values of zero-length segments repeat their predecessor's, which makes
 // the jumps the jacobian sums (U_i = sum dW alpha, M_i = sum dW per axis, as in the merge walk) vanish where nothing is crossed.
 // ~50 vector instructions per slab for 1.8 segments.  The roles (m, u, v) are per-lane data, not template parameters: strides,
@@ -365,13 +368,16 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, XVR_SLAB_
     // BRICK: LDS byte address of the table entry of the NEXT index along every role's axis, its step, and the current partial offsets
     int am_a = 0, au_a = 0, av_a = 0, st4m = 0, st4u = 0, st4v = 0;
     unsigned fm = 0, fu = 0, fv = 0, fm_n = 0, fu_n = 0, fv_n = 0;
-    auto tabrd = [&](int byte_addr) { return *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(slab_tab) + byte_addr); };
+    // (LDS addresses, the table's base included: added once here instead of in front of every ds_read)
+    typedef __attribute__((address_space(3))) const unsigned lds_u32;
+    const int tab0 = BRICK ? (int)(unsigned)(size_t)(lds_u32*)slab_tab : 0;
+    auto tabrd = [&](int lds_addr) { return *(lds_u32*)(size_t)(unsigned)lds_addr; };
     if (BRICK) {
         const int im = sel3i(m, i0s[0], i0s[1], i0s[2]), iu = sel3i(u, i0s[0], i0s[1], i0s[2]), iv = sel3i(v, i0s[0], i0s[1], i0s[2]);
         const int bm = sel3i(m, tbase[0], tbase[1], tbase[2]), bu = sel3i(u, tbase[0], tbase[1], tbase[2]), bv = sel3i(v, tbase[0], tbase[1], tbase[2]);
         st4m = stm > 0.f ? 4 : -4; st4u = stu > 0.f ? 4 : -4; st4v = stv > 0.f ? 4 : -4;
-        fm = tabrd((bm + im) * 4); fu = tabrd((bu + iu) * 4); fv = tabrd((bv + iv) * 4);
-        am_a = (bm + im) * 4 + st4m; au_a = (bu + iu) * 4 + st4u; av_a = (bv + iv) * 4 + st4v;
+        fm = tabrd(tab0 + (bm + im) * 4); fu = tabrd(tab0 + (bu + iu) * 4); fv = tabrd(tab0 + (bv + iv) * 4);
+        am_a = tab0 + (bm + im) * 4 + st4m; au_a = tab0 + (bu + iu) * 4 + st4u; av_a = tab0 + (bv + iv) * 4 + st4v;
         fm_n = tabrd(am_a); fu_n = tabrd(au_a); fv_n = tabrd(av_a);
         off = (int)(fm + fu + fv);
     }
@@ -392,7 +398,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, XVR_SLAB_
 
     // (terminates: the dominant plane counter moves every trip, so its alpha passes a_hi after at most D_m trips; a NaN alpha
     //  clamps to the slab's start and the next trip's differs)
-    const int tab_last = (A.D0 + A.D1 + A.D2 + 5) * 4;
+    const int tab_last = tab0 + (A.D0 + A.D1 + A.D2 + 5) * 4;
     if (__builtin_amdgcn_ballot_w64(ac < ahi)) do {             // wave-uniform: until every ray of the wavefront has left the volume
         const float am = (fpm + psm) * ivm;
         const float aend = med3f(am, ac, ahi);
@@ -413,7 +419,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, XVR_SLAB_
             // (the minor axes only ever cross interior planes: their next index stays in [-1, D], inside the padded tables; the
             //  dominant axis' address runs on while the wavefront's other rays finish -- those trips' loads are masked -- and is
             //  clamped into the table)
-            fu_n = tabrd(au_a); fv_n = tabrd(av_a); fm_n = tabrd(min(max(am_a, 0), tab_last));
+            fu_n = tabrd(au_a); fv_n = tabrd(av_a); fm_n = tabrd(min(max(am_a, tab0), tab_last));
         } else {
             const int du = cu ? su : 0, dv = cv ? sv : 0;
             off2 = off + (uf ? du : dv);
