@@ -14,35 +14,48 @@ def _pair(seed=0, b=2, h=40, w=36):
     return x1, x2
 
 
+@pytest.mark.gpu
 @pytest.mark.parametrize("patch", [None, 5, 9])
 def test_ncc_matches_unfold_formulation(patch):
     x1, x2 = _pair()
-    got = metrics.NormalizedCrossCorrelation2d(patch)(x1, x2)
+    got = metrics.NormalizedCrossCorrelation2d(patch)(x1.cuda(), x2.cuda()).cpu()
     want = ref.ncc(x1.double(), x2.double(), patch).float()
     assert torch.allclose(got, want, atol=2e-5)
 
 
+@pytest.mark.gpu
 def test_multiscale_and_gradient_ncc_match_and_differentiate():
     x1, x2 = _pair(1)
+    x1g, x2g = x1.cuda(), x2.cuda()
     m = metrics.MultiscaleNormalizedCrossCorrelation2d([None, 9], [0.5, 0.5])
-    assert torch.allclose(m(x1, x2), ref.multiscale_ncc(x1.double(), x2.double()).float(), atol=2e-5)
+    assert torch.allclose(m(x1g, x2g).cpu(), ref.multiscale_ncc(x1.double(), x2.double()).float(), atol=2e-5)
     for sigma in (0.0, 1.5):
-        g = metrics.GradientNormalizedCrossCorrelation2d(11, sigma)
-        assert torch.allclose(g(x1, x2), ref.gradient_ncc(x1.double(), x2.double(), 11, sigma).float(), atol=2e-5)
+        g = metrics.GradientNormalizedCrossCorrelation2d(11, sigma).cuda()
+        assert torch.allclose(g(x1g, x2g).cpu(), ref.gradient_ncc(x1.double(), x2.double(), 11, sigma).float(), atol=2e-5)
     # gradients agree with autograd through the unfold formulation
-    a = x2.clone().requires_grad_(True)
+    a = x2g.clone().requires_grad_(True)
     b = x2.double().clone().requires_grad_(True)
-    (0.5 * m(x1, a) + 0.5 * metrics.GradientNormalizedCrossCorrelation2d(11, 0.0)(x1, a)).sum().backward()
+    (0.5 * m(x1g, a) + 0.5 * metrics.GradientNormalizedCrossCorrelation2d(11, 0.0).cuda()(x1g, a)).sum().backward()
     (0.5 * ref.multiscale_ncc(x1.double(), b) + 0.5 * ref.gradient_ncc(x1.double(), b, 11, 0.0)).sum().backward()
-    assert torch.allclose(a.grad, b.grad.float(), atol=1e-5 * b.grad.abs().max().item() + 1e-9)
+    assert torch.allclose(a.grad.cpu(), b.grad.float(), atol=1e-5 * b.grad.abs().max().item() + 1e-9)
 
 
+def test_similarity_has_no_cpu_path():
+    x1, x2 = _pair(2)
+    for mod in (metrics.NormalizedCrossCorrelation2d(9), metrics.MultiscaleNormalizedCrossCorrelation2d([None, 9], [0.5, 0.5]),
+                metrics.GradientNormalizedCrossCorrelation2d(11, 0.0)):
+        with pytest.raises(RuntimeError, match="no CPU path"):
+            mod(x1, x2)
+
+
+@pytest.mark.gpu
 def test_ncc_of_identical_images_is_one_and_of_negated_is_minus_one():
     x1, _ = _pair(2)
+    x1 = x1.cuda()
     m = metrics.MultiscaleNormalizedCrossCorrelation2d([None, 9], [0.5, 0.5])
-    assert torch.allclose(m(x1, x1), torch.ones(2), atol=1e-3)
-    assert torch.allclose(m(x1, -x1), -torch.ones(2), atol=1e-3)
-    assert torch.allclose(m(x1, 2.5 * x1 + 0.7), torch.ones(2), atol=1e-3)  # affine invariance
+    assert torch.allclose(m(x1, x1).cpu(), torch.ones(2), atol=1e-3)
+    assert torch.allclose(m(x1, -x1).cpu(), -torch.ones(2), atol=1e-3)
+    assert torch.allclose(m(x1, 2.5 * x1 + 0.7).cpu(), torch.ones(2), atol=1e-3)  # affine invariance
 
 
 @pytest.mark.gpu

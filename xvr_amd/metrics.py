@@ -13,8 +13,8 @@ box filters -- mean(x1), mean(x2), mean(x1^2), mean(x2^2), mean(x1 x2) over ever
     ncc_patch = (E[x1 x2] - mu1 mu2) / sqrt((var1 + eps)(var2 + eps)),   score = mean over patches,
 
 with the box sums accumulated in float64 (E[x^2] - mu^2 cancels catastrophically in fp32 on flat
-patches, where eps = 1e-5 decides the value).  Plain torch ops on the GPU, autograd-differentiable;
-checked against the literal unfold formulation in oracle/metrics_restated.py.
+patches, where eps = 1e-5 decides the value).  That formulation serves the configurations of the shim that the fused HIP kernels (similarity.py) do not: torch ops on the
+GPU, autograd-differentiable, no CPU path; checked against the literal unfold formulation in oracle/metrics_restated.py.
 """
 
 from __future__ import annotations
@@ -37,6 +37,8 @@ class NormalizedCrossCorrelation2d(torch.nn.Module):
 
     def forward(self, x1: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
         assert x1.shape == x2.shape, "Input images must be the same size"
+        if not (x1.is_cuda and x2.is_cuda):
+            raise RuntimeError("NormalizedCrossCorrelation2d: CUDA images only (the similarity runs on the device, no CPU path)")
         dt = x1.dtype
         a, b = x1.double(), x2.double()
         if self.patch_size is None:
@@ -69,6 +71,7 @@ class MultiscaleNormalizedCrossCorrelation2d(torch.nn.Module):
             from .similarity import fused_mncc   # (imported late: similarity.py imports this module)
 
             return fused_mncc(x1, x2, self.nccs[1].patch_size, self.nccs[1].eps)
+        # (any other configuration of the shim -- other weights, patches beyond 15, several channels: box filters on the device)
         return sum(w * ncc(x1, x2) for w, ncc in zip(self.patch_weights, self.nccs))
 
     # ``[None, p]`` with weights ``[0.5, 0.5]`` -- the configuration of both of xvr's loops
