@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define XVR_DRR_ABI_VERSION 8   /* 8: volume_layout 3 + xvr_drr_pack_ytiles / _labels_ytiles (tiled y-pair copy), xvr_pose_camera_forward_param / xvr_pose_opt_step_param (device-resident registration for every parameterisation; xvr_pose_opt_state holds 13 parameters), xvr_sim_equalize_* write / take the normalised output, option tile_geom; 7: xvr_drr_foreground, xvr_drr_pack_labels_ypairs, xvr_sim_dice_bool, xvr_sim_transform_* (xvr_sim.h), xvr_pose_convert_* (xvr_pose.h); 6: xvr_drr_spec.alpha_window + xvr_drr_alpha_window (clip_to_volume = 2); 5: xvr_drr_set_option / xvr_drr_get_option (the A/B switches are no longer getenv calls per launch); 4: volume_layout 2 + xvr_drr_pack_bricks (siddon forward); 3: xvr_drr_spec.volume_layout + xvr_drr_pack_ypairs; 2: xvr_sim_spec grew, camera-driven forwards, packed labels, xvr_pose.h */
+#define XVR_DRR_ABI_VERSION 8   /* 8: volume_layout 3 + xvr_drr_pack_ytiles / _labels_ytiles (tiled y-pair copy), xvr_pose_camera_forward_param / xvr_pose_opt_step_param (device-resident registration for every parameterisation; xvr_pose_opt_state holds 13 parameters), xvr_sim_equalize_* write / take the normalised output, options tile_geom, siddon_slab, siddon_gather_fast; 7: xvr_drr_foreground, xvr_drr_pack_labels_ypairs, xvr_sim_dice_bool, xvr_sim_transform_* (xvr_sim.h), xvr_pose_convert_* (xvr_pose.h); 6: xvr_drr_spec.alpha_window + xvr_drr_alpha_window (clip_to_volume = 2); 5: xvr_drr_set_option / xvr_drr_get_option (the A/B switches are no longer getenv calls per launch); 4: volume_layout 2 + xvr_drr_pack_bricks (siddon forward); 3: xvr_drr_spec.volume_layout + xvr_drr_pack_ypairs; 2: xvr_sim_spec grew, camera-driven forwards, packed labels, xvr_pose.h */
 
 #define XVR_DRR_OK 0
 #define XVR_DRR_E_ARG (-1)     /* bad argument (null pointer, non-positive size, unsupported combo) */
@@ -96,6 +96,9 @@ const char* xvr_drr_last_error(void);
  *                              along the detector axis that runs along the volume's contiguous axis (per pose)     [1]
  *   "siddon_slab"   1 | 0      unsplit one-channel Siddon forward with the exact index map: dominant-axis slab march
  *                              (k_siddon_slab, both volume layouts) | the merge walk (k_siddon)                    [1]
+ *   "siddon_gather_fast" 1 | 0 Siddon voxel gather: pixel window from one projection of the block centre, four bricks along the
+ *                              viewing axis per workgroup | the window of the eight projected corners, one brick per
+ *                              workgroup (A/B: identical bits)                                                   [1]
  * Returns XVR_DRR_E_ARG for an unknown name or a value outside the option's range.
  */
 int xvr_drr_set_option(const char* name, int value);
