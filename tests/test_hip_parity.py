@@ -1054,14 +1054,23 @@ def test_fused_similarity_matches_torch_metrics_and_the_unfold_oracle(shape, bet
     mv = moving.cuda().requires_grad_(True)
     loss = sim(mv)
     loss.sum().backward()
-    # torch path
-    m2 = moving.clone().requires_grad_(True)
-    s1, s2 = MultiscaleNormalizedCrossCorrelation2d([None, 9], [0.5, 0.5]), GradientNormalizedCrossCorrelation2d(11, 0.0)
-    y2 = tf(m2)
-    ref = beta * s1(fixed, y2) + (1 - beta) * s2(fixed, y2)
-    ref.sum().backward()
-    assert torch.allclose(loss.cpu(), ref, atol=2e-5), (loss.cpu(), ref)
+    # the shim's modules with their box-filter formulation (torch ops on the device; the fused kernels switched off)
+    m2 = moving.cuda().requires_grad_(True)
+    s1, s2 = MultiscaleNormalizedCrossCorrelation2d([None, 9], [0.5, 0.5]), GradientNormalizedCrossCorrelation2d(11, 0.0).cuda()
+    MultiscaleNormalizedCrossCorrelation2d.FUSED, GradientNormalizedCrossCorrelation2d.FUSED = False, False
+    try:
+        y2 = XrayTransforms(H, W)(m2)
+        ref = beta * s1(fixed.cuda(), y2) + (1 - beta) * s2(fixed.cuda(), y2)
+        ref.sum().backward()
+    finally:
+        MultiscaleNormalizedCrossCorrelation2d.FUSED, GradientNormalizedCrossCorrelation2d.FUSED = True, True
+    assert torch.allclose(loss, ref, atol=2e-5), (loss, ref)
     _close(mv.grad, m2.grad, 2e-3, "d sim / d moving")
+    # ... and autograd through the oracle's torch lines on the CPU (float64)
+    m3 = moving.double().requires_grad_(True)
+    y3 = mref.xray_transforms(m3, H, W)
+    (beta * mref.multiscale_ncc(fixed.double(), y3) + (1 - beta) * mref.gradient_ncc(fixed.double(), y3, 11, 0.0)).sum().backward()
+    _close(mv.grad, m3.grad, 2e-3, "d sim / d moving (oracle)")
     # the literal unfold formulation (oracle), value only
     yo = mref.xray_transforms(moving.double(), H, W)
     oref = beta * mref.multiscale_ncc(fixed.double(), yo) + (1 - beta) * mref.gradient_ncc(fixed.double(), yo, 11, 0.0)
