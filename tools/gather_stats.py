@@ -41,6 +41,8 @@ if SIDDON:   # k_siddon_gather_vol2: one lane = one 2 x 2 x 2 block, one wavefro
     print(f"(lane, pose) visits with a window {v[0]:.4g} | candidates {v[4]:.4g} ({v[4] / max(v[0], 1):.2f} per visit) | wavefront visits {v[7]:.4g} | "
           f"wavefront rows {v[2]:.4g} ({v[2] / max(v[7], 1):.2f} per visit) | wavefront trips {v[6]:.4g} ({v[6] / max(v[7], 1):.2f} per visit, "
           f"{v[4] / max(v[6], 1):.1f} of 128 candidate slots filled per trip)")
+    print(f"wavefront visits served from LDS {v[1]:.4g} ({100 * v[1] / max(v[7], 1):.1f} %, {v[5] / max(v[1], 1):.0f} pixels staged each) | "
+          f"on sign-sorted planes {v[3]:.4g} ({100 * v[3] / max(v[7], 1):.1f} %)")
     sys.exit(0)
 print(f"(lane, pose) visits {v[0]:.4g} | steps {v[1]:.4g} | rows {v[2]:.4g} (empty {v[3]:.4g}) | candidates {v[4]:.4g} | "
       f"wavefront inner trips {v[6]:.4g} | wavefront pose iterations {v[7]:.4g}")

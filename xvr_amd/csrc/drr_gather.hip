@@ -226,6 +226,8 @@ __global__ __launch_bounds__(WG) void k_gather_prep(GatherArgs G) {
             P.rperp = P.ecl > 0.f ? sqrtf(dot3(cr, cr)) / P.ecl : 0.f;
             P.gn = sqrtf(dot3(nha, nha));
         }
+        P.ec_len = sqrtf(dot3(ec, ec));
+        P.er_len = sqrtf(dot3(er, er));
         P.nh_norm = sqrtf(dot3(P.nh, P.nh));
         P.gc_norm = sqrtf(dot3(gc, gc));
         P.gr_norm = sqrtf(dot3(gr, gr));
@@ -953,7 +955,14 @@ __global__ __launch_bounds__(WG) void k_siddon_cells_to_voxels(GatherArgs G) {
 //   * a candidate's eight entries / exits as v_max3_f32 / v_min3_f32 of the per-axis interval ends (the compiler shares
 //     max(xl, yl) between two voxels instead: 24 two-operand instructions where 16 three-operand ones do); plain fp32
 //     throughout -- a packed pair (v_pk_*_f32) occupies the SIMD for 1.3 x two plain instructions on this chip;
-//   * the loop body exists twice: poses none of whose rays is cut at alpha = 0 / 1 neither load nor apply (lo, hi).
+//   * the loop body exists twice: poses none of whose rays is cut at alpha = 0 / 1 neither load nor apply (lo, hi);
+//   * ... and twice again: where every ray of every lane's window runs the same way along each axis (the direction is affine in
+//     the pixel: its sign at the window's four corners decides, with a margin for the lattice tolerance), the lane's planes are
+//     put in the order the rays cross them and the per-axis interval ends ARE the plane alphas -- the twelve min / max per
+//     candidate go.  The lane's eight sums are then kept in crossing order too (index e ^ mask, permuted by conditional swaps
+//     when a pose's mask differs from the previous one's), so that every sum still adds its candidates in the same order:
+//     the result is the general body's, bit for bit.  A wavefront with a lane whose window straddles a sign change (the
+//     pixels around the principal ray, for two of the three axes) takes the general body for that pose.
 // ~53 vector instructions per candidate (57 with the cut) and ~110 per visit.
 __device__ __forceinline__ float max3_raw(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ float min3_raw(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
@@ -964,32 +973,56 @@ __device__ __forceinline__ float min_raw(float a, float b) { float r; asm("v_min
 //     pose's detector normal is closest to: every workgroup derives the same axis).  Their pixel footprints overlap, they
 //     run on one CU, and a q line fetched for one brick is in the L1 for the other three: on its own a wavefront finds
 //     almost nothing of its ~40 lines per visit in the L1 (1.15e9 L1-miss lines, 148 GB from L2 per C3 launch).
+//   * FAST: the candidates come from LDS.  With one 16-byte load per lane and candidate, each lane at its own address, the kernel
+//     is bound by the texture-address / L1 path (64 addresses per wavefront load: ~64 clocks of the CU's one TA each, 19 such
+//     loads per visit -- the vector-instruction savings above moved the launch by 2 % each until this was gone).  The 64
+//     lanes' windows overlap almost entirely: a visit reads ~900 (lane, candidate) pairs out of the ~300 pixels of the brick's
+//     footprint.  So the wavefront first copies the footprint -- the pixel window of the whole 8^3 brick, by the same
+//     one-projection bound, a few coalesced loads -- into its slice of LDS and the lanes read their candidates with
+//     ds_read_b128.  Footprints beyond the slice (SG_FOOT pixels), bricks that reach the source plane and poses with cut rays
+//     take the global loads as before.
+#ifndef XVR_SG_FOOT
+#define XVR_SG_FOOT 480
+#endif
+#ifndef XVR_SG_WAVES   // wavefronts per SIMD the LDS slices leave room for: 160 KB / (4 x 16 B x SG_FOOT) workgroups of four.  Measured at
+                       // C3 (ms, launch incl. prep / cull): 640 px x 4 -> 8.20, 512 x 5 (only four fit) 8.24, 416-496 x 5 -> 7.63, 400 x 6 -> 8.38
+                       // (spills), 320 x 7 -> 8.88, 256 x 8 -> 12.2, 960-1280 x 2 -> 12.9: occupancy matters more than the last footprints
+#define XVR_SG_WAVES 5
+#endif
+constexpr int SG_FOOT = XVR_SG_FOOT;
 template <bool FAST>
-__global__ __launch_bounds__(FAST ? 256 : 64) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_siddon_gather_vol2(GatherArgs G) {
+__global__ __launch_bounds__(FAST ? 256 : 64) __attribute__((amdgpu_waves_per_eu(FAST ? XVR_SG_WAVES : 6, FAST ? XVR_SG_WAVES : 6))) void k_siddon_gather_vol2(GatherArgs G) {
     if (*G.flag > __float_as_uint(GATHER_DEV_TOL)) return;
+    __shared__ float4 s_foot[FAST ? 4 : 1][FAST ? SG_FOOT : 1];
     int bx, by, bz;
     int brick = blockIdx.x;   // the brick's number in the cull array's order (brick_coords)
     if (FAST) {
-        const int nb[3] = {(G.D0 + G.bd[0] - 1) / G.bd[0], (G.D1 + G.bd[1] - 1) / G.bd[1], (G.D2 + G.bd[2] - 1) / G.bd[2]};
+        // (no array indexed by the axis: it would go through scratch and the brick number -- with it every per-pose load --
+        //  would stop being a scalar)
+        const int nb0 = (G.D0 + G.bd[0] - 1) / G.bd[0], nb1 = (G.D1 + G.bd[1] - 1) / G.bd[1], nb2 = (G.D2 + G.bd[2] - 1) / G.bd[2];
         const float n0 = fabsf(G.poses[0].nh[0] / G.sp.a[0]), n1 = fabsf(G.poses[0].nh[1] / G.sp.a[1]), n2 = fabsf(G.poses[0].nh[2] / G.sp.a[2]);
-        const int ax = (n0 >= n1 && n0 >= n2) ? 0 : (n1 >= n2 ? 1 : 2);            // (uniform: scalar loads, the same in every workgroup)
-        const int u = ax == 0 ? 1 : 0, v = ax == 2 ? 1 : 2;                        // the other two axes, v the faster one
-        const int groups = (nb[ax] + 3) >> 2;                                      // runs of four bricks along ax
+        const int ax = __builtin_amdgcn_readfirstlane((n0 >= n1 && n0 >= n2) ? 0 : (n1 >= n2 ? 1 : 2));   // (the same in every workgroup)
+        // the other two axes: u, and v the faster one
+        const int nba = ax == 0 ? nb0 : (ax == 1 ? nb1 : nb2), nbu = ax == 0 ? nb1 : nb0, nbv = ax == 2 ? nb1 : nb2;
+        const int groups = (nba + 3) >> 2;                                         // runs of four bricks along ax
         int g = blockIdx.x;
-        const int cv = g % nb[v]; g /= nb[v];
+        const int cv = g % nbv; g /= nbv;
         const int ga = g % groups, cu = g / groups;
         const int ca = ga * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (scalar: everything per brick and pose below is uniform)
-        if (ca >= nb[ax] || cu >= nb[u]) return;   // (no barrier below)
-        int c[3];
-        c[ax] = ca; c[u] = cu; c[v] = cv;
-        bx = c[0]; by = c[1]; bz = c[2];
-        brick = (bx * nb[1] + by) * nb[2] + bz;
+        if (ca >= nba || cu >= nbu) return;   // (no barrier below)
+        bx = ax == 0 ? ca : cu;
+        by = ax == 1 ? ca : (ax == 0 ? cu : cv);
+        bz = ax == 2 ? ca : cv;
+        brick = (bx * nb1 + by) * nb2 + bz;
     } else {
         brick_coords(blockIdx.x, G.D1, G.D2, G.bd, bx, by, bz);
     }
     const int tid = threadIdx.x & 63;
+    float4* const foot = s_foot[FAST ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0];
     const int vx = (bx * 4 + (tid >> 4)) * 2, vy = (by * 4 + ((tid >> 2) & 3)) * 2, vz = (bz * 4 + (tid & 3)) * 2;
     const bool inb = vx < G.D0 && vy < G.D1 && vz < G.D2;
+    // the brick's centre (uniform), in x coordinates: the middle of its 4 x 4 x 4 block centres
+    const float cbx = (float)(bx * 8 + 4) + G.sp.plane0[0], cby = (float)(by * 8 + 4) + G.sp.plane0[1], cbz = (float)(bz * 8 + 4) + G.sp.plane0[2];
     // the three planes per axis that bound the block's voxels, and the block centre, in x coordinates
     float px[3], py[3], pz[3];
 #pragma unroll
@@ -1002,6 +1035,21 @@ __global__ __launch_bounds__(FAST ? 256 : 64) __attribute__((amdgpu_waves_per_eu
     float acc[8];   // voxels (a, b, c)
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    unsigned cur = 0;   // the sum of voxel e lives in acc[e ^ cur]
+    auto permute = [&](const unsigned m) {   // acc[e] <- acc[e ^ m]
+        if (__builtin_amdgcn_ballot_w64(m != 0u) == 0ull) return;
+#pragma unroll
+        for (int bit = 4; bit >= 1; bit >>= 1) {
+            const bool sw = (m & (unsigned)bit) != 0u;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (!(e & bit)) {
+                    const float lo_ = acc[e], hi_ = acc[e | bit];
+                    acc[e] = sw ? hi_ : lo_;
+                    acc[e | bit] = sw ? lo_ : hi_;
+                }
+        }
+    };
 #ifdef XVR_GATHER_STATS   // 0 (lane, pose) visits with a window . 2 wavefront rows . 4 candidates . 6 wavefront trips . 7 wavefront visits
     unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -1012,8 +1060,8 @@ __global__ __launch_bounds__(FAST ? 256 : 64) __attribute__((amdgpu_waves_per_eu
             const int p = wd * 32 + __builtin_ctz(bits);
             bits &= bits - 1;
             const PoseLattice& P = G.poses[p];
-            // (uniform) does any ray of this pose end at alpha = 0 or 1?  If none does, the rays' (lo, hi) are not loaded: the
-            // kernel is bound by the L1's access rate (TCP 91 % busy, one access per lane and load), and they are a third of its loads
+            // (uniform) does any ray of this pose end at alpha = 0 or 1 (source or detector inside the volume)?  If none does, no
+            // voxel's chord needs the clamp to [0, 1]
             const bool cut_rays = !G.cmax || G.cmax[(size_t)p * G.cmax_stride] != 0u;
             const float s0 = P.s[0], s1 = P.s[1], s2 = P.s[2];
             const float w0 = cx - s0, w1 = cy - s1, w2 = cz - s2;
@@ -1061,20 +1109,61 @@ __global__ __launch_bounds__(FAST ? 256 : 64) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
             for (int k = 0; k < 3; ++k) { lx[k] = px[k] - s0; ly[k] = py[k] - s1; lz[k] = pz[k] - s2; }
             const float4* __restrict__ q = G.q + (size_t)p * G.n;
-            const float2* __restrict__ q2 = G.q2 + (size_t)p * G.n;
+            // the brick's footprint (uniform): the same bound on the whole brick -- four block half-sizes around its centre.  Every
+            // block's rays lie inside it; a lane's own window is a bound too and may stick out by its slack: it is clipped (the
+            // pixels dropped are rays that miss the block: exact zeros).
+            int Ilo = 0, Jlo = 0, fnc = 0;
+            bool staged = false;
+            if (FAST) {
+                const float u0 = cbx - s0, u1 = cby - s1, u2 = cbz - s2;
+                const float avB = P.nh[0] * u0 + P.nh[1] * u1 + P.nh[2] * u2, aminB = avB - 4.f * P.dalpha;
+                if (aminB > 1e-6f) {
+                    const float en0 = P.nh[0] * ea0, en1 = P.nh[1] * ea1, en2 = P.nh[2] * ea2;
+                    const float ec0 = P.gc[0] * ea0, ec1 = P.gc[1] * ea1, ec2 = P.gc[2] * ea2;
+                    const float er0 = P.gr[0] * ea0, er1 = P.gr[1] * ea1, er2 = P.gr[2] * ea2;
+                    const float iav = __builtin_amdgcn_rcpf(avB), iam = 4.f * __builtin_amdgcn_rcpf(aminB);
+                    const float jc = (P.gc[0] * u0 + P.gc[1] * u1 + P.gc[2] * u2) * iav, ic = (P.gr[0] * u0 + P.gr[1] * u1 + P.gr[2] * u2) * iav;
+                    const float hj = (fabsf(fmaf(-jc, en0, ec0)) + fabsf(fmaf(-jc, en1, ec1)) + fabsf(fmaf(-jc, en2, ec2))) * iam;
+                    const float hi = (fabsf(fmaf(-ic, en0, er0)) + fabsf(fmaf(-ic, en1, er1)) + fabsf(fmaf(-ic, en2, er2))) * iam;
+                    Jlo = __builtin_amdgcn_readfirstlane((int)ceilf(fmaxf(jc - hj + P.gc0 - GATHER_WIN_MARGIN, 0.f)));
+                    Ilo = __builtin_amdgcn_readfirstlane((int)ceilf(fmaxf(ic - hi + P.gr0 - GATHER_WIN_MARGIN, 0.f)));
+                    const int Jhi = __builtin_amdgcn_readfirstlane((int)floorf(fminf(jc + hj + P.gc0 + GATHER_WIN_MARGIN, (float)(G.W - 1))));
+                    const int Ihi = __builtin_amdgcn_readfirstlane((int)floorf(fminf(ic + hi + P.gr0 + GATHER_WIN_MARGIN, (float)(G.H - 1))));
+                    const int fnr = Ihi - Ilo + 1;
+                    fnc = Jhi - Jlo + 1;
+                    const int total = fnr * fnc;
+                    if (fnr > 0 && fnc > 0 && total <= SG_FOOT) {
+                        staged = true;
+                        XVR_STAT(5, tid == 0 ? total : 0);
+                        jlo = max(jlo, Jlo); jhi = min(jhi, Jhi); ilo = max(ilo, Ilo); ihi = min(ihi, Ihi);
+                        const float inc = __builtin_amdgcn_rcpf((float)fnc);   // ((f + 1/2) / fnc is at least 1 / (2 fnc) from an integer: 1 ulp is harmless)
+                        const float4* __restrict__ src = q + (size_t)Ilo * G.W + Jlo;
+                        for (int f = tid; f < total; f += 64) {
+                            const int r = (int)(((float)f + 0.5f) * inc), c = f - r * fnc;
+                            foot[f] = src[(size_t)r * G.W + c];
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+            }
             // one candidate ray into the eight sums: crossing alphas of the planes (forward's expression), per axis the two voxel
             // intervals (the ray's own [alpha_lo, alpha_hi] folded into the x intervals once), per voxel entry, exit, chord
-            auto candidate = [&](const float4 t, const float2 ab, auto cut) {
+            auto candidate = [&](const float4 t, auto cut, auto sorted) {
+                constexpr bool SORTED = decltype(sorted)::value;   // the planes are in crossing order: x0 <= x1 <= x2, ...
                 const float x0 = lx[0] * t.x, x1 = lx[1] * t.x, x2 = lx[2] * t.x;
                 const float y0 = ly[0] * t.y, y1 = ly[1] * t.y, y2 = ly[2] * t.y;
                 const float z0 = lz[0] * t.z, z1 = lz[1] * t.z, z2 = lz[2] * t.z;
-                float xl[2] = {min_raw(x0, x1), min_raw(x1, x2)}, xh[2] = {max_raw(x0, x1), max_raw(x1, x2)};
+                float xl[2] = {SORTED ? x0 : min_raw(x0, x1), SORTED ? x1 : min_raw(x1, x2)}, xh[2] = {SORTED ? x1 : max_raw(x0, x1), SORTED ? x2 : max_raw(x1, x2)};
                 if (decltype(cut)::value) {
-                    xl[0] = max_raw(xl[0], ab.x); xl[1] = max_raw(xl[1], ab.x);
-                    xh[0] = min_raw(xh[0], ab.y); xh[1] = min_raw(xh[1], ab.y);
+                    // the ray's own range [max(0, entry), min(1, exit)]: a voxel's cube lies inside the volume's, so only the cut
+                    // at the source (alpha = 0) and at the detector (alpha = 1) can shorten its chord -- constants, not a load
+                    // of the ray's (lo, hi) (round 4; the loads were a third of a cut pose's)
+                    xl[0] = max_raw(xl[0], 0.f); xl[1] = max_raw(xl[1], 0.f);
+                    xh[0] = min_raw(xh[0], 1.f); xh[1] = min_raw(xh[1], 1.f);
                 }
-                const float yl[2] = {min_raw(y0, y1), min_raw(y1, y2)}, yh[2] = {max_raw(y0, y1), max_raw(y1, y2)};
-                const float zl[2] = {min_raw(z0, z1), min_raw(z1, z2)}, zh[2] = {max_raw(z0, z1), max_raw(z1, z2)};
+                const float yl[2] = {SORTED ? y0 : min_raw(y0, y1), SORTED ? y1 : min_raw(y1, y2)}, yh[2] = {SORTED ? y1 : max_raw(y0, y1), SORTED ? y2 : max_raw(y1, y2)};
+                const float zl[2] = {SORTED ? z0 : min_raw(z0, z1), SORTED ? z1 : min_raw(z1, z2)}, zh[2] = {SORTED ? z1 : max_raw(z0, z1), SORTED ? z2 : max_raw(z1, z2)};
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int a = e >> 2, b = (e >> 1) & 1, c = e & 1;
@@ -1083,30 +1172,83 @@ __global__ __launch_bounds__(FAST ? 256 : 64) __attribute__((amdgpu_waves_per_eu
                     acc[e] = fmaf(__builtin_amdgcn_fmed3f(ex - en, 0.f, 1.f), t.w, acc[e]);
                 }
             };
+#if defined(XVR_SG_ABLATE) && XVR_SG_ABLATE == 3   // diagnostic build only: the visits without their candidates -- WRONG sums
+            acc[0] += (float)(ihi - ilo) + (float)(jhi - jlo);
+            ihi = ilo - 1;
+#endif
             XVR_STAT(0, (ihi >= ilo && jhi >= jlo) ? 1 : 0);
             XVR_STAT(4, (ihi >= ilo && jhi >= jlo) ? (ihi - ilo + 1) * (jhi - jlo + 1) : 0);
             XVR_STAT_WAVE(7);
-            auto rows = [&](auto cut) {
+            auto rows = [&](auto cut, auto sorted, auto from_lds) {
                 for (int i = ilo; i <= ihi; ++i) {
                     const float4* __restrict__ row = q + (size_t)i * G.W;
-                    const float2* __restrict__ row2 = q2 + (size_t)i * G.W;
+                    const float4* frow = foot + ((i - Ilo) * fnc - Jlo);   // (LDS)
                     XVR_STAT_WAVE(2);
                     // two candidates per trip: the loads are issued before either candidate is evaluated
                     for (int j = jlo; j <= jhi; j += 2) {
                         XVR_STAT_WAVE(6);
                         const int j1 = j < jhi ? j + 1 : j;
-                        float4 ta = row[j], tb = row[j1];
-                        float2 aa = make_float2(0.f, 1.f), ab = make_float2(0.f, 1.f);
-                        if (decltype(cut)::value) { aa = row2[j]; ab = row2[j1]; }
+                        float4 ta, tb;
+#if defined(XVR_SG_ABLATE) && XVR_SG_ABLATE == 1   // diagnostic build only (tools/ablate_siddon_gather.py): no candidate loads -- WRONG sums
+                        ta = make_float4(__int_as_float(0x3a000000 + j), __int_as_float(0x3a800000 + i), __int_as_float(0x3a400000 + j + i), 1.f);
+                        tb = make_float4(__int_as_float(0x3a000000 + j1), __int_as_float(0x3a800000 + i), __int_as_float(0x3a400000 + j1 + i), 1.f);
+#else
+                        if (decltype(from_lds)::value) { ta = frow[j]; tb = frow[j1]; } else { ta = row[j]; tb = row[j1]; }
+#endif
+#if defined(XVR_SG_ABLATE) && XVR_SG_ABLATE == 2   // diagnostic build only: the loads without the candidates' arithmetic -- WRONG sums
+                        acc[0] += ta.x + tb.x; acc[1] += ta.y + tb.y; acc[2] += ta.z + tb.z; acc[3] += ta.w + tb.w;
+                        continue;
+#endif
                         if (j1 == j) tb.w = 0.f;
-                        candidate(ta, aa, cut);
-                        candidate(tb, ab, cut);
+                        candidate(ta, cut, sorted);
+                        candidate(tb, cut, sorted);
                     }
                 }
             };
-            if (cut_rays) rows(std::true_type{}); else rows(std::false_type{});
+            // do all rays of the window run the same way along every axis?  d(i, j) = st + i er + j ec per axis, affine: its extremes
+            // over the window are at the corners; 0.05 of a pixel pitch covers the lattice tolerance (GATHER_DEV_TOL = 0.02)
+            bool same_way = true;
+            unsigned mask = cur;
+            if (FAST) {
+                // (the pose's constants are read outside the lane-dependent branch: scalar loads)
+                const float stv[3] = {P.st[0], P.st[1], P.st[2]}, erv[3] = {P.er[0], P.er[1], P.er[2]}, ecv[3] = {P.ec[0], P.ec[1], P.ec[2]};
+                const float marg = 0.05f * fmaxf(P.ec_len, P.er_len);
+                const bool has = ihi >= ilo && jhi >= jlo;
+                const float fi0 = (float)ilo, fj0 = (float)jlo, di = (float)(ihi - ilo), dj = (float)(jhi - jlo);
+                unsigned m = 0u;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float base = fmaf(fj0, ecv[k], fmaf(fi0, erv[k], stv[k])), ei = di * erv[k], ej = dj * ecv[k];
+                    const float dlo = base + fminf(ei, 0.f) + fminf(ej, 0.f), dhi = base + fmaxf(ei, 0.f) + fmaxf(ej, 0.f);
+                    same_way = same_way && (!has || dlo > marg || dhi < -marg);
+                    m |= (dhi < -marg) ? (4u >> k) : 0u;
+                }
+                mask = has ? m : cur;   // (a lane without a window keeps its order: nothing to permute)
+            }
+#ifdef XVR_GATHER_STATS   // 1 wavefront visits served from LDS . 3 wavefront visits on sign-sorted planes . 5 pixels staged
+            if (staged) { XVR_STAT_WAVE(1); }
+            if (FAST && __builtin_amdgcn_ballot_w64(!same_way) == 0ull) { XVR_STAT_WAVE(3); }
+#endif
+            if (FAST && __builtin_amdgcn_ballot_w64(!same_way) == 0ull) {
+                permute(cur ^ mask);
+                cur = mask;
+                if (mask & 4u) { const float t_ = lx[0]; lx[0] = lx[2]; lx[2] = t_; }
+                if (mask & 2u) { const float t_ = ly[0]; ly[0] = ly[2]; ly[2] = t_; }
+                if (mask & 1u) { const float t_ = lz[0]; lz[0] = lz[2]; lz[2] = t_; }
+                if (staged && cut_rays) rows(std::true_type{}, std::true_type{}, std::true_type{});
+                else if (staged) rows(std::false_type{}, std::true_type{}, std::true_type{});
+                else if (cut_rays) rows(std::true_type{}, std::true_type{}, std::false_type{});
+                else rows(std::false_type{}, std::true_type{}, std::false_type{});
+            } else {   // (rare: a lane's window straddles a sign change -- one body for it)
+                permute(cur);
+                cur = 0u;
+                if (staged) rows(std::true_type{}, std::false_type{}, std::true_type{});
+                else rows(std::true_type{}, std::false_type{}, std::false_type{});
+            }
+            if (FAST) __builtin_amdgcn_wave_barrier();   // (the slice is overwritten by the next visit)
         }
     }
+    permute(cur);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int x = vx + (e >> 2), y = vy + ((e >> 1) & 1), z = vz + (e & 1);
