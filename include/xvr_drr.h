@@ -97,8 +97,9 @@ const char* xvr_drr_last_error(void);
  *   "siddon_slab"   1 | 0      unsplit one-channel Siddon forward with the exact index map: dominant-axis slab march
  *                              (k_siddon_slab, both volume layouts) | the merge walk (k_siddon)                    [1]
  *   "siddon_gather_fast" 1 | 0 Siddon voxel gather: pixel window from one projection of the block centre, four bricks along the
- *                              viewing axis per workgroup | the window of the eight projected corners, one brick per
- *                              workgroup (A/B: identical bits)                                                   [1]
+ *                              viewing axis per workgroup, candidates from an LDS copy of the brick's footprint, planes in
+ *                              crossing order | the window of the eight projected corners, one brick per workgroup,
+ *                              candidates from global memory (A/B: identical bits)                              [1]
  * Returns XVR_DRR_E_ARG for an unknown name or a value outside the option's range.
  */
 int xvr_drr_set_option(const char* name, int value);

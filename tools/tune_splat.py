@@ -16,6 +16,8 @@ VARIANTS = [
     ("b16", [], "1"),
     ("b16_quarters", ["XVR_S16_SHARES=0"], "1"),
     ("b16_noadds", ["XVR_SP_ABLATE_ADDS=1"], "1"),
+    ("b16_noloads", ["XVR_S16_ABLATE_LOADS=1"], "1"),
+    ("b16_noadds_noloads", ["XVR_SP_ABLATE_ADDS=1", "XVR_S16_ABLATE_LOADS=1"], "1"),
     ("table", [], "0"),
 ]
 RENDERER = "trilinear"

@@ -1113,7 +1113,7 @@ __global__ __launch_bounds__(FAST ? 256 : 64) __attribute__((amdgpu_waves_per_eu
             // block's rays lie inside it; a lane's own window is a bound too and may stick out by its slack: it is clipped (the
             // pixels dropped are rays that miss the block: exact zeros).
             int Ilo = 0, Jlo = 0, fnc = 0;
-            bool staged = false;
+            bool staged_v = false;
             if (FAST) {
                 const float u0 = cbx - s0, u1 = cby - s1, u2 = cbz - s2;
                 const float avB = P.nh[0] * u0 + P.nh[1] * u1 + P.nh[2] * u2, aminB = avB - 4.f * P.dalpha;
@@ -1130,17 +1130,18 @@ __global__ __launch_bounds__(FAST ? 256 : 64) __attribute__((amdgpu_waves_per_eu
                     const int Jhi = __builtin_amdgcn_readfirstlane((int)floorf(fminf(jc + hj + P.gc0 + GATHER_WIN_MARGIN, (float)(G.W - 1))));
                     const int Ihi = __builtin_amdgcn_readfirstlane((int)floorf(fminf(ic + hi + P.gr0 + GATHER_WIN_MARGIN, (float)(G.H - 1))));
                     const int fnr = Ihi - Ilo + 1;
-                    fnc = Jhi - Jlo + 1;
-                    const int total = fnr * fnc;
-                    if (fnr > 0 && fnc > 0 && total <= SG_FOOT) {
-                        staged = true;
+                    const int fw = Jhi - Jlo + 1;
+                    fnc = fw;        // row stride in the slice (an odd stride, rows starting in different banks, measured no faster)
+                    const int total = fnr * fw;
+                    if (fnr > 0 && fw > 0 && fnr * fnc <= SG_FOOT) {
+                        staged_v = true;
                         XVR_STAT(5, tid == 0 ? total : 0);
                         jlo = max(jlo, Jlo); jhi = min(jhi, Jhi); ilo = max(ilo, Ilo); ihi = min(ihi, Ihi);
-                        const float inc = __builtin_amdgcn_rcpf((float)fnc);   // ((f + 1/2) / fnc is at least 1 / (2 fnc) from an integer: 1 ulp is harmless)
+                        const float inc = __builtin_amdgcn_rcpf((float)fw);   // ((f + 1/2) / fw is at least 1 / (2 fw) from an integer: 1 ulp is harmless)
                         const float4* __restrict__ src = q + (size_t)Ilo * G.W + Jlo;
                         for (int f = tid; f < total; f += 64) {
-                            const int r = (int)(((float)f + 0.5f) * inc), c = f - r * fnc;
-                            foot[f] = src[(size_t)r * G.W + c];
+                            const int r = (int)(((float)f + 0.5f) * inc), c = f - r * fw;
+                            foot[r * fnc + c] = src[(size_t)r * G.W + c];
                         }
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
@@ -1179,6 +1180,7 @@ __global__ __launch_bounds__(FAST ? 256 : 64) __attribute__((amdgpu_waves_per_eu
             XVR_STAT(0, (ihi >= ilo && jhi >= jlo) ? 1 : 0);
             XVR_STAT(4, (ihi >= ilo && jhi >= jlo) ? (ihi - ilo + 1) * (jhi - jlo + 1) : 0);
             XVR_STAT_WAVE(7);
+            const bool staged = __builtin_amdgcn_readfirstlane((int)staged_v) != 0;   // (uniform: the brick and the pose decide)
             auto rows = [&](auto cut, auto sorted, auto from_lds) {
                 for (int i = ilo; i <= ihi; ++i) {
                     const float4* __restrict__ row = q + (size_t)i * G.W;
