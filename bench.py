@@ -66,8 +66,8 @@ BINDING = {
         ("fabric_bandwidth", 2.156e8 / (1.809e9 / 64), LINE_CLK, 1, "profiles/r04_fetch_calibration.txt x TCC_EA0_RDREQ"),
     ],
     "siddon_backward": [
-        ("valu_issue", 6.052e9 / (5.576e9 / 64), VALU_CLK, 4 * CUS, "profiles/r03_microbench_valu_issue.txt x SQ_INSTS_VALU (profiles/r04_siddon_rocprof_summary.md)"),
-        ("fabric_bandwidth", 1.25e8 / (5.576e9 / 64), LINE_CLK, 1, "profiles/r04_fetch_calibration.txt x TCC_EA0_RDREQ"),
+        ("valu_issue", 5.95e9 / (5.576e9 / 64), VALU_CLK, 4 * CUS, "profiles/r03_microbench_valu_issue.txt x SQ_INSTS_VALU (profiles/r04_siddon_rocprof_summary.md)"),
+        ("fabric_bandwidth", 9.216e7 / (5.576e9 / 64), LINE_CLK, 1, "profiles/r04_fetch_calibration.txt x TCC_EA0_RDREQ"),
     ],
     "siddon_forward+jac": [
         ("valu_issue", 3.258e9 / (5.576e9 / 64), VALU_CLK, 4 * CUS, "profiles/r03_microbench_valu_issue.txt x SQ_INSTS_VALU (profiles/r04_siddon_rocprof_summary.md)"),

@@ -388,7 +388,11 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, XVR_SLAB_
     // beyond the buffer and gets 0 back WITHOUT a memory request -- predication with no exec-mask branch, so the three loads of a
     // slab are issued back to back (with branches the compiler chains each load behind its predecessor's select).
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vol), (short)0, vol_bytes, 0x00020000);
+#if defined(XVR_SLAB_ABLATE)   // diagnostic build only (tools/ablate_siddon_slab.py): voxel values made up from the offset, no loads -- WRONG image
+    auto ld = [&](bool p, int o) { return p ? __int_as_float(0x3f000000 | (o & 0xffff)) : 0.f; };
+#else
     auto ld = [&](bool p, int o) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, p ? o : -1, 0, 0)); };
+#endif
     // the first voxel's value opens the walk: the entry crossing (on axis ax_in, when the ray enters through a real plane) is
     // added after the loop, the loop's first "dominant-axis crossing" then sees no jump
     const bool walks = live && ahi > alo;
