@@ -384,9 +384,8 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, XVR_SLAB_
 
     float ac = alo, acc = 0.f;
     float Um = 0.f, Uu = 0.f, Uv = 0.f, Mm = 0.f, Mu = 0.f, Mv = 0.f;
-    // Loads go through a buffer resource over the volume: a lane whose segment has zero length hands the hardware an offset
-    // beyond the buffer and gets 0 back WITHOUT a memory request -- predication with no exec-mask branch, so the three loads of a
-    // slab are issued back to back (with branches the compiler chains each load behind its predecessor's select).
+    // Loads go through a buffer resource over the volume (an offset beyond it returns 0 without a memory request: the bounds net);
+    // the three loads of a slab are predicated in EXEC, see the loop.
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vol), (short)0, vol_bytes, 0x00020000);
 #if defined(XVR_SLAB_ABLATE)   // diagnostic build only (tools/ablate_siddon_slab.py): voxel values made up from the offset, no loads -- WRONG image
     auto ld = [&](bool p, int o) { return p ? __int_as_float(0x3f000000 | (o & 0xffff)) : 0.f; };
@@ -431,14 +430,50 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, XVR_SLAB_
             off_next = off3 + sm;
         }
         const bool p1 = l1 > 0.f, p2 = l2 > 0.f, p3 = l3 > 0.f;
-        const float t1 = ld(p1, off), t2 = ld(p2, off2), t3 = ld(p3, off3);
+#if !defined(XVR_SLAB_ABLATE)
+        // The three loads of a slab under EXEC masks, back to back, in one asm block (written as branches the compiler chains each
+        // load behind its predecessor's select).  A lane without the segment costs the texture-address unit nothing this way.
+        // Until late in round 4 such a lane passed the buffer resource an out-of-range offset instead (0 back, no memory
+        // request, no branch) -- not free: tools/microbench/ta_masked_loads.hip measures 32 clocks of the TA for a wavefront
+        // load of 40 live lanes in 8 lines with 24 out-of-range lanes against 8 with those lanes masked in EXEC, 39 % of the
+        // march's lanes are such lanes, and it ran with TA_BUSY at 85 %: 5.87 -> 5.00 ms.  (Letting them re-load the ray's
+        // current voxel -- a valid address in a line the wavefront fetches anyway -- was worse: 7.1 ms.)  The registers of
+        // masked lanes keep whatever they held: every use below is behind the segment's predicate.  The buffer resource
+        // stays as the bounds net.
+        float t1, t2, t3;
+        {
+            const unsigned long long m1 = __builtin_amdgcn_ballot_w64(p1), m2 = __builtin_amdgcn_ballot_w64(p2), m3 = __builtin_amdgcn_ballot_w64(p3);
+            unsigned long long sv;
+            asm volatile("s_mov_b64 %[sv], exec\n\t"
+                         "s_and_b64 exec, %[sv], %[m1]\n\t"
+                         "buffer_load_dword %[t1], %[o1], %[rs], 0 offen\n\t"
+                         "s_and_b64 exec, %[sv], %[m2]\n\t"
+                         "buffer_load_dword %[t2], %[o2], %[rs], 0 offen\n\t"
+                         "s_and_b64 exec, %[sv], %[m3]\n\t"
+                         "buffer_load_dword %[t3], %[o3], %[rs], 0 offen\n\t"
+                         "s_mov_b64 exec, %[sv]"
+                         : [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [sv] "=&s"(sv)
+                         : [o1] "v"(off), [o2] "v"(off2), [o3] "v"(off3), [rs] "s"(rsrc), [m1] "s"(m1), [m2] "s"(m2), [m3] "s"(m3)
+                         : "memory");
+        }
+#define XVR_SLAB_WAIT_LOADS() asm volatile("s_waitcnt vmcnt(0)" : "+v"(t1), "+v"(t2), "+v"(t3))
+#else
+        float t1 = ld(p1, off), t2 = ld(p2, off2), t3 = ld(p3, off3);
+#define XVR_SLAB_WAIT_LOADS() ((void)0)
+#endif
         if (A.work) cnt += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(p1)) + (unsigned)__popcll(__builtin_amdgcn_ballot_w64(p2)) +
                            (unsigned)__popcll(__builtin_amdgcn_ballot_w64(p3));
-        acc = fmaf(t1, l1, acc);                                // (a masked load returns 0 and its length is 0)
-        acc = fmaf(t2, l2, acc);
-        acc = fmaf(t3, l3, acc);
+        XVR_SLAB_WAIT_LOADS();
+        if (!JAC) {
+            acc = fmaf(p1 ? t1 : 0.f, l1, acc);
+            acc = fmaf(p2 ? t2 : 0.f, l2, acc);
+            acc = fmaf(p3 ? t3 : 0.f, l3, acc);
+        }
         if (JAC) {
             const float v1 = p1 ? t1 : Wprev, v2 = p2 ? t2 : v1, v3 = p3 ? t3 : v2;
+            acc = fmaf(v1, l1, acc);                            // (a zero-length segment repeats its predecessor's value, times 0)
+            acc = fmaf(v2, l2, acc);
+            acc = fmaf(v3, l3, acc);
             const float Jm = Wprev - v1, J1 = v1 - v2, J2 = v2 - v3;   // jumps at the slab's entry plane, at lo, at hi
             const float Ju = uf ? J1 : J2, Jv = uf ? J2 : J1;
             Um = fmaf(Jm, ac, Um); Mm += Jm;
