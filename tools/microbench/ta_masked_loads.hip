@@ -12,17 +12,19 @@
 #include <stdlib.h>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
-template <int MODE>   // 0 full / lines, 1 oob, 2 exec
+template <int MODE>   // 0 full / lines, 1 oob, 2 exec, 3 full with the lanes' dwords scattered inside their lines
 __global__ __launch_bounds__(256) void k(const float* buf, unsigned bytes, int iters, int live_of_8, int line_shift, float* out) {
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(buf), (short)0, bytes, 0x00020000);
     const int lane = threadIdx.x & 63;
     const bool live = (lane & 7) < live_of_8;
     int off = ((lane >> line_shift) << 7) + ((lane & 3) << 2) + (blockIdx.x & 1) * 8192;   // one 128-byte line per lane (or per 2^line_shift lanes)
+    if (MODE == 3) off = ((lane >> line_shift) << 7) + (((lane * 13) & 31) << 2) + (blockIdx.x & 1) * 8192;   // any of the line's 32 dwords
+    if (MODE == 4) off = ((lane >> line_shift) << 7) + (((lane * 13) & 7) << 4) + (blockIdx.x & 1) * 8192;    // any of the line's eight 16-byte pieces
     float acc = 0.f;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int o = (off + u * 16) & 16383;
+            const int o = MODE >= 3 ? ((off & ~127) + ((off + u * 20) & 127)) & 16383 : (off + u * 16) & 16383;
             if (MODE == 1) acc += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, live ? o : -1, 0, 0));
             else if (MODE == 2) { if (live) acc += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, o, 0, 0)); }
             else acc += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, o, 0, 0));
@@ -54,6 +56,9 @@ int main() {
     run<0>(buf, out, 8, 2, "full, 16 lines");
     run<0>(buf, out, 8, 3, "full, 8 lines");
     run<0>(buf, out, 8, 4, "full, 4 lines");
+    run<3>(buf, out, 8, 3, "full, 8 lines, scattered dwords");
+    run<3>(buf, out, 8, 2, "full, 16 lines, scattered dwords");
+    run<4>(buf, out, 8, 3, "full, 8 lines, scattered 16-B pieces");
     run<1>(buf, out, 5, 3, "oob, 5 of 8 lanes live, 8 lines");
     run<2>(buf, out, 5, 3, "exec, 5 of 8 lanes live, 8 lines");
     run<1>(buf, out, 2, 3, "oob, 2 of 8 lanes live, 8 lines");

@@ -463,6 +463,13 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, XVR_SLAB_
 #endif
         if (A.work) cnt += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(p1)) + (unsigned)__popcll(__builtin_amdgcn_ballot_w64(p2)) +
                            (unsigned)__popcll(__builtin_amdgcn_ballot_w64(p3));
+        // (what does not need the loaded values, while they are in flight)
+        const float ac0 = ac;
+        fpu += cu ? stu : 0.f;
+        fpv += cv ? stv : 0.f;
+        fpm += stm;
+        off = off_next;
+        ac = aend;
         XVR_SLAB_WAIT_LOADS();
         if (!JAC) {
             acc = fmaf(p1 ? t1 : 0.f, l1, acc);
@@ -476,16 +483,11 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, XVR_SLAB_
             acc = fmaf(v3, l3, acc);
             const float Jm = Wprev - v1, J1 = v1 - v2, J2 = v2 - v3;   // jumps at the slab's entry plane, at lo, at hi
             const float Ju = uf ? J1 : J2, Jv = uf ? J2 : J1;
-            Um = fmaf(Jm, ac, Um); Mm += Jm;
+            Um = fmaf(Jm, ac0, Um); Mm += Jm;
             Uu = fmaf(Ju, au, Uu); Mu += Ju;
             Uv = fmaf(Jv, av, Uv); Mv += Jv;
             Wprev = v3;
         }
-        fpu += cu ? stu : 0.f;
-        fpv += cv ? stv : 0.f;
-        fpm += stm;
-        off = off_next;
-        ac = aend;
     } while (__builtin_amdgcn_ballot_w64(ac < ahi));
 
     if (valid) {
