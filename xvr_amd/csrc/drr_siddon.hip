@@ -454,7 +454,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, XVR_SLAB_
                          "s_mov_b64 exec, %[sv]"
                          : [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [sv] "=&s"(sv)
                          : [o1] "v"(off), [o2] "v"(off2), [o3] "v"(off3), [rs] "s"(rsrc), [m1] "s"(m1), [m2] "s"(m2), [m3] "s"(m3)
-                         : "memory");
+                         : "memory", "scc");
         }
 #define XVR_SLAB_WAIT_LOADS() asm volatile("s_waitcnt vmcnt(0)" : "+v"(t1), "+v"(t2), "+v"(t3))
 #else
