@@ -99,7 +99,7 @@ const char* xvr_drr_last_error(void);
  *   "siddon_gather_fast" 1 | 0 Siddon voxel gather: pixel window from one projection of the block centre, four bricks along the
  *                              viewing axis per workgroup, candidates from an LDS copy of the brick's footprint, planes in
  *                              crossing order | the window of the eight projected corners, one brick per workgroup,
- *                              candidates from global memory (A/B: identical bits)                              [1]
+ *                              candidates from global memory (A/B: equal to rounding)                           [1]
  * Returns XVR_DRR_E_ARG for an unknown name or a value outside the option's range.
  */
 int xvr_drr_set_option(const char* name, int value);

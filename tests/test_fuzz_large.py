@@ -19,7 +19,7 @@ the HIP kernels are (tools/_build/diag_large.py printed them: e.g. d out / d tar
 float32 oracle), -0.17 (float64 oracle) for a ray with d = (-5, 402, -22)).  On the two seeds with most such rays (16 and 26 of 1.3e5 beyond 2e-3 against the float32
 oracle) the HIP kernels agree with the float64 oracle to 1e-8 on two thirds of them and the float32 oracle does not.  So the
 reference here is the oracle run in FLOAT64, the per-ray gradients are held to the tolerance on ALL BUT 16 RAYS per case (1e-4 of
-them), the source gradient -- the sum over a pose's rays, which inherits those rays -- to 2e-2, and the image and the voxel
+them; or as many as the float32 oracle itself has beyond the tolerance of its float64 run, where that is more), the source gradient -- the sum over a pose's rays, which inherits those rays -- to 2e-2, and the image and the voxel
 gradient to the suite's tolerances in the maximum norm."""
 import numpy as np
 import pytest
@@ -32,33 +32,44 @@ pytestmark = pytest.mark.gpu
 MAX_OUTLIER_RAYS = 16
 
 
-def _close_rays(a, b, tol, what):
-    """Per-ray gradients [B, n, 3] or [B, 1, n]: relative to the largest reference entry, within tol on all but a few rays."""
+def _outlier_rays(a, b, tol):
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     if a.dim() == 3 and a.shape[1] == 1:
         a, b = a[:, 0, :, None], b[:, 0, :, None]
     err = (a - b).abs().amax(dim=-1) / max(b.abs().max().item(), 1e-12)
-    bad = int((err > tol).sum())
-    assert bad <= MAX_OUTLIER_RAYS, f"{what}: {bad} of {err.numel()} rays beyond {tol:.1e} (max {err.max().item():.3e})"
+    return int((err > tol).sum()), err.numel(), err.max().item()
 
 
-def _oracle64(case, spec, w):
-    """The torch oracle in float64: (out, grad_volume, grad_source, grad_target, grad_img)."""
+def _close_rays(a, b, tol, what, b32):
+    """Per-ray gradients [B, n, 3] or [B, 1, n]: relative to the largest reference entry, within tol on all but a few rays -- 16, or as
+    many as the float32 oracle itself has beyond tol of its float64 run where a case has more of them (a fresh seed with 21 such rays
+    for the HIP kernels had 49 for the float32 oracle)."""
+    bad, n, worst = _outlier_rays(a, b, tol)
+    allowed = max(MAX_OUTLIER_RAYS, _outlier_rays(b32, b, tol)[0])
+    assert bad <= allowed, f"{what}: {bad} of {n} rays beyond {tol:.1e} (max {worst:.3e}; allowed {allowed})"
+
+
+def _oracle(case, spec, w, dtype):
+    """The torch oracle in float64 / float32: (out, grad_volume, grad_source, grad_target, grad_img)."""
     from conftest import to_oracle_spec
     from oracle.diffdrr_restated import render
 
-    vol, src, tgt, img = (case[k].double().requires_grad_(True) for k in ("volume", "source", "target", "img"))
+    vol, src, tgt, img = (case[k].to(dtype).requires_grad_(True) for k in ("volume", "source", "target", "img"))
     out = render(vol, src, tgt, img, to_oracle_spec(spec), None)
-    (out * w.double()).sum().backward()
+    (out * w.to(dtype)).sum().backward()
     return out.detach(), vol.grad, src.grad, tgt.grad, img.grad
 
 
-def _check_grads(hip, ref):
-    """(grad_volume, grad_source, grad_target, grad_img) of the HIP path against the oracle's."""
+def _oracle64(case, spec, w):
+    return _oracle(case, spec, w, torch.float64)
+
+
+def _check_grads(hip, ref, ref32):
+    """(grad_volume, grad_source, grad_target, grad_img) of the HIP path against the float64 oracle's (ref32: the float32 oracle's)."""
     _close(hip[0], ref[0], GRAD_TOL, "grad_volume")
     _close(hip[1], ref[1], 2e-2, "grad_source")
-    _close_rays(hip[2], ref[2], GRAD_TOL, "grad_target")
-    _close_rays(hip[3], ref[3], GRAD_TOL, "grad_img")
+    _close_rays(hip[2], ref[2], GRAD_TOL, "grad_target", ref32[2])
+    _close_rays(hip[3], ref[3], GRAD_TOL, "grad_img", ref32[3])
 
 
 def _smooth(shape, seed):
@@ -104,7 +115,7 @@ def test_large_siddon_launch_against_the_oracle(seed):
     assert torch.equal(hip[0], again[0]) and torch.equal(hip[1], again[1])          # image and voxel gradient: deterministic
     ref = _oracle64(case, spec, wgt)
     _close(hip[0], ref[0], FWD_TOL, "out")
-    _check_grads(hip[1:], ref[1:])
+    _check_grads(hip[1:], ref[1:], _oracle(case, spec, wgt, torch.float32)[1:])
 
 
 @pytest.mark.parametrize("seed", range(10))
@@ -132,4 +143,4 @@ def test_large_trilinear_launch_on_the_tiled_copy_against_the_oracle(seed):
     assert torch.equal(first, out.detach())                                          # the copy changes no bit
     ref = _oracle64(case, spec, wgt)
     _close(out, ref[0], FWD_TOL, "out")
-    _check_grads((vol.grad, src.grad, tgt.grad, img.grad), ref[1:])
+    _check_grads((vol.grad, src.grad, tgt.grad, img.grad), ref[1:], _oracle(case, spec, wgt, torch.float32)[1:])

@@ -580,7 +580,7 @@ def test_siddon_voxel_gather_with_source_inside_the_volume():
 def test_siddon_gather_one_projection_window_equals_the_projected_corners_window(seed):
     """k_siddon_gather_vol2<true> (default) bounds a voxel block's pixel window from ONE projection of its centre,
     |j - jc| <= sum_k |ec_k - jc en_k| / alpha_min; option siddon_gather_fast = 0 keeps the bounding box of the eight projected
-    corners.  Extra candidates contribute exact zeros and the sums run in the same order, so the two must agree BIT FOR BIT
+    corners.  Extra candidates contribute exact zeros, so the two must agree to the rounding of the sums
     -- on oblique poses, magnified / minified detectors and a source inside the volume alike."""
     from xvr_amd import _lib
     from xvr_amd.spec import RenderSpec
@@ -600,7 +600,9 @@ def test_siddon_gather_one_projection_window_equals_the_projected_corners_window
     with _lib.option("siddon_gather_fast", 0):
         corners = _hip_render(case, spec, grid_w=wd, grads=True, w=w)[1]
     assert fast.abs().max() > 0
-    assert torch.equal(fast, corners), f"max diff {(fast - corners).abs().max().item():.3e}"
+    # (bit for bit until the default kernel began to keep 3-D prefix sums of a block's eight sums on sign-sorted visits, taking
+    #  differences when a block's orientation changes: the same candidates, other roundings -- a few ulp of the block's largest sum)
+    _close(fast, corners, 1e-5, "one-projection window / LDS candidates / prefix sums vs the round-3 structure")
     _close(fast, _oracle_render(case, spec, grads=True, w=w)[1], GRAD_TOL, "grad_volume vs oracle")
 
 

@@ -981,6 +981,9 @@ __device__ __forceinline__ float min_raw(float a, float b) { float r; asm("v_min
 //     one-projection bound, a few coalesced loads -- into its slice of LDS and the lanes read their candidates with
 //     ds_read_b128.  Footprints beyond the slice (SG_FOOT pixels), bricks that reach the source plane and poses with cut rays
 //     take the global loads as before.
+#ifndef XVR_SG_CUM     // 1: sign-sorted visits accumulate 3-D prefix sums of the eight sums (see the candidate)
+#define XVR_SG_CUM 1
+#endif
 #ifndef XVR_SG_FOOT
 #define XVR_SG_FOOT 480
 #endif
@@ -1049,6 +1052,23 @@ __global__ __launch_bounds__(FAST ? 256 : 64) __attribute__((amdgpu_waves_per_eu
                     acc[e | bit] = sw ? lo_ : hi_;
                 }
         }
+    };
+    bool cum = false;   // (uniform) acc holds the 3-D prefix sums of the eight sums, in the orientation `cur`
+    auto to_cum = [&]() {
+#pragma unroll
+        for (int bit = 1; bit <= 4; bit <<= 1)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (e & bit) acc[e] += acc[e ^ bit];
+        cum = true;
+    };
+    auto to_chords = [&]() {
+#pragma unroll
+        for (int bit = 1; bit <= 4; bit <<= 1)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (e & bit) acc[e] -= acc[e ^ bit];
+        cum = false;
     };
 #ifdef XVR_GATHER_STATS   // 0 (lane, pose) visits with a window . 2 wavefront rows . 4 candidates . 6 wavefront trips . 7 wavefront visits
     unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1165,6 +1185,21 @@ __global__ __launch_bounds__(FAST ? 256 : 64) __attribute__((amdgpu_waves_per_eu
                 }
                 const float yl[2] = {SORTED ? y0 : min_raw(y0, y1), SORTED ? y1 : min_raw(y1, y2)}, yh[2] = {SORTED ? y1 : max_raw(y0, y1), SORTED ? y2 : max_raw(y1, y2)};
                 const float zl[2] = {SORTED ? z0 : min_raw(z0, z1), SORTED ? z1 : min_raw(z1, z2)}, zh[2] = {SORTED ? z1 : max_raw(z0, z1), SORTED ? z2 : max_raw(z1, z2)};
+#if XVR_SG_CUM
+                if (SORTED) {
+                    // planes in crossing order: the ray is inside {x < x_i, y < y_j, z < z_k} from its entry into the block to the first
+                    // of the three planes -- nested prefixes of one ray.  Their lengths are the 3-D PREFIX SUMS of the eight chords, so the
+                    // lane keeps prefix sums (one entry alpha for all eight, no per-voxel max3) and takes the differences when the
+                    // orientation changes: 25 instead of 32 vector instructions per candidate
+                    const float en = max3_raw(xl[0], yl[0], zl[0]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int a = e >> 2, b = (e >> 1) & 1, c = e & 1;
+                        acc[e] = fmaf(__builtin_amdgcn_fmed3f(min3_raw(xh[a], yh[b], zh[c]) - en, 0.f, 1.f), t.w, acc[e]);
+                    }
+                    return;
+                }
+#endif
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int a = e >> 2, b = (e >> 1) & 1, c = e & 1;
@@ -1232,7 +1267,15 @@ __global__ __launch_bounds__(FAST ? 256 : 64) __attribute__((amdgpu_waves_per_eu
             if (FAST && __builtin_amdgcn_ballot_w64(!same_way) == 0ull) { XVR_STAT_WAVE(3); }
 #endif
             if (FAST && __builtin_amdgcn_ballot_w64(!same_way) == 0ull) {
+#if XVR_SG_CUM
+                if (__builtin_amdgcn_ballot_w64(cur != mask) != 0ull) {   // (uniform) some lane turns its block around
+                    if (cum) to_chords();
+                    permute(cur ^ mask);
+                }
+                if (!cum) to_cum();
+#else
                 permute(cur ^ mask);
+#endif
                 cur = mask;
                 if (mask & 4u) { const float t_ = lx[0]; lx[0] = lx[2]; lx[2] = t_; }
                 if (mask & 2u) { const float t_ = ly[0]; ly[0] = ly[2]; ly[2] = t_; }
@@ -1242,6 +1285,7 @@ __global__ __launch_bounds__(FAST ? 256 : 64) __attribute__((amdgpu_waves_per_eu
                 else if (cut_rays) rows(std::true_type{}, std::true_type{}, std::false_type{});
                 else rows(std::false_type{}, std::true_type{}, std::false_type{});
             } else {   // (rare: a lane's window straddles a sign change -- one body for it)
+                if (cum) to_chords();
                 permute(cur);
                 cur = 0u;
                 if (staged) rows(std::true_type{}, std::false_type{}, std::true_type{});
@@ -1250,6 +1294,7 @@ __global__ __launch_bounds__(FAST ? 256 : 64) __attribute__((amdgpu_waves_per_eu
             if (FAST) __builtin_amdgcn_wave_barrier();   // (the slice is overwritten by the next visit)
         }
     }
+    if (cum) to_chords();
     permute(cur);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
