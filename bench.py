@@ -66,8 +66,8 @@ BINDING = {
         ("fabric_bandwidth", 2.156e8 / (1.809e9 / 64), LINE_CLK, 1, "profiles/r04_fetch_calibration.txt x TCC_EA0_RDREQ"),
     ],
     "siddon_backward": [
-        ("valu_issue", 5.95e9 / (5.576e9 / 64), VALU_CLK, 4 * CUS, "profiles/r03_microbench_valu_issue.txt x SQ_INSTS_VALU (profiles/r04_siddon_rocprof_summary.md)"),
-        ("fabric_bandwidth", 9.216e7 / (5.576e9 / 64), LINE_CLK, 1, "profiles/r04_fetch_calibration.txt x TCC_EA0_RDREQ"),
+        ("valu_issue", 5.399e9 / (5.576e9 / 64), VALU_CLK, 4 * CUS, "profiles/r03_microbench_valu_issue.txt x SQ_INSTS_VALU (profiles/r04_siddon_rocprof_summary.md)"),
+        ("fabric_bandwidth", 9.109e7 / (5.576e9 / 64), LINE_CLK, 1, "profiles/r04_fetch_calibration.txt x TCC_EA0_RDREQ"),
     ],
     "siddon_forward+jac": [
         # TA_BUSY of the committed PMC pass: 9.8e6 clocks of every CU's texture-address unit per C3 launch (three scattered 4-byte
