@@ -15,7 +15,7 @@ different one-sided derivatives for that ray.  On white-noise volumes (the small
 rays in the maximum norm, for either implementation.  On a smooth field a handful of rays per case remain -- rays that graze a
 plane family (d_x / |d| ~ 1e-2: the crossing alpha is ill-conditioned) or enter through an edge of the volume; measured on ten
 seeds: 1-4 of 1.8e5 rays beyond 2e-3, and on every one of them the float32 torch oracle is as far from its own float64 run as
-the HIP kernels are (tools/_build/diag_large.py printed them: e.g. d out / d target_x = 0.00 (slab march), 4.51 (merge walk and
+the HIP kernels are (tools/diag_fuzz_large.py prints them: e.g. d out / d target_x = 0.00 (slab march), 4.51 (merge walk and
 float32 oracle), -0.17 (float64 oracle) for a ray with d = (-5, 402, -22)).  On the two seeds with most such rays (16 and 26 of 1.3e5 beyond 2e-3 against the float32
 oracle) the HIP kernels agree with the float64 oracle to 1e-8 on two thirds of them and the float32 oracle does not.  So the
 reference here is the oracle run in FLOAT64, the per-ray gradients are held to the tolerance on ALL BUT 16 RAYS per case (1e-4 of
