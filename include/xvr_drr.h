@@ -65,7 +65,7 @@ typedef struct xvr_drr_spec {
                               lanes are mapped to 8x8 pixel tiles; 0: rays are mapped linearly             */
     int32_t volume_layout; /* forward only: 0 = `volume` is [D0][D1][D2]; 1 (trilinear) = it is the y-pair interleaved
                               copy written by xvr_drr_pack_ypairs; 2 (siddon) = the 4 x 2 x 4 bricks written by
-                              xvr_drr_pack_bricks; 3 (trilinear) = the y-pair copy in 4 x 4 tiles written by
+                              xvr_drr_pack_bricks; 3 (trilinear) = the y-pair copy in 2 x 8 tiles written by
                               xvr_drr_pack_ytiles (same results, bit for bit)                               */
     const float* alpha_window; /* clip_to_volume == 2: device buffer of xvr_drr_alpha_window_bytes(B) bytes, 16-byte aligned, written by
                               xvr_drr_alpha_window() on the same stream before the render (the kernels read the call's
@@ -270,11 +270,11 @@ int xvr_drr_pack_ypairs(const float* volume, int D0, int D1, int D2, float* pair
 /* The y-pair copy of the LABEL-CARRYING volume (xvr_drr_pack_labels then xvr_drr_pack_ypairs) in one pass over volume and mask:
  * for masked renders of large launches whose volume is new every call (xvr's training step, trainer.py:185-230). */
 int xvr_drr_pack_labels_ypairs(const float* volume, const float* mask, int D0, int D1, int D2, float* pairs, void* stream);
-/* The same y-pairs cut into 128-byte lines of 4 x-rows x 4 z-entries, tiles [ceil(D0 / 4)][D1 + 1][(D2 - 2) / 3 + 1][4][4][2] that
- * OVERLAP by one entry along z (tile b holds z = 3 b .. 3 b + 3: the 16 bytes of any (z, z + 1) pair lie in one tile), for
+/* The same y-pairs cut into 128-byte lines of 2 x-rows x 8 z-entries, tiles [ceil(D0 / 2)][D1 + 1][(D2 - 2) / 7 + 1][2][8][2] that
+ * OVERLAP by one entry along z (tile b holds z = 7 b .. 7 b + 7: the 16 bytes of any (z, z + 1) pair lie in one tile), for
  * volume_layout = 3 (round 4).  The forward is bound by fabric bandwidth, one 128-byte line per L2 miss whatever part is used
- * (profiles/r04_fetch_calibration.txt); an oblique view cuts a z-run of 16 entries after ~2 voxels, a 4 x 4 tile is used two to
- * three times as densely.  4/3 of the row copy's memory; same results, bit for bit. */
+ * (profiles/r04_fetch_calibration.txt); an oblique view cuts a z-run of 16 entries after ~2 voxels, a compact tile is used more
+ * densely.  8/7 of the row copy's memory; same results, bit for bit.  D2 < 8192. */
 size_t xvr_drr_ytiles_bytes(int D0, int D1, int D2);
 int xvr_drr_pack_ytiles(const float* volume, int D0, int D1, int D2, float* tiles, void* stream);
 int xvr_drr_pack_labels_ytiles(const float* volume, const float* mask, int D0, int D1, int D2, float* tiles, void* stream);

@@ -749,11 +749,11 @@ static int trilinear_forward_impl(const float* volume, const float* mask, int D0
     if (sp->alpha_window && jac && (mask || packed))
         return fail(XVR_DRR_E_UNSUPPORTED, "clip_to_volume == 2: the jacobian is implemented for one channel");
     if (sp->volume_layout != 0 && sp->volume_layout != 1 && sp->volume_layout != 3) return fail(XVR_DRR_E_ARG, "unknown volume_layout");
-    const bool ypl = sp->volume_layout == 1 || sp->volume_layout == 3;   // a y-pair copy: rows (1) or 4 x 4 tiles (3)
+    const bool ypl = sp->volume_layout == 1 || sp->volume_layout == 3;   // a y-pair copy: rows (1) or 2 x 8 tiles (3)
     if (ypl && mask) return fail(XVR_DRR_E_UNSUPPORTED, "the y-pair layouts take labels packed into the volume, not a mask volume");
     if (sp->volume_layout == 1 && (long long)D0 * (D1 + 1) * D2 * 2 >= (1LL << 31))
         return fail(XVR_DRR_E_UNSUPPORTED, "y-pair copy has >= 2^31 elements");
-    if (sp->volume_layout == 3 && ((long long)((D0 + 3) / 4) * (D1 + 1) * ((D2 - 2) / 3 + 1) * 32 >= (1LL << 31) || D2 >= 98304))
+    if (sp->volume_layout == 3 && ((long long)((D0 + 1) / 2) * (D1 + 1) * ((D2 - 2) / 7 + 1) * 32 >= (1LL << 31) || D2 >= 8192))
         return fail(XVR_DRR_E_UNSUPPORTED, "tiled y-pair copy has >= 2^31 elements");
     RenderArgs A;
     fill_args(A, volume, mask, D0, D1, D2, C, source, target, raylen, B, n, sp, cam);

@@ -189,31 +189,32 @@ __global__ __launch_bounds__(TB) void k_pack_ypairs(const float* __restrict__ vo
     }
 }
 
-// tiles[x / 4][yp][z / 3][x % 4][z - 3 (z / 3) in 0..3] = (V[x][yp - 1][z], V[x][yp][z]): the y-pair copy cut into 128-byte lines of
-// 4 x-rows x 4 z-entries, the tiles OVERLAPPING by one entry along z (tile b holds z = 3 b .. 3 b + 3), so that the 16 bytes of any
-// (z, z + 1) pair lie inside one tile -- a third more memory than the row layout.  A planar patch of samples cuts z-runs of 16
-// entries after ~2 voxels when the view is oblique; a 4 x 4 tile of the same 128 bytes is used two to three times as densely
-// (tools/sim_forward_lines.py: 0.146 lines per sample against 0.222).  One thread per row of a tile: two 16-byte stores.
+// tiles[x / 2][yp][z / 7][x % 2][z - 7 (z / 7) in 0..7] = (V[x][yp - 1][z], V[x][yp][z]): the y-pair copy cut into 128-byte lines of
+// 2 x-rows x 8 z-entries, the tiles OVERLAPPING by one entry along z (tile b holds z = 7 b .. 7 b + 7), so that the 16 bytes of any
+// (z, z + 1) pair lie inside one tile -- a seventh more memory than the row layout.  A planar patch of samples cuts z-runs of 16
+// entries after ~2 voxels when the view is oblique; a compact tile of the same 128 bytes is used more densely
+// (tools/sim_forward_lines.py).  Until late in round 4 the tiles were 4 x 4 at stride 3 (a third more memory): the forward is
+// bound by fabric lines, and the 2 x 8 tiles need fewer of them per voxel -- 5.23 against 5.42 ms at C2.
 template <bool LABELS>
 __global__ __launch_bounds__(TB) void k_pack_ytiles(const float* __restrict__ vol, const float* __restrict__ mask, int D0, int D1, int D2,
                                                     float* __restrict__ tiles) {
     // one thread per 16 bytes of the copy (two z-entries of one tile row): consecutive threads write consecutive 16 bytes
-    const int nbx = (D0 + 3) >> 2, nbz = (D2 - 2) / 3 + 1;
+    const int nbx = (D0 + 1) >> 1, nbz = (D2 - 2) / 7 + 1;
     const long long total = (long long)nbx * (D1 + 1) * nbz * 8;
     auto pk = [](const float d, const float l) {
         const unsigned lab = (unsigned)min(max((int)l, 0), 15);
         return __uint_as_float((__float_as_uint(d) & ~15u) | lab);
     };
     for (long long t = (long long)blockIdx.x * TB + threadIdx.x; t < total; t += (long long)gridDim.x * TB) {
-        const int piece = (int)(t & 7), xr = piece >> 1, half = piece & 1;
+        const int piece = (int)(t & 7), xr = piece >> 2, quarter = piece & 3;
         const long long tile = t >> 3;
         const int bz = (int)(tile % nbz);
         const long long row = tile / nbz;
-        const int yp = (int)(row % (D1 + 1)), x = (int)(row / (D1 + 1)) * 4 + xr;
+        const int yp = (int)(row % (D1 + 1)), x = (int)(row / (D1 + 1)) * 2 + xr;
         float v[4];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const int z = 3 * bz + 2 * half + r;
+            const int z = 7 * bz + 2 * quarter + r;
             const bool in = x < D0 && z < D2;
             const long long olo = ((long long)x * D1 + (yp - 1)) * D2 + z, ohi = ((long long)x * D1 + yp) * D2 + z;
             v[2 * r] = in && yp >= 1 ? (LABELS ? pk(vol[olo], mask[olo]) : vol[olo]) : 0.f;
@@ -298,13 +299,13 @@ int xvr_drr_pack_labels_ypairs(const float* volume, const float* mask, int D0, i
 
 size_t xvr_drr_ytiles_bytes(int D0, int D1, int D2) {
     if (D0 <= 0 || D1 <= 0 || D2 < 2) return 0;
-    return (size_t)((D0 + 3) / 4) * (size_t)(D1 + 1) * (size_t)((D2 - 2) / 3 + 1) * 32 * sizeof(float);
+    return (size_t)((D0 + 1) / 2) * (size_t)(D1 + 1) * (size_t)((D2 - 2) / 7 + 1) * 32 * sizeof(float);
 }
 
 static int pack_ytiles_impl(const float* volume, const float* mask, int D0, int D1, int D2, float* tiles, void* stream_) {
     if (!volume || !tiles || D0 < 2 || D1 < 2 || D2 < 2) return vfail(XVR_DRR_E_ARG, "bad argument");
     if (reinterpret_cast<uintptr_t>(tiles) & 15u) return vfail(XVR_DRR_E_ARG, "the tiled copy must be 16-byte aligned");
-    const long long total = (long long)((D0 + 3) / 4) * (D1 + 1) * ((D2 - 2) / 3 + 1) * 8;   // 16-byte pieces
+    const long long total = (long long)((D0 + 1) / 2) * (D1 + 1) * ((D2 - 2) / 7 + 1) * 8;   // 16-byte pieces
     if (total * 4 >= (1LL << 31)) return vfail(XVR_DRR_E_UNSUPPORTED, "tiled y-pair copy has >= 2^31 elements");
     const long long blocks = (total + TB - 1) / TB;
     const dim3 grid((unsigned)(blocks < 65536 ? blocks : 65536));

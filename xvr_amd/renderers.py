@@ -199,7 +199,7 @@ def _packed_ypair_volume(lib, volume, mask):
 # its version counter, built the third time a version is rendered: see _ypair_volume).  False (or XVR_DRR_YPAIRS=0):
 # natural layout.
 YPAIR_LAYOUT = _os.environ.get("XVR_DRR_YPAIRS", "1") != "0"
-# ... and that copy is cut into 4 x 4 tiles overlapping along z (xvr_drr_pack_ytiles, volume_layout 3; round 4): the forward is
+# ... and that copy is cut into 2 x 8 tiles overlapping along z (xvr_drr_pack_ytiles, volume_layout 3; round 4): the forward is
 # bound by fabric bandwidth and a tile's 128 bytes are used two to three times as densely as a z-run's.  XVR_DRR_YTILES=0: rows.
 # The label-carrying copy of a training step is packed EVERY step (a fresh HU -> density map, rendered twice): there the tiled
 # copy's larger write (0.96 against 0.53 ms at 512^3) costs more than its two renders save (C5: 15.98 against 15.76 ms per step),
@@ -249,7 +249,7 @@ def _layout_copy(lib, volume, kind):
 
 
 def _ypair_volume(lib, volume):
-    """-> (copy or None, its volume_layout code: 3 = 4 x 4 tiles, 1 = rows)"""
+    """-> (copy or None, its volume_layout code: 3 = 2 x 8 tiles, 1 = rows)"""
     return _layout_copy(lib, volume, "ypairs"), (3 if YPAIR_TILES else 1)
 
 
@@ -270,7 +270,7 @@ def _use_bricks(spec, volume, B, n, C=1):
 def _use_ypairs(spec, volume, B, n):
     """(one channel, or labels packed into the volume's mantissa bits -- never with a separate mask volume)"""
     D0, D1, D2 = volume.shape
-    elements = ((D0 + 3) // 4) * (D1 + 1) * ((D2 - 2) // 3 + 1) * 32 if YPAIR_TILES else D0 * (D1 + 1) * D2 * 2
+    elements = ((D0 + 1) // 2) * (D1 + 1) * ((D2 - 2) // 7 + 1) * 32 if YPAIR_TILES else D0 * (D1 + 1) * D2 * 2
     return (YPAIR_LAYOUT and spec.renderer == "trilinear" and B * ((n + 63) // 64) >= YPAIR_MIN_WAVEFRONTS
             and elements < 2 ** 31 and min(D0, D1, D2) >= 2)
 
