@@ -50,7 +50,7 @@ BINDING = {
         # tools/microbench/lds_atomics.hip: a ds_add_u32 wavefront instruction costs >= 4.4 LDS clocks however few lanes are
         # live; 8 per sample; 54.3 of 64 lanes live
         ("lds_atomic_issue", 8 / (54.3 / 64), 4.4, CUS, "profiles/r02_microbench_lds_atomics.txt"),
-        ("valu_issue", 3.767e9 / (1.809e9 / 64), VALU_CLK, 4 * CUS, "profiles/r03_microbench_valu_issue.txt x SQ_INSTS_VALU (profiles/r04_trilinear_rocprof_summary.md)"),
+        ("valu_issue", 3.804e9 / (1.809e9 / 64), VALU_CLK, 4 * CUS, "profiles/r03_microbench_valu_issue.txt x SQ_INSTS_VALU (profiles/r04_trilinear_rocprof_summary.md)"),
         ("fabric_bandwidth", 6.038e7 / (1.809e9 / 64), LINE_CLK, 1, "profiles/r04_fetch_calibration.txt x TCC_EA0_RDREQ"),
     ],
     "trilinear_forward+jac": [
@@ -58,12 +58,12 @@ BINDING = {
         # two 16-byte gathers per sample (y-pair copy), ~3 lines by that estimate
         ("texture_address", 2, 36.0, CUS, "profiles/r01_microbench_gather_lines.txt"),
         ("valu_issue", 2.769e9 / (1.809e9 / 64), VALU_CLK, 4 * CUS, "profiles/r03_microbench_valu_issue.txt x SQ_INSTS_VALU (profiles/r04_trilinear_rocprof_summary.md)"),
-        ("fabric_bandwidth", 2.298e8 / (1.809e9 / 64), LINE_CLK, 1, "profiles/r04_fetch_calibration.txt x TCC_EA0_RDREQ"),
+        ("fabric_bandwidth", 2.049e8 / (1.809e9 / 64), LINE_CLK, 1, "profiles/r04_fetch_calibration.txt x TCC_EA0_RDREQ"),
     ],
     "trilinear_forward": [
         ("texture_address", 2, 36.0, CUS, "profiles/r01_microbench_gather_lines.txt"),
         ("valu_issue", 2.103e9 / (1.809e9 / 64), VALU_CLK, 4 * CUS, "profiles/r03_microbench_valu_issue.txt x SQ_INSTS_VALU (profiles/r04_trilinear_rocprof_summary.md)"),
-        ("fabric_bandwidth", 2.156e8 / (1.809e9 / 64), LINE_CLK, 1, "profiles/r04_fetch_calibration.txt x TCC_EA0_RDREQ"),
+        ("fabric_bandwidth", 1.956e8 / (1.809e9 / 64), LINE_CLK, 1, "profiles/r04_fetch_calibration.txt x TCC_EA0_RDREQ"),
     ],
     "siddon_backward": [
         ("valu_issue", 5.399e9 / (5.576e9 / 64), VALU_CLK, 4 * CUS, "profiles/r03_microbench_valu_issue.txt x SQ_INSTS_VALU (profiles/r04_siddon_rocprof_summary.md)"),
