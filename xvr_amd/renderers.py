@@ -201,11 +201,11 @@ def _packed_ypair_volume(lib, volume, mask):
 YPAIR_LAYOUT = _os.environ.get("XVR_DRR_YPAIRS", "1") != "0"
 # ... and that copy is cut into 2 x 8 tiles overlapping along z (xvr_drr_pack_ytiles, volume_layout 3; round 4): the forward is
 # bound by fabric bandwidth and a tile's 128 bytes are used two to three times as densely as a z-run's.  XVR_DRR_YTILES=0: rows.
-# The label-carrying copy of a training step is packed EVERY step (a fresh HU -> density map, rendered twice): there the tiled
-# copy's larger write (0.96 against 0.53 ms at 512^3) costs more than its two renders save (C5: 15.98 against 15.76 ms per step),
-# so it stays on rows unless XVR_DRR_YTILES_PACKED=1.
+# The label-carrying copy of a training step is packed EVERY step (a fresh HU -> density map, rendered twice).  With 4 x 4 tiles at
+# stride 3 the larger write (0.96 against 0.53 ms at 512^3) cost more than the two renders saved; with 2 x 8 tiles at stride 7 it
+# is 0.66 ms and the renders save 0.5 (C5: 15.46-15.69 against 15.65-15.81 ms per step): tiled too, unless XVR_DRR_YTILES_PACKED=0.
 YPAIR_TILES = _os.environ.get("XVR_DRR_YTILES", "1") != "0"
-YPAIR_TILES_PACKED = _os.environ.get("XVR_DRR_YTILES_PACKED", "0") != "0"
+YPAIR_TILES_PACKED = _os.environ.get("XVR_DRR_YTILES_PACKED", "1") != "0"
 YPAIR_MIN_WAVEFRONTS = 2048     # smaller launches take the sample-split kernels on the natural layout
 # Siddon's counterpart: 4 x 2 x 4-voxel bricks, one per cache line (xvr_drr_pack_bricks); same caching rule.  XVR_DRR_BRICKS=0: off.
 BRICK_LAYOUT = _os.environ.get("XVR_DRR_BRICKS", "1") != "0"
