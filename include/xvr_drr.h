@@ -64,7 +64,7 @@ typedef struct xvr_drr_spec {
     int32_t ray_grid_w;    /* >0: the n rays form an (n / ray_grid_w) x ray_grid_w row-major detector and
                               lanes are mapped to 8x8 pixel tiles; 0: rays are mapped linearly             */
     int32_t volume_layout; /* forward only: 0 = `volume` is [D0][D1][D2]; 1 (trilinear) = it is the y-pair interleaved
-                              copy written by xvr_drr_pack_ypairs; 2 (siddon) = the 4 x 2 x 4 bricks written by
+                              copy written by xvr_drr_pack_ypairs; 2 (siddon) = the 2 x 2 x 8 bricks written by
                               xvr_drr_pack_bricks; 3 (trilinear) = the y-pair copy in 2 x 8 tiles written by
                               xvr_drr_pack_ytiles (same results, bit for bit)                               */
     const float* alpha_window; /* clip_to_volume == 2: device buffer of xvr_drr_alpha_window_bytes(B) bytes, 16-byte aligned, written by
@@ -281,8 +281,8 @@ int xvr_drr_pack_labels_ytiles(const float* volume, const float* mask, int D0, i
 
 /*
  * Bricked copy of a volume for the Siddon forward (spec.volume_layout = 2):
- *     bricks[x / 4][y / 2][z / 4][x % 4][y % 2][z % 4],  zeros beyond the volume
- * i.e. one 128-byte cache line per 4 x 2 x 4 block of voxels; ceil(D0/4) ceil(D1/2) ceil(D2/4) 32 floats =
+ *     bricks[x / 2][y / 2][z / 8][x % 2][y % 2][z % 8],  zeros beyond the volume
+ * i.e. one 128-byte cache line per 2 x 2 x 8 block of voxels; ceil(D0/2) ceil(D1/2) ceil(D2/8) 32 floats =
  * xvr_drr_bricks_bytes().  The traversal is bound by the number of distinct lines one wavefront load touches (its 64 rays
  * sit at different depths): the bricks halve it (tools/sim_siddon_lines.py).  Same arithmetic, identical output bits.
  */

@@ -1684,7 +1684,7 @@ def test_voxel_gather_with_more_than_one_cull_word(renderer, B):
 @pytest.mark.parametrize("shape", [(40, 44, 48), (33, 31, 29)], ids=["even", "odd"])
 def test_bricked_volume_layout_is_bit_identical_for_siddon(kw, shape, slab, monkeypatch, request):
     """Large Siddon launches -- the slab march (default) and the merge walk (option siddon_slab = 0) alike -- take a
-    4 x 2 x 4-bricked copy of the volume (xvr_drr_pack_bricks, one brick per cache line).
+    2 x 2 x 8-bricked copy of the volume (xvr_drr_pack_bricks, one brick per cache line).
     Same traversal, same voxels: image and jacobian-borne pose gradients must be IDENTICAL to the natural layout's, bit for
     bit, also for sizes that do not fill the last bricks and with the labels packed into the taps."""
     from xvr_amd import _lib, renderers

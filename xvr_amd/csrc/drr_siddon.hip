@@ -40,7 +40,7 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAX : WG) __attribute__((amdgpu_
     const float* __restrict__ vol = A.volume;
     const int D0 = A.D0, D1 = A.D1, D2 = A.D2;
     constexpr bool bricked = BRICK;   // (forward, one channel, exact map, unsplit: the only instantiations)
-    const int nby = (D1 + 1) >> 1, nbz = (D2 + 3) >> 2;
+    const int nby = (D1 + 1) >> 1, nbz = (D2 + 7) >> 3;
     constexpr bool BWD = MODE == 2;
     constexpr bool DERIV = MODE == 1 || (BWD && GPOSE);
 
@@ -161,10 +161,10 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAX : WG) __attribute__((amdgpu_
         }
         const bool inb = (unsigned)ix < (unsigned)D0 && (unsigned)iy < (unsigned)D1 && (unsigned)iz < (unsigned)D2;
         const int off = inb ? (ix * D1 + iy) * D2 + iz : 0;
-        // volume_layout 2: 4 x 2 x 4 voxel bricks, one per 128-byte line (xvr_drr_pack_bricks) -- the lanes of a wavefront sit
+        // volume_layout 2: 2 x 2 x 8 voxel bricks, one per 128-byte line (xvr_drr_pack_bricks) -- the lanes of a wavefront sit
         // at different depths of neighbouring rays, and their voxels fall into half as many lines as in [x][y][z] rows
         const int voff = !bricked ? off
-                                  : (inb ? ((((ix >> 2) * nby + (iy >> 1)) * nbz + (iz >> 2)) << 5) + ((ix & 3) << 3) + ((iy & 1) << 2) + (iz & 3) : 0);
+                                  : (inb ? ((((ix >> 1) * nby + (iy >> 1)) * nbz + (iz >> 3)) << 5) + ((ix & 1) << 4) + ((iy & 1) << 3) + (iz & 7) : 0);
         const float v_new = vol[voff];                      // always loadable (offset 0 when outside)
         // MASK == 2: the label rides in the low mantissa bits of the voxel just loaded (xvr_drr_pack_labels)
         const float lab_new = MASK == 2 ? (float)(__float_as_uint(v_new) & LABEL_MASK) : (MASK ? A.mask[off] : 0.f);
@@ -304,7 +304,8 @@ __device__ __forceinline__ float sel3f(int k, float a, float b, float c) { retur
 __device__ __forceinline__ int sel3i(int k, int a, int b, int c) { return k == 0 ? a : (k == 1 ? b : c); }
 __device__ __forceinline__ float med3f(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
 
-// BRICK: the volume is the 4 x 2 x 4-bricked copy (xvr_drr_pack_bricks, one brick per 128-byte line).  On [x][y][z] rows a
+// BRICK: the volume is the 2 x 2 x 8-bricked copy (xvr_drr_pack_bricks, one brick per 128-byte line; 4 x 2 x 4 until late in round 4:
+// 5.03 against 4.84 ms -- the texture-address unit pays per line a wavefront load touches, and the longer z-run means fewer of them).  On [x][y][z] rows a
 // wavefront's 64 voxels of one slab sit in ~6 rows of which it uses a fifth, and the next slab (the usual dominant axis is y) is
 // another set of rows: 5.3e8 L1-miss lines per C3 launch (67 GB), 25 GB from the fabric.  A brick holds two slabs of a 4 x 4 patch.
 // The brick offset is separable, offset = fx(ix) + fy(iy) + fz(iz), so every axis keeps its own partial offset and replaces it
@@ -319,20 +320,20 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, XVR_SLAB_
     ray_setup(A, b, r, valid, R);
     const float* __restrict__ vol = A.volume;
     const int D[3] = {A.D0, A.D1, A.D2};
-    const int nby = (A.D1 + 1) >> 1, nbz = (A.D2 + 3) >> 2;
+    const int nby = (A.D1 + 1) >> 1, nbz = (A.D2 + 7) >> 3;
     const int tbase[3] = {1, A.D0 + 3, A.D0 + A.D1 + 5};                     // entry of index 0 of every axis' table
     if (BRICK) {
         const int total = A.D0 + A.D1 + A.D2 + 6;
         for (int e = threadIdx.x; e < total; e += WG) {
             const int ax = e < A.D0 + 2 ? 0 : (e < A.D0 + A.D1 + 4 ? 1 : 2);
             const int ic = min(max(e - tbase[ax], 0), D[ax] - 1);
-            const int f = ax == 0 ? (((ic >> 2) * nby * nbz) << 5) + ((ic & 3) << 3) : (ax == 1 ? (((ic >> 1) * nbz) << 5) + ((ic & 1) << 2) : ((ic >> 2) << 5) + (ic & 3));
+            const int f = ax == 0 ? (((ic >> 1) * nby * nbz) << 5) + ((ic & 1) << 4) : (ax == 1 ? (((ic >> 1) * nbz) << 5) + ((ic & 1) << 3) : ((ic >> 3) << 5) + (ic & 7));
             slab_tab[e] = (unsigned)f * 4u;
         }
         __syncthreads();
     }
     const int strd[3] = {A.D1 * A.D2 * 4, A.D2 * 4, 4};   // (natural layout; byte offsets: the buffer loads take them as they are)
-    const unsigned vol_bytes = BRICK ? (unsigned)((A.D0 + 3) >> 2) * (unsigned)nby * (unsigned)nbz * 128u
+    const unsigned vol_bytes = BRICK ? (unsigned)((A.D0 + 1) >> 1) * (unsigned)nby * (unsigned)nbz * 128u
                                      : (unsigned)A.D0 * (unsigned)A.D1 * (unsigned)A.D2 * 4u;
     const bool live = valid && (R.amax > R.amin);
     const float alo = live ? R.amin : 0.f;

@@ -224,16 +224,16 @@ __global__ __launch_bounds__(TB) void k_pack_ytiles(const float* __restrict__ vo
     }
 }
 
-// bricks[x / 4][y / 2][z / 4][x % 4][y % 2][z % 4]: one 128-byte line = a 4 x 2 x 4 block of voxels (zeros beyond the volume);
+// bricks[x / 2][y / 2][z / 8][x % 2][y % 2][z % 8]: one 128-byte line = a 2 x 2 x 8 block of voxels (zeros beyond the volume);
 // one thread per 4 z of one (x, y) = one 16-byte load (where aligned) and one 16-byte store
 __global__ __launch_bounds__(TB) void k_pack_bricks(const float* __restrict__ vol, int D0, int D1, int D2, float* __restrict__ bricks) {
-    const int nx = (D0 + 3) / 4, ny = (D1 + 1) / 2, nz = (D2 + 3) / 4;
-    const long long total = (long long)nx * ny * nz * 8;   // (x % 4, y % 2) rows of 4 z
+    const int nx = (D0 + 1) / 2, ny = (D1 + 1) / 2, nz = (D2 + 7) / 8;
+    const long long total = (long long)nx * ny * nz * 8;   // (x % 2, y % 2, half of the 8 z) pieces of 4 z
     for (long long t = (long long)blockIdx.x * TB + threadIdx.x; t < total; t += (long long)gridDim.x * TB) {
         const int row = (int)(t & 7);
         const long long blk = t >> 3;
         const int bz = (int)(blk % nz), by = (int)((blk / nz) % ny), bx = (int)(blk / ((long long)nz * ny));
-        const int x = bx * 4 + (row >> 1), y = by * 2 + (row & 1), z = bz * 4;
+        const int x = bx * 2 + (row >> 2), y = by * 2 + ((row >> 1) & 1), z = bz * 8 + (row & 1) * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (x < D0 && y < D1) {
             const float* src = vol + ((long long)x * D1 + y) * D2 + z;
@@ -252,13 +252,13 @@ extern "C" {
 
 size_t xvr_drr_bricks_bytes(int D0, int D1, int D2) {
     if (D0 <= 0 || D1 <= 0 || D2 <= 0) return 0;
-    return (size_t)((D0 + 3) / 4) * (size_t)((D1 + 1) / 2) * (size_t)((D2 + 3) / 4) * 32 * sizeof(float);
+    return (size_t)((D0 + 1) / 2) * (size_t)((D1 + 1) / 2) * (size_t)((D2 + 7) / 8) * 32 * sizeof(float);
 }
 
 int xvr_drr_pack_bricks(const float* volume, int D0, int D1, int D2, float* bricks, void* stream_) {
     if (!volume || !bricks || D0 < 2 || D1 < 2 || D2 < 2) return vfail(XVR_DRR_E_ARG, "bad argument");
     if (reinterpret_cast<uintptr_t>(bricks) & 15u) return vfail(XVR_DRR_E_ARG, "the brick copy must be 16-byte aligned");
-    const long long total = (long long)((D0 + 3) / 4) * ((D1 + 1) / 2) * ((D2 + 3) / 4) * 8;
+    const long long total = (long long)((D0 + 1) / 2) * ((D1 + 1) / 2) * ((D2 + 7) / 8) * 8;
     if (total * 4 >= (1LL << 31)) return vfail(XVR_DRR_E_UNSUPPORTED, "brick copy has >= 2^31 elements");
     const long long blocks = (total + TB - 1) / TB;
     hipLaunchKernelGGL(k_pack_bricks, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(TB), 0, (hipStream_t)stream_, volume, D0, D1,

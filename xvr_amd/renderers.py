@@ -207,7 +207,7 @@ YPAIR_LAYOUT = _os.environ.get("XVR_DRR_YPAIRS", "1") != "0"
 YPAIR_TILES = _os.environ.get("XVR_DRR_YTILES", "1") != "0"
 YPAIR_TILES_PACKED = _os.environ.get("XVR_DRR_YTILES_PACKED", "1") != "0"
 YPAIR_MIN_WAVEFRONTS = 2048     # smaller launches take the sample-split kernels on the natural layout
-# Siddon's counterpart: 4 x 2 x 4-voxel bricks, one per cache line (xvr_drr_pack_bricks); same caching rule.  XVR_DRR_BRICKS=0: off.
+# Siddon's counterpart: 2 x 2 x 8-voxel bricks, one per cache line (xvr_drr_pack_bricks); same caching rule.  XVR_DRR_BRICKS=0: off.
 BRICK_LAYOUT = _os.environ.get("XVR_DRR_BRICKS", "1") != "0"
 # renders of a volume version BEFORE its copy is built (measured with the volume changing every step, bench.py --update-volume:
 # the y-pair copy costs 0.54 ms and saves 0.70 of the forward -- 14.75 -> 14.96 ms per step with the splat behind it, no gain --;
@@ -254,7 +254,7 @@ def _ypair_volume(lib, volume):
 
 
 def _brick_volume(lib, volume):
-    """(4 x 2 x 4-voxel bricks for the Siddon forward, xvr_drr_pack_bricks; cached by the y-pair copy's rule)"""
+    """(2 x 2 x 8-voxel bricks for the Siddon forward, xvr_drr_pack_bricks; cached by the y-pair copy's rule)"""
     return _layout_copy(lib, volume, "bricks")
 
 
@@ -264,7 +264,7 @@ def _use_bricks(spec, volume, B, n, C=1):
     D0, D1, D2 = volume.shape
     return (BRICK_LAYOUT and spec.renderer == "siddon" and C == 1 and spec.norm_dims_offset == 0 and not spec.align_corners
             and B * ((n + 63) // 64) >= YPAIR_MIN_WAVEFRONTS
-            and ((D0 + 3) // 4) * ((D1 + 1) // 2) * ((D2 + 3) // 4) * 32 < 2 ** 31 and min(D0, D1, D2) >= 2)
+            and ((D0 + 1) // 2) * ((D1 + 1) // 2) * ((D2 + 7) // 8) * 32 < 2 ** 31 and min(D0, D1, D2) >= 2)
 
 
 def _use_ypairs(spec, volume, B, n):
