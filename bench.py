@@ -70,11 +70,11 @@ BINDING = {
         ("fabric_bandwidth", 9.109e7 / (5.576e9 / 64), LINE_CLK, 1, "profiles/r04_fetch_calibration.txt x TCC_EA0_RDREQ"),
     ],
     "siddon_forward+jac": [
-        # TA_BUSY of the committed PMC pass: 9.8e6 clocks of every CU's texture-address unit per C3 launch (three scattered 4-byte
-        # loads per slab at ~19 clocks each, tools/microbench/ta_masked_loads.hip), i.e. 28.8 clocks per 64 voxel segments
-        ("texture_address", 1.0, 28.8, CUS, "TA_BUSY x profiles/r04_microbench_ta_masked_loads.txt"),
+        # TA_BUSY of a PMC pass: 9.0e6 clocks of every CU's texture-address unit per C3 launch (three scattered 4-byte loads per
+        # slab at ~17 clocks each, tools/microbench/ta_masked_loads.hip), i.e. 26.4 clocks per 64 voxel segments
+        ("texture_address", 1.0, 26.4, CUS, "TA_BUSY x profiles/r04_microbench_ta_masked_loads.txt"),
         ("valu_issue", 3.163e9 / (5.576e9 / 64), VALU_CLK, 4 * CUS, "profiles/r03_microbench_valu_issue.txt x SQ_INSTS_VALU (profiles/r04_siddon_rocprof_summary.md)"),
-        ("fabric_bandwidth", 1.01e8 / (5.576e9 / 64), LINE_CLK, 1, "profiles/r04_fetch_calibration.txt x TCC_EA0_RDREQ"),
+        ("fabric_bandwidth", 1.023e8 / (5.576e9 / 64), LINE_CLK, 1, "profiles/r04_fetch_calibration.txt x TCC_EA0_RDREQ"),
     ],
     "siddon_forward": [
         ("valu_issue", 2.655e9 / (5.576e9 / 64), VALU_CLK, 4 * CUS, "profiles/r03_microbench_valu_issue.txt x SQ_INSTS_VALU (profiles/r04_siddon_rocprof_summary.md)"),
