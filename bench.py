@@ -39,53 +39,63 @@ CUS, CLK_GHZ = 256, 2.4
 VALU_CLK = 3.0   # clocks a plain wave64 vector instruction occupies its SIMD (2.9-3.4 measured with 4 wavefronts per SIMD,
                  # tools/microbench/valu_issue.hip, profiles/r03_microbench_valu_issue.txt; v_pk_*_f32 7.5, v_mad_u64_u32 6.0)
 # candidate units per timed call: (unit, wavefront instructions per 64 units of work, clocks each on the unit's 256 CU-wide or
-# 1024 SIMD-wide resource, source).  Vector-instruction counts per 64 units are SQ_INSTS_VALU of the committed PMC passes
-# (profiles/r03_*_rocprof_summary.md) over the kernels' own unit counts.
+# 1024 SIMD-wide resource, source).  The instruction and line counts are NOT literals: they are read at run time from the newest
+# committed PMC summaries (profiles/rNN_{trilinear,siddon}_rocprof_summary.md, written by tools/profile.sh + summarize_profile.py)
+# and divided by the unit count of the very run they were collected under (profiles/rNN_*_bench_under_trace.json), so a kernel
+# edit followed by a profile run re-prices the floors without touching this file (tests/test_bench_contract.py checks the
+# parse against the files).
 # fabric_bandwidth: an L2 miss moves one whole 128-byte line (tools/microbench/fetch_calib.hip, profiles/r04_fetch_calibration.txt);
 # random lines of a working set far beyond the Infinity Cache arrive at 43-46 G lines/s (5.5-5.9 TB/s) -- 0.054 clocks per line for
-# the chip.  Lines per 64 units are TCC_EA0_RDREQ of the committed PMC passes over the kernels' own unit counts.
+# the chip.
 LINE_CLK = CLK_GHZ / 44.5
-BINDING = {
-    "trilinear_backward": [
-        # tools/microbench/lds_atomics.hip: a ds_add_u32 wavefront instruction costs >= 4.4 LDS clocks however few lanes are
-        # live; 8 per sample; 54.3 of 64 lanes live
-        ("lds_atomic_issue", 8 / (54.3 / 64), 4.4, CUS, "profiles/r02_microbench_lds_atomics.txt"),
-        ("valu_issue", 3.804e9 / (1.809e9 / 64), VALU_CLK, 4 * CUS, "profiles/r03_microbench_valu_issue.txt x SQ_INSTS_VALU (profiles/r04_trilinear_rocprof_summary.md)"),
-        ("fabric_bandwidth", 6.038e7 / (1.809e9 / 64), LINE_CLK, 1, "profiles/r04_fetch_calibration.txt x TCC_EA0_RDREQ"),
-    ],
-    "trilinear_forward+jac": [
-        # tools/microbench/gather.hip: a 64-lane gather costs ~15 clk per CU on one 128-B line and 10-14 more per further line;
-        # two 16-byte gathers per sample (y-pair copy), ~3 lines by that estimate
-        ("texture_address", 2, 36.0, CUS, "profiles/r01_microbench_gather_lines.txt"),
-        ("valu_issue", 2.769e9 / (1.809e9 / 64), VALU_CLK, 4 * CUS, "profiles/r03_microbench_valu_issue.txt x SQ_INSTS_VALU (profiles/r04_trilinear_rocprof_summary.md)"),
-        ("fabric_bandwidth", 2.049e8 / (1.809e9 / 64), LINE_CLK, 1, "profiles/r04_fetch_calibration.txt x TCC_EA0_RDREQ"),
-    ],
-    "trilinear_forward": [
-        ("texture_address", 2, 36.0, CUS, "profiles/r01_microbench_gather_lines.txt"),
-        ("valu_issue", 2.103e9 / (1.809e9 / 64), VALU_CLK, 4 * CUS, "profiles/r03_microbench_valu_issue.txt x SQ_INSTS_VALU (profiles/r04_trilinear_rocprof_summary.md)"),
-        ("fabric_bandwidth", 1.956e8 / (1.809e9 / 64), LINE_CLK, 1, "profiles/r04_fetch_calibration.txt x TCC_EA0_RDREQ"),
-    ],
-    "siddon_backward": [
-        ("valu_issue", 5.399e9 / (5.576e9 / 64), VALU_CLK, 4 * CUS, "profiles/r03_microbench_valu_issue.txt x SQ_INSTS_VALU (profiles/r04_siddon_rocprof_summary.md)"),
-        ("fabric_bandwidth", 9.109e7 / (5.576e9 / 64), LINE_CLK, 1, "profiles/r04_fetch_calibration.txt x TCC_EA0_RDREQ"),
-    ],
-    "siddon_forward+jac": [
-        # TA_BUSY of a PMC pass: 9.0e6 clocks of every CU's texture-address unit per C3 launch (three scattered 4-byte loads per
-        # slab at ~17 clocks each, tools/microbench/ta_masked_loads.hip), i.e. 26.4 clocks per 64 voxel segments
-        ("texture_address", 1.0, 26.4, CUS, "TA_BUSY x profiles/r04_microbench_ta_masked_loads.txt"),
-        ("valu_issue", 3.163e9 / (5.576e9 / 64), VALU_CLK, 4 * CUS, "profiles/r03_microbench_valu_issue.txt x SQ_INSTS_VALU (profiles/r04_siddon_rocprof_summary.md)"),
-        ("fabric_bandwidth", 1.023e8 / (5.576e9 / 64), LINE_CLK, 1, "profiles/r04_fetch_calibration.txt x TCC_EA0_RDREQ"),
-    ],
-    "siddon_forward": [
-        ("valu_issue", 2.655e9 / (5.576e9 / 64), VALU_CLK, 4 * CUS, "profiles/r03_microbench_valu_issue.txt x SQ_INSTS_VALU (profiles/r04_siddon_rocprof_summary.md)"),
-        ("fabric_bandwidth", 1.03e8 / (5.576e9 / 64), LINE_CLK, 1, "profiles/r04_fetch_calibration.txt x TCC_EA0_RDREQ"),
-    ],
+# timed call -> (which summary, regex of the kernel instantiation that IS the call's steady state)
+BINDING_KERNELS = {
+    "trilinear_backward": ("trilinear", r"k_trilinear_splat_b16"),
+    "trilinear_forward+jac": ("trilinear", r"k_trilinear_fwd<true, 0, false, [1-9]"),
+    "trilinear_forward": ("trilinear", r"k_trilinear_fwd<false, 0, false, [1-9]"),
+    "siddon_backward": ("siddon", r"k_siddon_gather_vol2"),
+    "siddon_forward+jac": ("siddon", r"k_siddon_slab<true, true"),
+    "siddon_forward": ("siddon", r"k_siddon_slab<false, true"),
 }
+_BINDING_CACHE = {}
+
+
+def binding_candidates(base):
+    """[(unit, wavefront instructions per 64 units, clocks each, width, source)] for one timed call, from the committed counters."""
+    if base in _BINDING_CACHE:
+        return _BINDING_CACHE[base]
+    sys.path.insert(0, str(ROOT / "tools"))
+    import benchlib
+
+    cands = []
+    kind, pattern = BINDING_KERNELS.get(base, (None, None))
+    c = benchlib.committed_counters(kind, pattern) if kind else None
+    if c:
+        per64 = lambda counter: c[counter] / (c["units"] / 64.0)   # noqa: E731
+        src = f"{c['file']} / units of {c['units_file']}"
+        if base == "trilinear_backward" and "SQ_THREAD_CYCLES_VALU" in c:
+            # tools/microbench/lds_atomics.hip: a ds_add_u32 wavefront instruction costs >= 4.4 LDS clocks however few lanes are
+            # live; 8 per sample; live lanes per vector instruction from the same PMC pass
+            live = c["SQ_THREAD_CYCLES_VALU"] / c["SQ_INSTS_VALU"]
+            cands.append(("lds_atomic_issue", 8 / (live / 64.0), 4.4, CUS, f"profiles/r02_microbench_lds_atomics.txt; {live:.1f} live lanes ({src})"))
+        if base.startswith("trilinear_forward"):
+            # tools/microbench/gather.hip: a 64-lane gather costs ~15 clk per CU on one 128-B line and 10-14 more per further line;
+            # two 16-byte gathers per sample (y-pair copy), ~3 lines by that estimate
+            cands.append(("texture_address", 2, 36.0, CUS, "profiles/r01_microbench_gather_lines.txt"))
+        if base == "siddon_forward+jac" and "TA_BUSY_avr" in c:
+            # clocks the CUs' texture-address units were busy (TA_BUSY_avr: mean over the TA instances), per 64 voxel segments
+            cands.append(("texture_address", 1.0, c["TA_BUSY_avr"] / (c["units"] / 64.0) * CUS, CUS, f"TA_BUSY_avr ({src})"))
+        if "SQ_INSTS_VALU" in c:
+            cands.append(("valu_issue", per64("SQ_INSTS_VALU"), VALU_CLK, 4 * CUS, f"profiles/r03_microbench_valu_issue.txt x SQ_INSTS_VALU ({src})"))
+        if "TCC_EA0_RDREQ_sum" in c:
+            cands.append(("fabric_bandwidth", per64("TCC_EA0_RDREQ_sum"), LINE_CLK, 1, f"profiles/r04_fetch_calibration.txt x TCC_EA0_RDREQ ({src})"))
+    _BINDING_CACHE[base] = cands
+    return cands
 
 
 def binding_floor(tag, units, avg_ms):
     """The unit with the largest floor for one timed call, and every candidate's floor next to it."""
-    cands = BINDING.get(tag.split("[")[0])
+    cands = binding_candidates(tag.split("[")[0])
     if not cands or not units:
         return None
     floors = {}

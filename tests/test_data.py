@@ -67,8 +67,18 @@ def test_read_from_file_builds_a_centred_density_subject(tmp_path):
 
 
 def test_transform_hu_to_density_piecewise():
+    """the definition (oracle) and the loader's one-off host pass agree; the per-step product function has no CPU path"""
+    from oracle.data_restated import transform_hu_to_density as oracle_hu
+    from xvr_amd.data import _density_at_load
+
     hu = torch.tensor([[-1000.0, -800.0, -500.0, 0.0, 350.0, 351.0, 1000.0]]).reshape(1, 1, 7).expand(2, 2, 7)
-    d = transform_hu_to_density(hu, 3.0)
+    d = oracle_hu(hu, 3.0)
+    assert torch.equal(d, _density_at_load(hu, 3.0))
+    g = torch.Generator().manual_seed(5)
+    big = torch.rand(9, 8, 7, generator=g) * 2800 - 1100
+    assert torch.equal(oracle_hu(big, 4.2), _density_at_load(big, 4.2))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        transform_hu_to_density(hu, 3.0)
     assert torch.isclose(d[0, 0, 0], d[0, 0, 2]) and d[0, 0, 0] == 0  # air -> soft-tissue minimum
     assert d[0, 0, 6] == 1.0 and d[0, 0, 5] > d[0, 0, 4]                # bone scaled, normalised to [0, 1]
 

@@ -1209,7 +1209,8 @@ def test_training_step_c5_render_twice_and_backprop_into_a_regressor():
 
 @pytest.mark.parametrize("case", ["ct-like", "no-soft", "only-soft", "odd-size"])
 def test_fused_hu_to_density_matches_the_torch_definition(case):
-    from xvr_amd.data import _transform_hu_to_density_torch, transform_hu_to_density
+    from oracle.data_restated import transform_hu_to_density as _transform_hu_to_density_torch
+    from xvr_amd.data import transform_hu_to_density
 
     g = torch.Generator().manual_seed(12)
     shape = (33, 21, 19) if case == "odd-size" else (48, 40, 32)

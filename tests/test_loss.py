@@ -83,3 +83,25 @@ def test_pose_regression_loss_matches_the_oracle_value_and_gradient():
         assert torch.allclose(a, b, rtol=2e-4, atol=2e-4), (name, a, b)
     assert torch.allclose(outs["cuda"][1], outs["cpu"][1], rtol=2e-3, atol=1e-4)
     assert (outs["cuda"][2] - outs["cpu"][2]).abs().max() <= 2e-3 * outs["cpu"][2].abs().max()
+
+
+@pytest.mark.gpu
+def test_pose_regression_loss_of_an_empty_batch_is_empty_not_an_error():
+    """Every sample of a training step can be dropped by `keep` (/root/reference/src/xvr/model/trainer.py:202-204); the reference's
+    torch lines then give empty [0] terms.  The HIP entry points reject N = 0, so the product short-circuits."""
+    from xvr_amd.loss import PoseRegressionLoss, _Geodesic
+
+    img, mask, rot, xyz, _ = _loss_case()
+    pose = convert(rot.cuda(), xyz.cuda(), parameterization="euler_angles", convention="ZXY")
+    r2 = rot.cuda().requires_grad_(True)
+    pred = convert(r2, xyz.cuda(), parameterization="euler_angles", convention="ZXY")
+    keep = torch.zeros(len(img), dtype=torch.bool, device="cuda")
+    pi = img.cuda().requires_grad_(True)
+    res = PoseRegressionLoss(1020.0)(img.cuda()[keep], mask.cuda()[keep], pose[keep], pi[keep], mask.cuda()[keep], pred[keep])
+    assert all(t.shape == (0,) for t in res[:5]) and res[6].shape == (0,)
+    # (the reference's own DiceMetric raises on an empty batch -- `.view(0, C, -1)` is ambiguous, loss.py:73 -- and the trainer
+    #  swallows that per step, trainer.py:171-175; the product returns the empty terms the remaining torch lines would give)
+    res[0].sum().backward()            # (a zero-size sum: gradients exist and are zero)
+    assert r2.grad is not None and float(r2.grad.abs().sum()) == 0.0
+    ang, trans, dist = _Geodesic.apply(pose.matrix[:0], pred.matrix[:0], 1020.0, 1e-6)
+    assert ang.shape == trans.shape == dist.shape == (0,)

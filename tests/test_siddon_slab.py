@@ -106,6 +106,36 @@ def test_slab_march_known_answers_axis_aligned_and_on_planes(shift):
 
 
 @pytest.mark.parametrize("shift", [0.5, 0.0])
+def test_slab_march_axis_aligned_rays_with_eps_zero(shift):
+    """RenderSpec.eps = 0 is allowed, and an axis-aligned ray then has direction components of exactly (+-)0: 1 / d = inf made
+    the far-plane bound -inf and the ray rendered as 0.  Uniform box => density x chord, as the merge walk gives."""
+    from xvr_amd.spec import RenderSpec
+
+    spec = RenderSpec(renderer="siddon", voxel_shift=shift, eps=0.0)
+    D = (10, 12, 14)
+    vol = torch.full(D, 0.75)
+    for axis in range(3):
+        u, v = [a for a in range(3) if a != axis]
+        for cu, cv in ((3.3, 4.1), (0.2, 7.6), (D[u] - 1.4, 0.1)):
+            for sign in (1.0, -1.0):
+                a, b = [0.0, 0.0, 0.0], [0.0, 0.0, 0.0]
+                a[u] = b[u] = cu
+                a[v] = b[v] = cv
+                a[axis], b[axis] = (-50.0, 150.0) if sign > 0 else (150.0, -50.0)
+                case = dict(volume=vol, **_rays(a, [b]))
+                new, old = _render(case, spec, 1).item(), _render(case, spec, 0).item()
+                assert abs(new - 0.75 * D[axis]) < 2e-3 and abs(old - new) < 1e-4, (shift, axis, sign, cu, cv, new, old)
+    # one zero component only (a ray in a coordinate plane, oblique in the other two): against the oracle
+    from oracle.diffdrr_restated import render as oracle_render
+
+    volr = torch.rand(D, generator=torch.Generator().manual_seed(3))
+    rays = _rays([-30.0, 4.25, -20.0], [[45.0, 4.25, 31.0], [40.0, 4.25, 2.0]])
+    out = _render(dict(volume=volr, **rays), spec, 1)
+    ref = oracle_render(volr, rays["source"], rays["target"], rays["img"], to_oracle_spec(spec), None)
+    _close(out, ref, FWD_TOL, "eps = 0, one zero direction component")
+
+
+@pytest.mark.parametrize("shift", [0.5, 0.0])
 def test_slab_march_known_answers_diagonals(shift):
     """45-degree rays: |d_u| = |d_m| exactly, every slab has a minor crossing, and a ray aimed through voxel corners crosses two
     planes at the same alpha in every slab.  Uniform box => density x chord (L x fraction of alpha inside)."""

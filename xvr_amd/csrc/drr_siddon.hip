@@ -345,18 +345,22 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, XVR_SLAB_
     float ahi = live ? R.amax : 0.f;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        inv_d[i] = 1.f / R.d[i];
+        // (a direction component of exactly 0 -- an axis-aligned ray under eps = 0, or t - s = -eps -- : 1 / d = +-inf would
+        //  make the far-plane bound below -inf for the lower plane (the ray is silently rendered as 0) and a minor plane's
+        //  alpha -inf < a_end (a crossing that does not exist).  A huge FINITE reciprocal of the travel direction's sign puts
+        //  every plane of that axis beyond a_hi, which is what the merge walk's min / max over +-inf amounts to)
+        inv_d[i] = R.d[i] == 0.f ? 1e30f : 1.f / R.d[i];
         ps[i] = A.sp.plane0[i] - R.s[i];
         const float f = fmaf(alo, R.d[i], R.s[i]) - A.sp.plane0[i];   // entry position in plane-index units
         const int i0 = min(max((int)floorf(f), 0), D[i] - 1);
-        const bool fwd = R.d[i] > 0.f;
+        const bool fwd = R.d[i] >= 0.f;   // (d = 0 counts as forward: its next plane, strictly above the ray, lies at alpha = +huge)
         i0s[i] = i0;
         fp[i] = (float)(i0 + (fwd ? 1 : 0));
         fpfar[i] = fwd ? (float)D[i] : 0.f;
         stpf[i] = fwd ? 1.f : -1.f;
         sstr[i] = fwd ? strd[i] : -strd[i];
         off += i0 * strd[i];
-        ahi = fminf(ahi, (fpfar[i] + ps[i]) * inv_d[i]);   // the loop's own plane arithmetic: no far plane is ever crossed
+        if (R.d[i] != 0.f) ahi = fminf(ahi, (fpfar[i] + ps[i]) * inv_d[i]);   // the loop's own plane arithmetic: no far plane is ever crossed
     }
     const float ad0 = fabsf(R.d[0]), ad1 = fabsf(R.d[1]), ad2 = fabsf(R.d[2]);
     const int m = (ad0 >= ad1 && ad0 >= ad2) ? 0 : (ad1 >= ad2 ? 1 : 2);

@@ -307,6 +307,7 @@ static int pack_ytiles_impl(const float* volume, const float* mask, int D0, int 
     if (reinterpret_cast<uintptr_t>(tiles) & 15u) return vfail(XVR_DRR_E_ARG, "the tiled copy must be 16-byte aligned");
     const long long total = (long long)((D0 + 1) / 2) * (D1 + 1) * ((D2 - 2) / 7 + 1) * 8;   // 16-byte pieces
     if (total * 4 >= (1LL << 31)) return vfail(XVR_DRR_E_UNSUPPORTED, "tiled y-pair copy has >= 2^31 elements");
+    if (D2 >= 8192) return vfail(XVR_DRR_E_UNSUPPORTED, "tiled y-pair copy: D2 must be below 8192 (the march's z / 7 is a multiply-shift)");
     const long long blocks = (total + TB - 1) / TB;
     const dim3 grid((unsigned)(blocks < 65536 ? blocks : 65536));
     if (mask) hipLaunchKernelGGL(k_pack_ytiles<true>, grid, dim3(TB), 0, (hipStream_t)stream_, volume, mask, D0, D1, D2, tiles);

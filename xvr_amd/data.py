@@ -49,22 +49,28 @@ def transform_hu_to_density(volume: torch.Tensor, bone_attenuation_multiplier: f
     """Piecewise HU -> density map used before every training render
     (/root/reference/src/xvr/model/trainer.py:124,196-197): air (<= -800 HU) is set to the minimum
     soft-tissue value, bone (> 350 HU) is scaled, then the result is min-max normalised to [0, 1].
-    On the GPU this is one fused streaming pass; the torch formulation below is the CPU path / definition."""
-    if volume.is_cuda and volume.dtype == torch.float32 and not volume.requires_grad:
-        return _hu_to_density_hip(volume, float(bone_attenuation_multiplier))
-    return _transform_hu_to_density_torch(volume, bone_attenuation_multiplier)
+    One fused streaming HIP pass over a float32 CUDA volume; there is no CPU path and no autograd through it (xvr's volume is
+    a buffer, model/utils.py:162,169).  The torch lines it is checked against: oracle/data_restated.py."""
+    if not (volume.is_cuda and volume.dtype == torch.float32):
+        raise RuntimeError("transform_hu_to_density: a float32 CUDA volume (HIP kernel, no CPU path)")
+    if volume.requires_grad:
+        raise NotImplementedError("transform_hu_to_density: the HU map is not differentiable here (the volume is a buffer upstream)")
+    return _hu_to_density_hip(volume, float(bone_attenuation_multiplier))
 
 
-def _transform_hu_to_density_torch(volume: torch.Tensor, bone_attenuation_multiplier: float) -> torch.Tensor:
-    volume = volume.to(torch.float32)
-    air = volume <= -800
-    bone = volume > 350
-    soft = ~(air | bone)
-    soft_min = volume[soft].min() if soft.any() else volume.min()
-    density = torch.where(air, soft_min, volume)
-    density = torch.where(bone, volume * bone_attenuation_multiplier, density)
-    density = density - density.min()
-    return density / density.max().clamp_min(torch.finfo(torch.float32).tiny)
+def _density_at_load(volume: torch.Tensor, bone_attenuation_multiplier: float) -> torch.Tensor:
+    """The ONE-OFF density of ``read()``: file loading is host code (as the reference's torchio / diffdrr.data.read is, and as
+    this module's NIfTI decode is), so a CT that arrives as a host tensor gets its density on the host, once, before anything
+    is on the GPU; a CUDA tensor takes the HIP pass.  Never on the per-step path -- that is transform_hu_to_density above."""
+    if volume.is_cuda:
+        return _hu_to_density_hip(volume.to(torch.float32), float(bone_attenuation_multiplier))
+    v = volume.to(torch.float32)
+    bone = v > 350
+    soft = (v > -800) & ~bone
+    floor_ = v[soft].min() if bool(soft.any()) else v.min()
+    d = torch.where(bone, v * bone_attenuation_multiplier, torch.where(v <= -800, floor_, v))
+    d = d - d.min()
+    return d / d.max().clamp_min(torch.finfo(torch.float32).tiny)
 
 
 @dataclass
@@ -195,7 +201,7 @@ def read(volume, labelmap=None, labels=None, orientation="AP", bone_attenuation_
             for lab in labels:
                 keep |= mask == float(lab)
             mask = torch.where(keep, mask, torch.zeros_like(mask))
-    density = transform_hu_to_density(volume, bone_attenuation_multiplier) if hu else volume
+    density = _density_at_load(volume, bone_attenuation_multiplier) if hu else volume
     if mask is not None and labels is not None:
         density = torch.where(mask > 0, density, torch.zeros_like(density))
     return Subject(volume=volume, affine=affine, density=density, mask=mask, orientation=orientation)

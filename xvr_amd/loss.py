@@ -30,8 +30,9 @@ class _Geodesic(torch.autograd.Function):
         a_c, b_c = a.contiguous(), b.contiguous()
         out = torch.empty(3, N, device=a.device, dtype=torch.float32)
         gb = torch.empty(N, 12, device=a.device, dtype=torch.float32) if ctx.needs_input_grad[1] else None
-        _lib.check(lib.xvr_pose_geodesic(_ptr(a_c), _ptr(b_c), N, float(sdd), float(eps), _ptr(out), _ptr(gb), _stream()),
-                   "xvr_pose_geodesic")
+        if N > 0:   # (an empty batch -- every sample dropped by `keep`, trainer.py:202-204 -- is three empty [0] results, no launch)
+            _lib.check(lib.xvr_pose_geodesic(_ptr(a_c), _ptr(b_c), N, float(sdd), float(eps), _ptr(out), _ptr(gb), _stream()),
+                       "xvr_pose_geodesic")
         ctx.save_for_backward(gb)
         # the SAME tensor objects must be marked and returned (marking a temporary view has no effect): the fused
         # kernel carries the gradient of the combined distance only, so the angular and translational terms are
@@ -43,6 +44,8 @@ class _Geodesic(torch.autograd.Function):
     @staticmethod
     def backward(ctx, _g_ang, _g_trans, g_d):
         (gb,) = ctx.saved_tensors
+        if gb is None:
+            return None, None, None, None
         grad = torch.zeros(gb.shape[0], 4, 4, device=gb.device, dtype=gb.dtype)
         g = gb * g_d.reshape(-1, 1)
         grad[:, :3, :3] = g[:, :9].reshape(-1, 3, 3)
@@ -137,6 +140,16 @@ class PoseRegressionLoss(torch.nn.Module):
         fused mNCC, boolean Dice, one launch for the geodesics, one for the multiview term (true poses carry no gradient)."""
         if not _hip_poses(pose, pred_pose) or pose.matrix.requires_grad:
             raise RuntimeError("PoseRegressionLoss: float32 CUDA poses, the true pose without a gradient (HIP kernels, no CPU path)")
+        if len(pose) != len(pred_pose):
+            raise ValueError("PoseRegressionLoss: the two batches of poses differ in length")
+        if len(pose) == 0:
+            # every sample of the step was dropped by `keep` (trainer.py:202-204): empty [0] terms, as the reference's per-image
+            # torch lines give (its DiceMetric's `.view(0, C, -1)` raises instead, loss.py:73, which the trainer swallows per
+            # step, trainer.py:171-175); no kernel is launched on nothing.  The loss stays attached to the prediction (a zero-size sum is 0 with a
+            # zero gradient), so `loss.mean().backward()` of the caller behaves as it does upstream.
+            z = pred_pose.matrix.sum(dim=(-1, -2)) * 0 + pred_img.reshape(0, -1).sum(dim=1)
+            e = z.detach()
+            return z, e, e, e, e, e, e
         mncc = self.imagesim(img, pred_img)
         dice = self.diceloss(mask, pred_mask)
         rgeo, tgeo, dgeo = _Geodesic.apply(pose.matrix, pred_pose.matrix, self.geodesic.sdd, self.geodesic.eps)

@@ -26,6 +26,7 @@ from copy import deepcopy
 
 import torch
 
+from . import _lib
 from .drr import DRR
 from .metrics import (GradientNormalizedCrossCorrelation2d, MultiscaleNormalizedCrossCorrelation2d,
                       XrayTransforms)
@@ -34,6 +35,7 @@ from .pose_opt import RegistrationStage
 from .registration import Registration
 from .pose_opt import PARAM_KINDS
 from .similarity import EqualizedSimilarity, FusedSimilarity, GeneralSimilarity
+from .xray import XrayPreparation
 
 
 def parse_scales(scales, crop: int, height: int):
@@ -48,8 +50,13 @@ class Registrar:
     def __init__(self, drr: DRR, scales="8", n_itrs="500", parameterization="euler_angles", convention="ZXY",
                  lr_rot=1e-2, lr_xyz=1e0, patience=10, threshold=1e-4, max_n_plateaus=3, crop=0, equalize=False,
                  mncc_patch_size=9, gncc_patch_size=11, sigma=0.0, beta=0.5, verbose=0, use_graph=None, fused=None,
-                 device_loop=None, check_every=8):
+                 device_loop=None, check_every=8, subtract_background=False, linearize=False, reducefn="max"):
         self.drr = drr
+        # what turns the raw pixel array into the registration target (xvr_amd/xray.py; the reference's read_xray options,
+        # /root/reference/src/xvr/registrar/base.py:128-141): `prepare_xray(raw)` applies it, parameters.pt records it.  The
+        # defaults leave an already prepared image (a rendered DRR, a linearised X-ray) as it is but for the crop.
+        self.xray_preparation = XrayPreparation(trim=int(crop), subtract_background=bool(subtract_background),
+                                                linearize=bool(linearize), frames=reducefn)
         self.scales = scales.split(",") if isinstance(scales, str) else [str(s) for s in scales]
         self.n_itrs = [int(n) for n in (n_itrs.split(",") if isinstance(n_itrs, str) else n_itrs)]
         assert len(self.scales) == len(self.n_itrs)
@@ -72,6 +79,17 @@ class Registrar:
         self.device_loop, self.check_every = device_loop, check_every
         self.sim1 = MultiscaleNormalizedCrossCorrelation2d([None, mncc_patch_size], [0.5, 0.5])
         self.sim2 = GradientNormalizedCrossCorrelation2d(gncc_patch_size, sigma)
+
+    def prepare_xray(self, raw: torch.Tensor) -> torch.Tensor:
+        """raw pixel array [1, 1, (T,) H, W] -> the target image `run` takes: collimator crop, rescale, optional background
+        subtraction / linearisation / frame reduction (xvr_amd/xray.py), wherever `raw` lives."""
+        return self.xray_preparation(raw)
+
+    def xray_block(self, filename=None) -> dict:
+        """parameters.pt's "xray" entry (/root/reference/src/xvr/registrar/base.py:367-373): what prepare_xray really does."""
+        p = self.xray_preparation
+        return {"filename": filename, "crop": self.crop, "subtract_background": p.subtract_background, "linearize": p.linearize,
+                "reducefn": p.frames}
 
     def imagesim(self, x, y):
         self.sim2.to(x.device)
@@ -156,9 +174,15 @@ class Registrar:
                             static_loss = iteration()
                         graph.replay()   # capturing enqueues nothing: this replay IS iteration `itr`
                         loss = static_loss
-                    except Exception as e:  # capture is an optimisation, never a requirement
-                        if self.verbose:
-                            print(f"graph capture failed ({e}); continuing eagerly")
+                    except RuntimeError as e:
+                        # capture is an optimisation, never a requirement -- but only a CAPTURE failure (torch raises
+                        # RuntimeError / AcceleratorError for an op that cannot be captured) is taken for one, and never
+                        # silently: a HipLibraryError, a shape error or anything else in the iteration propagates
+                        if isinstance(e, _lib.HipLibraryError):
+                            raise
+                        import warnings
+
+                        warnings.warn(f"Registrar: HIP-graph capture of the iteration failed ({e}); continuing eagerly", RuntimeWarning)
                         graph, graphed = None, False
                         optimizer.zero_grad()
                         loss = iteration()
@@ -197,6 +221,9 @@ class Registrar:
         cfg = (h, w, self.mncc_patch_size, self.gncc_patch_size, self.sigma, self.equalize)
         if fused_sim is not None:
             return fused_sim
+        if self.fused is False:   # the caller asked for the composed formulation (the A/B reference of the fused calls)
+            tf = transform if not per_image else XrayTransforms(h, w, equalize=self.equalize, per_image=True)
+            return GeneralSimilarity(img, tf, self.mncc_patch_size, self.gncc_patch_size, self.sigma, self.beta)
         if FusedSimilarity.supported(*cfg):
             return FusedSimilarity(img, self.mncc_patch_size, self.gncc_patch_size, self.beta, per_image=per_image)
         if EqualizedSimilarity.supported(*cfg):
@@ -251,10 +278,10 @@ class Registrar:
             transform = XrayTransforms(h, w, equalize=self.equalize)
             img = torch.cat([transform(gt[b:b + 1]) for b in range(gt.shape[0])])   # every target standardised on its own
             fixed = img.expand(B, -1, -1, -1) if img.shape[0] == 1 else img   # one target for all starts, or one per pose
-            sim = self._stage_similarity(fixed.contiguous(), transform, h, w, per_image=True)
             step_size_scalar *= 2 ** (stage - 1)
-            if n_itr <= 0:
+            if n_itr <= 0:   # (a stage without iterations only rescales the detector: no similarity object, no workspaces)
                 continue
+            sim = self._stage_similarity(fixed.contiguous(), transform, h, w, per_image=True)
             stage_run = RegistrationStage(drr, sim, rot, xyz, self.convention, self.lr_rot / step_size_scalar,
                                           self.lr_xyz / step_size_scalar, self.patience, self.threshold, self.max_n_plateaus,
                                           max_iters=n_itr, parameterization=self.parameterization)
@@ -305,7 +332,7 @@ class Registrar:
             "drr": {"volume": volume, "mask": mask, "labels": None, "orientation": self.drr.subject.orientation, **intr,
                     "reverse_x_axis": d.reverse_x_axis, "renderer": self.drr.renderer.renderer_name,
                     "read_kwargs": {}, "drr_kwargs": {"voxel_shift": self.drr.renderer.voxel_shift}},
-            "xray": {"filename": xray, "crop": self.crop, "subtract_background": False, "linearize": False, "reducefn": "max"},
+            "xray": self.xray_block(xray),
             "optimization": {"equalize": self.equalize, "init_only": False, "scales": self.scales, "n_itrs": self.n_itrs,
                              "parameterization": self.parameterization, "convention": self.convention,
                              "lr_rot": self.lr_rot, "lr_xyz": self.lr_xyz, "patience": self.patience,

@@ -271,8 +271,10 @@ def _use_ypairs(spec, volume, B, n):
     """(one channel, or labels packed into the volume's mantissa bits -- never with a separate mask volume)"""
     D0, D1, D2 = volume.shape
     elements = ((D0 + 1) // 2) * (D1 + 1) * ((D2 - 2) // 7 + 1) * 32 if YPAIR_TILES else D0 * (D1 + 1) * D2 * 2
+    # (tiles: the kernel's z / 7 is a multiply-shift that holds below 8192 -- xvr_drr_trilinear_forward and xvr_drr_pack_ytiles
+    #  refuse longer volumes, which therefore stay on the natural layout instead of raising at render time)
     return (YPAIR_LAYOUT and spec.renderer == "trilinear" and B * ((n + 63) // 64) >= YPAIR_MIN_WAVEFRONTS
-            and elements < 2 ** 31 and min(D0, D1, D2) >= 2)
+            and elements < 2 ** 31 and min(D0, D1, D2) >= 2 and (D2 < 8192 or not YPAIR_TILES))
 
 
 class _Render(torch.autograd.Function):

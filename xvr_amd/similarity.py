@@ -86,7 +86,10 @@ class _ChainNCC(torch.autograd.Function):
         B = moving.shape[0]
         loss = torch.empty(B, device=moving.device, dtype=torch.float32)
         grad = torch.empty_like(sim.fixed)
-        sim.evaluate(moving.contiguous(), loss, grad)
+        mc = moving.contiguous()
+        if mc.data_ptr() % 16:   # (a contiguous view at an odd offset: xvr_sim_transform_forward wants 16-byte aligned images)
+            mc = mc.clone()
+        sim.evaluate(mc, loss, grad)
         ctx.save_for_backward(grad)
         ctx.per_image = sim.per_image
         return loss
@@ -140,6 +143,8 @@ class EqualizedSimilarity(torch.nn.Module):
                 and min(height, width) >= big and torch.cuda.is_available())
 
     def evaluate(self, img, loss, grad_img):
+        if img.data_ptr() % 16 or not img.is_contiguous():
+            raise ValueError("EqualizedSimilarity.evaluate: a contiguous, 16-byte aligned image buffer (clone a misaligned view)")
         lib, s = _lib.load(), _stream()
         B, _, H, W = self.fixed.shape
         n, pi = H * W, int(self.per_image)
