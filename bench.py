@@ -458,6 +458,20 @@ def main():
         variants["pose_only_ms_per_step"] = {"trilinear": variants["trilinear_pose_only"]["ms_per_step"],
                                              "siddon": variants["siddon_pose_only"]["ms_per_step"]}
         torch.cuda.empty_cache()
+        # (vi) the two knob sets SURVEY.md Appendix A RECALLS for upstream where this build's defaults are the other choice
+        # (parity is unpinned: if the pin lands there, these are the numbers) -- trilinear with the per-ray alpha window,
+        # Siddon with dims = shape + 1 -- each as the full step and as the pose-only step xvr itself requests
+        recalled = {}
+        for name, rend, kwd in (("trilinear_clip_per_ray", "trilinear", {"clip_to_volume": True}),
+                                ("siddon_dims_plus_1", "siddon", {"norm_dims_offset": 1})):
+            full = leg_summary(render_leg(dev, subject, rend, True, rot, xyz, H, delx, args.n_points, nsec, 1, drr_kwargs=kwd), B)
+            torch.cuda.empty_cache()
+            pose = leg_summary(render_leg(dev, subject, rend, False, rot, xyz, H, delx, args.n_points, nsec, 1, drr_kwargs=kwd), B)
+            torch.cuda.empty_cache()
+            recalled[name] = {"spec": kwd, "ms_per_step": full["ms_per_step"], "DRRs_per_s": full["DRRs_per_s"],
+                              "pose_only_ms_per_step": pose["ms_per_step"], "pose_only_DRRs_per_s": pose["DRRs_per_s"],
+                              "kernels": full["kernels"], "roofline": full["roofline"]}
+        variants["recalled_knobs"] = recalled
         sys.path.insert(0, str(ROOT / "tools"))
         import benchlib
 

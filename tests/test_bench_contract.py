@@ -48,6 +48,10 @@ def test_bench_json_contract(renderer):
         assert v["siddon_ms_per_step"] > 0 and v["siddon"]["roofline"]["unit_name"] == "voxel segments" and v["siddon"]["kernels"]
         assert v["pose_only_ms_per_step"]["trilinear"] > 0 and v["pose_only_ms_per_step"]["siddon"] > 0
         assert "trilinear_forward+jac" in v["trilinear_pose_only"]["kernels"] and v["trilinear_pose_only"]["roofline"]["forward_backward_pair"]["bytes_per_unit"] == 32
+        rk = v["recalled_knobs"]     # SURVEY Appendix A's recalled knob sets, step and pose-only
+        assert set(rk) == {"trilinear_clip_per_ray", "siddon_dims_plus_1"}
+        assert all(e["ms_per_step"] > 0 and e["pose_only_ms_per_step"] > 0 and e["kernels"] for e in rk.values())
+        assert rk["siddon_dims_plus_1"]["spec"] == {"norm_dims_offset": 1}
         c4 = v["c4_register_ms_per_pose_iteration"]
         assert set(c4) == {"32", "64"} and all(c4[k]["single"] > 0 and c4[k]["batched8"] > 0 and c4[k]["kernels"] for k in c4)
         assert all(c4[k]["ncc"][1] > c4[k]["ncc"][0] for k in c4)

@@ -1681,7 +1681,7 @@ def test_voxel_gather_with_more_than_one_cull_word(renderer, B):
 
 
 @pytest.mark.parametrize("slab", [1, 0], ids=["slab-march", "merge-walk"])
-@pytest.mark.parametrize("kw", [dict(), dict(voxel_shift=0.0)], ids=_id)
+@pytest.mark.parametrize("kw", [dict(), dict(voxel_shift=0.0), dict(norm_dims_offset=1), dict(align_corners=True, voxel_shift=0.0)], ids=_id)
 @pytest.mark.parametrize("shape", [(40, 44, 48), (33, 31, 29)], ids=["even", "odd"])
 def test_bricked_volume_layout_is_bit_identical_for_siddon(kw, shape, slab, monkeypatch, request):
     """Large Siddon launches -- the slab march (default) and the merge walk (option siddon_slab = 0) alike -- take a
@@ -1717,7 +1717,8 @@ def test_bricked_volume_layout_is_bit_identical_for_siddon(kw, shape, slab, monk
         out = render(vol, src, tgt, img, spec, ray_grid_w=128)           # third render of this volume: the copy is built and used
         names = [e[0] for e in renderers.PROFILER]
         renderers.PROFILER = None
-        assert ("pack_bricks" in names) == flag
+        exact = not kw.get("norm_dims_offset") and not kw.get("align_corners")
+        assert ("pack_bricks" in names) == (flag and (exact or slab == 1))   # (non-exact maps: bricks through the slab march only)
         assert torch.equal(first, out.detach())
         (out * w).sum().backward()
         res.append((out.detach(), src.grad, tgt.grad, img.grad))
@@ -1726,16 +1727,21 @@ def test_bricked_volume_layout_is_bit_identical_for_siddon(kw, shape, slab, monk
             _close(a, b, 1e-5, name)
         else:
             assert torch.equal(a, b), name
-    if not kw.get("norm_dims_offset"):   # (non-exact maps: midpoint ties, see test_fuzz_voxel_gather_equals_atomic_scatter)
+    if exact:   # (non-exact maps: midpoint ties, see test_fuzz_voxel_gather_equals_atomic_scatter)
         _close(res[0][0], _oracle_render(case, spec), 1e-3, "forward vs oracle")
-    # labels packed into the taps and non-exact index maps stay on the natural layout (measured slower with bricks): the
-    # library says so rather than walking the wrong layout
+    else:       # all but a handful of rays (a midpoint within an ulp of the lookup threshold flips a whole segment's voxel)
+        ref = _oracle_render(case, spec)
+        bad = ((res[0][0].cpu() - ref).abs() > 1e-3 * ref.abs().max()).sum().item()
+        assert bad <= 1e-4 * ref.numel(), f"{bad} of {ref.numel()} rays differ from the oracle"
+    # non-exact index maps walk the bricked copy through the slab march only (round 5), and maps that look up voxels outside the
+    # volume (norm_dims_offset = -1) not at all: the library says so rather than walking the wrong layout
     from xvr_amd import _lib
     from xvr_amd.renderers import make_cspec
     lib = _lib.load()
-    cs = make_cspec(tuple(shape), RenderSpec(renderer="siddon", norm_dims_offset=1), 128, volume_layout=2)
     v = case["volume"].cuda()
     out = torch.empty(12, 1, 128 * 128, device="cuda")
-    rc = lib.xvr_drr_siddon_forward(v.data_ptr(), None, *shape, 1, src.data_ptr(), tgt.data_ptr(), img.data_ptr(), 12, 128 * 128,
-                                    ctypes.byref(cs), out.data_ptr(), None, None, None)
-    assert rc != 0
+    for off, want_ok in ((1, slab == 1), (-1, False)):
+        cs = make_cspec(tuple(shape), RenderSpec(renderer="siddon", norm_dims_offset=off), 128, volume_layout=2)
+        rc = lib.xvr_drr_siddon_forward(v.data_ptr(), None, *shape, 1, src.data_ptr(), tgt.data_ptr(), img.data_ptr(), 12, 128 * 128,
+                                        ctypes.byref(cs), out.data_ptr(), None, None, None)
+        assert (rc == 0) == want_ok, (off, slab, rc)

@@ -30,8 +30,9 @@ const OptionDef OPTIONS[] = {
     {"fwd_slabs", "XVR_DRR_FWD_SLABS", 0, -1, 64},
     {"fwd_slab_axis", "XVR_DRR_FWD_SLAB_AXIS", 1, 0, 2},
     {"tile_geom", "XVR_DRR_TILE_GEOM", 1, 0, 2},
-    {"siddon_slab", "XVR_DRR_SIDDON_SLAB", 1, 0, 1},
+    {"siddon_slab", "XVR_DRR_SIDDON_SLAB", 1, 0, 2},
     {"siddon_gather_fast", "XVR_DRR_SIDDON_GATHER_FAST", 1, 0, 1},
+    {"siddon_splat", "XVR_DRR_SIDDON_SPLAT", 1, 0, 2},
 };
 constexpr int N_OPTIONS = sizeof(OPTIONS) / sizeof(OPTIONS[0]);
 std::atomic<int> g_opt[N_OPTIONS];

@@ -311,7 +311,15 @@ __device__ __forceinline__ float med3f(float x, float lo, float hi) { return __b
 // The brick offset is separable, offset = fx(ix) + fy(iy) + fz(iz), so every axis keeps its own partial offset and replaces it
 // when its plane is crossed; the partial offsets come from three small tables in LDS (built by the workgroup at the start) -- a
 // ds_read per axis and slab, issued one slab ahead, instead of ~5 vector instructions of shifts and multiplies each.
-template <bool JAC, bool BRICK>
+// NX (round 5): a NON-exact index map (norm_dims_offset = +-1, align_corners: what SURVEY.md Appendix A recalls for upstream) on the same
+// march.  The planes a ray crosses are the same -- they are geometry -- only the voxel a segment is credited with is the nearest voxel
+// of its MIDPOINT under index = a x + b, as the merge walk's EXACT = false branch looks it up.  The march keeps its alpha bookkeeping
+// and drops the incremental offsets: every segment's voxel is one fma per axis on the sum of its end alphas (0.5 a d folded into the
+// coefficient), v_cvt_rpi, a clamp into the volume (a midpoint an ulp outside the entry face must not wrap into the next row; the
+// host admits only maps that stay inside the volume for points inside it, siddon_map_in_bounds), and the row strides -- or, on
+// bricks, the three LDS tables read by index instead of one slab ahead.  ~32 vector instructions per slab on top of the exact
+// march's; the merge walk it replaces for these maps spends ~90 per SEGMENT.
+template <bool JAC, bool BRICK, bool NX = false>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, XVR_SLAB_WAVES))) void k_siddon_slab(RenderArgs A) {
     extern __shared__ unsigned slab_tab[];   // BRICK: byte offsets fx[-1 .. D0], fy[-1 .. D1], fz[-1 .. D2] (indices clamped)
     int b, r;
@@ -377,7 +385,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, XVR_SLAB_
     typedef __attribute__((address_space(3))) const unsigned lds_u32;
     const int tab0 = BRICK ? (int)(unsigned)(size_t)(lds_u32*)slab_tab : 0;
     auto tabrd = [&](int lds_addr) { return *(lds_u32*)(size_t)(unsigned)lds_addr; };
-    if (BRICK) {
+    if (BRICK && !NX) {
         const int im = sel3i(m, i0s[0], i0s[1], i0s[2]), iu = sel3i(u, i0s[0], i0s[1], i0s[2]), iv = sel3i(v, i0s[0], i0s[1], i0s[2]);
         const int bm = sel3i(m, tbase[0], tbase[1], tbase[2]), bu = sel3i(u, tbase[0], tbase[1], tbase[2]), bv = sel3i(v, tbase[0], tbase[1], tbase[2]);
         st4m = stm > 0.f ? 4 : -4; st4u = stu > 0.f ? 4 : -4; st4v = stv > 0.f ? 4 : -4;
@@ -387,6 +395,26 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, XVR_SLAB_
         off = (int)(fm + fu + fv);
     }
 
+    // NX: index of a segment's voxel along axis k = clamp(floor(S * hA_k + Bc_k + 1/2), 0, D_k - 1), S = the sum of its end alphas
+    float hA0 = 0.f, hA1 = 0.f, hA2 = 0.f, Bc0 = 0.f, Bc1 = 0.f, Bc2 = 0.f;
+    if (NX) {
+        hA0 = 0.5f * A.sp.a[0] * R.d[0]; hA1 = 0.5f * A.sp.a[1] * R.d[1]; hA2 = 0.5f * A.sp.a[2] * R.d[2];
+        Bc0 = fmaf(A.sp.a[0], R.s[0], A.sp.b[0]); Bc1 = fmaf(A.sp.a[1], R.s[1], A.sp.b[1]); Bc2 = fmaf(A.sp.a[2], R.s[2], A.sp.b[2]);
+    }
+    const int Dm0 = A.D0 - 1, Dm1 = A.D1 - 1, Dm2 = A.D2 - 1, SXe = A.D1 * A.D2, SYe = A.D2;   // (element strides: D1 D2 < 2^24, the host checks)
+    const int tx0 = tab0 + tbase[0] * 4, tx1 = tab0 + tbase[1] * 4, tx2 = tab0 + tbase[2] * 4;
+    auto nx_idx = [&](const float p, const int hi) -> int {   // clamp(floor(p + 1/2), 0, hi): two instructions
+        int i, r;
+        asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(i) : "v"(p));
+        asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(i), "v"(hi));
+        return r;
+    };
+    auto nx_off = [&](const float S) -> int {
+        const int ix = nx_idx(fmaf(S, hA0, Bc0), Dm0), iy = nx_idx(fmaf(S, hA1, Bc1), Dm1), iz = nx_idx(fmaf(S, hA2, Bc2), Dm2);
+        if (BRICK) return (int)(tabrd(tx0 + ix * 4) + tabrd(tx1 + iy * 4) + tabrd(tx2 + iz * 4));
+        // (v_mad_u32_u24, full rate: a 32-bit v_mul_lo_u32 occupies the SIMD four times as long)
+        return (int)((unsigned)__umul24((unsigned)ix, (unsigned)SXe) + (unsigned)__umul24((unsigned)iy, (unsigned)SYe) + (unsigned)iz) << 2;
+    };
     float ac = alo, acc = 0.f;
     float Um = 0.f, Uu = 0.f, Uv = 0.f, Mm = 0.f, Mu = 0.f, Mv = 0.f;
     // Loads go through a buffer resource over the volume (an offset beyond it returns 0 without a memory request: the bounds net);
@@ -400,7 +428,19 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, XVR_SLAB_
     // the first voxel's value opens the walk: the entry crossing (on axis ax_in, when the ray enters through a real plane) is
     // added after the loop, the loop's first "dominant-axis crossing" then sees no jump
     const bool walks = live && ahi > alo;
-    const float vfirst = ld(walks, off);
+    float vfirst;
+    if (NX) {
+        // the value of the FIRST segment (the jacobian's entry term, and Wprev of the first trip: no jump at the slab's entry): under
+        // the exact map it is the entry voxel's, known up front; here it is looked up at the midpoint of the first trip's first
+        // segment of positive length -- the first trip's own expressions, evaluated once more in front of the loop
+        const float am = (fpm + psm) * ivm, aend = med3f(am, ac, ahi);
+        const float au = med3f((fpu + psu) * ivu, ac, aend), av = med3f((fpv + psv) * ivv, ac, aend);
+        const float lo = fminf(au, av), hi = fmaxf(au, av);
+        const float Sf = lo > ac ? ac + lo : (hi > lo ? lo + hi : hi + aend);
+        vfirst = ld(walks, nx_off(Sf));
+    } else {
+        vfirst = ld(walks, off);
+    }
     float Wprev = vfirst;
     unsigned cnt = 0;
 
@@ -416,8 +456,10 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, XVR_SLAB_
         const bool uf = au <= av;                               // u is crossed first
         const float lo = uf ? au : av, hi = uf ? av : au;
         const float l1 = lo - ac, l2 = hi - lo, l3 = aend - hi;
-        int off2, off3, off_next;
-        if (BRICK) {
+        int off2, off3, off_next = 0;
+        if (NX) {
+            off = nx_off(ac + lo); off2 = nx_off(lo + hi); off3 = nx_off(hi + aend);
+        } else if (BRICK) {
             const unsigned fu2 = cu ? fu_n : fu, fv2 = cv ? fv_n : fv;      // partial offsets behind the minor crossings
             off2 = (int)(fm + (uf ? fu2 + fv : fu + fv2));
             off3 = (int)(fm + fu2 + fv2);
@@ -473,7 +515,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, XVR_SLAB_
         fpu += cu ? stu : 0.f;
         fpv += cv ? stv : 0.f;
         fpm += stm;
-        off = off_next;
+        if (!NX) off = off_next;
         ac = aend;
         XVR_SLAB_WAIT_LOADS();
         if (!JAC) {
@@ -530,8 +572,8 @@ static int siddon_forward_impl(const float* volume, const float* mask, int D0, i
     if (sp->volume_layout != 0 && sp->volume_layout != 2) return fail(XVR_DRR_E_UNSUPPORTED, "siddon takes the natural or the bricked volume layout");
     const bool packed = !mask && C > 1;
     // (bricks: one channel, exact index map -- where they pay; masked / non-exact walks measured slower with them)
-    if (sp->volume_layout == 2 && (mask || packed || !siddon_exact_geometry(sp)))
-        return fail(XVR_DRR_E_UNSUPPORTED, "the bricked layout serves the one-channel forward with the exact index map");   // labels in the low mantissa bits of `volume` (xvr_drr_pack_labels)
+    if (sp->volume_layout == 2 && (mask || packed || (!siddon_exact_geometry(sp) && !siddon_map_in_bounds(sp, D0, D1, D2))))
+        return fail(XVR_DRR_E_UNSUPPORTED, "the bricked layout serves the one-channel forward (exact index map, or one that stays inside the volume)");   // labels in the low mantissa bits of `volume` (xvr_drr_pack_labels)
     if (packed && C > (1 << LABEL_BITS)) return fail(XVR_DRR_E_ARG, "packed labels hold at most 16 channels");
     RenderArgs A;
     fill_args(A, volume, mask, D0, D1, D2, C, source, target, raylen, B, n, sp, cam);
@@ -543,17 +585,24 @@ static int siddon_forward_impl(const float* volume, const float* mask, int D0, i
     if (mask && jac) return (ex ? launch(k_siddon<1, true, false, false, true>, A, lds, stream) : launch(k_siddon<1, true, false, false, false>, A, lds, stream));
     if (mask) return (ex ? launch(k_siddon<0, true, false, false, true>, A, lds, stream) : launch(k_siddon<0, true, false, false, false>, A, lds, stream));
     bool tile16 = false;
-    if ((sp->volume_layout == 0 || sp->volume_layout == 2) && ex && xvr_detail::option(xvr_detail::OPT_SIDDON_SLAB) &&
+    // the dominant-axis slab march (round 4) -- and, round 5, the same march for NON-exact index maps that keep points of the
+    // volume inside it (option siddon_slab: 1 = both, 2 = the exact map only, 0 = the merge walk)
+    const int slab_opt = xvr_detail::option(xvr_detail::OPT_SIDDON_SLAB);
+    const bool nx = !ex && slab_opt == 1 && siddon_map_in_bounds(sp, D0, D1, D2) && (long long)D1 * D2 < (1LL << 24);
+    if ((sp->volume_layout == 0 || sp->volume_layout == 2) && (ex ? slab_opt != 0 : nx) &&
         (long long)D0 * D1 * D2 < (1LL << 29) && (size_t)(D0 + D1 + D2 + 6) * 4 <= 48 * 1024 &&
-        split_factor(B, n, (long long)D0 * D1 * D2, true, &tile16) == 1) {   // the dominant-axis slab march (round 4)
+        split_factor(B, n, (long long)D0 * D1 * D2, true, &tile16) == 1) {
+        const size_t tab = sp->volume_layout == 2 ? (size_t)(D0 + D1 + D2 + 6) * 4 : 0;
         if (sp->volume_layout == 2) {
-            const size_t tab = (size_t)(D0 + D1 + D2 + 6) * 4;
+            if (nx) return jac ? launch(k_siddon_slab<true, true, true>, A, tab, stream) : launch(k_siddon_slab<false, true, true>, A, tab, stream);
             if (jac) return launch(k_siddon_slab<true, true>, A, tab, stream);
             return launch(k_siddon_slab<false, true>, A, tab, stream);
         }
+        if (nx) return jac ? launch(k_siddon_slab<true, false, true>, A, 0, stream) : launch(k_siddon_slab<false, false, true>, A, 0, stream);
         if (jac) return launch(k_siddon_slab<true, false>, A, 0, stream);
         return launch(k_siddon_slab<false, false>, A, 0, stream);
     }
+    if (sp->volume_layout == 2 && !ex) return fail(XVR_DRR_E_UNSUPPORTED, "the bricked layout serves non-exact index maps through the slab march only");
     if (sp->volume_layout == 2) {
         if (jac) return launch(k_siddon<1, false, false, false, true, 0, true>, A, 0, stream);
         return launch(k_siddon<0, false, false, false, true, 0, true>, A, 0, stream);

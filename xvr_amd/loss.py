@@ -147,7 +147,7 @@ class PoseRegressionLoss(torch.nn.Module):
             # torch lines give (its DiceMetric's `.view(0, C, -1)` raises instead, loss.py:73, which the trainer swallows per
             # step, trainer.py:171-175); no kernel is launched on nothing.  The loss stays attached to the prediction (a zero-size sum is 0 with a
             # zero gradient), so `loss.mean().backward()` of the caller behaves as it does upstream.
-            z = pred_pose.matrix.sum(dim=(-1, -2)) * 0 + pred_img.reshape(0, -1).sum(dim=1)
+            z = pred_pose.matrix.sum(dim=(-1, -2)) * 0 + pred_img.sum(dim=tuple(range(1, pred_img.dim()))) * 0
             e = z.detach()
             return z, e, e, e, e, e, e
         mncc = self.imagesim(img, pred_img)

@@ -258,12 +258,35 @@ def _brick_volume(lib, volume):
     return _layout_copy(lib, volume, "bricks")
 
 
+# ... also for the non-exact index maps that the slab march serves since round 5 (norm_dims_offset = +1, align_corners: maps under
+# which the volume's points look up voxels inside it).  XVR_DRR_BRICKS_NX=0: those maps march the natural layout (A/B).
+BRICK_NX = _os.environ.get("XVR_DRR_BRICKS_NX", "1") != "0"
+
+
+def _siddon_map_in_bounds(spec, shape) -> bool:
+    """Python mirror of siddon_map_in_bounds (csrc/drr_common.hiph): idx = rint(a x + b) stays in [0, D - 1] on the volume's box."""
+    a, b = spec.index_map(shape)
+    for k, S in enumerate(shape):
+        x0, x1 = -spec.voxel_shift + 1e-4, -spec.voxel_shift + S - 1e-4
+        if round(a[k] * x0 + b[k]) < 0 or round(a[k] * x1 + b[k]) > S - 1:
+            return False
+    return True
+
+
 def _use_bricks(spec, volume, B, n, C=1):
-    """(large one-channel Siddon launches with the exact index map: 10.3 -> 9.7 ms at C3.  Measured SLOWER, by 0.2 / 0.7 ms,
-    for non-exact maps and for labels packed into the taps -- their walks are bound by arithmetic the brick address adds to.)"""
+    """(large one-channel Siddon launches: 10.3 -> 9.7 ms at C3 on the merge walk, 6.9 -> 4.9 on the slab march.  Labels packed into
+    the taps measured SLOWER with bricks -- their walk is bound by arithmetic the brick address adds to.)"""
     D0, D1, D2 = volume.shape
-    return (BRICK_LAYOUT and spec.renderer == "siddon" and C == 1 and spec.norm_dims_offset == 0 and not spec.align_corners
-            and B * ((n + 63) // 64) >= YPAIR_MIN_WAVEFRONTS
+    waves = B * ((n + 63) // 64)
+    exact = spec.norm_dims_offset == 0 and not spec.align_corners
+    if not exact:
+        # (the bricked copy serves these maps through the slab march ONLY -- xvr_drr_siddon_forward refuses it otherwise: the
+        #  march's own conditions, mirrored; everything else keeps the natural layout and the merge walk)
+        if not (BRICK_NX and _lib.get_option("siddon_slab") == 1 and _lib.get_option("fwd_split") in (0, 1)
+                and _siddon_map_in_bounds(spec, (D0, D1, D2)) and D1 * D2 < 2 ** 24 and D0 * D1 * D2 < 2 ** 29
+                and (D0 + D1 + D2 + 6) * 4 <= 48 * 1024 and waves > YPAIR_MIN_WAVEFRONTS):
+            return False
+    return (BRICK_LAYOUT and spec.renderer == "siddon" and C == 1 and waves >= YPAIR_MIN_WAVEFRONTS
             and ((D0 + 1) // 2) * ((D1 + 1) // 2) * ((D2 + 7) // 8) * 32 < 2 ** 31 and min(D0, D1, D2) >= 2)
 
 
