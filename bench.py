@@ -335,6 +335,8 @@ def main():
     ap.add_argument("--check-gather", action="store_true",
                     help="with N > 1 (or --force-dist): rank 0 re-renders EVERY rank's poses itself through the HIP path and compares "
                          "the all-gathered tensor with it value by value (`gather_check` in the JSON line)")
+    ap.add_argument("--drr-kwargs", default="", help='JSON of extra DRR / RenderSpec keywords for the headline leg, e.g. \'{"norm_dims_offset": 1}\' '
+                                                     "(the recalled knob sets; recorded in config.workload)")
     ap.add_argument("--dry-run-collectives", action="store_true",
                     help="allocate the exact tensors of the N-rank step (--gpus N names N; this process is ONE rank), run the rank-local "
                          "part once with the all-gather on a one-rank group of the chosen backend, check the gathered block against "
@@ -378,8 +380,9 @@ def main():
     Bmax = B if args.scaling == "weak" else -(-B_total // world)
     exchange = Exchange(world, B, Bmax, H, dev) if use_dist else None
 
+    drr_kwargs = json.loads(args.drr_kwargs) if args.drr_kwargs else None
     leg = render_leg(dev, subject, args.renderer, not args.no_voxel_grad, rot, xyz, H, delx, args.n_points, args.steps, args.warmup,
-                     exchange=exchange, update_volume=args.update_volume)
+                     exchange=exchange, update_volume=args.update_volume, drr_kwargs=drr_kwargs)
     elapsed = leg["elapsed"]
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -395,7 +398,8 @@ def main():
         "config": {
             "workload": f"single {args.size}^3 CT, {args.renderer} fwd+bwd(pose{'' if args.no_voxel_grad else '+voxel'}), "
                         f"{H}x{H} detector, batch_size={B} per GPU" + (f" ({B_total} in total, strong scaling)" if args.scaling == "strong" else "")
-                        + (f", n_points={args.n_points}" if args.renderer == "trilinear" else ""),
+                        + (f", n_points={args.n_points}" if args.renderer == "trilinear" else "")
+                        + (f", spec {drr_kwargs}" if drr_kwargs else ""),
             "global_batch": B_total, "parallelism": f"pose-sharded x{world}, replicated volume, all-gather of DRRs"
             if world > 1 else "single GPU",
         },
@@ -430,7 +434,7 @@ def main():
     # pose-only backward -- the only backward xvr itself requests (registrar/base.py:252, trainer.py:223) -- for both renderers;
     # (iv) C4 = one registration iteration at 256^2 and 512^2, single and 8 starts batched; (v) C5 = the render side of one
     # training step.  Each leg carries its own kernel table.
-    if world == 1 and not args.no_variants and args.renderer == "trilinear" and not args.no_voxel_grad and not use_dist:
+    if world == 1 and not args.no_variants and args.renderer == "trilinear" and not args.no_voxel_grad and not use_dist and not drr_kwargs:
         step = leg["step"]
 
         def timed_loop(n, **kws):

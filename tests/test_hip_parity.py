@@ -540,6 +540,8 @@ def test_siddon_voxel_gather_equals_atomic_scatter_and_oracle(kw, hw):
     from xvr_amd import renderers
     from xvr_amd.spec import RenderSpec
 
+    from xvr_amd import _lib
+
     spec = RenderSpec(renderer="siddon", **kw)
     case = make_case(seed=19, shape=(20, 24, 28), height=hw[0], width=hw[1], delx=1.5 * 24 / max(hw))
     w = torch.rand(2, 1, hw[0] * hw[1], generator=torch.Generator().manual_seed(5))
@@ -551,6 +553,12 @@ def test_siddon_voxel_gather_equals_atomic_scatter_and_oracle(kw, hw):
         finally:
             renderers.VOXEL_GATHER = True
     _close(grads[0], grads[1], 1e-4, "gather vs scatter")
+    # round 5: non-exact maps take the ray-driven brick splat (k_siddon_splat) by default; option siddon_splat = 0 keeps the per-cell
+    # gather of round 2, = 2 sends the exact map through the splat as well: all of them against the same scatter
+    exact = not kw.get("norm_dims_offset") and not kw.get("align_corners")
+    with _lib.option("siddon_splat", 2 if exact else 0):
+        other = _hip_render(case, spec, grid_w=hw[1], grads=True, w=w)[1]
+    _close(other, grads[1], 1e-4, "siddon_splat = 2 (exact map through the splat)" if exact else "siddon_splat = 0 (per-cell gather)")
     if not kw.get("norm_dims_offset"):
         # (with the recalled +1 offset the nearest-voxel lookup no longer coincides with the plane
         #  crossings, so fp32 rounding decides some lookups differently in torch and in HIP; the

@@ -141,9 +141,14 @@ __global__ __launch_bounds__(WG) void k_gather_prep(GatherArgs G) {
                                                    (G.mask ? 1.f : G.gout[(size_t)b * G.n + r]) * G.raylen[(size_t)b * G.n + r]);
             G.q2[(size_t)b * G.n + r] = make_float2(lo, hi);
             if (G.cells) G.q[(size_t)G.B * G.n + (size_t)b * G.n + r] = make_float4(ddx, ddy, ddz, 0.f);   // d itself, for the midpoints
+            if (G.sid_splat) {   // the splat's bound: a chord of length l (index units) is worth |g L| l / |d| <= |g L| l min_k |1 / d_k|
+                cabs = fabsf(G.gout[(size_t)b * G.n + r] * G.raylen[(size_t)b * G.n + r]) * fminf(fminf(fabsf(1.f / ddx), fabsf(1.f / ddy)), fabsf(1.f / ddz));
+                if (!(cabs == cabs)) cabs = INFINITY;
+            }
         }
     }
-    if (G.cmax) {   // max |c| of the pose: the fixed-point scale of the brick-local splat
+    const int cmax_word = G.siddon ? 1 : 0;   // (siddon: word 0 of the pose's line is the "a ray is cut" flag)
+    if (G.cmax && (!G.siddon || G.sid_splat)) {   // max |c| of the pose: the fixed-point scale of the brick-local splat
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) cabs = fmaxf(cabs, __shfl_xor(cabs, o));
         // (256 workgroups per pose meet in its word: the poses' words sit in different cache lines -- packed, the 116
@@ -154,8 +159,8 @@ __global__ __launch_bounds__(WG) void k_gather_prep(GatherArgs G) {
         __syncthreads();
         if (threadIdx.x == 0) {
             for (int w = 1; w < WG / 64; ++w) cabs = fmaxf(cabs, s_cabs[w]);
-            if (cabs > 0.f && __float_as_uint(cabs) > __hip_atomic_load(G.cmax + (size_t)b * G.cmax_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                atomicMax(G.cmax + (size_t)b * G.cmax_stride, __float_as_uint(cabs));
+            if (cabs > 0.f && __float_as_uint(cabs) > __hip_atomic_load(G.cmax + (size_t)b * G.cmax_stride + cmax_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                atomicMax(G.cmax + (size_t)b * G.cmax_stride + cmax_word, __float_as_uint(cabs));
         }
     }
 #pragma unroll
@@ -600,6 +605,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(XVR_TAB_WAVE
 }
 
 #include "drr_splat.hiph"   // k_trilinear_splat_b16, k_trilinear_splat_px: the brick-local fixed-point splats (the default)
+#include "drr_siddon_splat.hiph"   // k_siddon_splat: the ray-driven brick splat of the Siddon voxel gradient (non-exact index maps)
 
 // ---------------------------------------------------------------------------------------------
 // Pixel-major voxel gather for the renders the lattice-of-planes kernels above cannot take (round 2):
@@ -1323,13 +1329,15 @@ __global__ __launch_bounds__(FAST ? 256 : 64) __attribute__((amdgpu_waves_per_eu
 // (with skip_unless_flag_gt = the returned flag) right behind it.
 int xvr_detail::launch_gather(bool siddon, const float* source, const float* target, const float* raylen, const float* grad_out,
                   int B, int n, int gw, int D0, int D1, int D2, const xvr_drr_spec* sp, float* grad_volume,
-                  void* workspace, void* stream, unsigned** flag_out, const float* mask, int C, const int* siddon_olo) {
+                  void* workspace, void* stream, unsigned** flag_out, const float* mask, int C, const int* siddon_olo, int siddon_splat) {
     char* ws = static_cast<char*>(workspace);
     GatherArgs G = {};
-    if (siddon && siddon_olo) {   // non-exact index map: per-cell octant sums in the scratch behind the regular workspace
-        G.cells = reinterpret_cast<float*>(ws + align256(ws_bytes(B, n, D0, D1, D2)));
+    const bool sid_splat = siddon && siddon_splat && !mask;
+    if (siddon && siddon_olo) {   // non-exact index map: per-cell octant sums in the scratch behind the regular workspace (the splat needs none)
+        if (!sid_splat) G.cells = reinterpret_cast<float*>(ws + align256(ws_bytes(B, n, D0, D1, D2)));
         for (int k = 0; k < 3; ++k) G.olo[k] = siddon_olo[k];
     }
+    G.sid_splat = sid_splat ? 1 : 0;
     G.mask = mask;
     G.C = C;
     G.clip = (!siddon && sp->clip_to_volume == 1) ? 1 : 0;
@@ -1371,7 +1379,8 @@ int xvr_detail::launch_gather(bool siddon, const float* source, const float* tar
         G.cmax_stride = 4 * n < CMAX_STRIDE ? 4 * n : CMAX_STRIDE;
     }
     if (psplat) G.bd[0] = G.bd[1] = G.bd[2] = 16;
-    if (splat) G.bd[0] = G.bd[1] = G.bd[2] = 16;
+    if (splat || sid_splat) G.bd[0] = G.bd[1] = G.bd[2] = 16;
+    if (sid_splat && G.cmax_stride < 2) return fail(XVR_DRR_E_UNSUPPORTED, "siddon splat: detector too small for its per-pose words");
     G.cull = reinterpret_cast<unsigned*>(ws + ws_cull_off(B, n));
     G.words = (B + 31) / 32;
     G.gvol = grad_volume;
@@ -1385,7 +1394,18 @@ int xvr_detail::launch_gather(bool siddon, const float* source, const float* tar
     if (bricks >= (1LL << 31)) return fail(XVR_DRR_E_UNSUPPORTED, "grid too large");
     hipLaunchKernelGGL(k_gather_cull, dim3((unsigned)((bricks + WG / 32 - 1) / (WG / 32))), dim3(WG), 0,
                        (hipStream_t)stream, G, (int)bricks);
-    if (siddon && G.cells) {
+    if (sid_splat) {
+        const bool nx = siddon_olo != nullptr;
+        const void* kern = nx ? (const void*)k_siddon_splat<true> : (const void*)k_siddon_splat<false>;
+        int per_cu = 0, dev = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        const long long resident = (long long)per_cu * cus;
+        const dim3 grid((unsigned)(bricks < resident ? bricks : resident));
+        if (nx) hipLaunchKernelGGL(k_siddon_splat<true>, grid, dim3(256), 0, (hipStream_t)stream, G);
+        else hipLaunchKernelGGL(k_siddon_splat<false>, grid, dim3(256), 0, (hipStream_t)stream, G);
+    }
+    else if (siddon && G.cells) {
         hipLaunchKernelGGL(k_siddon_gather_cells, dim3((unsigned)bricks), dim3(WG), 0, (hipStream_t)stream, G);
         const long long nvox = (long long)D0 * D1 * D2;
         hipLaunchKernelGGL(k_siddon_cells_to_voxels, dim3((unsigned)((nvox + WG - 1) / WG)), dim3(WG), 0, (hipStream_t)stream, G);
@@ -1466,6 +1486,7 @@ size_t xvr_drr_siddon_backward_workspace_bytes(int B, int n, int D0, int D1, int
     int olo[3];
     const size_t base = ws_bytes(B, n, D0, D1, D2);
     if (siddon_exact_geometry(sp) || !siddon_cell_offsets(sp, D0, D1, D2, olo)) return base;
+    if (xvr_detail::option(xvr_detail::OPT_SIDDON_SPLAT) >= 1) return base;   // (the brick splat needs no per-cell scratch)
     return align256(base) + siddon_cells_bytes(D0, D1, D2);
 }
 

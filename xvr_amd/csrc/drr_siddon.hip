@@ -658,14 +658,19 @@ int xvr_drr_siddon_backward(const float* volume, const float* mask, int D0, int 
     // (a non-exact index map gathers per plane cell into octant sums: needs the larger workspace of
     //  xvr_drr_siddon_backward_workspace_bytes and a map that drifts by less than a voxel)
     int olo[3] = {0, 0, 0};
-    const bool cells = !exact_geom && siddon_cell_offsets(sp, D0, D1, D2, olo) &&
+    const bool drift_ok = !exact_geom && siddon_cell_offsets(sp, D0, D1, D2, olo);
+    // option siddon_splat: 1 (default) = the ray-driven brick splat (k_siddon_splat, round 5) for non-exact maps; 2 = for the exact
+    // map too (A/B against k_siddon_gather_vol2); 0 = the round-2 per-cell gather (needs the larger workspace)
+    const int splat_opt = xvr_detail::option(xvr_detail::OPT_SIDDON_SPLAT);
+    const bool splat = !mask && ((drift_ok && splat_opt >= 1) || (exact_geom && splat_opt == 2));
+    const bool cells = drift_ok && !splat &&
                        workspace_bytes >= align256(ws_bytes(B, n, D0, D1, D2)) + siddon_cells_bytes(D0, D1, D2);
     // (a mask with a per-channel gradient: the one-voxel-per-lane gather that looks the upstream value up by the voxel's own
     //  label -- exact geometry, where a segment's voxel is the voxel whose box holds it)
-    if (gvol && ((!mask && (exact_geom || cells)) || (mask && exact_geom)) && gather_usable(sp, n, workspace, workspace_bytes, B, D0, D1, D2)) {
+    if (gvol && ((!mask && (exact_geom || cells || splat)) || (mask && exact_geom)) && gather_usable(sp, n, workspace, workspace_bytes, B, D0, D1, D2)) {
         unsigned* flag = nullptr;
         rc = launch_gather(true, source, target, raylen, grad_out, B, n, sp->ray_grid_w, D0, D1, D2, sp, grad_volume,
-                           workspace, stream, &flag, mask, C, exact_geom ? nullptr : olo);
+                           workspace, stream, &flag, mask, C, exact_geom ? nullptr : olo, splat ? 1 : 0);
         if (rc) return rc;
         RenderArgs Ap = A, Av = A;
         Ap.gvol = nullptr;
