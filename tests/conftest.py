@@ -82,3 +82,29 @@ def format_accuracy_table(rows, names):
         cells = [f"{r[n]['median']:.1e} / {r[n]['p99']:.1e} / {r[n]['max']:.1e}" if n in r else "-" for n in names]
         lines.append(f"| 1e-{r['decade'] + 1} .. 1e-{r['decade']} | {r['voxels']} | " + " | ".join(cells) + " |")
     return "\n".join(lines)
+
+
+def has_structural_tie(size: int, voxel_shift=0.5, norm_dims_offset=0, align_corners=False, tol=2e-3) -> bool:
+    """Non-exact Siddon index maps (idx = rint(a x + b), oracle/diffdrr_restated.py::index_map) can put the MIDPOINT of a fully
+    crossed plane cell exactly on a rounding boundary: under dims = shape + 1 the middle cell of an even-sized axis maps to
+    k + 1/2 in exact arithmetic, and the last bit of alpha then decides which of two voxels gets the whole segment -- in torch
+    and in every HIP kernel family differently.  True if an axis of this size has such a cell (comparisons ACROSS
+    implementations use sizes without one; the forward / backward pair of one family is held to the adjoint identity on sizes WITH)."""
+    S = size
+    dims = S + norm_dims_offset
+    a, b = ((S - 1) / dims, voxel_shift * (S - 1) / dims) if align_corners else (S / dims, voxel_shift * S / dims - 0.5)
+    for c in range(S):
+        t = a * (c + 0.5 - voxel_shift) + b
+        if abs((t - 0.5) - round(t - 0.5)) < tol:
+            return True
+    return False
+
+
+def tie_free_shape(rng, lo, hi, **map_kw):
+    """Three sizes in [lo, hi) none of which has a structural tie under the map (see has_structural_tie)."""
+    out = []
+    while len(out) < 3:
+        s = int(rng.integers(lo, hi))
+        if not has_structural_tie(s, **map_kw):
+            out.append(s)
+    return tuple(out)

@@ -68,9 +68,11 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_MAX : WG) __attribute__((amdgpu_
     bool on_plane = false;   // the walk starts on a plane (always at the entry face; at a cut: see plane_at_cut)
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        inv_d[i] = 1.f / R.d[i];
+        // (a direction component of exactly 0 -- an axis-aligned ray under eps = 0: a huge finite reciprocal and "forward" put every
+        //  plane of that axis at alpha = +huge, never selected; 1 / 0 = inf gave NaN alphas and an empty image, round 5)
+        inv_d[i] = R.d[i] == 0.f ? 1e30f : 1.f / R.d[i];
         const float f = fmaf(alo, R.d[i], R.s[i]) - A.sp.plane0[i];  // position in plane-index units
-        if (R.d[i] > 0.f) { stp[i] = 1; ip[i] = (int)floorf(f) + 1; }
+        if (R.d[i] >= 0.f) { stp[i] = 1; ip[i] = (int)floorf(f) + 1; }
         else { stp[i] = -1; ip[i] = (int)ceilf(f) - 1; }
         an3[i] = (((float)ip[i] + A.sp.plane0[i]) - R.s[i]) * inv_d[i];
         if (an3[i] <= alo) {  // a plane at or behind the entry point (fp noise) is skipped
@@ -591,7 +593,9 @@ static int siddon_forward_impl(const float* volume, const float* mask, int D0, i
     const bool nx = !ex && slab_opt == 1 && siddon_map_in_bounds(sp, D0, D1, D2) && (long long)D1 * D2 < (1LL << 24);
     if ((sp->volume_layout == 0 || sp->volume_layout == 2) && (ex ? slab_opt != 0 : nx) &&
         (long long)D0 * D1 * D2 < (1LL << 29) && (size_t)(D0 + D1 + D2 + 6) * 4 <= 48 * 1024 &&
-        split_factor(B, n, (long long)D0 * D1 * D2, true, &tile16) == 1) {
+        // (non-exact maps take the march at EVERY launch size: there is no alpha-split walk for them, the unsplit march beats the
+        //  unsplit merge walk, and forward and voxel gradient -- k_siddon_splat -- then break the map's ties the same way)
+        (nx || split_factor(B, n, (long long)D0 * D1 * D2, true, &tile16) == 1)) {
         const size_t tab = sp->volume_layout == 2 ? (size_t)(D0 + D1 + D2 + 6) * 4 : 0;
         if (sp->volume_layout == 2) {
             if (nx) return jac ? launch(k_siddon_slab<true, true, true>, A, tab, stream) : launch(k_siddon_slab<false, true, true>, A, tab, stream);

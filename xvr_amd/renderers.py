@@ -85,6 +85,18 @@ def _check_gpu_f32(name, t):
 # VOXEL_GATHER = False withholds it, which forces the atomic scatter fallback (tests, A/B runs).
 VOXEL_GATHER = True
 _WORKSPACES = {}
+# The brick-local splats (k_trilinear_splat_b16 / _px, k_siddon_splat) sum in int32 fixed point inside three quarters of the range;
+# a sum found in the guard band at a flush means the bound on a voxel's sum was optimistic: the voxels are poisoned with NaN (loud
+# downstream, no host sync) and word 2 of the workspace is set.  XVR_DRR_CHECK_OVERFLOW=1 reads that word after every backward (one
+# device -> host sync per step) and raises; last_backward_overflowed() reads it on demand.
+CHECK_OVERFLOW = __import__("os").environ.get("XVR_DRR_CHECK_OVERFLOW", "0") == "1"
+_LAST_VOL_WORKSPACE = None
+
+
+def last_backward_overflowed() -> bool:
+    """Did the most recent voxel-gradient launch of this process see a fixed-point sum outside its range?  (Synchronises.)"""
+    ws = _LAST_VOL_WORKSPACE
+    return bool(ws is not None and ws[:4].view(torch.int32)[2].item() != 0)
 
 
 # Siddon under a non-exact index map gathers per plane cell into octant sums first: 32 bytes per voxel MORE scratch
@@ -417,6 +429,13 @@ class _Render(torch.autograd.Function):
                         _ptr(gsrc) if pose_here else None, _ptr(gtgt) if pose_here else None,
                         _ptr(glen) if pose_here else None, _ptr(ws), ws_bytes, _stream())
             _lib.check(rc, f"xvr_drr_{spec.renderer}_backward")
+            if need_vol and ws is not None:
+                global _LAST_VOL_WORKSPACE
+                _LAST_VOL_WORKSPACE = ws
+                if CHECK_OVERFLOW and last_backward_overflowed():
+                    raise RuntimeError("voxel gradient: a fixed-point sum of the brick-local splat left its range (the bound on a voxel's "
+                                       "sum was optimistic); the affected voxels are NaN.  Option gather_splat = 0 / siddon_splat = 0 "
+                                       "selects the fp32 gathers.")
         g_source = gsrc.reshape(ctx.src_shape) if need_pose and ctx.needs_input_grad[1] else None
         g_target = gtgt if need_pose and ctx.needs_input_grad[2] else None
         g_img = glen.reshape(ctx.img_shape) if need_pose and ctx.needs_input_grad[3] else None
