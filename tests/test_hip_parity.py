@@ -1754,7 +1754,7 @@ def test_bricked_volume_layout_is_bit_identical_for_siddon(kw, shape, slab, monk
     from xvr_amd import _lib
     from xvr_amd.renderers import make_cspec
     lib = _lib.load()
-    v = case["volume"].cuda()
+    v = torch.zeros(lib.xvr_drr_bricks_bytes(*shape) // 4, device="cuda")     # (a buffer of the bricked copy's size: the accepted call walks it)
     out = torch.empty(12, 1, 128 * 128, device="cuda")
     for off, want_ok in ((1, slab == 1), (-1, False)):
         cs = make_cspec(tuple(shape), RenderSpec(renderer="siddon", norm_dims_offset=off), 128, volume_layout=2)

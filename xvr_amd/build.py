@@ -16,7 +16,7 @@ ROOT = PKG.parent
 SRC = [PKG / "csrc" / f for f in ("drr_trilinear.hip", "drr_siddon.hip", "drr_gather.hip", "drr_rays.hip", "drr_api.hip",
                                   "sim_kernels.hip", "volume_kernels.hip", "pose_kernels.hip")]
 HDR = [ROOT / "include" / "xvr_drr.h", ROOT / "include" / "xvr_sim.h", ROOT / "include" / "xvr_pose.h",
-       PKG / "csrc" / "drr_common.hiph", PKG / "csrc" / "drr_splat.hiph",
+       PKG / "csrc" / "drr_common.hiph", PKG / "csrc" / "drr_splat.hiph", PKG / "csrc" / "drr_siddon_splat.hiph",
        Path(__file__).resolve()]   # (this file holds the compiler flags: a change of flags makes the library stale too)
 OBJ = PKG / "lib" / "obj"
 LIB = PKG / "lib" / "libxvr_drr.so"

@@ -1395,7 +1395,7 @@ int xvr_detail::launch_gather(bool siddon, const float* source, const float* tar
     hipLaunchKernelGGL(k_gather_cull, dim3((unsigned)((bricks + WG / 32 - 1) / (WG / 32))), dim3(WG), 0,
                        (hipStream_t)stream, G, (int)bricks);
     if (sid_splat) {
-        const bool nx = siddon_olo != nullptr;
+        const bool nx = siddon_splat == 2;   // (2: a non-exact index map; 1: the exact one, A/B)
         const void* kern = nx ? (const void*)k_siddon_splat<true> : (const void*)k_siddon_splat<false>;
         int per_cu = 0, dev = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
@@ -1486,7 +1486,7 @@ size_t xvr_drr_siddon_backward_workspace_bytes(int B, int n, int D0, int D1, int
     int olo[3];
     const size_t base = ws_bytes(B, n, D0, D1, D2);
     if (siddon_exact_geometry(sp) || !siddon_cell_offsets(sp, D0, D1, D2, olo)) return base;
-    if (xvr_detail::option(xvr_detail::OPT_SIDDON_SPLAT) >= 1) return base;   // (the brick splat needs no per-cell scratch)
+    if (xvr_detail::option(xvr_detail::OPT_SIDDON_SPLAT) >= 1 && siddon_map_in_bounds(sp, D0, D1, D2)) return base;   // (the brick splat needs no per-cell scratch)
     return align256(base) + siddon_cells_bytes(D0, D1, D2);
 }
 

@@ -666,7 +666,10 @@ int xvr_drr_siddon_backward(const float* volume, const float* mask, int D0, int 
     // option siddon_splat: 1 (default) = the ray-driven brick splat (k_siddon_splat, round 5) for non-exact maps; 2 = for the exact
     // map too (A/B against k_siddon_gather_vol2); 0 = the round-2 per-cell gather (needs the larger workspace)
     const int splat_opt = xvr_detail::option(xvr_detail::OPT_SIDDON_SPLAT);
-    const bool splat = !mask && ((drift_ok && splat_opt >= 1) || (exact_geom && splat_opt == 2));
+    // (the maps the forward's slab march serves -- points of the volume look up voxels inside it --, so that forward and voxel gradient
+    //  are one pair; a map that leaves the volume keeps the merge walk's family: per-cell gather or scatter)
+    const bool nx_in = !exact_geom && siddon_map_in_bounds(sp, D0, D1, D2);
+    const bool splat = !mask && ((nx_in && splat_opt >= 1) || (exact_geom && splat_opt == 2));
     const bool cells = drift_ok && !splat &&
                        workspace_bytes >= align256(ws_bytes(B, n, D0, D1, D2)) + siddon_cells_bytes(D0, D1, D2);
     // (a mask with a per-channel gradient: the one-voxel-per-lane gather that looks the upstream value up by the voxel's own
@@ -674,7 +677,7 @@ int xvr_drr_siddon_backward(const float* volume, const float* mask, int D0, int 
     if (gvol && ((!mask && (exact_geom || cells || splat)) || (mask && exact_geom)) && gather_usable(sp, n, workspace, workspace_bytes, B, D0, D1, D2)) {
         unsigned* flag = nullptr;
         rc = launch_gather(true, source, target, raylen, grad_out, B, n, sp->ray_grid_w, D0, D1, D2, sp, grad_volume,
-                           workspace, stream, &flag, mask, C, exact_geom ? nullptr : olo, splat ? 1 : 0);
+                           workspace, stream, &flag, mask, C, exact_geom ? nullptr : olo, splat ? (exact_geom ? 1 : 2) : 0);
         if (rc) return rc;
         RenderArgs Ap = A, Av = A;
         Ap.gvol = nullptr;
