@@ -87,15 +87,22 @@ const char* xvr_drr_last_error(void);
  *   "block_order"   -1 | 0-4   logical block -> (pose, tile) map; -1: by batch size                              [-1]
  *   "order_group"   0 | gx + 256 gy   tiles per group of the grouped block orders; 0: full-width strips          [0]
  *   "fwd_split"     0 | n | 100 + n   sample slices per ray of small forwards: measured table | 8x8 tiles x n | 16x16 tiles x n [0]
- *   "gather_splat"  1 | 0 | 2  trilinear voxel gradient: brick-local fixed-point splat | fp32 voxel-driven gathers | the ray-major
- *                              splat (clip_to_volume = 1 and per-channel masks always use it) for every render (A/B) [1]
+ *   "gather_splat"  1 | 0 | 2 | 3  trilinear voxel gradient: brick-local fixed-point splat, except launches with more than ~48
+ *                              samples of a pose per voxel (counted on the device), which take the fp32 gather | fp32 voxel-driven
+ *                              gathers | the ray-major splat (clip_to_volume = 1 and per-channel masks always use it) for every
+ *                              render (A/B) | the splat whatever the sampling density                               [1]
  *   "fwd_slabs"     0 | -1 | n  slab-major trilinear forward (one launch per slab of the volume, all poses; measured SLOWER,
  *                              HISTORY.md 4.4): never | by size | n slabs                                         [0]
  *   "fwd_slab_axis" 0-2        volume axis the slabs are cut along                                               [1]
  *   "tile_geom"     1 | 0 | 2  pixels a workgroup takes of a detector that is a multiple of 64: 8 x 32 | 16 x 16 | 4 x 64, long side
  *                              along the detector axis that runs along the volume's contiguous axis (per pose)     [1]
- *   "siddon_slab"   1 | 0      unsplit one-channel Siddon forward with the exact index map: dominant-axis slab march
- *                              (k_siddon_slab, both volume layouts) | the merge walk (k_siddon)                    [1]
+ *   "siddon_slab"   1 | 0 | 2  one-channel Siddon forward: dominant-axis slab march (k_siddon_slab, both volume layouts) for the
+ *                              exact index map (unsplit launches) and for non-exact maps that keep the volume's points inside it
+ *                              (norm_dims_offset = +1, align_corners; every launch size) | the merge walk (k_siddon) | the march for
+ *                              the exact map only                                                                   [1]
+ *   "siddon_splat"  1 | 0 | 2  Siddon voxel gradient under a non-exact index map: ray-driven brick-local fixed-point splat
+ *                              (k_siddon_splat; shares the march's plane alphas and index arithmetic) | the per-cell fp32 gather
+ *                              (needs the larger workspace) | the splat for the exact map as well (A/B)            [1]
  *   "siddon_gather_fast" 1 | 0 Siddon voxel gather: pixel window from one projection of the block centre, four bricks along the
  *                              viewing axis per workgroup, candidates from an LDS copy of the brick's footprint, planes in
  *                              crossing order | the window of the eight projected corners, one brick per workgroup,
@@ -180,6 +187,10 @@ int xvr_drr_trilinear_forward(const float* volume, const float* mask, int D0, in
  *                  - worst case measured, pixels 15 x finer than voxels (~1500 samples of a pose per voxel; the bound, hence
  *                    the LSB, is 30 x the benchmark's): median 3e-6 relative in the top decade (fp32 gather 8e-7), 3e-4 at
  *                    1e-4 max|g| (fp32 gather 4e-6).  A contribution below bound * 2^-32 rounds to zero.
+ *                    Since round 5 that regime does not reach the splat by default: k_gather_prep estimates the samples per
+ *                    voxel of every pose and above ~48 the launch is the fp32 table gather's (option gather_splat = 3 forces the splat).
+ *                The sums live in three quarters of the int32 range; one found in the guard band at a flush (the bound on a voxel's
+ *                sum was optimistic) turns its voxels into NaN and sets word 2 of the workspace -- never a silently wrapped number.
  *                Callers that need fp32 sums throughout set the option gather_splat = 0 (the table gather, 1.6 x slower).
  *                A non-finite grad_out turns the voxels of the 16^3 bricks its pose touches into NaN.  Otherwise -- or when the kernel finds on the
  *                device that the targets are not a lattice -- it falls back to a scatter with fp32 atomics: same result

@@ -26,7 +26,7 @@ const OptionDef OPTIONS[] = {
     {"block_order", "XVR_DRR_BLOCK_ORDER", -1, -1, 4},
     {"order_group", "XVR_DRR_ORDER_GROUP", 0, 0, 0xffff},
     {"fwd_split", "XVR_DRR_FWD_SPLIT", 0, 0, 199},
-    {"gather_splat", "XVR_DRR_GATHER_SPLAT", 1, 0, 2},
+    {"gather_splat", "XVR_DRR_GATHER_SPLAT", 1, 0, 3},
     {"fwd_slabs", "XVR_DRR_FWD_SLABS", 0, -1, 64},
     {"fwd_slab_axis", "XVR_DRR_FWD_SLAB_AXIS", 1, 0, 2},
     {"tile_geom", "XVR_DRR_TILE_GEOM", 1, 0, 2},

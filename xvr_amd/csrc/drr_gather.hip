@@ -38,6 +38,9 @@ namespace {
 // =============================================================================================
 
 constexpr int CMAX_STRIDE = 32;   // words between two poses' max |c| (GatherArgs.cmax): one 128-byte line each
+// above this many samples of one pose per voxel the plain trilinear voxel gradient takes the fp32 table gather instead of the
+// fixed-point splat (the benchmark geometry has ~2, registration ~3; the "fine detector" case of tests/test_splat.py ~1500)
+constexpr float SPLAT_MAX_SAMPLES_PER_VOXEL = 48.f;
 
 __device__ __forceinline__ void cross3(const float* a, const float* b, float* o) {
     o[0] = a[1] * b[2] - a[2] * b[1];
@@ -238,6 +241,20 @@ __global__ __launch_bounds__(WG) void k_gather_prep(GatherArgs G) {
         P.gr_norm = sqrtf(dot3(gr, gr));
         P.gc0 = dot3(gc, st);
         P.gr0 = dot3(gr, st);
+        if (G.spv_limit > 0.f && !G.siddon) {
+            // samples of this pose per voxel at the volume's centre: the sample lattice's three spacings in index units are
+            // alpha * ecl (pixels of a row), alpha * rperp (rows), step / gn (planes).  Beyond spv_limit the fixed-point floor of the
+            // brick-local splat shows (its LSB scales with the bound on a voxel's sum, i.e. with this number): word 3 of the flag
+            // line sends the launch to the fp32 table gather instead (round 5; include/xvr_drr.h, "ACCURACY")
+            float wc[3];
+            const float Dm[3] = {0.5f * (float)(G.D0 - 1), 0.5f * (float)(G.D1 - 1), 0.5f * (float)(G.D2 - 1)};
+            for (int i = 0; i < 3; ++i) wc[i] = (Dm[i] - G.sp.b[i]) / G.sp.a[i] - s[i];
+            const float ac = fmaxf(dot3(P.nh, wc), 0.05f);
+            const int N = G.sp.n_points;
+            const float stepa = N > 1 ? (spec_window(G.sp).far_ - spec_window(G.sp).near_) / (float)(N - 1) : 1.f;
+            const float cellv = (ac * P.ecl) * (ac * P.rperp) * (stepa / fmaxf(P.gn, 1e-20f));
+            if (cellv > 0.f && 1.f / cellv > G.spv_limit) atomicOr(G.flag + 3, 1u);
+        }
         const float chk = P.dalpha + P.hwc + P.hwr + P.gc0 + P.gr0;
         if (!(chk == chk) || !(fabsf(chk) < 1e30f) || h == 0.f) atomicMax(G.flag, __float_as_uint(INFINITY));
         G.poses[b] = P;
@@ -255,6 +272,7 @@ __device__ __forceinline__ void brick_coords(int blk, int D1, int D2, const int*
 // one thread per (brick, pose): can any sample of the pose fall inside the brick grown by one voxel?
 // (bounding sphere against the pose's sample pyramid, conservative).  32 poses per word.
 __global__ __launch_bounds__(WG) void k_gather_cull(GatherArgs G, int nbricks) {
+    if (G.only_if_fine >= 0 && (int)(G.flag[3] != 0u) != G.only_if_fine) return;   // (the kernel pair of the other regime runs instead)
     const int brick = blockIdx.x * (WG / 32) + (threadIdx.x >> 5);
     const int lane = threadIdx.x & 31;
     if (brick >= nbricks) return;
@@ -410,6 +428,7 @@ __device__ __forceinline__ void gather_row(const float4* __restrict__ row, const
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(XVR_TAB_WAVES, XVR_TAB_WAVES))) void k_trilinear_gather_tab(GatherArgs G) {
     if (*G.flag > __float_as_uint(GATHER_DEV_TOL)) return;  // not a lattice: the scatter kernel runs instead
+    if (G.only_if_fine >= 0 && (int)(G.flag[3] != 0u) != G.only_if_fine) return;   // (the splat took the launch)
     __shared__ uint2 tab[TAB_ROWS * 64];
     constexpr float HS = 1.5f, CO = 0.5f;
     int bx, by, bz;
@@ -1360,7 +1379,7 @@ int xvr_detail::launch_gather(bool siddon, const float* source, const float* tar
     // unless the option "gather_splat" is 0 (A/B switch: the fp32 voxel-driven table gather)
     const int splat_mode = xvr_detail::option(xvr_detail::OPT_GATHER_SPLAT);   // (2: the ray-major splat for every render, A/B)
     const bool use_splat = splat_mode != 0;
-    const bool splat = !siddon && splat_mode == 1 && sp->clip_to_volume != 1 && !mask;
+    const bool splat = !siddon && (splat_mode == 1 || splat_mode == 3) && sp->clip_to_volume != 1 && !mask;
     if (siddon && (G.cells || G.mask)) { G.bd[0] = 4; G.bd[1] = 8; G.bd[2] = 8; }
     else if (siddon) G.bd[0] = G.bd[1] = G.bd[2] = 8;
     else {
@@ -1380,6 +1399,13 @@ int xvr_detail::launch_gather(bool siddon, const float* source, const float* tar
     }
     if (psplat) G.bd[0] = G.bd[1] = G.bd[2] = 16;
     if (splat || sid_splat) G.bd[0] = G.bd[1] = G.bd[2] = 16;
+    // gather_splat = 1: the splat, EXCEPT where a pose puts more than SPLAT_MAX_SAMPLES_PER_VOXEL samples on a voxel (decided on the
+    // device by k_gather_prep: the fp32 table gather then takes the whole launch); = 3: the splat whatever the sampling density
+    const int bd8[3] = {8, 8, 8}, bd16[3] = {16, 16, 16};
+    const bool auto_fp32 = splat && splat_mode == 1 && G.V == 2 && (long long)n / gw * (gw + 1) <= (long long)TAB_MAX_RAYS &&
+                           n_bricks(D0, D1, D2, bd16) + n_bricks(D0, D1, D2, bd8) <= n_bricks_max(D0, D1, D2);   // (both culls fit the workspace)
+    G.only_if_fine = auto_fp32 ? 0 : -1;
+    G.spv_limit = auto_fp32 ? SPLAT_MAX_SAMPLES_PER_VOXEL : 0.f;
     if (sid_splat && G.cmax_stride < 2) return fail(XVR_DRR_E_UNSUPPORTED, "siddon splat: detector too small for its per-pose words");
     G.cull = reinterpret_cast<unsigned*>(ws + ws_cull_off(B, n));
     G.words = (B + 31) / 32;
@@ -1436,6 +1462,18 @@ int xvr_detail::launch_gather(bool siddon, const float* source, const float* tar
     else if (G.clip) hipLaunchKernelGGL((k_trilinear_gather_px<true, false>), dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
     else if (G.mask) hipLaunchKernelGGL((k_trilinear_gather_px<false, true>), dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
     else if (splat) {
+        if (auto_fp32) {
+            // the fine-sampling regime's pair behind the splat: cull on the table gather's 8^3 bricks (into the words behind the
+            // splat's) and the gather itself, both of which return at once unless k_gather_prep raised word 3 of the flag line
+            GatherArgs T = G;
+            T.only_if_fine = 1;
+            T.cmax = nullptr;
+            T.bd[0] = T.bd[1] = T.bd[2] = 4 * T.V;
+            T.cull = G.cull + (size_t)bricks * G.words;
+            const long long tb = n_bricks(D0, D1, D2, T.bd);
+            hipLaunchKernelGGL(k_gather_cull, dim3((unsigned)((tb + WG / 32 - 1) / (WG / 32))), dim3(WG), 0, (hipStream_t)stream, T, (int)tb);
+            hipLaunchKernelGGL(k_trilinear_gather_tab, dim3((unsigned)tb), dim3(64), 0, (hipStream_t)stream, T);
+        }
         // persistent workgroups: as many as run at once (the occupancy the runtime reports x the CUs), never more than bricks
         static const int resident = [] {
             int per_cu = 0, dev = 0, cus = 0;
