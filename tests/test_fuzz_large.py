@@ -118,6 +118,54 @@ def test_large_siddon_launch_against_the_oracle(seed):
     _check_grads(hip[1:], ref[1:], _oracle(case, spec, wgt, torch.float32)[1:])
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_large_siddon_launch_under_the_recalled_index_maps(seed):
+    """Round 5: dims = shape + 1 -- what SURVEY.md Appendix A recalls for upstream's Siddon -- and align_corners
+    at launch sizes that take the slab march on the BRICKED copy (k_siddon_slab<.., BRICK, NX>) and the ray-driven brick splat
+    (k_siddon_splat).  Two checks.  (i) The pair against itself, on the shape as drawn (even sizes carry the map's structural tie,
+    conftest.has_structural_tie): <A v, w> = <v, A^T w> to rounding, and two runs bit-identical.  (ii) Against the float64 oracle
+    on a tie-free shape: a lookup a x_mid + b computed from float32 alphas lands on the other side of a threshold for ~1e-5 of the
+    segments, which moves one segment of a ray to the neighbouring voxel -- so image and per-ray gradients are held on all but
+    2.5e-3 of the rays (measured ~1e-3), the voxel gradient on all but as many voxels."""
+    from conftest import has_structural_tie
+    from xvr_amd import renderers
+    from xvr_amd.spec import RenderSpec
+
+    kw = [dict(norm_dims_offset=1), dict(norm_dims_offset=1, voxel_shift=0.0), dict(align_corners=True),
+          dict(norm_dims_offset=1, align_corners=True, voxel_shift=0.0)][seed % 4]
+    case, h, w, n_poses = _case(200 + seed, 9)
+    assert n_poses * h * w // 64 > 2048
+    spec = RenderSpec(renderer="siddon", **kw)
+    wgt = torch.rand(n_poses, 1, h * w, generator=torch.Generator().manual_seed(seed))
+    renderers.PROFILER = []
+    hip = _hip_render(case, spec, grid_w=w, grads=True, w=wgt)
+    names = [e[0] for e in renderers.PROFILER]
+    renderers.PROFILER = None
+    assert "pack_bricks" in names and "siddon_forward+jac" in names and "siddon_backward[vol]" in names, names
+    again = _hip_render(case, spec, grid_w=w, grads=True, w=wgt)
+    assert torch.equal(hip[0], again[0]) and torch.equal(hip[1], again[1])
+    lhs = (hip[0].double() * wgt.cuda().double()).sum().item()
+    rhs = (hip[1].double() * case["volume"].cuda().double()).sum().item()
+    assert abs(lhs - rhs) <= 2e-5 * abs(lhs), (kw, case["volume"].shape, lhs, rhs)
+    # (ii) a tie-free shape: every size with a tie grows by one
+    shape = tuple(S + 1 if has_structural_tie(S, **kw) else S for S in case["volume"].shape)
+    if shape != tuple(case["volume"].shape):
+        case = dict(case, volume=_smooth(shape, 300 + seed))
+        hip = _hip_render(case, spec, grid_w=w, grads=True, w=wgt)
+    ref, ref32 = _oracle64(case, spec, wgt), _oracle(case, spec, wgt, torch.float32)
+    rays = n_poses * h * w
+    allowed = 16 + int(2.5e-3 * rays)
+    for name, a, b, b32, tol in (("out", hip[0], ref[0], ref32[0], FWD_TOL), ("grad_target", hip[3], ref[3], ref32[3], GRAD_TOL),
+                                 ("grad_img", hip[4], ref[4], ref32[4], GRAD_TOL)):
+        bad, n, worst = _outlier_rays(a, b, tol)
+        assert bad <= max(allowed, _outlier_rays(b32, b, tol)[0]), f"{name}: {bad} of {n} rays beyond {tol:.1e} (max {worst:.2e}; allowed {allowed})"
+    gv, rv = hip[1].double().cpu(), ref[1].double()
+    bad = int(((gv - rv).abs() > GRAD_TOL * rv.abs().max()).sum())
+    assert bad <= allowed, f"grad_volume: {bad} of {gv.numel()} voxels beyond {GRAD_TOL:.1e} (allowed {allowed})"
+    assert abs(gv.sum().item() - rv.sum().item()) <= 1e-4 * rv.abs().sum().item()
+    _close(hip[2], ref[2], 5e-2, "grad_source")
+
+
 @pytest.mark.parametrize("seed", range(10))
 def test_large_trilinear_launch_on_the_tiled_copy_against_the_oracle(seed):
     from xvr_amd import renderers
