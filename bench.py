@@ -161,21 +161,33 @@ class Exchange:
     all_gather_into_tensor over RCCL, issued async right after the forward and waited for after the backward.  The unequal
     shares of a ragged strong-scaling split are padded to the largest share (no backend gathers uneven tensors in one call)."""
 
-    def __init__(self, world, B, Bmax, H, dev):
+    def __init__(self, world, B, Bmax, H, dev, volume_grad=True, buckets=8):
         self.B = B
         self.gathered = torch.empty(world * Bmax, 1, H, H, device=dev)
         self.send = torch.zeros(Bmax, 1, H, H, device=dev) if Bmax != B else None
         self.handle = None
+        # the second exchange of the fwd+bwd(pose+voxel) step (SURVEY.md section 8e): every rank rendered different poses of the SAME
+        # volume, so the voxel gradients are summed -- bucketed async all-reduces over slabs of the gradient, issued when the backward
+        # has written it, waited for at the end of the step (xvr_amd.distributed.allreduce_volume_grad_bucketed)
+        self.volume_grad, self.buckets, self.works = volume_grad, buckets, []
 
     def post_forward(self, img):
         if self.send is not None:
             self.send[:self.B].copy_(img.detach())
         self.handle = dist.all_gather_into_tensor(self.gathered, img.detach() if self.send is None else self.send, async_op=True)
 
+    def post_backward(self, grad):
+        if self.volume_grad and grad is not None:
+            from xvr_amd.distributed import allreduce_volume_grad_bucketed
+            self.works = allreduce_volume_grad_bucketed(grad, self.buckets, force=True)
+
     def wait(self):
         if self.handle is not None:
             self.handle.wait()
             self.handle = None
+        for w in self.works:
+            w.wait()
+        self.works = []
 
 
 def render_leg(dev, subject, renderer, voxel_grad, rot0, xyz0, H, delx, n_points, steps, warmup, exchange=None, update_volume=False,
@@ -208,6 +220,7 @@ def render_leg(dev, subject, renderer, voxel_grad, rot0, xyz0, H, delx, n_points
             exchange.post_forward(img)
         (img * w).sum().backward()
         if exchange is not None:
+            exchange.post_backward(density.grad)
             exchange.wait()
         return img
 
@@ -297,7 +310,7 @@ def render_leg(dev, subject, renderer, voxel_grad, rot0, xyz0, H, delx, n_points
         "kernel_ms_per_step": kernel_ms, "bytes_per_unit": bytes_per_unit * (2 if voxel_grad else 1),
     }
     return {"elapsed": elapsed, "ms_per_step": 1e3 * elapsed / steps, "kernels": kernels, "roofline": roofline, "units": units,
-            "step": step, "drr": drr, "spec": spec, "rot": rot, "xyz": xyz, "B": B}
+            "step": step, "drr": drr, "spec": spec, "rot": rot, "xyz": xyz, "B": B, "density": density}
 
 
 def leg_summary(leg, B):
@@ -335,6 +348,11 @@ def main():
     ap.add_argument("--check-gather", action="store_true",
                     help="with N > 1 (or --force-dist): rank 0 re-renders EVERY rank's poses itself through the HIP path and compares "
                          "the all-gathered tensor with it value by value (`gather_check` in the JSON line)")
+    ap.add_argument("--no-volume-grad-exchange", action="store_true",
+                    help="N > 1: leave the all-reduce of the voxel gradient out of the step (the all-gather of the DRRs stays)")
+    ap.add_argument("--check-volume-grad", action="store_true",
+                    help="with N > 1 (or --force-dist): rank 0 renders the UNION of all ranks' poses itself and compares its voxel "
+                         "gradient with the all-reduced one (`volume_grad_check` in the JSON line)")
     ap.add_argument("--drr-kwargs", default="", help='JSON of extra DRR / RenderSpec keywords for the headline leg, e.g. \'{"norm_dims_offset": 1}\' '
                                                      "(the recalled knob sets; recorded in config.workload)")
     ap.add_argument("--dry-run-collectives", action="store_true",
@@ -378,7 +396,7 @@ def main():
     else:
         rot, xyz = deepfluoro_poses(B, seed=rank).convert("euler_angles", "ZXY")
     Bmax = B if args.scaling == "weak" else -(-B_total // world)
-    exchange = Exchange(world, B, Bmax, H, dev) if use_dist else None
+    exchange = Exchange(world, B, Bmax, H, dev, volume_grad=not args.no_volume_grad_exchange and not args.no_voxel_grad) if use_dist else None
 
     drr_kwargs = json.loads(args.drr_kwargs) if args.drr_kwargs else None
     leg = render_leg(dev, subject, args.renderer, not args.no_voxel_grad, rot, xyz, H, delx, args.n_points, args.steps, args.warmup,
@@ -407,10 +425,66 @@ def main():
                         + (f", n_points={args.n_points}" if args.renderer == "trilinear" else "")
                         + (f", spec {drr_kwargs}" if drr_kwargs else ""),
             "global_batch": B_total, "parallelism": f"pose-sharded x{world}, replicated volume, all-gather of DRRs"
+            + ("" if args.no_volume_grad_exchange or args.no_voxel_grad else " + all-reduce of the voxel gradient")
             if world > 1 else "single GPU",
         },
         "roofline": leg["roofline"], "kernels": leg["kernels"],
     }
+
+    if use_dist:
+        vg = exchange.volume_grad
+        result["volume_grad_exchange"] = {
+            "in_the_timed_step": bool(vg), "buckets": exchange.buckets if vg else 0,
+            "MB_per_rank": (args.size ** 3) * 4 / 1e6 if vg else 0.0,
+            "how": "bucketed async all_reduce (SUM) of density.grad over slabs of the first axis, issued after the backward, waited for "
+                   "at the end of the step; not overlapped with the splat (one autograd call writes the whole gradient)",
+        }
+        if vg:   # the same step without it, a short loop behind the timed region (same barrier discipline)
+            exchange.volume_grad = False
+            leg["step"]()
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(min(args.steps, 5)):
+                leg["step"]()
+            torch.cuda.synchronize()
+            dist.barrier()
+            t_wo = torch.tensor([(time.perf_counter() - t0) / min(args.steps, 5)], device=dev, dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(t_wo, op=dist.ReduceOp.MAX)
+            exchange.volume_grad = True
+            result["volume_grad_exchange"]["ms_per_step_without_it"] = 1e3 * t_wo.item()
+            result["volume_grad_exchange"]["value_without_it"] = B_total / t_wo.item()
+
+    if args.check_volume_grad and use_dist and exchange.volume_grad:
+        # the all-reduced voxel gradient against the gradient of the UNION batch rendered by rank 0 alone through the same HIP path
+        # (the per-pose fixed-point sums are converted and added pose by pose in fp32: the grouping differs, so a tolerance)
+        leg["step"]()
+        torch.cuda.synchronize()
+        summed = leg["density"].grad.detach().clone()
+        dist.barrier()
+        if rank == 0:
+            from xvr_amd.pose import convert  # noqa: F401
+            kwr = {"n_points": args.n_points} if args.renderer == "trilinear" else {}
+            rr_all, xx_all, ww = [], [], []
+            for r in range(world):
+                if args.scaling == "strong":
+                    from xvr_amd.distributed import shard_bounds
+                    l, h = shard_bounds(B_total, r, world)
+                    rr, xx = (t[l:h] for t in deepfluoro_poses(B_total, seed=0).convert("euler_angles", "ZXY"))
+                else:
+                    rr, xx = deepfluoro_poses(args.batch, seed=r).convert("euler_angles", "ZXY")
+                rr_all.append(rr); xx_all.append(xx)
+                ww.append(torch.rand(rr.shape[0], 1, H, H, device=dev, generator=torch.Generator(device=dev).manual_seed(1234)))
+            dens = leg["density"].detach().clone().requires_grad_(True)
+            img_u = leg["drr"](torch.cat(rr_all).to(dev), torch.cat(xx_all).to(dev), parameterization="euler_angles", convention="ZXY",
+                               density=dens, **kwr)
+            (img_u * torch.cat(ww)).sum().backward()
+            ref_g = dens.grad
+            err = (summed - ref_g).abs().max().item() / max(ref_g.abs().max().item(), 1e-30)
+            result["volume_grad_check"] = {"max_rel_err": err, "ok": bool(err <= 2e-6), "ranks": world,
+                                           "nonzero_voxels": int((ref_g != 0).sum().item())}
+        dist.barrier()
 
     if args.check_gather and use_dist:
         # the exchange moved the right numbers to the right place: every rank's block of the gathered tensor against a render of
@@ -558,16 +632,26 @@ def dry_run_collectives(args):
         with torch.no_grad():
             img = leg["drr"](leg["rot"], leg["xyz"], parameterization="euler_angles", convention="ZXY",
                              **({"n_points": args.n_points} if args.renderer == "trilinear" else {}))
+        # the voxel gradient's bucketed all-reduce ran inside that step (on the one-rank group: a sum over one rank); the same step
+        # without it must leave the very same gradient
+        g_with = leg["density"].grad.detach().clone() if not args.no_voxel_grad else None
+        ex.volume_grad = False
+        leg["step"]()
+        torch.cuda.synchronize()
+        ok_grad = bool(g_with is None or torch.equal(g_with, leg["density"].grad))
         full[rank * Bmax:rank * Bmax + Bmax].copy_(ex.gathered)
         ok_block = bool(torch.equal(ex.gathered[:Bl], img))
         ok_pad = bool((ex.gathered[Bl:] == 0).all()) if Bmax > Bl else True
         ok_rest = bool(torch.isnan(full[:rank * Bmax]).all() and torch.isnan(full[(rank + 1) * Bmax:]).all())
         report["legs"].append({"as_rank": rank, "poses": Bl, "share_padded_to": Bmax, "gather_buffer_MB": full.numel() * 4 / 1e6,
                                "send_MB": Bmax * H * H * 4 / 1e6, "gathered_block_equals_render": ok_block, "padding_is_zero": ok_pad,
-                               "rest_untouched": ok_rest, "ms_step": leg["ms_per_step"]})
+                               "rest_untouched": ok_rest, "volume_grad_allreduce_identity": ok_grad,
+                               "volume_grad_buckets": 0 if args.no_voxel_grad else 8, "volume_grad_MB": 0.0 if args.no_voxel_grad else args.size ** 3 * 4 / 1e6,
+                               "ms_step": leg["ms_per_step"]})
         del full, ex, leg
         torch.cuda.empty_cache()
-    report["ok"] = all(l["gathered_block_equals_render"] and l["padding_is_zero"] and l["rest_untouched"] for l in report["legs"])
+    report["ok"] = all(l["gathered_block_equals_render"] and l["padding_is_zero"] and l["rest_untouched"] and l["volume_grad_allreduce_identity"]
+                       for l in report["legs"])
     print(json.dumps(report))
     dist.destroy_process_group()
     if not report["ok"]:

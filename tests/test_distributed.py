@@ -51,10 +51,15 @@ def _worker(rank, world, port, B, out_q):
 
     grad = torch.full((4, 4, 4), float(rank + 1))
     xd.allreduce_volume_grad(grad)
+    # the bucketed, asynchronous form bench.py's N > 1 step uses: slabs of the first axis, summed in place
+    g2 = (torch.arange(5 * 3 * 2, dtype=torch.float32).reshape(5, 3, 2) + 100.0 * rank)
+    works = xd.allreduce_volume_grad_bucketed(g2, n_buckets=3)
+    xd.wait_all(works)
+    bucket_ok = len(works) == 3 and torch.equal(g2, 2 * torch.arange(30, dtype=torch.float32).reshape(5, 3, 2) + 100.0)
     score = torch.tensor(0.5 + 0.1 * ((rank * 7) % 3))
     best_score, best_pose, best_rank = xd.multistart_best(score, pose.matrix[lo])
     out_q.put(dict(rank=rank, bounds=(lo, hi), same=torch.allclose(gathered, full, atol=1e-6), ok_async=ok_async,
-                   grad=grad[0, 0, 0].item(), best_rank=best_rank, best_score=best_score.item(),
+                   grad=grad[0, 0, 0].item(), bucket_ok=bucket_ok, best_rank=best_rank, best_score=best_score.item(),
                    best_pose_ok=torch.allclose(best_pose, pose.matrix[xd.shard_bounds(B, best_rank, world)[0]])))
     dist.destroy_process_group()
 
@@ -75,6 +80,7 @@ def test_pose_sharded_render_world2_gloo(B):
     for d in res:
         assert d["same"] and d["ok_async"], "all-gathered shards must equal the single-process render"
         assert d["grad"] == 3.0  # 1 + 2
+        assert d["bucket_ok"], "bucketed async all-reduce of the volume gradient: the in-place sum over both ranks"
         assert d["best_rank"] == 1 and abs(d["best_score"] - 0.6) < 1e-6 and d["best_pose_ok"]
 
 

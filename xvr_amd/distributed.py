@@ -113,6 +113,31 @@ def allreduce_volume_grad(grad: torch.Tensor) -> torch.Tensor:
     return grad
 
 
+def allreduce_volume_grad_bucketed(grad: torch.Tensor, n_buckets: int = 8, force: bool = False):
+    """The same sum as ``allreduce_volume_grad`` issued as ``n_buckets`` ASYNC all-reduces over contiguous slabs of the volume's
+    first axis (a [512, 512, 512] float32 gradient is 512 MiB: eight 64 MiB collectives are in flight together, which is what
+    lets RCCL use all seven xGMI links of a GPU instead of one ring -- SURVEY.md section 8e).  Returns the list of work handles
+    (empty on one rank unless ``force``: the one-rank groups of bench.py's dry run); ``wait_all`` blocks on them.  The slabs are
+    views of ``grad``: the sum lands in place."""
+    if (_world() == 1 and not force) or not (dist.is_available() and dist.is_initialized()):
+        return []
+    flat = grad.view(grad.shape[0], -1) if grad.dim() > 1 and grad.is_contiguous() else grad.reshape(-1, 1)
+    n = flat.shape[0]
+    n_buckets = max(1, min(int(n_buckets), n))
+    works = []
+    for k in range(n_buckets):
+        lo, hi = shard_bounds(n, k, n_buckets)
+        if hi > lo:
+            works.append(dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+    return works
+
+
+def wait_all(works) -> None:
+    for w in works:
+        if w is not None:
+            w.wait()
+
+
 def multistart_best(score: torch.Tensor, pose_matrix: torch.Tensor):
     """Every rank ran its own registration; return (best_score, best_pose[4,4], best_rank) everywhere.
     ``score`` is a scalar tensor (higher is better), ``pose_matrix`` is [4,4] or [1,4,4]."""
