@@ -562,7 +562,7 @@ def main():
         # (2048^2 X-ray at 0.136 mm, scales "8,4": 256^2 then 512^2, registrar/base.py:402-407; scaled with --det for the tiny test runs)
         c4_delx = 0.1360 * 8 * 256 / H
         # (every parameterisation the reference's registrar offers runs the device-resident loop, and Equalize runs inside it)
-        c4_extra = tuple(dict(parameterization=p) for p in ("se3_log_map", "axis_angle", "quaternion", "quaternion_adjugate", "rotation_6d")) + \
+        c4_extra = tuple(dict(parameterization=p) for p in ("se3_log_map", "axis_angle", "quaternion", "quaternion_adjugate", "rotation_6d", "rotation_10d")) + \
                    (dict(equalize=True),)
         variants["c4_register_ms_per_pose_iteration"] = benchlib.c4_register(dev, subject, sizes=((H, c4_delx), (2 * H, c4_delx / 2)), extra=c4_extra)
         torch.cuda.empty_cache()

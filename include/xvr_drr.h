@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define XVR_DRR_ABI_VERSION 8   /* 8: volume_layout 3 + xvr_drr_pack_ytiles / _labels_ytiles (tiled y-pair copy), xvr_pose_camera_forward_param / xvr_pose_opt_step_param (device-resident registration for every parameterisation; xvr_pose_opt_state holds 13 parameters), xvr_sim_equalize_* write / take the normalised output, options tile_geom, siddon_slab, siddon_gather_fast; 7: xvr_drr_foreground, xvr_drr_pack_labels_ypairs, xvr_sim_dice_bool, xvr_sim_transform_* (xvr_sim.h), xvr_pose_convert_* (xvr_pose.h); 6: xvr_drr_spec.alpha_window + xvr_drr_alpha_window (clip_to_volume = 2); 5: xvr_drr_set_option / xvr_drr_get_option (the A/B switches are no longer getenv calls per launch); 4: volume_layout 2 + xvr_drr_pack_bricks (siddon forward); 3: xvr_drr_spec.volume_layout + xvr_drr_pack_ypairs; 2: xvr_sim_spec grew, camera-driven forwards, packed labels, xvr_pose.h */
+#define XVR_DRR_ABI_VERSION 9   /* 9: xvr_drr_pack_hu_labels_ytiles, options siddon_splat / gather_splat = 3 / siddon_slab = 2, pose kind 6 (rotation_10d), non-exact Siddon index maps on the slab march and the brick splat, guard-banded fixed point; 8: volume_layout 3 + xvr_drr_pack_ytiles / _labels_ytiles (tiled y-pair copy), xvr_pose_camera_forward_param / xvr_pose_opt_step_param (device-resident registration for every parameterisation; xvr_pose_opt_state holds 13 parameters), xvr_sim_equalize_* write / take the normalised output, options tile_geom, siddon_slab, siddon_gather_fast; 7: xvr_drr_foreground, xvr_drr_pack_labels_ypairs, xvr_sim_dice_bool, xvr_sim_transform_* (xvr_sim.h), xvr_pose_convert_* (xvr_pose.h); 6: xvr_drr_spec.alpha_window + xvr_drr_alpha_window (clip_to_volume = 2); 5: xvr_drr_set_option / xvr_drr_get_option (the A/B switches are no longer getenv calls per launch); 4: volume_layout 2 + xvr_drr_pack_bricks (siddon forward); 3: xvr_drr_spec.volume_layout + xvr_drr_pack_ypairs; 2: xvr_sim_spec grew, camera-driven forwards, packed labels, xvr_pose.h */
 
 #define XVR_DRR_OK 0
 #define XVR_DRR_E_ARG (-1)     /* bad argument (null pointer, non-positive size, unsupported combo) */
@@ -289,6 +289,11 @@ int xvr_drr_pack_labels_ypairs(const float* volume, const float* mask, int D0, i
 size_t xvr_drr_ytiles_bytes(int D0, int D1, int D2);
 int xvr_drr_pack_ytiles(const float* volume, int D0, int D1, int D2, float* tiles, void* stream);
 int xvr_drr_pack_labels_ytiles(const float* volume, const float* mask, int D0, int D1, int D2, float* tiles, void* stream);
+/* ... and with the HU -> density map of xvr_drr_hu_to_density applied on the way (`hu`: Hounsfield units; `stats`: xvr_drr_hu_stats
+ * of it): the tiles hold exactly the bits xvr_drr_hu_to_density followed by xvr_drr_pack_labels_ytiles would, without the density
+ * volume in between -- the per-step 512 MiB round trip of /root/reference/src/xvr/model/trainer.py:196-197 (round 5). */
+int xvr_drr_pack_hu_labels_ytiles(const float* hu, const float* mask, const void* stats, float bone_multiplier, int D0, int D1, int D2,
+                                  float* tiles, void* stream);
 
 /*
  * Bricked copy of a volume for the Siddon forward (spec.volume_layout = 2):

@@ -125,7 +125,8 @@ int xvr_pose_multiview_backward(const float* true_pose, const float* pred_pose, 
  * each (/root/reference/src/xvr/model/network.py:49-56 on the regressor's output every training step; the registrar with
  * non-Euler parameterisations, registrar/base.py:168): the framework's 40-110 tiny launches cost 0.8-2.0 ms at 116 poses.
  *   kind   0 euler_angles (axes = the convention, 0 = X .. 2 = Z; radians)   1 axis_angle   2 quaternion (real first)
- *          3 quaternion_adjugate (10 numbers)   4 rotation_6d   5 se3_log_map        rot [B][3 | 3 | 4 | 10 | 6 | 3]
+ *          3 quaternion_adjugate (10 numbers)   4 rotation_6d   5 se3_log_map   6 rotation_10d (the upper triangle of a symmetric
+ *          4 x 4 whose smallest eigenvector is the quaternion: Jacobi iteration per pose)   rot [B][3 | 3 | 4 | 10 | 6 | 3 | 10]
  *   matrix [B][16] row-major;  jac: xvr_pose_convert_jacobian_floats(B) floats, written by the forward (the 12 x (k + 3)
  *          Jacobian of every pose, by forward-mode differentiation of the same formulas) and read by the backward
  *   backward: grad_matrix [B][16] (row 3 ignored) -> grad_rot [B][k], grad_xyz [B][3]

@@ -1,0 +1,99 @@
+"""The WHOLE benchmark batch through the oracle, once: BASELINE.json configs[1] / configs[2] -- the 512^3
+phantom and the 116 DeepFluoro poses of bench.py, 256 x 256 detector, trilinear (n_points = 500) and Siddon -- rendered by
+oracle/diffdrr_restated.py in chunks on the CPU, every pixel of every pose, with the gradient of a weighted image sum w.r.t. the six
+pose parameters.  What is committed (tests/golden/c2c3_oracle_batch.npz, ~2 MB; the full images would be 60 MB):
+
+  * 4096 pixels of every pose at fixed seeded positions, float32                       (pixel-exact comparison)
+  * the sums over all 256 tiles of 16 x 16 pixels of every pose, float64               (every pixel of every pose is in one)
+  * the image's maximum and sum per pose
+  * d (sum_pixels w_b * img_b) / d (rot_b, xyz_b), Euler ZXY, per pose, float64        (the pose gradient over all pixels)
+
+tests/test_configs.py::test_benchmark_batch_against_the_oracle_fixture compares the HIP path with it on the GPU.
+
+    python tests/golden/make_golden_c2c3.py [--threads 6] [--poses 0:116] [--renderers trilinear,siddon] [--out DIR]
+
+Resumable: every pose is written to DIR (default tests/golden/_c2c3_parts, git-ignored) as it finishes; the last step packs the
+parts into the .npz.  ~25 s (trilinear) + ~45 s (Siddon) per pose on 8 cores.
+"""
+import argparse
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+
+SIZE, H, B, N_POINTS, SDD, DELX = 512, 256, 116, 500, 1020.0, 1.08821875
+N_SAMPLED = 4096
+
+
+def weights(b):
+    return torch.from_numpy(np.random.default_rng(1000 + b).uniform(0.0, 1.0, size=(1, 1, H, H))).to(torch.float32)
+
+
+def sampled_pixels():
+    return np.sort(np.random.default_rng(77).choice(H * H, size=N_SAMPLED, replace=False))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--threads", type=int, default=6)
+    ap.add_argument("--poses", default=f"0:{B}")
+    ap.add_argument("--renderers", default="trilinear,siddon")
+    ap.add_argument("--out", default=str(Path(__file__).resolve().parent / "_c2c3_parts"))
+    ap.add_argument("--pack-only", action="store_true")
+    args = ap.parse_args()
+    torch.set_num_threads(args.threads)
+    out = Path(args.out)
+    out.mkdir(parents=True, exist_ok=True)
+    lo, hi = (int(x) for x in args.poses.split(":"))
+    renderers = args.renderers.split(",")
+    if not args.pack_only:
+        from oracle.diffdrr_restated import RenderSpec, drr_from_pose
+        from xvr_amd.data import make_phantom, read
+        from xvr_amd.pose import convert
+        from xvr_amd.training import get_random_pose
+
+        vol, _ = make_phantom(SIZE, n_ellipsoids=64, seed=0)
+        affine = read(vol, orientation="AP").affine
+        g = torch.Generator().manual_seed(0)   # (bench.py::deepfluoro_poses(116, seed=0))
+        rot, xyz = get_random_pose(135.0, 225.0, -45.0, 45.0, -15.0, 15.0, -150.0, 150.0, 450.0, 1000.0, -150.0, 150.0, B,
+                                   generator=g).convert("euler_angles", "ZXY")
+        pix = torch.from_numpy(sampled_pixels())
+        for renderer in renderers:
+            spec = RenderSpec(renderer=renderer, n_points=N_POINTS)
+            for b in range(lo, hi):
+                part = out / f"{renderer}_{b:03d}.npz"
+                if part.exists():
+                    continue
+                t0 = time.time()
+                r = rot[b:b + 1].clone().requires_grad_(True)
+                x = xyz[b:b + 1].clone().requires_grad_(True)
+                pose = convert(r, x, parameterization="euler_angles", convention="ZXY")
+                img = drr_from_pose(vol, affine, pose.matrix, H, H, SDD, DELX, DELX, 0.0, 0.0, spec, orientation="AP",
+                                    reverse_x_axis=False, chunk=8192 if renderer == "trilinear" else 2048)
+                (img * weights(b)).sum().backward()
+                im = img.detach()[0, 0]
+                tiles = im.double().reshape(16, 16, 16, 16).sum(dim=(1, 3))
+                np.savez(part, pixels=im.reshape(-1)[pix].numpy(), tiles=tiles.numpy(), imax=im.max().item(), isum=im.double().sum().item(),
+                         grad=torch.cat([r.grad, x.grad], dim=-1).double().numpy()[0], rot=rot[b].numpy(), xyz=xyz[b].numpy())
+                print(f"{renderer} pose {b}: {time.time() - t0:.1f} s, max {im.max().item():.3f}", flush=True)
+    packed = {"pixel_index": sampled_pixels()}
+    for renderer in ("trilinear", "siddon"):
+        parts = [out / f"{renderer}_{b:03d}.npz" for b in range(B)]
+        if not all(p.exists() for p in parts):
+            print(f"{renderer}: {sum(p.exists() for p in parts)} of {B} poses done; not packed")
+            continue
+        loaded = [np.load(p) for p in parts]
+        for key in ("pixels", "tiles", "imax", "isum", "grad", "rot", "xyz"):
+            packed[f"{renderer}_{key}"] = np.stack([d[key] for d in loaded])
+    if len(packed) > 1:
+        np.savez_compressed(Path(__file__).resolve().parent / "c2c3_oracle_batch.npz", **packed)
+        print({k: v.shape for k, v in packed.items()})
+
+
+if __name__ == "__main__":
+    main()

@@ -148,6 +148,33 @@ def test_c5_full_size_masked_renders_512_to_256_batch_116_eight_labels():
     frac_ref = (o_mask[:, 1:].sum(1) > 0).float().flatten(1).mean(1)
     assert (frac_hip - frac_ref).abs().max().item() < 2e-3, (frac_hip, frac_ref)
     assert keep.shape == (B,) and 0 < int(keep.sum()) <= B
+    # Round 5: the density volume need not exist.  transform_hu_to_density(..., lazy=True) hands the renders an object whose map is
+    # applied inside their own packing pass (xvr_drr_pack_hu_labels_ytiles): the same bits, one 512 MiB write and read less per step
+    from xvr_amd import renderers
+    lazy = transform_hu_to_density(hu, 4.2, lazy=True)
+    renderers.PROFILER = []
+    with torch.no_grad():
+        img2, mask2, keep2 = render_samples(drr, lazy, drr.mask, drr.affine_inverse, pose)
+    names = [e[0] for e in renderers.PROFILER]
+    renderers.PROFILER = None
+    assert "pack_hu_labels_ytiles" in names and "hu_to_density" not in names, names
+    assert torch.equal(img2, img) and torch.equal(mask2, mask) and torch.equal(keep2, keep)
+    # ... with the pose gradient of the second render of a step, and nothing written behind the scenes
+    rot, xyz = pose.convert("euler_angles", "ZXY")
+    grads = []
+    for vol_arg in (tmp, lazy):
+        r, x = rot.clone().requires_grad_(True), xyz.clone().requires_grad_(True)
+        from xvr_amd.pose import convert
+        out, _, _ = render_samples(drr, vol_arg, drr.mask, drr.affine_inverse, convert(r, x, parameterization="euler_angles", convention="ZXY"))
+        out.sum().backward()
+        grads.append((r.grad.clone(), x.grad.clone()))
+    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
+    assert lazy._dense is None, "the lazy density was written although no consumer needed it"
+    # an unmasked render, which packs nothing of its own, gets the density written on demand -- the same image
+    with torch.no_grad():
+        plain2, _, _ = render_samples(drr, lazy, None, drr.affine_inverse, pose[:4])
+        plain4, _, _ = render_samples(drr, tmp, None, drr.affine_inverse, pose[:4])
+    assert lazy._dense is not None and torch.equal(plain2, plain4)
 
 
 def test_c4_full_size_multistart_registration_pyramid_8_4_of_a_2048_xray():

@@ -101,7 +101,7 @@ def test_projection_helpers_invert_the_detector_geometry():
 @pytest.mark.gpu
 @pytest.mark.parametrize("param,convention", [("euler_angles", "ZXY"), ("euler_angles", "XYZ"), ("euler_angles", "ZYZ"), ("axis_angle", None),
                                                ("quaternion", None), ("quaternion_adjugate", None), ("rotation_6d", None),
-                                               ("se3_log_map", None)])
+                                               ("se3_log_map", None), ("rotation_10d", None)])
 def test_fused_convert_matches_the_torch_formulation_value_and_gradient(param, convention):
     """xvr_pose_convert_forward / _backward (one launch each, forward-mode Jacobians) against the torch formulas of this module,
     which the regressor's head goes through every training step (network.py:49-56): matrices and the gradients w.r.t. the
@@ -118,6 +118,11 @@ def test_fused_convert_matches_the_torch_formulation_value_and_gradient(param, c
     if param == "quaternion_adjugate":      # q q^T of a random quaternion (any scale), mildly perturbed as a regressor's output would be
         q = torch.randn(B, 4, generator=g) * (0.5 + torch.rand(B, 1, generator=g))
         rot = P.quaternion_to_quaternion_adjugate(q) + 0.02 * torch.randn(B, 10, generator=g)
+    if param == "rotation_10d":             # a symmetric 4 x 4 whose smallest eigenvector is a random quaternion, perturbed: I - q q^T + noise
+        q = torch.nn.functional.normalize(torch.randn(B, 4, generator=g), dim=-1)
+        A = (0.5 + torch.rand(B, 1, 1, generator=g)) * (torch.eye(4) - q[:, :, None] * q[:, None, :])
+        idx, jdx = torch.triu_indices(4, 4)
+        rot = A[:, idx, jdx] + 0.03 * torch.randn(B, 10, generator=g)
     xyz = torch.randn(B, 3, generator=g) * torch.tensor([50.0, 300.0, 50.0])
     w = torch.randn(B, 4, 4, generator=g)
     kw = dict(parameterization=param, convention=convention)

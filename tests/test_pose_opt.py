@@ -599,7 +599,7 @@ def test_equalize_hip_matches_the_torch_formulation_value_and_gradient(shape):
 # ---------------------------------------------------------------------------------------------------------------
 # round 4: the device-resident loop for every parameterisation (/root/reference/src/xvr/registrar/base.py:168-169)
 # ---------------------------------------------------------------------------------------------------------------
-NON_EULER = ["axis_angle", "quaternion", "quaternion_adjugate", "rotation_6d", "se3_log_map"]
+NON_EULER = ["axis_angle", "quaternion", "quaternion_adjugate", "rotation_6d", "se3_log_map", "rotation_10d"]
 
 
 @pytest.mark.gpu

@@ -159,7 +159,8 @@ def c5_train_step(dev, size=512, B=116, H=256, n=9, warm=3):
         e.record()
         pose = get_random_pose(135.0, 225.0, -45.0, 45.0, -15.0, 15.0, -150.0, 150.0, 450.0, 1000.0, -150.0, 150.0, B, generator=g).to(dev)
         e = lap("sample poses", e)
-        tmp = transform_hu_to_density(drr.volume, float(torch.empty(1).uniform_(1.0, 10.0, generator=g)))
+        # (lazy: the density volume is never written -- the map rides in the renders' packing pass, xvr_amd.data.HUDensity)
+        tmp = transform_hu_to_density(drr.volume, float(torch.empty(1).uniform_(1.0, 10.0, generator=g)), lazy=True)
         e = lap("HU -> density", e)
         with torch.no_grad():
             img, mask, keep = render_samples(drr, tmp, drr.mask, drr.affine_inverse, pose)

@@ -11,7 +11,7 @@ import warnings
 
 from .build import LIB, HipccMissing, build_library, is_stale
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 JAC_STRIDE = 8
 ALPHA_WINDOW_FLOATS = 16   # XVR_DRR_ALPHA_WINDOW_FLOATS
 
@@ -129,6 +129,7 @@ EXPORTS = {
     "xvr_drr_ytiles_bytes": ([_I, _I, _I], ctypes.c_size_t),
     "xvr_drr_pack_ytiles": ([_P, _I, _I, _I, _P, _P], ctypes.c_int),
     "xvr_drr_pack_labels_ytiles": ([_P, _P, _I, _I, _I, _P, _P], ctypes.c_int),
+    "xvr_drr_pack_hu_labels_ytiles": ([_P, _P, _P, ctypes.c_float, _I, _I, _I, _P, _P], ctypes.c_int),
     "xvr_drr_bricks_bytes": ([_I, _I, _I], ctypes.c_size_t),
     "xvr_drr_pack_bricks": ([_P, _I, _I, _I, _P, _P], ctypes.c_int),
     "xvr_drr_jac_to_camera_workspace_bytes": ([_I, _I, _I], ctypes.c_size_t),

@@ -483,6 +483,67 @@ __device__ inline void convert_dual(const float* __restrict__ rot, const float* 
         R[6] = b1[1] * b2[2] - b1[2] * b2[1];
         R[7] = b1[2] * b2[0] - b1[0] * b2[2];
         R[8] = b1[0] * b2[1] - b1[1] * b2[0];
+    } else if (kind == 6) {
+        // rotation_10d (Peretroukhin et al. 2020; pose.py rotation_10d_to_quaternion): the 10 numbers are the upper triangle of a
+        // symmetric 4 x 4 A, the quaternion is the unit eigenvector of its SMALLEST eigenvalue.  Values: cyclic Jacobi on the 4 x 4
+        // (converges quadratically; 8 sweeps are far past float32 resolution).  Derivatives by first-order perturbation theory,
+        // dq = sum_{j != 0} v_j (v_j^T dA q) / (lambda_0 - lambda_j), with dA / d r_i the symmetric unit matrix of entry i -- the
+        // gradient torch.linalg.eigh's backward gives (the sign of q is free: R(q) = R(-q)).
+        float A[4][4], V[4][4];
+        {
+            int q = 0;
+            for (int i = 0; i < 4; ++i)
+                for (int j = i; j < 4; ++j) { A[i][j] = A[j][i] = r[q].v; ++q; }
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j) V[i][j] = i == j ? 1.f : 0.f;
+        }
+        for (int sweep = 0; sweep < 8; ++sweep) {
+            for (int pp = 0; pp < 3; ++pp) {
+                for (int qq = pp + 1; qq < 4; ++qq) {
+                    const float apq = A[pp][qq];
+                    if (fabsf(apq) < 1e-30f) continue;
+                    const float tau = (A[qq][qq] - A[pp][pp]) / (2.f * apq);
+                    const float tt = (tau >= 0.f ? 1.f : -1.f) / (fabsf(tau) + sqrtf(1.f + tau * tau));
+                    const float cc = 1.f / sqrtf(1.f + tt * tt), ss = tt * cc;
+                    for (int kx = 0; kx < 4; ++kx) {   // A <- A J (columns pp, qq)
+                        const float akp = A[kx][pp], akq = A[kx][qq];
+                        A[kx][pp] = cc * akp - ss * akq;
+                        A[kx][qq] = ss * akp + cc * akq;
+                    }
+                    for (int kx = 0; kx < 4; ++kx) {   // A <- J^T A (rows pp, qq)
+                        const float apk = A[pp][kx], aqk = A[qq][kx];
+                        A[pp][kx] = cc * apk - ss * aqk;
+                        A[qq][kx] = ss * apk + cc * aqk;
+                    }
+                    for (int kx = 0; kx < 4; ++kx) {   // V <- V J
+                        const float vkp = V[kx][pp], vkq = V[kx][qq];
+                        V[kx][pp] = cc * vkp - ss * vkq;
+                        V[kx][qq] = ss * vkp + cc * vkq;
+                    }
+                }
+            }
+        }
+        int m0 = 0;
+        for (int j = 1; j < 4; ++j)
+            if (A[j][j] < A[m0][m0]) m0 = j;
+        Dual qd[4];
+        for (int i = 0; i < 4; ++i) qd[i] = dconst(V[i][m0]);
+        {
+            int e = 0;
+            for (int ri = 0; ri < 4; ++ri) {
+                for (int ci = ri; ci < 4; ++ci) {
+                    for (int j = 0; j < 4; ++j) {
+                        if (j == m0) continue;
+                        const float gap = A[m0][m0] - A[j][j];
+                        const float num = ri == ci ? V[ri][j] * V[ri][m0] : V[ri][j] * V[ci][m0] + V[ci][j] * V[ri][m0];
+                        const float cf = num / gap;
+                        for (int i = 0; i < 4; ++i) qd[i].d[e] = fmaf(cf, V[i][j], qd[i].d[e]);
+                    }
+                    ++e;
+                }
+            }
+        }
+        quat_to_matrix(qd, R);
     } else {   // se(3) twist (omega, v): R = exp(omega), t = V(omega) v -- no further rotation of t
         Dual a, b, c, V[9];
         so3_coeffs(r[0] * r[0] + r[1] * r[1] + r[2] * r[2], a, b, c);
@@ -573,13 +634,13 @@ extern "C" int xvr_pose_opt_init(xvr_pose_opt_state* state, int B, float lr_rot,
     return launched("pose_opt_init");
 }
 
-static const int POSE_K[6] = {3, 3, 4, 10, 6, 3};
+static const int POSE_K[7] = {3, 3, 4, 10, 6, 3, 10};
 
 extern "C" int xvr_pose_opt_step_param(float* rot, float* xyz, int B, int kind, const xvr_pose_opt_spec* spec, const float* G,
                                        const float* jac, float* grad_cam, const float* loss, xvr_pose_opt_state* state, float* history,
                                        void* stream) {
     if (!rot || !xyz || !spec || !G || !grad_cam || !loss || !state || B <= 0) return pfail(XVR_DRR_E_ARG, "bad argument");
-    if (kind < 0 || kind > 5) return pfail(XVR_DRR_E_ARG, "bad parameterisation");
+    if (kind < 0 || kind > 6) return pfail(XVR_DRR_E_ARG, "bad parameterisation");
     if (kind == 0 && !axes_ok(spec->axes)) return pfail(XVR_DRR_E_ARG, "axes must be in {0,1,2} with the middle one distinct from its neighbours");
     if (kind != 0 && !jac) return pfail(XVR_DRR_E_ARG, "a non-Euler parameterisation needs the Jacobian xvr_pose_camera_forward_param stored");
     if (spec->max_n_plateaus < 1 || spec->patience < 0 || (history && spec->max_iters < 1))
@@ -635,7 +696,7 @@ static int convert_axes(int kind, const int axes[3], Axes* ax) {
 extern "C" int xvr_pose_convert_forward(const float* rot, const float* xyz, int B, int kind, const int axes[3], float* matrix,
                                         float* jac, void* stream) {
     if (!rot || !xyz || !matrix || !jac) return pfail(XVR_DRR_E_ARG, "null pointer argument");
-    if (B <= 0 || kind < 0 || kind > 5) return pfail(XVR_DRR_E_ARG, "bad batch size or parameterisation");
+    if (B <= 0 || kind < 0 || kind > 6) return pfail(XVR_DRR_E_ARG, "bad batch size or parameterisation");
     Axes ax;
     if (int rc = convert_axes(kind, axes, &ax)) return rc;
     hipLaunchKernelGGL(k_pose_convert_fwd, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, (hipStream_t)stream, rot, xyz, B, kind, POSE_K[kind], ax,
@@ -646,7 +707,7 @@ extern "C" int xvr_pose_convert_forward(const float* rot, const float* xyz, int 
 extern "C" int xvr_pose_camera_forward_param(const float* rot, const float* xyz, int B, int kind, const int axes[3], const float* G,
                                              const float* c, float* cam, float* jac, void* stream) {
     if (!rot || !xyz || !G || !c || !cam || !jac) return pfail(XVR_DRR_E_ARG, "null pointer argument");
-    if (B <= 0 || kind < 0 || kind > 5) return pfail(XVR_DRR_E_ARG, "bad batch size or parameterisation");
+    if (B <= 0 || kind < 0 || kind > 6) return pfail(XVR_DRR_E_ARG, "bad batch size or parameterisation");
     Axes ax;
     if (int rc = convert_axes(kind, axes, &ax)) return rc;
     hipLaunchKernelGGL(k_pose_convert_fwd, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, (hipStream_t)stream, rot, xyz, B, kind, POSE_K[kind], ax,
@@ -657,7 +718,7 @@ extern "C" int xvr_pose_camera_forward_param(const float* rot, const float* xyz,
 extern "C" int xvr_pose_convert_backward(const float* jac, const float* grad_matrix, int B, int kind, float* grad_rot, float* grad_xyz,
                                          void* stream) {
     if (!jac || !grad_matrix || !grad_rot || !grad_xyz) return pfail(XVR_DRR_E_ARG, "null pointer argument");
-    if (B <= 0 || kind < 0 || kind > 5) return pfail(XVR_DRR_E_ARG, "bad batch size or parameterisation");
+    if (B <= 0 || kind < 0 || kind > 6) return pfail(XVR_DRR_E_ARG, "bad batch size or parameterisation");
     const int n = B * (POSE_K[kind] + 3);
     hipLaunchKernelGGL(k_pose_convert_bwd, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, (hipStream_t)stream, jac, grad_matrix, B, POSE_K[kind],
                        grad_rot, grad_xyz);

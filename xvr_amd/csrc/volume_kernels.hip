@@ -195,9 +195,19 @@ __global__ __launch_bounds__(TB) void k_pack_ypairs(const float* __restrict__ vo
 // entries after ~2 voxels when the view is oblique; a compact tile of the same 128 bytes is used more densely
 // (tools/sim_forward_lines.py).  Until late in round 4 the tiles were 4 x 4 at stride 3 (a third more memory): the forward is
 // bound by fabric lines, and the 2 x 8 tiles need fewer of them per voxel -- 5.23 against 5.42 ms at C2.
-template <bool LABELS>
+// HU (round 5): `vol` holds Hounsfield units and the copy holds their DENSITY -- k_hu_map's piecewise map, the same expressions, applied
+// on the way: the masked renders of a training step (/root/reference/src/xvr/model/trainer.py:196-204) then never write or read a
+// density volume of their own (512 MiB each way at 512^3).
+template <bool LABELS, bool HU = false>
 __global__ __launch_bounds__(TB) void k_pack_ytiles(const float* __restrict__ vol, const float* __restrict__ mask, int D0, int D1, int D2,
-                                                    float* __restrict__ tiles) {
+                                                    float* __restrict__ tiles, const unsigned* __restrict__ hu_stats = nullptr, float hu_mult = 1.f) {
+    HuMap hm = {0.f, 0.f, 1.f};
+    if (HU) hm = hu_constants(hu_stats, hu_mult);
+    auto dens = [&](const float v) {
+        if (!HU) return v;
+        const float d = v <= HU_AIR ? hm.soft_min : (v > HU_BONE ? v * hu_mult : v);
+        return (d - hm.dmin) / hm.inv_range;
+    };
     // one thread per 16 bytes of the copy (two z-entries of one tile row): consecutive threads write consecutive 16 bytes
     const int nbx = (D0 + 1) >> 1, nbz = (D2 - 2) / 7 + 1;
     const long long total = (long long)nbx * (D1 + 1) * nbz * 8;
@@ -217,8 +227,8 @@ __global__ __launch_bounds__(TB) void k_pack_ytiles(const float* __restrict__ vo
             const int z = 7 * bz + 2 * quarter + r;
             const bool in = x < D0 && z < D2;
             const long long olo = ((long long)x * D1 + (yp - 1)) * D2 + z, ohi = ((long long)x * D1 + yp) * D2 + z;
-            v[2 * r] = in && yp >= 1 ? (LABELS ? pk(vol[olo], mask[olo]) : vol[olo]) : 0.f;
-            v[2 * r + 1] = in && yp <= D1 - 1 ? (LABELS ? pk(vol[ohi], mask[ohi]) : vol[ohi]) : 0.f;
+            v[2 * r] = in && yp >= 1 ? (LABELS ? pk(dens(vol[olo]), mask[olo]) : dens(vol[olo])) : 0.f;
+            v[2 * r + 1] = in && yp <= D1 - 1 ? (LABELS ? pk(dens(vol[ohi]), mask[ohi]) : dens(vol[ohi])) : 0.f;
         }
         reinterpret_cast<float4*>(tiles)[t] = make_float4(v[0], v[1], v[2], v[3]);
     }
@@ -302,7 +312,8 @@ size_t xvr_drr_ytiles_bytes(int D0, int D1, int D2) {
     return (size_t)((D0 + 1) / 2) * (size_t)(D1 + 1) * (size_t)((D2 - 2) / 7 + 1) * 32 * sizeof(float);
 }
 
-static int pack_ytiles_impl(const float* volume, const float* mask, int D0, int D1, int D2, float* tiles, void* stream_) {
+static int pack_ytiles_impl(const float* volume, const float* mask, int D0, int D1, int D2, float* tiles, void* stream_,
+                            const void* hu_stats = nullptr, float hu_mult = 1.f) {
     if (!volume || !tiles || D0 < 2 || D1 < 2 || D2 < 2) return vfail(XVR_DRR_E_ARG, "bad argument");
     if (reinterpret_cast<uintptr_t>(tiles) & 15u) return vfail(XVR_DRR_E_ARG, "the tiled copy must be 16-byte aligned");
     const long long total = (long long)((D0 + 1) / 2) * (D1 + 1) * ((D2 - 2) / 7 + 1) * 8;   // 16-byte pieces
@@ -310,8 +321,11 @@ static int pack_ytiles_impl(const float* volume, const float* mask, int D0, int 
     if (D2 >= 8192) return vfail(XVR_DRR_E_UNSUPPORTED, "tiled y-pair copy: D2 must be below 8192 (the march's z / 7 is a multiply-shift)");
     const long long blocks = (total + TB - 1) / TB;
     const dim3 grid((unsigned)(blocks < 65536 ? blocks : 65536));
-    if (mask) hipLaunchKernelGGL(k_pack_ytiles<true>, grid, dim3(TB), 0, (hipStream_t)stream_, volume, mask, D0, D1, D2, tiles);
-    else hipLaunchKernelGGL(k_pack_ytiles<false>, grid, dim3(TB), 0, (hipStream_t)stream_, volume, mask, D0, D1, D2, tiles);
+    const unsigned* st = static_cast<const unsigned*>(hu_stats);
+    if (st && mask) hipLaunchKernelGGL((k_pack_ytiles<true, true>), grid, dim3(TB), 0, (hipStream_t)stream_, volume, mask, D0, D1, D2, tiles, st, hu_mult);
+    else if (st) hipLaunchKernelGGL((k_pack_ytiles<false, true>), grid, dim3(TB), 0, (hipStream_t)stream_, volume, mask, D0, D1, D2, tiles, st, hu_mult);
+    else if (mask) hipLaunchKernelGGL((k_pack_ytiles<true, false>), grid, dim3(TB), 0, (hipStream_t)stream_, volume, mask, D0, D1, D2, tiles, st, hu_mult);
+    else hipLaunchKernelGGL((k_pack_ytiles<false, false>), grid, dim3(TB), 0, (hipStream_t)stream_, volume, mask, D0, D1, D2, tiles, st, hu_mult);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? XVR_DRR_OK : vfail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
 }
@@ -323,6 +337,12 @@ int xvr_drr_pack_ytiles(const float* volume, int D0, int D1, int D2, float* tile
 int xvr_drr_pack_labels_ytiles(const float* volume, const float* mask, int D0, int D1, int D2, float* tiles, void* stream_) {
     if (!mask) return vfail(XVR_DRR_E_ARG, "bad argument");
     return pack_ytiles_impl(volume, mask, D0, D1, D2, tiles, stream_);
+}
+
+int xvr_drr_pack_hu_labels_ytiles(const float* hu, const float* mask, const void* stats, float bone_multiplier, int D0, int D1, int D2,
+                                  float* tiles, void* stream_) {
+    if (!mask || !stats) return vfail(XVR_DRR_E_ARG, "bad argument");
+    return pack_ytiles_impl(hu, mask, D0, D1, D2, tiles, stream_, stats, bone_multiplier);
 }
 
 int xvr_drr_pack_labels(const float* volume, const float* mask, long long n, float* packed, void* stream_) {

@@ -26,18 +26,7 @@ def _hu_to_density_hip(volume: torch.Tensor, mult: float) -> torch.Tensor:
     from .renderers import _ptr, _stream, _timed
 
     lib = _lib.load()
-    vol = volume if volume.is_contiguous() else volume.contiguous()
-    cached = getattr(volume, "_xvr_hu_stats", None)
-    if cached is not None and cached[0] == volume._version and vol is volume:
-        stats = cached[1]
-    else:
-        stats = torch.empty(16, dtype=torch.int32, device=vol.device)
-        _lib.check(lib.xvr_drr_hu_stats(_ptr(vol), ctypes.c_longlong(vol.numel()), _ptr(stats), _stream()), "xvr_drr_hu_stats")
-        if vol is volume:
-            try:
-                volume._xvr_hu_stats = (volume._version, stats)
-            except AttributeError:
-                pass
+    vol, stats = _hu_stats(volume)
     out = torch.empty_like(vol)
     rc = _timed("hu_to_density", lib.xvr_drr_hu_to_density, _ptr(vol), ctypes.c_longlong(vol.numel()), _ptr(stats),
                 ctypes.c_float(mult), _ptr(out), _stream())
@@ -45,7 +34,56 @@ def _hu_to_density_hip(volume: torch.Tensor, mult: float) -> torch.Tensor:
     return out
 
 
-def transform_hu_to_density(volume: torch.Tensor, bone_attenuation_multiplier: float) -> torch.Tensor:
+def _hu_stats(volume: torch.Tensor):
+    """(contiguous volume, its per-class statistics) -- reduced once per tensor version and remembered on the tensor object."""
+    import ctypes
+
+    from . import _lib
+    from .renderers import _ptr, _stream
+
+    vol = volume if volume.is_contiguous() else volume.contiguous()
+    cached = getattr(volume, "_xvr_hu_stats", None)
+    if cached is not None and cached[0] == volume._version and vol is volume:
+        return vol, cached[1]
+    stats = torch.empty(16, dtype=torch.int32, device=vol.device)
+    _lib.check(_lib.load().xvr_drr_hu_stats(_ptr(vol), ctypes.c_longlong(vol.numel()), _ptr(stats), _stream()), "xvr_drr_hu_stats")
+    if vol is volume:
+        try:
+            volume._xvr_hu_stats = (volume._version, stats)
+        except AttributeError:
+            pass
+    return vol, stats
+
+
+class HUDensity:
+    """``transform_hu_to_density(volume, multiplier, lazy=True)``: the density of a training step that has NOT been written yet.
+
+    The reference maps the whole CT to a density volume before the two renders of every step
+    (/root/reference/src/xvr/model/trainer.py:196-197): 512 MiB written and read back at 512^3.  The renders' own copy of the
+    volume -- labels in the mantissa bits, y-pair tiles (xvr_drr_pack_labels_ytiles) -- is rebuilt every step anyway, so the map
+    is applied on the way into it (xvr_drr_pack_hu_labels_ytiles: same bits) and the density volume never exists.  Whatever else
+    asks for it -- an unmasked render, a small launch, a voxel gradient -- calls ``materialize()``, the plain HIP pass (cached)."""
+
+    def __init__(self, hu: torch.Tensor, stats: torch.Tensor, multiplier: float):
+        self.hu, self.stats, self.multiplier = hu, stats, float(multiplier)
+        self._dense = None
+
+    shape = property(lambda self: self.hu.shape)
+    device = property(lambda self: self.hu.device)
+    dtype = property(lambda self: self.hu.dtype)
+    is_cuda = property(lambda self: self.hu.is_cuda)
+    requires_grad = False
+
+    def dim(self):
+        return self.hu.dim()
+
+    def materialize(self) -> torch.Tensor:
+        if self._dense is None:
+            self._dense = _hu_to_density_hip(self.hu, self.multiplier)
+        return self._dense
+
+
+def transform_hu_to_density(volume: torch.Tensor, bone_attenuation_multiplier: float, lazy: bool = False):
     """Piecewise HU -> density map used before every training render
     (/root/reference/src/xvr/model/trainer.py:124,196-197): air (<= -800 HU) is set to the minimum
     soft-tissue value, bone (> 350 HU) is scaled, then the result is min-max normalised to [0, 1].
@@ -55,6 +93,9 @@ def transform_hu_to_density(volume: torch.Tensor, bone_attenuation_multiplier: f
         raise RuntimeError("transform_hu_to_density: a float32 CUDA volume (HIP kernel, no CPU path)")
     if volume.requires_grad:
         raise NotImplementedError("transform_hu_to_density: the HU map is not differentiable here (the volume is a buffer upstream)")
+    if lazy:   # (see HUDensity: the masked renders of a training step take the map inside their packing pass)
+        vol, stats = _hu_stats(volume)
+        return HUDensity(vol, stats, float(bone_attenuation_multiplier))
     return _hu_to_density_hip(volume, float(bone_attenuation_multiplier))
 
 

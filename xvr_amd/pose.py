@@ -390,9 +390,12 @@ class RigidTransform(torch.nn.Module):
 
 # parameters -> 4x4 as ONE HIP launch (and one for the backward) for float32 CUDA batches: xvr_pose_convert_forward /
 # _backward (include/xvr_pose.h) evaluate the formulas below in forward-mode dual numbers.  False: the torch formulation
-# (the cross-check in tests/test_pose.py); "rotation_10d" (an eigen-decomposition) and "matrix" always take it.
+# (the cross-check in tests/test_pose.py); "matrix" always takes it.  Round 5: "rotation_10d" too is a kernel -- a cyclic Jacobi
+# eigen-decomposition of its 4 x 4 per pose, the eigenvector's derivative by perturbation theory -- so that every parameterisation
+# of N_ANGULAR_COMPONENTS (/root/reference/src/xvr/model/network.py:4,28) runs the device-resident registration loop.
 FUSED_CONVERT = True
-_FUSED_KINDS = {"euler_angles": 0, "axis_angle": 1, "quaternion": 2, "quaternion_adjugate": 3, "rotation_6d": 4, "se3_log_map": 5}
+_FUSED_KINDS = {"euler_angles": 0, "axis_angle": 1, "quaternion": 2, "quaternion_adjugate": 3, "rotation_6d": 4, "se3_log_map": 5,
+                "rotation_10d": 6}
 
 
 class _ConvertFused(torch.autograd.Function):

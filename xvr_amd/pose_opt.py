@@ -37,7 +37,7 @@ STATE_DTYPE = np.dtype([("m", "f4", MAX_PARAMS), ("v", "f4", MAX_PARAMS), ("lr",
 
 # parameterisations the device loop knows (xvr_pose_convert_forward's kinds) and their number of rotation parameters
 PARAM_KINDS = {"euler_angles": (0, 3), "axis_angle": (1, 3), "quaternion": (2, 4), "quaternion_adjugate": (3, 10), "rotation_6d": (4, 6),
-               "se3_log_map": (5, 3)}
+               "se3_log_map": (5, 3), "rotation_10d": (6, 10)}
 
 
 def axes_of(convention: str):

@@ -183,7 +183,7 @@ def _packed_volume(lib, volume, mask):
     return packed
 
 
-def _packed_ypair_volume(lib, volume, mask):
+def _packed_ypair_volume(lib, volume, mask, hu_map=None):
     """The y-pair interleaved copy of the label-carrying volume, written in ONE pass over (volume, mask)
     (xvr_drr_pack_labels_ypairs): masked renders of large launches take it at once -- their volume is typically the fresh
     HU -> density map of a training step, rendered exactly twice (trainer.py:185-230), for which the "third render" rule of
@@ -192,14 +192,19 @@ def _packed_ypair_volume(lib, volume, mask):
     key = (mask.data_ptr(), mask._version, volume._version)
     slot = _cache_slot(volume)
     tiles = YPAIR_TILES and YPAIR_TILES_PACKED
-    key = key + (tiles,)
+    key = key + (tiles, None if hu_map is None else hu_map.multiplier)
     hit = slot.get("packed_ypairs")
     if hit is not None and hit[0] == key and hit[2]() is mask:
         return hit[1], (3 if tiles else 1)
     nbytes, pack = ((lib.xvr_drr_ytiles_bytes, lib.xvr_drr_pack_labels_ytiles) if tiles
                     else (lib.xvr_drr_ypairs_bytes, lib.xvr_drr_pack_labels_ypairs))
-    buf = torch.empty(nbytes(D0, D1, D2) // 4, device=volume.device, dtype=torch.float32)
-    rc = _timed("pack_labels_ypairs", pack, _ptr(volume), _ptr(mask), D0, D1, D2, _ptr(buf), _stream())
+    buf = hit[1] if hit is not None and hit[1].numel() * 4 == nbytes(D0, D1, D2) and hu_map is not None else \
+        torch.empty(nbytes(D0, D1, D2) // 4, device=volume.device, dtype=torch.float32)
+    if hu_map is not None:   # (`volume` holds HU: the density map rides in the same pass, data.HUDensity; the step's buffer is reused)
+        rc = _timed("pack_hu_labels_ytiles", lib.xvr_drr_pack_hu_labels_ytiles, _ptr(volume), _ptr(mask), _ptr(hu_map.stats),
+                    ctypes.c_float(hu_map.multiplier), D0, D1, D2, _ptr(buf), _stream())
+    else:
+        rc = _timed("pack_labels_ypairs", pack, _ptr(volume), _ptr(mask), D0, D1, D2, _ptr(buf), _stream())
     _lib.check(rc, "xvr_drr_pack_labels_ypairs")
     slot["packed_ypairs"] = (key, buf, weakref.ref(mask))
     return buf, (3 if tiles else 1)
@@ -317,7 +322,7 @@ class _Render(torch.autograd.Function):
     backward: elementwise-from-jacobian for the pose, a re-march with scatter for the voxels."""
 
     @staticmethod
-    def forward(ctx, volume, source, target, img, mask, spec: RenderSpec, ray_grid_w: int, C: int, work):
+    def forward(ctx, volume, source, target, img, mask, spec: RenderSpec, ray_grid_w: int, C: int, work, hu_map=None):
         lib = _lib.load()
         D0, D1, D2 = volume.shape
         B, n, _ = target.shape
@@ -335,7 +340,7 @@ class _Render(torch.autograd.Function):
         pairs, pairs_layout = None, 1
         if msk_c is not None and PACK_LABELS and 2 <= C <= 16 and vol_c.data_ptr() % 16 == 0 and msk_c.data_ptr() % 16 == 0:
             if _use_ypairs(spec, vol_c, B, n):
-                (pairs, pairs_layout), msk_f = _packed_ypair_volume(lib, vol_c, msk_c), None   # labels in the taps AND the y-pair layout, one pass
+                (pairs, pairs_layout), msk_f = _packed_ypair_volume(lib, vol_c, msk_c, hu_map), None   # labels in the taps AND the y-pair layout, one pass
             else:
                 vol_f, msk_f = _packed_volume(lib, vol_c, msk_c), None     # labels ride in the taps
         if pairs is None and msk_f is None and _use_ypairs(spec, vol_c, B, n):
@@ -361,9 +366,11 @@ class _Render(torch.autograd.Function):
                     _ptr(vol_f), _ptr(msk_f), D0, D1, D2, C, _ptr(src_c), _ptr(tgt_c), _ptr(len_c), B, n,
                     ctypes.byref(cs), _ptr(out), _ptr(jac), _ptr(work), _stream())
         _lib.check(rc, f"xvr_drr_{spec.renderer}_forward")
+        if hu_map is not None and pairs is None:
+            raise RuntimeError("internal: a lazy HU density reached a render that does not pack its own copy")
         ctx.spec, ctx.ray_grid_w, ctx.C = spec, ray_grid_w, C
         ctx.src_shape, ctx.img_shape = source.shape, img.shape
-        ctx.window = window
+        ctx.window, ctx.hu_map = window, hu_map
         ctx.save_for_backward(vol_c, src_c, tgt_c, len_c, msk_c, jac)
         return out
 
@@ -406,6 +413,8 @@ class _Render(torch.autograd.Function):
                             _ptr(tgt_c), _ptr(len_c), B, n, ctypes.byref(cw), _ptr(window), _ptr(gsrc), _ptr(gtgt), _stream())
                 _lib.check(rc, "xvr_drr_alpha_window_backward")
         if need_vol or (need_pose and not from_jac):
+            if ctx.hu_map is not None:   # (the forward rendered from HU through its packing pass; a backward kernel that reads the
+                vol_c = ctx.hu_map.materialize()   # volume -- the re-march -- gets the density written after all)
             cs = make_cspec((D0, D1, D2), spec, ctx.ray_grid_w)
             if window is not None:
                 cs.alpha_window = window.data_ptr()
@@ -439,7 +448,7 @@ class _Render(torch.autograd.Function):
         g_source = gsrc.reshape(ctx.src_shape) if need_pose and ctx.needs_input_grad[1] else None
         g_target = gtgt if need_pose and ctx.needs_input_grad[2] else None
         g_img = glen.reshape(ctx.img_shape) if need_pose and ctx.needs_input_grad[3] else None
-        return gvol, g_source, g_target, g_img, None, None, None, None, None
+        return gvol, g_source, g_target, g_img, None, None, None, None, None, None
 
 
 class _RenderFromCamera(torch.autograd.Function):
@@ -503,6 +512,9 @@ def render_from_camera(volume, cam, spec: RenderSpec, height: int, width: int):
 def render(volume, source, target, img, spec: RenderSpec, mask=None, ray_grid_w: int = 0, n_channels=None, work=None):
     """Functional form.  ``work``: optional cuda uint64/int64 scalar the kernel adds its count of
     volume-touching samples (trilinear) or voxel segments (siddon) to."""
+    hu_map = None
+    if type(volume).__name__ == "HUDensity":   # (xvr_amd.data.HUDensity: a density that has not been written yet)
+        hu_map, volume = volume, volume.hu
     for name, t in (("volume", volume), ("source", source), ("target", target), ("img", img)):
         _check_gpu_f32(name, t)
     if volume.dim() != 3:
@@ -527,7 +539,18 @@ def render(volume, source, target, img, spec: RenderSpec, mask=None, ray_grid_w:
         # an empty batch (xvr's `img[keep]` can select nothing, trainer.py:202-204) renders to an empty
         # image that still hangs off the inputs' autograd graph
         return (source.sum() + target.sum() + img.sum() + 0 * volume.sum()).expand(B, C, n)
-    return _Render.apply(volume, source, target, img, mask, spec, int(ray_grid_w), C, work)
+    if hu_map is not None:
+        # the one consumer that takes the HU map inside its own pass: a masked trilinear launch large enough for the tiled,
+        # label-carrying y-pair copy, with nothing to differentiate w.r.t. the voxels; everything else gets the density written
+        if not (mask is not None and _packed_tiles_ok(spec, volume, mask, B, n, C) and YPAIR_TILES and YPAIR_TILES_PACKED):
+            hu_map, volume = None, hu_map.materialize()
+    return _Render.apply(volume, source, target, img, mask, spec, int(ray_grid_w), C, work, hu_map)
+
+
+def _packed_tiles_ok(spec, volume, mask, B, n, C) -> bool:
+    """Will _Render.forward render this masked launch from the label-carrying y-pair copy (_packed_ypair_volume)?"""
+    return (PACK_LABELS and 2 <= C <= 16 and volume.is_contiguous() and mask.is_contiguous() and volume.data_ptr() % 16 == 0
+            and mask.data_ptr() % 16 == 0 and _use_ypairs(spec, volume, B, n))
 
 
 class _RendererBase(torch.nn.Module):
