@@ -168,7 +168,9 @@ def test_c5_full_size_masked_renders_512_to_256_batch_116_eight_labels():
         out, _, _ = render_samples(drr, vol_arg, drr.mask, drr.affine_inverse, convert(r, x, parameterization="euler_angles", convention="ZXY"))
         out.sum().backward()
         grads.append((r.grad.clone(), x.grad.clone()))
-    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
+    # (the source's gradient is a sum over rays by float atomics: same terms, any order)
+    _close(grads[1][0], grads[0][0], 1e-5, "lazy density: d / d rotation")
+    _close(grads[1][1], grads[0][1], 1e-5, "lazy density: d / d translation")
     assert lazy._dense is None, "the lazy density was written although no consumer needed it"
     # an unmasked render, which packs nothing of its own, gets the density written on demand -- the same image
     with torch.no_grad():

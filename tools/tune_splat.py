@@ -14,11 +14,11 @@ sys.path.insert(0, str(ROOT))
 # (name, defines, XVR_DRR_GATHER_SPLAT: 0 = the table gather)
 VARIANTS = [
     ("b16", [], "1"),
-    ("b16_quarters", ["XVR_S16_SHARES=0"], "1"),
+    ("b16_pose_global", ["XVR_S16_POSE_GLOBAL=1"], "1"),
     ("b16_noadds", ["XVR_SP_ABLATE_ADDS=1"], "1"),
+    ("b16_half_the_adds", ["XVR_SP_ABLATE_ADDS=2"], "1"),
     ("b16_noloads", ["XVR_S16_ABLATE_LOADS=1"], "1"),
     ("b16_noadds_noloads", ["XVR_SP_ABLATE_ADDS=1", "XVR_S16_ABLATE_LOADS=1"], "1"),
-    ("table", [], "0"),
 ]
 RENDERER = "trilinear"
 
@@ -30,11 +30,11 @@ def lib(name):
 if sys.argv[1:] == ["build"]:
     from xvr_amd.build import build_diagnostic_library
     for name, defs, _ in VARIANTS:
-        print(build_diagnostic_library(defs or ["XVR_TUNE_DEFAULT=1"], lib(name)))
+        print(build_diagnostic_library(defs or ["XVR_TUNE_DEFAULT=1"], lib(name), only=["drr_gather.hip"]))
 else:
     for name, defs, mode in VARIANTS:
         env = dict(os.environ, XVR_DRR_LIBRARY=str(lib(name)), XVR_DRR_GATHER_SPLAT=mode)
-        out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--renderer", RENDERER],
+        out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-variants", "--renderer", RENDERER],
                              env=env, capture_output=True, text=True)
         try:
             d = json.loads(out.stdout.strip().splitlines()[-1])
