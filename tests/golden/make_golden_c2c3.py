@@ -45,6 +45,11 @@ def main():
     ap.add_argument("--renderers", default="trilinear,siddon")
     ap.add_argument("--out", default=str(Path(__file__).resolve().parent / "_c2c3_parts"))
     ap.add_argument("--pack-only", action="store_true")
+    ap.add_argument("--dtype", default="float32", choices=["float32", "float64"],
+                    help="arithmetic of the oracle run.  Siddon's pose gradient is a sum of jumps of a piecewise-constant integrand over "
+                         "65536 rays: on the phantom's sharp ellipsoid surfaces the float32 oracle is 1e-2 from its own float64 run, so the "
+                         "committed Siddon fixture is the float64 run (tests/test_fuzz_large.py makes the same choice); parts of both "
+                         "kinds may coexist, the packer prefers float64 ones")
     args = ap.parse_args()
     torch.set_num_threads(args.threads)
     out = Path(args.out)
@@ -57,8 +62,10 @@ def main():
         from xvr_amd.pose import convert
         from xvr_amd.training import get_random_pose
 
+        dt = getattr(torch, args.dtype)
         vol, _ = make_phantom(SIZE, n_ellipsoids=64, seed=0)
-        affine = read(vol, orientation="AP").affine
+        affine = read(vol, orientation="AP").affine.to(dt)
+        vol = vol.to(dt)
         g = torch.Generator().manual_seed(0)   # (bench.py::deepfluoro_poses(116, seed=0))
         rot, xyz = get_random_pose(135.0, 225.0, -45.0, 45.0, -15.0, 15.0, -150.0, 150.0, 450.0, 1000.0, -150.0, 150.0, B,
                                    generator=g).convert("euler_angles", "ZXY")
@@ -66,24 +73,27 @@ def main():
         for renderer in renderers:
             spec = RenderSpec(renderer=renderer, n_points=N_POINTS)
             for b in range(lo, hi):
-                part = out / f"{renderer}_{b:03d}.npz"
+                part = out / (f"{renderer}_{b:03d}.npz" if args.dtype == "float32" else f"{renderer}_{b:03d}_f64.npz")
                 if part.exists():
                     continue
                 t0 = time.time()
-                r = rot[b:b + 1].clone().requires_grad_(True)
-                x = xyz[b:b + 1].clone().requires_grad_(True)
+                r = rot[b:b + 1].clone().to(dt).requires_grad_(True)
+                x = xyz[b:b + 1].clone().to(dt).requires_grad_(True)
                 pose = convert(r, x, parameterization="euler_angles", convention="ZXY")
                 img = drr_from_pose(vol, affine, pose.matrix, H, H, SDD, DELX, DELX, 0.0, 0.0, spec, orientation="AP",
                                     reverse_x_axis=False, chunk=8192 if renderer == "trilinear" else 2048)
-                (img * weights(b)).sum().backward()
+                (img * weights(b).to(dt)).sum().backward()
                 im = img.detach()[0, 0]
                 tiles = im.double().reshape(16, 16, 16, 16).sum(dim=(1, 3))
-                np.savez(part, pixels=im.reshape(-1)[pix].numpy(), tiles=tiles.numpy(), imax=im.max().item(), isum=im.double().sum().item(),
+                np.savez(part, pixels=im.reshape(-1)[pix].float().numpy(), tiles=tiles.numpy(), imax=im.max().item(), isum=im.double().sum().item(),
                          grad=torch.cat([r.grad, x.grad], dim=-1).double().numpy()[0], rot=rot[b].numpy(), xyz=xyz[b].numpy())
                 print(f"{renderer} pose {b}: {time.time() - t0:.1f} s, max {im.max().item():.3f}", flush=True)
     packed = {"pixel_index": sampled_pixels()}
     for renderer in ("trilinear", "siddon"):
-        parts = [out / f"{renderer}_{b:03d}.npz" for b in range(B)]
+        parts = [out / f"{renderer}_{b:03d}_f64.npz" for b in range(B)]
+        if not all(p.exists() for p in parts):
+            parts = [out / f"{renderer}_{b:03d}.npz" for b in range(B)]
+        packed[f"{renderer}_oracle_dtype"] = np.array("float64" if parts[0].name.endswith("_f64.npz") else "float32")
         if not all(p.exists() for p in parts):
             print(f"{renderer}: {sum(p.exists() for p in parts)} of {B} poses done; not packed")
             continue
