@@ -244,3 +244,37 @@ def test_ray_major_splat_edge_cases(what, shape, hw, kw, case_kw, batch, monkeyp
             _close(ray_major, _hip_render(case, spec, grid_w=hw[1], grads=True, w=w)[1], 2e-5, f"ray-major vs plane-major splat: {what}")
     if hw[0] * hw[1] * kw["n_points"] * batch <= 4_000_000:
         _close(ray_major, _oracle_render(case, spec, grads=True, w=w)[1], GRAD_TOL, f"ray-major splat vs oracle: {what}")
+
+
+@pytest.mark.parametrize("what,case_kw,spec_kw", [
+    ("the source inside a brick: the box reaches the source plane, the bound falls back to counting runs",
+     dict(shape=(40, 36, 44), height=40, width=36, sdd=140.0, xyz=((1.0, 6.0, -2.0), (-3.0, 9.0, 4.0)), delx=1.2), dict(n_points=90)),
+     ("a source just outside the volume, a magnifying detector: hundreds of samples of a pose on the nearest voxels",
+     dict(shape=(33, 29, 31), height=64, width=60, sdd=90.0, xyz=((0.0, 24.0, 0.0), (2.0, 27.0, -1.0)), delx=0.6), dict(n_points=200)),
+    ("a near-degenerate gap: near ~ far, every sample plane of a pose within a voxel of the next",
+     dict(shape=(36, 40, 34), height=48, width=44, delx=0.9), dict(n_points=300, near=0.70, far=0.74)),
+    ("one step (n_points = 1) and two", dict(shape=(24, 20, 28), height=32, width=28, delx=1.1), dict(n_points=2)),
+    ("all samples of a ray in ONE plane of voxels: a detector pixel pitch of 0.05 voxels",
+     dict(shape=(20, 18, 22), height=128, width=120, delx=0.9 * 22 / 2400), dict(n_points=40)),
+], ids=["source-inside", "source-at-the-face", "degenerate-gap", "two-steps", "pitch-0.05"])
+def test_adversarial_geometries_stay_inside_the_fixed_point_range(what, case_kw, spec_kw):
+    """geometries chosen to stress the BOUND on a voxel's sum that the splat's fixed-point scale is made from
+    (every upstream value +1: the sums cannot cancel).  The forced splat (option gather_splat = 3) must neither poison a voxel nor
+    raise the sticky word -- the bound holds -- and must equal the fp32 table gather; the default route (which hands dense
+    samplings to that gather) likewise."""
+    from xvr_amd import _lib, renderers
+    from xvr_amd.spec import RenderSpec
+
+    spec = RenderSpec(renderer="trilinear", **spec_kw)
+    case = make_case(seed=41, **case_kw)
+    hw = (case_kw["height"], case_kw["width"])
+    w = torch.ones(2, 1, hw[0] * hw[1])
+    res = {}
+    for mode in (3, 1, 0):
+        with _lib.option("gather_splat", mode):
+            res[mode] = _hip_render(case, spec, grid_w=hw[1], grads=True, w=w)[1]
+        assert torch.isfinite(res[mode]).all(), (what, mode)
+        assert not renderers.last_backward_overflowed(), (what, mode)
+    assert res[3].abs().max() > 0, what
+    _close(res[3], res[0], 2e-5, f"forced splat vs fp32 gather: {what}")
+    _close(res[1], res[0], 2e-5, f"default route vs fp32 gather: {what}")
