@@ -100,6 +100,11 @@ def main():
         loaded = [np.load(p) for p in parts]
         for key in ("pixels", "tiles", "imax", "isum", "grad", "rot", "xyz"):
             packed[f"{renderer}_{key}"] = np.stack([d[key] for d in loaded])
+        f32 = [out / f"{renderer}_{b:03d}.npz" for b in range(B)]
+        if parts[0].name.endswith("_f64.npz") and all(p.exists() for p in f32):
+            # the float32 run's gradient next to the float64 one: where the two disagree the gradient is ill-conditioned in float32
+            # (Siddon, pose 77: 9e-2 of the largest entry) and the test allows the HIP path as much
+            packed[f"{renderer}_grad_f32"] = np.stack([np.load(p)["grad"] for p in f32])
     if len(packed) > 1:
         np.savez_compressed(Path(__file__).resolve().parent / "c2c3_oracle_batch.npz", **packed)
         print({k: v.shape for k, v in packed.items()})

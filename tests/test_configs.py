@@ -331,6 +331,15 @@ def test_benchmark_batch_against_the_oracle_fixture(renderer):
     assert np.allclose(im.double().sum(dim=(1, 2)).numpy(), gold[f"{renderer}_isum"], rtol=fwd_tol)
     ref_g = torch.from_numpy(gold[f"{renderer}_grad"])
     got_g = torch.cat([rot.grad, xyz.grad], dim=-1).double().cpu()
+    # Siddon's pose gradient is a sum over 65 536 rays of the JUMPS of a piecewise-constant integrand times d alpha / d pose, and
+    # d alpha / d pose ~ 1 / d_k blows up for the rays that run along a plane family (a pose that looks almost down a volume axis:
+    # pose 77).  There the float32 oracle is 9e-2 from its own float64 run, so the fixture is the FLOAT64 run and carries the float32
+    # run's gradient beside it: the HIP path is held to 5e-3 of the largest entry, or to twice the float32 oracle's own distance.
+    ref32 = torch.from_numpy(gold[f"{renderer}_grad_f32"]) if f"{renderer}_grad_f32" in gold else ref_g
     for name, sl in (("d / d rotation", slice(0, 3)), ("d / d translation", slice(3, 6))):
-        gerr = (got_g[:, sl] - ref_g[:, sl]).abs() / ref_g[:, sl].abs().max()
-        assert gerr.max().item() <= 5e-3, f"{name}: {gerr.max().item():.2e} (pose {int(gerr.amax(dim=1).argmax())})"
+        scale = ref_g[:, sl].abs().max()
+        gerr = ((got_g[:, sl] - ref_g[:, sl]).abs() / scale).amax(dim=1)
+        allowed = torch.clamp(2.0 * ((ref32[:, sl] - ref_g[:, sl]).abs() / scale).amax(dim=1), min=5e-3)
+        worst = int((gerr / allowed).argmax())
+        assert bool((gerr <= allowed).all()), f"{name}: pose {worst}: {gerr[worst].item():.2e} (allowed {allowed[worst].item():.2e})"
+        assert int((gerr > 5e-3).sum()) <= 4, f"{name}: {int((gerr > 5e-3).sum())} poses beyond 5e-3"

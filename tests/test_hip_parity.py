@@ -718,7 +718,7 @@ def test_recompute_backward_equals_jacobian_backward(renderer):
         _close(a, b, 1e-5, name)
 
 
-@pytest.mark.parametrize("name", sorted(p.stem for p in GOLDEN.glob("*.npz") if not p.stem.startswith("xvr_reference")))
+@pytest.mark.parametrize("name", sorted(p.stem for p in GOLDEN.glob("*.npz") if not p.stem.startswith(("xvr_reference", "c2c3_oracle", "diffdrr_pin"))))
 def test_golden_fixtures_on_gpu(name):
     from xvr_amd.renderers import render
     from xvr_amd.spec import RenderSpec
@@ -1525,6 +1525,12 @@ def test_fuzz_voxel_gather_equals_atomic_scatter(seed):
     case = make_case(shape=shape, height=H, width=W, sdd=float(rng.uniform(1.5, 3.0) * depth), delx=float(rng.uniform(0.5, 3.0)),
                      n_labels=int(rng.integers(2, 6)), seed=seed, rot=rot, xyz=xyz, spacing=spacing)
     spec = RenderSpec(**kw)
+    if renderer == "siddon" and kw["align_corners"] and kw["norm_dims_offset"] == -1:
+        # the one index map whose EVERY fully crossed cell is a rounding tie (xvr_amd/spec.py): refused, not rendered -- the class
+        # of the soak's red seeds of rounds 3 and 4 (52075, "6 in 620")
+        with pytest.raises(ValueError, match="degenerate"):
+            render(*(case[k].cuda() for k in ("volume", "source", "target", "img")), spec, None, ray_grid_w=W)
+        return
     # (clip + mask is left out: the first / last sample then sits exactly on a volume face, where the label is a rounding tie)
     masked = renderer == "trilinear" and bool(rng.random() < 0.35) and not kw.get("clip_to_volume")
     mask = case["mask"].cuda() if masked else None

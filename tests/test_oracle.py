@@ -194,7 +194,7 @@ def test_drr_from_pose_plumbing_c1_shape():
     assert (out > 0).float().mean() > 0.3
 
 
-@pytest.mark.parametrize("name", sorted(p.stem for p in GOLDEN.glob("*.npz") if not p.stem.startswith("xvr_reference")))
+@pytest.mark.parametrize("name", sorted(p.stem for p in GOLDEN.glob("*.npz") if not p.stem.startswith(("xvr_reference", "c2c3_oracle", "diffdrr_pin"))))
 def test_golden_fixtures(name):
     """The committed vectors (inputs + expected outputs + expected gradients) reproduce."""
     d = np.load(GOLDEN / f"{name}.npz")

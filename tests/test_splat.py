@@ -253,7 +253,7 @@ def test_ray_major_splat_edge_cases(what, shape, hw, kw, case_kw, batch, monkeyp
      dict(shape=(33, 29, 31), height=64, width=60, sdd=90.0, xyz=((0.0, 24.0, 0.0), (2.0, 27.0, -1.0)), delx=0.6), dict(n_points=200)),
     ("a near-degenerate gap: near ~ far, every sample plane of a pose within a voxel of the next",
      dict(shape=(36, 40, 34), height=48, width=44, delx=0.9), dict(n_points=300, near=0.70, far=0.74)),
-    ("one step (n_points = 1) and two", dict(shape=(24, 20, 28), height=32, width=28, delx=1.1), dict(n_points=2)),
+    ("two sample planes per ray, both inside the volume", dict(shape=(24, 20, 28), height=32, width=28, delx=1.1), dict(n_points=2, near=0.70, far=0.78)),
     ("all samples of a ray in ONE plane of voxels: a detector pixel pitch of 0.05 voxels",
      dict(shape=(20, 18, 22), height=128, width=120, delx=0.9 * 22 / 2400), dict(n_points=40)),
 ], ids=["source-inside", "source-at-the-face", "degenerate-gap", "two-steps", "pitch-0.05"])

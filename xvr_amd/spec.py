@@ -46,6 +46,16 @@ class RenderSpec:
             raise ValueError(f"clip_to_volume must be False, True or 'batch', got {self.clip_to_volume!r}")
         if not self.far >= self.near:
             raise ValueError("far must be >= near")
+        if self.renderer == "siddon" and self.align_corners and self.norm_dims_offset == -1:
+            # index = rint(a x + b) with a = (S - 1) / (S - 1) = 1 and b = voxel_shift: the MIDPOINT of every fully crossed plane cell
+            # (x = c - voxel_shift + 1/2) maps to exactly c + 1/2, for every cell, every size and either shift.  Which of two voxels
+            # a whole segment is credited with is then decided by the last bit of float32 arithmetic -- in torch as in any kernel --
+            # for most segments of most rays: the render is not a function of its inputs in any useful sense, and the fuzz soak of
+            # rounds 3 and 4 kept finding seeds where two correct traversals disagree on > 1 % of the voxels (seed 52075 and its
+            # class).  Refused rather than rendered.  One structural tie per axis (dims = shape + 1 on an
+            # even-sized axis: its middle cell) is served; tests/conftest.py::has_structural_tie.
+            raise ValueError("siddon with align_corners=True and norm_dims_offset=-1 is degenerate: the midpoint of every fully crossed "
+                             "cell lies exactly on a rounding boundary of the index map (see xvr_amd/spec.py)")
         if self.renderer == "siddon" and not self.per_ray_clamp:
             raise NotImplementedError(
                 "per_ray_clamp=False (the literal batch-filtered sort formulation) is an oracle-only "
