@@ -54,8 +54,12 @@ BINDING_KERNELS = {
     "trilinear_forward+jac": ("trilinear", r"k_trilinear_fwd<true, 0, false, [1-9]"),
     "trilinear_forward": ("trilinear", r"k_trilinear_fwd<false, 0, false, [1-9]"),
     "siddon_backward": ("siddon", r"k_siddon_gather_vol2"),
-    "siddon_forward+jac": ("siddon", r"k_siddon_slab<true, true"),
-    "siddon_forward": ("siddon", r"k_siddon_slab<false, true"),
+    "siddon_forward+jac": ("siddon", r"k_siddon_slab<true, true(, false)?>"),
+    "siddon_forward": ("siddon", r"k_siddon_slab<false, true(, false)?>"),
+    # the recalled index map (dims = shape + 1): the slab march's NX instantiations and the ray-driven brick splat
+    "siddon_backward@nx": ("siddon_nx", r"k_siddon_splat"),
+    "siddon_forward+jac@nx": ("siddon_nx", r"k_siddon_slab<true, true, true>"),
+    "siddon_forward@nx": ("siddon_nx", r"k_siddon_slab<false, true, true>"),
 }
 _BINDING_CACHE = {}
 
@@ -82,7 +86,7 @@ def binding_candidates(base):
             # tools/microbench/gather.hip: a 64-lane gather costs ~15 clk per CU on one 128-B line and 10-14 more per further line;
             # two 16-byte gathers per sample (y-pair copy), ~3 lines by that estimate
             cands.append(("texture_address", 2, 36.0, CUS, "profiles/r01_microbench_gather_lines.txt"))
-        if base == "siddon_forward+jac" and "TA_BUSY_avr" in c:
+        if base.startswith("siddon_forward+jac") and "TA_BUSY_avr" in c:
             # clocks the CUs' texture-address units were busy (TA_BUSY_avr: mean over the TA instances), per 64 voxel segments
             cands.append(("texture_address", 1.0, c["TA_BUSY_avr"] / (c["units"] / 64.0) * CUS, CUS, f"TA_BUSY_avr ({src})"))
         if "SQ_INSTS_VALU" in c:
@@ -93,9 +97,10 @@ def binding_candidates(base):
     return cands
 
 
-def binding_floor(tag, units, avg_ms):
-    """The unit with the largest floor for one timed call, and every candidate's floor next to it."""
-    cands = binding_candidates(tag.split("[")[0])
+def binding_floor(tag, units, avg_ms, variant=""):
+    """The unit with the largest floor for one timed call, and every candidate's floor next to it.  ``variant`` "nx": the leg renders
+    under a non-exact Siddon index map (other kernels, other committed profile)."""
+    cands = binding_candidates(tag.split("[")[0] + ("@" + variant if variant else ""))
     if not cands or not units:
         return None
     floors = {}
@@ -117,7 +122,7 @@ TRAFFIC_KERNELS = {
 }
 
 
-def pmc_traffic(tag):
+def pmc_traffic(tag, variant=""):
     """HBM-side bytes per launch of the kernels behind one timed call, from the committed rocprofv3 PMC
     passes (profiles/traffic.json, written by tools/summarize_profile.py: FETCH_SIZE + WRITE_SIZE, in
     bytes MOVED: the fetch side is the reported FETCH_SIZE doubled, as calibrated in profiles/r04_fetch_calibration.txt).
@@ -133,13 +138,17 @@ def pmc_traffic(tag):
     keys = TRAFFIC_KERNELS.get(base)
     if not keys:
         return None
+    nx = variant == "nx"
+    if base == "siddon_backward":   # (the exact map's voxel gather, or the brick splat of a non-exact one: never both)
+        keys = [k for k in keys if k != "k_siddon_gather_vol"] + ["k_siddon_splat"] if nx else keys
     fam = {}   # kernel family (name up to its template list) -> traffic of each profiled instantiation that matches
     for name, v in table.items():
         if "k_siddon<" in name:   # k_siddon<MODE, ...>: 0 forward, 1 forward + jacobian, 2 backward
             mode = "2" if base == "siddon_backward" else ("1" if "+jac" in tag else "0")
             if f"k_siddon<{mode}," not in name:
                 continue
-        if "k_siddon_slab<" in name and (("k_siddon_slab<true" in name) != ("+jac" in tag) or base != "siddon_forward"):
+        if "k_siddon_slab<" in name and (("k_siddon_slab<true" in name) != ("+jac" in tag) or base != "siddon_forward"
+                                         or name.split("k_siddon_slab<")[1].split(">")[0].endswith(", true") != nx):
             continue
         if any(k in name for k in keys) and (("fwd<true" in name) == ("+jac" in tag) or "fwd<" not in name):
             fam.setdefault(name.split("<")[0], []).append(v.get("fetch_bytes", 0.0) + v.get("write_bytes", 0.0))
@@ -271,8 +280,9 @@ def render_leg(dev, subject, renderer, voxel_grad, rot0, xyz0, H, delx, n_points
         v["algorithmic_GBps"] = (units * bytes_per_unit / (v["avg_ms"] * 1e-3) / 1e9) if tapk else None
     dom = kernels[dominant]
     nominal_units = B * H * H * (n_points if renderer == "trilinear" else 0)
+    variant = "nx" if renderer == "siddon" and drr_kwargs and (drr_kwargs.get("norm_dims_offset") or drr_kwargs.get("align_corners")) else ""
     for k, v in kernels.items():
-        bf = binding_floor(k, units, v["avg_ms"])
+        bf = binding_floor(k, units, v["avg_ms"], variant)
         if bf:
             v["binding"] = bf
     roofline = {
@@ -282,7 +292,7 @@ def render_leg(dev, subject, renderer, voxel_grad, rot0, xyz0, H, delx, n_points
         "achieved": dom["algorithmic_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": (dom["algorithmic_GBps"] or 0.0) / HBM_PEAK_GBS,
         "frac_of_measured_copy_peak": (dom["algorithmic_GBps"] or 0.0) / HBM_COPY_GBS,
-        "traffic": pmc_traffic(dominant),
+        "traffic": pmc_traffic(dominant, variant),
         "units_per_launch": units, "unit_name": "volume-touching samples" if renderer == "trilinear" else "voxel segments",
         "bytes_per_unit": bytes_per_unit, "avg_launch_ms": dom["avg_ms"],
         "nominal_units_per_launch": nominal_units or None,

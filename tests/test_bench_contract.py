@@ -139,14 +139,19 @@ def test_pmc_traffic_reads_the_committed_counter_table():
 
     table = json.loads((ROOT / "profiles" / "traffic.json").read_text())
     splat = sum(v["fetch_bytes"] + v["write_bytes"] for k, v in table.items()
-                if any(t in k for t in ("k_trilinear_splat_b16", "k_gather_prep", "k_gather_cull", "k_trilinear_bwd")))
+                if any(t in k for t in ("k_trilinear_splat_b16", "k_trilinear_gather_tab", "k_gather_prep", "k_gather_cull", "k_trilinear_bwd")))
     assert bench.pmc_traffic("trilinear_backward[vol]") == pytest.approx(splat)
     fwd = [v["fetch_bytes"] + v["write_bytes"] for k, v in table.items() if "k_trilinear_fwd<true" in k]
     assert len(fwd) >= 1 and bench.pmc_traffic("trilinear_forward+jac") == pytest.approx(sum(fwd) / len(fwd))
     # the Siddon forward of the default path is the slab march: <true, ...> carries the jacobian, <false, ...> does not
-    jac = [v["fetch_bytes"] + v["write_bytes"] for k, v in table.items() if "k_siddon_slab<true" in k]
-    plain = [v["fetch_bytes"] + v["write_bytes"] for k, v in table.items() if "k_siddon_slab<false" in k]
+    # ... and <.., .., true> is the instantiation for non-exact index maps (the recalled dims = shape + 1): its own leg
+    jac = [v["fetch_bytes"] + v["write_bytes"] for k, v in table.items() if "k_siddon_slab<true, true, false>" in k or "k_siddon_slab<true, true>" in k]
+    plain = [v["fetch_bytes"] + v["write_bytes"] for k, v in table.items() if "k_siddon_slab<false, true, false>" in k or "k_siddon_slab<false, true>" in k]
     assert jac and plain
+    nx = [v["fetch_bytes"] + v["write_bytes"] for k, v in table.items() if "k_siddon_slab<true, true, true>" in k]
+    assert nx and bench.pmc_traffic("siddon_forward+jac", "nx") == pytest.approx(sum(nx) / len(nx))
+    sp = sum(v["fetch_bytes"] + v["write_bytes"] for k, v in table.items() if any(t in k for t in ("k_siddon_splat", "k_gather_prep", "k_gather_cull", "k_siddon<2")))
+    assert bench.pmc_traffic("siddon_backward[vol]", "nx") == pytest.approx(sp, rel=0.05)
     assert bench.pmc_traffic("siddon_forward+jac") == pytest.approx(sum(jac) / len(jac))
     assert bench.pmc_traffic("siddon_forward") == pytest.approx(sum(plain) / len(plain))
     assert bench.pmc_traffic("no_such_call") is None

@@ -1,0 +1,30 @@
+#!/bin/bash
+# The round's rocprofv3 evidence in one go, ON the GPU box:  bash tools/profile_round.sh r05
+# -> gpurun_out/<round>_{trilinear,pose_only,siddon,siddon_nx}/ (tools/profile.sh each), then the default bench line and the Siddon one.
+set -u
+RD=${1:-r05}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+bash $R/tools/profile.sh ${RD}_trilinear > /dev/null 2>&1
+bash $R/tools/profile.sh ${RD}_pose_only --no-voxel-grad > /dev/null 2>&1
+bash $R/tools/profile.sh ${RD}_siddon --renderer siddon > /dev/null 2>&1
+bash $R/tools/profile.sh ${RD}_siddon_nx --renderer siddon --drr-kwargs '{"norm_dims_offset":1}' > /dev/null 2>&1
+for t in trilinear pose_only siddon siddon_nx; do
+  O=$R/gpurun_out/${RD}_$t
+  cp $(ls -t $O/trace/*/*_kernel_stats.csv 2>/dev/null | head -1) $O/kernel_stats.csv 2>/dev/null
+  rm -rf $O/trace $O/pmc_*/ 2>/dev/null
+done
+cd $R
+python bench.py --steps 20 --warmup 5 > gpurun_out/${RD}_bench_final_default.json 2> gpurun_out/${RD}_bench_final_default.err
+python bench.py --steps 20 --warmup 5 --renderer siddon --no-variants > gpurun_out/${RD}_bench_final_siddon.json 2>/dev/null
+python - <<PY
+import json
+d = json.load(open("gpurun_out/${RD}_bench_final_default.json"))
+v = d["variants"]
+print("headline", round(d["ms_per_step"], 3), "ms", round(d["value"], 1), "DRRs/s; roofline frac", round(d["roofline"]["frac"], 3), "binding", d["roofline"].get("binding", {}).get("unit"), round(d["roofline"].get("binding", {}).get("frac", 0), 3))
+print({k: round(x["avg_ms"], 3) for k, x in d["kernels"].items()})
+print("volume changing", round(v["ms_per_step_volume_changing"], 2), "clip", round(v["clip_to_volume_ms_per_step"], 2), "siddon", round(v["siddon_ms_per_step"], 2), "pose-only", v["pose_only_ms_per_step"])
+print("recalled", {k: (round(x["ms_per_step"], 2), round(x["pose_only_ms_per_step"], 2)) for k, x in v["recalled_knobs"].items()})
+print("c4", {k: {a: round(b, 4) for a, b in x.items() if isinstance(b, float)} for k, x in v["c4_register_ms_per_pose_iteration"].items()})
+print("c5", round(v["c5_train_step_ms"], 2), v["c5_train_step"]["min_median_max_ms"], {k: round(x, 2) for k, x in v["c5_train_step"]["phases"].items()})
+print("cpu", d["cpu_baseline"]["value"], d["cpu_baseline"]["cores"])
+PY
