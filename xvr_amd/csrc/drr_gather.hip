@@ -1430,6 +1430,16 @@ int xvr_detail::launch_gather(bool siddon, const float* source, const float* tar
         const dim3 grid((unsigned)(bricks < resident ? bricks : resident));
         if (nx) hipLaunchKernelGGL(k_siddon_splat<true>, grid, dim3(256), 0, (hipStream_t)stream, G);
         else hipLaunchKernelGGL(k_siddon_splat<false>, grid, dim3(256), 0, (hipStream_t)stream, G);
+#ifdef XVR_SS_STATS
+        {
+            hipStreamSynchronize((hipStream_t)stream);
+            unsigned long long st[8];
+            hipMemcpyFromSymbol(st, HIP_SYMBOL(g_ss_stats), sizeof(st));
+            fprintf(stderr, "ss_stats trips %llu live_lane_trips %llu walks %llu walk_lanes %llu chunks %llu cands %llu live %llu pose_visits %llu\n", st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7]);
+            unsigned long long z[8] = {0};
+            hipMemcpyToSymbol(HIP_SYMBOL(g_ss_stats), z, sizeof(z));
+        }
+#endif
     }
     else if (siddon && G.cells) {
         hipLaunchKernelGGL(k_siddon_gather_cells, dim3((unsigned)bricks), dim3(WG), 0, (hipStream_t)stream, G);
@@ -1524,7 +1534,7 @@ size_t xvr_drr_siddon_backward_workspace_bytes(int B, int n, int D0, int D1, int
     int olo[3];
     const size_t base = ws_bytes(B, n, D0, D1, D2);
     if (siddon_exact_geometry(sp) || !siddon_cell_offsets(sp, D0, D1, D2, olo)) return base;
-    if (xvr_detail::option(xvr_detail::OPT_SIDDON_SPLAT) >= 1 && siddon_map_in_bounds(sp, D0, D1, D2)) return base;   // (the brick splat needs no per-cell scratch)
+    if (xvr_detail::option(xvr_detail::OPT_SIDDON_SPLAT) >= 1 && siddon_map_in_bounds(sp, D0, D1, D2) && siddon_splat_detector_ok(sp, n)) return base;   // (the brick splat needs no per-cell scratch)
     return align256(base) + siddon_cells_bytes(D0, D1, D2);
 }
 

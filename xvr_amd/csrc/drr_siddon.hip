@@ -669,7 +669,7 @@ int xvr_drr_siddon_backward(const float* volume, const float* mask, int D0, int 
     // (the maps the forward's slab march serves -- points of the volume look up voxels inside it --, so that forward and voxel gradient
     //  are one pair; a map that leaves the volume keeps the merge walk's family: per-cell gather or scatter)
     const bool nx_in = !exact_geom && siddon_map_in_bounds(sp, D0, D1, D2);
-    const bool splat = !mask && ((nx_in && splat_opt >= 1) || (exact_geom && splat_opt == 2));
+    const bool splat = !mask && siddon_splat_detector_ok(sp, n) && ((nx_in && splat_opt >= 1) || (exact_geom && splat_opt == 2));
     const bool cells = drift_ok && !splat &&
                        workspace_bytes >= align256(ws_bytes(B, n, D0, D1, D2)) + siddon_cells_bytes(D0, D1, D2);
     // (a mask with a per-channel gradient: the one-voxel-per-lane gather that looks the upstream value up by the voxel's own
