@@ -428,7 +428,7 @@ def main():
                                 "int32 fixed point per (pose, 16^3 brick) in LDS, three quarters of the range used, a sum in the guard band "
                                 "poisons its voxels (k_trilinear_splat_b16); fp32 table gather above ~48 samples of a pose per voxel"
                                 if args.renderer == "trilinear" else
-                                "fp32 (k_siddon_gather_vol2); int32 fixed point per (pose, 16^3 brick) under a non-exact index map (k_siddon_splat)"),
+                                "fp32 (k_siddon_gather_vol2); int32 fixed point per 16^3 brick (one scale for the brick's poses) under a non-exact index map (k_siddon_splat)"),
         "config": {
             "workload": f"single {args.size}^3 CT, {args.renderer} fwd+bwd(pose{'' if args.no_voxel_grad else '+voxel'}), "
                         f"{H}x{H} detector, batch_size={B} per GPU" + (f" ({B_total} in total, strong scaling)" if args.scaling == "strong" else "")

@@ -101,8 +101,9 @@ const char* xvr_drr_last_error(void);
  *                              (norm_dims_offset = +1, align_corners; every launch size) | the merge walk (k_siddon) | the march for
  *                              the exact map only                                                                   [1]
  *   "siddon_splat"  1 | 0 | 2  Siddon voxel gradient under a non-exact index map: ray-driven brick-local fixed-point splat
- *                              (k_siddon_splat; shares the march's plane alphas and index arithmetic) | the per-cell fp32 gather
- *                              (needs the larger workspace) | the splat for the exact map as well (A/B)            [1]
+ *                              (k_siddon_splat; shares the march's plane alphas and index arithmetic; one scale per 16^3 brick;
+ *                              detectors up to 2^25 pixels, < 32768 rows and columns -- larger ones take the gather) | the
+ *                              per-cell fp32 gather (needs the larger workspace) | the splat for the exact map as well (A/B) [1]
  *   "siddon_gather_fast" 1 | 0 Siddon voxel gather: pixel window from one projection of the block centre, four bricks along the
  *                              viewing axis per workgroup, candidates from an LDS copy of the brick's footprint, planes in
  *                              crossing order | the window of the eight projected corners, one brick per workgroup,
