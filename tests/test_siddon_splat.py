@@ -165,3 +165,45 @@ def test_an_optimistic_bound_is_seen_not_wrapped(tmp_path):
         assert out.returncode == 0, out.stderr[-2000:]
         lines = [l for l in out.stdout.splitlines() if l.startswith(("siddon", "trilinear"))]
         assert lines == [f"siddon {want}", f"trilinear {want}"], (env_lib, out.stdout)
+
+
+_FALLBACK_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/tests")
+from conftest import make_case
+from xvr_amd import renderers
+from xvr_amd.renderers import render
+from xvr_amd.spec import RenderSpec
+case = make_case(seed=37, shape=(37, 41, 35), height=40, width=44, delx=0.9)
+vol, src, tgt, img = (case[k].cuda() for k in ("volume", "source", "target", "img"))
+vol.requires_grad_(True)
+w = torch.randn(2, 1, 40 * 44, generator=torch.Generator().manual_seed(6)).cuda()
+out = render(vol, src, tgt, img, RenderSpec(renderer="siddon", norm_dims_offset=1), ray_grid_w=44)
+(out * w.reshape(out.shape)).sum().backward()
+torch.cuda.synchronize()
+torch.save(vol.grad.cpu(), {out!r})
+print("workspace", renderers._LAST_VOL_WORKSPACE.numel() * renderers._LAST_VOL_WORKSPACE.element_size())
+"""
+
+
+def test_a_detector_beyond_the_queue_entries_takes_the_per_cell_gather(tmp_path):
+    """k_siddon_splat's queue entries hold (pose slot, pixel) in 32 bits: detectors beyond 2^25 pixels keep round 2's per-cell gather
+    -- dispatch AND workspace size (the gather needs 32 B per voxel more).  Nobody allocates such a detector in a test: a
+    diagnostic build with 10 pixel bits makes this 40 x 44 one too large."""
+    from xvr_amd.build import build_diagnostic_library, diagnostic_path
+
+    lib = build_diagnostic_library("XVR_SIDDON_SPLAT_PX_BITS=10", diagnostic_path("small_splat_detector"), only=["drr_gather.hip", "drr_siddon.hip"])
+    grads, sizes = [], []
+    for env_lib in (None, str(lib)):
+        env = dict(os.environ)
+        if env_lib:
+            env["XVR_DRR_LIBRARY"] = env_lib
+        script, out_pt = tmp_path / f"fallback{len(grads)}.py", tmp_path / f"g{len(grads)}.pt"
+        script.write_text(_FALLBACK_SCRIPT.format(root=str(ROOT), out=str(out_pt)))
+        out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode == 0, out.stderr[-2000:]
+        sizes.append(int([l for l in out.stdout.splitlines() if l.startswith("workspace")][0].split()[1]))
+        grads.append(torch.load(out_pt))
+    assert sizes[1] >= sizes[0] + 32 * 37 * 41 * 35, sizes     # (the per-cell scratch)
+    assert torch.isfinite(grads[1]).all() and grads[1].abs().max() > 0
+    assert _differing(grads[0], grads[1]) <= 8 + int(2.5e-3 * 2 * 40 * 44), _differing(grads[0], grads[1])    # (cross-family ties, see above)
