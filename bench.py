@@ -170,25 +170,43 @@ class Exchange:
     all_gather_into_tensor over RCCL, issued async right after the forward and waited for after the backward.  The unequal
     shares of a ragged strong-scaling split are padded to the largest share (no backend gathers uneven tensors in one call)."""
 
-    def __init__(self, world, B, Bmax, H, dev, volume_grad=True, buckets=8):
+    def __init__(self, world, B, Bmax, H, dev, volume_grad=True, buckets=8, slabs=4):
         self.B = B
         self.gathered = torch.empty(world * Bmax, 1, H, H, device=dev)
         self.send = torch.zeros(Bmax, 1, H, H, device=dev) if Bmax != B else None
         self.handle = None
         # the second exchange of the fwd+bwd(pose+voxel) step (SURVEY.md section 8e): every rank rendered different poses of the SAME
-        # volume, so the voxel gradients are summed -- bucketed async all-reduces over slabs of the gradient, issued when the backward
-        # has written it, waited for at the end of the step (xvr_amd.distributed.allreduce_volume_grad_bucketed)
+        # volume, so the voxel gradients are summed.  slabs > 1 (default): the backward computes the voxel gradient in x slabs and
+        # every finished slab goes into an async all-reduce while the next one is computed (xvr_amd.distributed.SlabAllReduce) --
+        # only the last slab's collective is exposed.  slabs <= 1: bucketed async all-reduces issued when the backward has written
+        # the whole gradient (allreduce_volume_grad_bucketed).  Either way waited for at the end of the step.
+        from xvr_amd.distributed import SlabAllReduce
         self.volume_grad, self.buckets, self.works = volume_grad, buckets, []
+        self.slabs = int(slabs)
+        self.slab = SlabAllReduce(self.slabs, force=True) if self.slabs > 1 else None
+        self.pending = None
 
     def post_forward(self, img):
         if self.send is not None:
             self.send[:self.B].copy_(img.detach())
         self.handle = dist.all_gather_into_tensor(self.gathered, img.detach() if self.send is None else self.send, async_op=True)
 
+    def pre_backward(self):
+        if self.slab is not None:
+            if self.volume_grad:
+                self.slab.install()
+            else:
+                self.slab.remove()
+
     def post_backward(self, grad):
+        if self.slab is not None:
+            self.slab.remove()
         if self.volume_grad and grad is not None:
-            from xvr_amd.distributed import allreduce_volume_grad_bucketed
-            self.works = allreduce_volume_grad_bucketed(grad, self.buckets, force=True)
+            if self.slab is not None and self.slab.fired():
+                self.pending = grad
+            else:
+                from xvr_amd.distributed import allreduce_volume_grad_bucketed
+                self.works = allreduce_volume_grad_bucketed(grad, self.buckets, force=True)
 
     def wait(self):
         if self.handle is not None:
@@ -197,6 +215,9 @@ class Exchange:
         for w in self.works:
             w.wait()
         self.works = []
+        if self.pending is not None:
+            self.slab.finish(self.pending)
+            self.pending = None
 
 
 def render_leg(dev, subject, renderer, voxel_grad, rot0, xyz0, H, delx, n_points, steps, warmup, exchange=None, update_volume=False,
@@ -227,6 +248,7 @@ def render_leg(dev, subject, renderer, voxel_grad, rot0, xyz0, H, delx, n_points
         img = (module or drr)(rot, xyz, parameterization="euler_angles", convention="ZXY", density=density, **kw)
         if exchange is not None:
             exchange.post_forward(img)
+            exchange.pre_backward()
         (img * w).sum().backward()
         if exchange is not None:
             exchange.post_backward(density.grad)
@@ -360,6 +382,9 @@ def main():
                          "the all-gathered tensor with it value by value (`gather_check` in the JSON line)")
     ap.add_argument("--no-volume-grad-exchange", action="store_true",
                     help="N > 1: leave the all-reduce of the voxel gradient out of the step (the all-gather of the DRRs stays)")
+    ap.add_argument("--volume-grad-slabs", type=int, default=4,
+                    help="N > 1: the voxel gradient is computed in this many x slabs and each goes into its all-reduce while the next is "
+                         "computed (1: the whole gradient first, then bucketed all-reduces)")
     ap.add_argument("--check-volume-grad", action="store_true",
                     help="with N > 1 (or --force-dist): rank 0 renders the UNION of all ranks' poses itself and compares its voxel "
                          "gradient with the all-reduced one (`volume_grad_check` in the JSON line)")
@@ -406,7 +431,8 @@ def main():
     else:
         rot, xyz = deepfluoro_poses(B, seed=rank).convert("euler_angles", "ZXY")
     Bmax = B if args.scaling == "weak" else -(-B_total // world)
-    exchange = Exchange(world, B, Bmax, H, dev, volume_grad=not args.no_volume_grad_exchange and not args.no_voxel_grad) if use_dist else None
+    exchange = Exchange(world, B, Bmax, H, dev, volume_grad=not args.no_volume_grad_exchange and not args.no_voxel_grad,
+                        slabs=args.volume_grad_slabs) if use_dist else None
 
     drr_kwargs = json.loads(args.drr_kwargs) if args.drr_kwargs else None
     leg = render_leg(dev, subject, args.renderer, not args.no_voxel_grad, rot, xyz, H, delx, args.n_points, args.steps, args.warmup,
@@ -444,10 +470,13 @@ def main():
     if use_dist:
         vg = exchange.volume_grad
         result["volume_grad_exchange"] = {
-            "in_the_timed_step": bool(vg), "buckets": exchange.buckets if vg else 0,
+            "in_the_timed_step": bool(vg), "slabs": exchange.slabs if vg else 0, "buckets": exchange.buckets if vg and exchange.slabs <= 1 else 0,
             "MB_per_rank": (args.size ** 3) * 4 / 1e6 if vg else 0.0,
-            "how": "bucketed async all_reduce (SUM) of density.grad over slabs of the first axis, issued after the backward, waited for "
-                   "at the end of the step; not overlapped with the splat (one autograd call writes the whole gradient)",
+            "how": ("the backward computes the voxel gradient in x slabs of whole 16^3-brick planes (one launch per slab, same bits as one "
+                    "launch); each finished slab goes into an async all_reduce (SUM) while the next is computed -- only the last slab's "
+                    "collective is exposed; waited for at the end of the step" if exchange.slabs > 1 else
+                    "bucketed async all_reduce (SUM) of density.grad over slabs of the first axis, issued after the backward, waited for "
+                    "at the end of the step; not overlapped with the splat"),
         }
         if vg:   # the same step without it, a short loop behind the timed region (same barrier discipline)
             exchange.volume_grad = False
@@ -656,7 +685,7 @@ def dry_run_collectives(args):
         report["legs"].append({"as_rank": rank, "poses": Bl, "share_padded_to": Bmax, "gather_buffer_MB": full.numel() * 4 / 1e6,
                                "send_MB": Bmax * H * H * 4 / 1e6, "gathered_block_equals_render": ok_block, "padding_is_zero": ok_pad,
                                "rest_untouched": ok_rest, "volume_grad_allreduce_identity": ok_grad,
-                               "volume_grad_buckets": 0 if args.no_voxel_grad else 8, "volume_grad_MB": 0.0 if args.no_voxel_grad else args.size ** 3 * 4 / 1e6,
+                               "volume_grad_slabs": 0 if args.no_voxel_grad else ex.slabs, "volume_grad_MB": 0.0 if args.no_voxel_grad else args.size ** 3 * 4 / 1e6,
                                "ms_step": leg["ms_per_step"]})
         del full, ex, leg
         torch.cuda.empty_cache()

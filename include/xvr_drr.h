@@ -108,6 +108,12 @@ const char* xvr_drr_last_error(void);
  *                              viewing axis per workgroup, candidates from an LDS copy of the brick's footprint, planes in
  *                              crossing order | the window of the eight projected corners, one brick per workgroup,
  *                              candidates from global memory (A/B: equal to rounding)                           [1]
+ *   "gather_slab"   0 | index + 256 * count   the voxel gradient of xvr_drr_*_backward in `count` slabs of whole 16^3-brick planes
+ *                              along x, ONE backward call per slab: index 0 first, same arguments and workspace.  Call i adds the
+ *                              gradient of the voxels x in [16 * (i * nb / count), 16 * ((i + 1) * nb / count)), nb = ceil(D0 / 16);
+ *                              pose gradients, and renders the brick splats do not serve (the whole volume), come with call 0.
+ *                              A caller can hand slab i to a collective while slab i + 1 is computed (xvr_amd.distributed
+ *                              .SlabAllReduce).  The caller resets the option to 0 afterwards.                      [0]
  * Returns XVR_DRR_E_ARG for an unknown name or a value outside the option's range.
  */
 int xvr_drr_set_option(const char* name, int value);

@@ -84,7 +84,7 @@ def test_bench_dry_run_collectives_as_rank_of_eight(extra):
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert d["ok"] and d["as_world_size"] == 8 and [l["as_rank"] for l in d["legs"]] == [0, 7]
-    assert all(l["volume_grad_allreduce_identity"] and l["volume_grad_buckets"] == 8 for l in d["legs"])
+    assert all(l["volume_grad_allreduce_identity"] and l["volume_grad_slabs"] == 4 for l in d["legs"])
     if "strong" in extra:   # 13 poses over 8 ranks: shares of 2 and 1, padded to 2
         assert [l["poses"] for l in d["legs"]] == [2, 1] and all(l["share_padded_to"] == 2 for l in d["legs"])
     else:
@@ -104,14 +104,16 @@ def _torchrun_bench(extra, port):
 
 
 @pytest.mark.gpu
-def test_bench_two_ranks_weak_scaling_contract():
-    d = _torchrun_bench(["--batch", "4", "--check-gather", "--check-volume-grad"], 29611)
+@pytest.mark.parametrize("slabs", [4, 1], ids=["overlapped slabs", "buckets after the backward"])
+def test_bench_two_ranks_weak_scaling_contract(slabs):
+    d = _torchrun_bench(["--batch", "4", "--check-gather", "--check-volume-grad", "--volume-grad-slabs", str(slabs)], 29611 + slabs)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8
-    # the step's second exchange: the voxel gradients of the two ranks, summed by bucketed async
-    # all-reduces inside the timed step -- equal to the gradient of the union batch rendered by one process through the HIP path --
+    # the step's second exchange: the voxel gradients of the two ranks, summed inside the timed step (slab by slab
+    # while the backward runs, or by bucketed async all-reduces behind it) -- equal to the gradient of the union batch rendered by one process through the HIP path --
     # and the same step timed without it next to the headline
     x = d["volume_grad_exchange"]
-    assert x["in_the_timed_step"] and x["buckets"] == 8 and x["ms_per_step_without_it"] > 0 and x["value_without_it"] > 0
+    assert x["in_the_timed_step"] and x["slabs"] == slabs and x["buckets"] == (8 if slabs == 1 else 0)
+    assert x["ms_per_step_without_it"] > 0 and x["value_without_it"] > 0
     assert d["volume_grad_check"]["ok"] and d["volume_grad_check"]["nonzero_voxels"] > 0, d["volume_grad_check"]
     assert "all-reduce of the voxel gradient" in d["config"]["parallelism"]
     # the gathered tensor, value by value, against a single-process render of both ranks' poses through the HIP path

@@ -56,10 +56,20 @@ def _worker(rank, world, port, B, out_q):
     works = xd.allreduce_volume_grad_bucketed(g2, n_buckets=3)
     xd.wait_all(works)
     bucket_ok = len(works) == 3 and torch.equal(g2, 2 * torch.arange(30, dtype=torch.float32).reshape(5, 3, 2) + 100.0)
+    # the overlapped form: the renderer hands every finished x slab of the gradient to the hook (here: by hand), the sums land in
+    # place -- and in a COPY of the gradient too, which is what .grad is if autograd did not adopt the backward's tensor
+    g3 = (torch.arange(5 * 3 * 2, dtype=torch.float32).reshape(5, 3, 2) + 100.0 * rank)
+    sl = xd.SlabAllReduce(count=3)
+    for i, (a, b) in enumerate(((0, 2), (2, 3), (3, 5))):
+        sl._hook(i, g3[a:b])
+    fired, copy = sl.fired(), torch.zeros_like(g3)
+    sl.finish(copy)
+    want3 = 2 * torch.arange(30, dtype=torch.float32).reshape(5, 3, 2) + 100.0
+    slab_ok = fired and not sl.fired() and torch.equal(g3, want3) and torch.equal(copy, want3)
     score = torch.tensor(0.5 + 0.1 * ((rank * 7) % 3))
     best_score, best_pose, best_rank = xd.multistart_best(score, pose.matrix[lo])
     out_q.put(dict(rank=rank, bounds=(lo, hi), same=torch.allclose(gathered, full, atol=1e-6), ok_async=ok_async,
-                   grad=grad[0, 0, 0].item(), bucket_ok=bucket_ok, best_rank=best_rank, best_score=best_score.item(),
+                   grad=grad[0, 0, 0].item(), bucket_ok=bucket_ok, slab_ok=slab_ok, best_rank=best_rank, best_score=best_score.item(),
                    best_pose_ok=torch.allclose(best_pose, pose.matrix[xd.shard_bounds(B, best_rank, world)[0]])))
     dist.destroy_process_group()
 
@@ -81,6 +91,7 @@ def test_pose_sharded_render_world2_gloo(B):
         assert d["same"] and d["ok_async"], "all-gathered shards must equal the single-process render"
         assert d["grad"] == 3.0  # 1 + 2
         assert d["bucket_ok"], "bucketed async all-reduce of the volume gradient: the in-place sum over both ranks"
+        assert d["slab_ok"], "slab-by-slab all-reduce of the volume gradient (SlabAllReduce): in place, and into a copied .grad"
         assert d["best_rank"] == 1 and abs(d["best_score"] - 0.6) < 1e-6 and d["best_pose_ok"]
 
 

@@ -33,6 +33,7 @@ const OptionDef OPTIONS[] = {
     {"siddon_slab", "XVR_DRR_SIDDON_SLAB", 1, 0, 2},
     {"siddon_gather_fast", "XVR_DRR_SIDDON_GATHER_FAST", 1, 0, 1},
     {"siddon_splat", "XVR_DRR_SIDDON_SPLAT", 1, 0, 2},
+    {"gather_slab", "XVR_DRR_GATHER_SLAB", 0, 0, 0xffff},
 };
 constexpr int N_OPTIONS = sizeof(OPTIONS) / sizeof(OPTIONS[0]);
 std::atomic<int> g_opt[N_OPTIONS];

@@ -1411,15 +1411,36 @@ int xvr_detail::launch_gather(bool siddon, const float* source, const float* tar
     G.words = (B + 31) / 32;
     G.gvol = grad_volume;
     *flag_out = G.flag;
-    hipError_t e = hipMemsetAsync(G.flag, 0, 16, (hipStream_t)stream);
-    if (e == hipSuccess && G.cmax) e = hipMemsetAsync(G.cmax, 0, (size_t)B * G.cmax_stride * sizeof(unsigned), (hipStream_t)stream);
-    if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
-    hipLaunchKernelGGL(k_gather_prep, dim3((unsigned)((n + WG - 1) / WG), (unsigned)B), dim3(WG), 0,
-                       (hipStream_t)stream, G);
+    // option gather_slab = index | count << 8: the voxel gradient in `count` x slabs of whole brick planes, one backward call per slab
+    // (index 0 first; same arguments and workspace), so that the caller can hand slab i to a collective while slab i + 1 is computed.
+    // The brick splats take their slab's bricks; every other path does the whole volume in call 0 and nothing afterwards.
+    const int slab_opt = xvr_detail::option(xvr_detail::OPT_GATHER_SLAB), slab_K = slab_opt >> 8, slab_i = slab_opt & 0xff;
+    if (slab_K > 1 && slab_i >= slab_K) return fail(XVR_DRR_E_ARG, "gather_slab: index >= count");
+    const bool later_slab = slab_K > 1 && slab_i > 0;
+    const bool brick_splat = sid_splat || (!siddon && (psplat || (!G.clip && !G.mask && splat)));
+    const int nb0 = (D0 + 15) / 16;
+    G.bx0 = 0;
+    G.bxn = nb0;
+    if (slab_K > 1 && brick_splat) {
+        G.bx0 = (int)((long long)slab_i * nb0 / slab_K);
+        G.bxn = (int)((long long)(slab_i + 1) * nb0 / slab_K) - G.bx0;
+    }
+    if (later_slab && !brick_splat) return XVR_DRR_OK;
     const long long bricks = n_bricks(D0, D1, D2, G.bd);
     if (bricks >= (1LL << 31)) return fail(XVR_DRR_E_UNSUPPORTED, "grid too large");
-    hipLaunchKernelGGL(k_gather_cull, dim3((unsigned)((bricks + WG / 32 - 1) / (WG / 32))), dim3(WG), 0,
-                       (hipStream_t)stream, G, (int)bricks);
+    hipError_t e = hipSuccess;
+    if (later_slab) e = hipMemsetAsync(G.flag + 1, 0, sizeof(unsigned), (hipStream_t)stream);   // (the brick queue; lattice flag, sticky words, poses and cull stand from call 0)
+    else {
+        e = hipMemsetAsync(G.flag, 0, 16, (hipStream_t)stream);
+        if (e == hipSuccess && G.cmax) e = hipMemsetAsync(G.cmax, 0, (size_t)B * G.cmax_stride * sizeof(unsigned), (hipStream_t)stream);
+    }
+    if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
+    if (!later_slab) {
+        hipLaunchKernelGGL(k_gather_prep, dim3((unsigned)((n + WG - 1) / WG), (unsigned)B), dim3(WG), 0,
+                           (hipStream_t)stream, G);
+        hipLaunchKernelGGL(k_gather_cull, dim3((unsigned)((bricks + WG / 32 - 1) / (WG / 32))), dim3(WG), 0,
+                           (hipStream_t)stream, G, (int)bricks);
+    }
     if (sid_splat) {
         const bool nx = siddon_splat == 2;   // (2: a non-exact index map; 1: the exact one, A/B)
         const void* kern = nx ? (const void*)k_siddon_splat<true> : (const void*)k_siddon_splat<false>;
@@ -1472,7 +1493,7 @@ int xvr_detail::launch_gather(bool siddon, const float* source, const float* tar
     else if (G.clip) hipLaunchKernelGGL((k_trilinear_gather_px<true, false>), dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
     else if (G.mask) hipLaunchKernelGGL((k_trilinear_gather_px<false, true>), dim3((unsigned)bricks), dim3(64), 0, (hipStream_t)stream, G);
     else if (splat) {
-        if (auto_fp32) {
+        if (auto_fp32 && !later_slab) {
             // the fine-sampling regime's pair behind the splat: cull on the table gather's 8^3 bricks (into the words behind the
             // splat's) and the gather itself, both of which return at once unless k_gather_prep raised word 3 of the flag line
             GatherArgs T = G;

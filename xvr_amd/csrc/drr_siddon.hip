@@ -678,7 +678,7 @@ int xvr_drr_siddon_backward(const float* volume, const float* mask, int D0, int 
         unsigned* flag = nullptr;
         rc = launch_gather(true, source, target, raylen, grad_out, B, n, sp->ray_grid_w, D0, D1, D2, sp, grad_volume,
                            workspace, stream, &flag, mask, C, exact_geom ? nullptr : olo, splat ? (exact_geom ? 1 : 2) : 0);
-        if (rc) return rc;
+        if (rc || gather_slab_later()) return rc;
         RenderArgs Ap = A, Av = A;
         Ap.gvol = nullptr;
         Av.gsrc = nullptr; Av.gtgt = nullptr; Av.glen = nullptr;
@@ -694,6 +694,7 @@ int xvr_drr_siddon_backward(const float* volume, const float* mask, int D0, int 
         if (gpose) { rc = launch(k_siddon<2, false, true, false, false>, Ap, 0, stream); if (rc) return rc; }
         return launch(k_siddon<2, false, false, true, false>, Av, 0, stream);
     }
+    if (gather_slab_later()) return XVR_DRR_OK;   // (option gather_slab: the call for slab 0 did everything)
 #define SID_BWD2(M, E)                                                                  \
     (gpose ? (gvol ? launch(k_siddon<2, M, true, true, E>, A, lds, stream)              \
                    : launch(k_siddon<2, M, true, false, E>, A, lds, stream))            \

@@ -887,11 +887,12 @@ int xvr_drr_trilinear_backward(const float* volume, const float* mask, int D0, i
     // table kernel for the plain render, the pixel-major kernel under clip_to_volume and / or a mask; the scatter kernel
     // stays as the general fallback and is launched right behind it, reading the lattice flag on the device (no host sync).
     const bool gather = gvol && gather_usable(sp, n, workspace, workspace_bytes, B, D0, D1, D2);
+    if (gather_slab_later() && !gather) return XVR_DRR_OK;   // (option gather_slab: the call for slab 0 did everything)
     if (gather) {
         unsigned* flag = nullptr;
         rc = launch_gather(false, source, target, raylen, grad_out, B, n, sp->ray_grid_w, D0, D1, D2, sp, grad_volume,
                            workspace, stream, &flag, mask, C);
-        if (rc) return rc;
+        if (rc || gather_slab_later()) return rc;
         RenderArgs Ap = A, Av = A;
         Ap.gvol = nullptr;
         Av.gsrc = nullptr; Av.gtgt = nullptr; Av.glen = nullptr;

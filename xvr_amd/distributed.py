@@ -132,6 +132,55 @@ def allreduce_volume_grad_bucketed(grad: torch.Tensor, n_buckets: int = 8, force
     return works
 
 
+class SlabAllReduce:
+    """The voxel-gradient sum of a fwd+bwd(pose+voxel) step, OVERLAPPED with the backward that produces it: while installed, the
+    renderer computes the voxel gradient in ``count`` x slabs (xvr_amd.renderers.VOXEL_GRAD_SLABS, option gather_slab of the library)
+    and every finished slab goes into an async all-reduce at once -- RCCL moves slab i over xGMI while the splat works on slab i + 1;
+    only the last slab's collective is exposed.  ``finish(grad)`` waits and makes sure the sums are in ``grad`` (autograd normally
+    adopts the backward's tensor as ``.grad``; if it copied instead, the reduced slabs are copied over)."""
+
+    def __init__(self, count: int = 4, force: bool = False):
+        self.count, self.force = int(count), force
+        self.slabs, self.works = [], []
+
+    def _active(self) -> bool:
+        return dist.is_available() and dist.is_initialized() and (_world() > 1 or self.force)
+
+    def _hook(self, i, slab):
+        self.slabs.append(slab)
+        if self._active():
+            self.works.append(dist.all_reduce(slab, op=dist.ReduceOp.SUM, async_op=True))
+
+    def install(self):
+        from . import renderers
+        renderers.VOXEL_GRAD_SLABS = (self.count, self._hook)
+        return self
+
+    def remove(self):
+        from . import renderers
+        renderers.VOXEL_GRAD_SLABS = None
+
+    __enter__ = install
+
+    def __exit__(self, *exc):
+        self.remove()
+
+    def fired(self) -> bool:
+        return bool(self.slabs)
+
+    def finish(self, grad) -> None:
+        wait_all(self.works)
+        slabs, self.slabs, self.works = self.slabs, [], []
+        if grad is None or not slabs:
+            return
+        base = slabs[0]._base if slabs[0]._base is not None else slabs[0]
+        if base.data_ptr() != grad.data_ptr():
+            row = base.stride(0)
+            for sl in slabs:
+                x0 = (sl.storage_offset() - base.storage_offset()) // row
+                grad[x0:x0 + sl.shape[0]].copy_(sl)
+
+
 def wait_all(works) -> None:
     for w in works:
         if w is not None:

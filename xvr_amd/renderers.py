@@ -90,6 +90,11 @@ _WORKSPACES = {}
 # downstream, no host sync) and word 2 of the workspace is set.  XVR_DRR_CHECK_OVERFLOW=1 reads that word after every backward (one
 # device -> host sync per step) and raises; last_backward_overflowed() reads it on demand.
 CHECK_OVERFLOW = __import__("os").environ.get("XVR_DRR_CHECK_OVERFLOW", "0") == "1"
+# (count, hook) | None.  With count > 1 the voxel gradient of a backward is computed in `count` x slabs (whole planes of 16^3 bricks),
+# one launch per slab, and hook(i, grad_volume[x0:x1]) is called on the current stream's timeline right after slab i's launch: an
+# async collective issued there (torch.distributed orders it behind the stream's work so far) overlaps the remaining slabs
+# (bench.py at N > 1, xvr_amd.distributed.SlabAllReduce).  The sums are the same bits as the single launch's.
+VOXEL_GRAD_SLABS = None
 _LAST_VOL_WORKSPACE = None
 
 
@@ -432,11 +437,32 @@ class _Render(torch.autograd.Function):
                 # (the per-cell scratch only when the cells gather will really run: Siddon, no mask left, rays on a lattice)
                 ws, ws_bytes = _workspace(lib, B, n, (D0, D1, D2), dev, cs,
                                           cells=spec.renderer == "siddon" and msk_c is None and ctx.ray_grid_w > 1)
-            rc = _timed(f"{spec.renderer}_backward[{tag.strip('+')}]", fn,
-                        _ptr(vol_c), _ptr(msk_c), D0, D1, D2, C, _ptr(src_c), _ptr(tgt_c), _ptr(len_c), B, n,
-                        ctypes.byref(cs), _ptr(gout), _ptr(gvol),
-                        _ptr(gsrc) if pose_here else None, _ptr(gtgt) if pose_here else None,
-                        _ptr(glen) if pose_here else None, _ptr(ws), ws_bytes, _stream())
+            def call():
+                return fn(_ptr(vol_c), _ptr(msk_c), D0, D1, D2, C, _ptr(src_c), _ptr(tgt_c), _ptr(len_c), B, n,
+                          ctypes.byref(cs), _ptr(gout), _ptr(gvol),
+                          _ptr(gsrc) if pose_here else None, _ptr(gtgt) if pose_here else None,
+                          _ptr(glen) if pose_here else None, _ptr(ws), ws_bytes, _stream())
+
+            def call_in_slabs(count, hook):
+                # the voxel gradient in x slabs of whole brick planes, one call per slab (option gather_slab): slab i is complete
+                # when call i has been issued, and the hook may hand it to a collective while call i + 1 runs
+                nb0 = (D0 + 15) // 16
+                try:
+                    for i in range(count):
+                        _lib.set_option("gather_slab", i | (count << 8))
+                        rc = call()
+                        if rc:
+                            return rc
+                        x0, x1 = min(16 * (i * nb0 // count), D0), min(16 * ((i + 1) * nb0 // count), D0)
+                        if hook is not None and x1 > x0:
+                            hook(i, gvol[x0:x1])
+                finally:
+                    _lib.set_option("gather_slab", 0)
+                return 0
+
+            slabs = VOXEL_GRAD_SLABS if (need_vol and ws is not None and gvol.dim() == 3) else None
+            name = f"{spec.renderer}_backward[{tag.strip('+')}]"    # (one timed region per step, slabs or not)
+            rc = _timed(name, call) if slabs is None or slabs[0] <= 1 else _timed(name, call_in_slabs, *slabs)
             _lib.check(rc, f"xvr_drr_{spec.renderer}_backward")
             if need_vol and ws is not None:
                 global _LAST_VOL_WORKSPACE
