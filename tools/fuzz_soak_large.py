@@ -12,7 +12,8 @@ import test_fuzz_large as T  # noqa: E402
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 fails = 0
-for fn in (T.test_large_siddon_launch_against_the_oracle, T.test_large_trilinear_launch_on_the_tiled_copy_against_the_oracle):
+for fn in (T.test_large_siddon_launch_against_the_oracle, T.test_large_siddon_launch_under_the_recalled_index_maps,
+           T.test_large_trilinear_launch_on_the_tiled_copy_against_the_oracle):
     bad = []
     for seed in range(first, first + count):
         try:
