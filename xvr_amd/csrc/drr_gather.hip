@@ -332,6 +332,26 @@ __global__ __launch_bounds__(WG) void k_gather_cull(GatherArgs G, int nbricks) {
 // max(1 - |d|, 0), the trilinear weight of a voxel at signed distance d, in ONE instruction: 1 - |d| never
 // exceeds 1, so the [0, 1] clamp equals the max and folds into the subtraction's clamp bit
 // (v_sub_f32 dst, 1.0, |d| clamp) -- the gather's inner loop is VALU-bound and has six of these per candidate.
+// A lane's 2 x 2 x 2 voxel sums added to the gradient: the eight loads first, then the stores -- ONE memory round trip instead of
+// eight guarded read-modify-writes in a row at the end of every workgroup (the lane's voxels are its own: no other lane of the launch
+// writes them).
+__device__ __forceinline__ void add_block8(float* __restrict__ gvol, const float (&acc)[8], const int vx, const int vy, const int vz,
+                                           const int D0, const int D1, const int D2) {
+    float old[8];
+    size_t at[8];
+    bool on[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int x = vx + (e >> 2 & 1), y = vy + (e >> 1 & 1), z = vz + (e & 1);
+        on[e] = x < D0 && y < D1 && z < D2 && acc[e] != 0.f;
+        at[e] = ((size_t)x * D1 + y) * D2 + z;
+        old[e] = on[e] ? gvol[at[e]] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+        if (on[e]) gvol[at[e]] = old[e] + acc[e];
+}
+
 __device__ __forceinline__ float hat01(float d) { return __builtin_amdgcn_fmed3f(1.f - fabsf(d), 0.f, 1.f); }
 
 // linspace_at() with both halves evaluated and one select (same values, no exec-masked branches in the inner loops)
@@ -616,11 +636,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(XVR_TAB_WAVE
     for (int i = 0; i < 8; ++i)
         if (st[i]) atomicAdd(&g_gather_stats[i], st[i]);
 #endif
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int x = vx + (e >> 2 & 1), y = vy + (e >> 1 & 1), z = vz + (e & 1);
-        if (x < G.D0 && y < G.D1 && z < G.D2 && acc[e] != 0.f) G.gvol[((size_t)x * G.D1 + y) * G.D2 + z] += acc[e];
-    }
+    add_block8(G.gvol, acc, vx, vy, vz, G.D0, G.D1, G.D2);
 }
 
 #include "drr_splat.hiph"   // k_trilinear_splat_b16, k_trilinear_splat_px: the brick-local fixed-point splats (the default)
@@ -760,11 +776,7 @@ __global__ __launch_bounds__(64) void k_trilinear_gather_px(GatherArgs G) {
             }
         }
     }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int x = vx + (e >> 2 & 1), y = vy + (e >> 1 & 1), z = vz + (e & 1);
-        if (x < G.D0 && y < G.D1 && z < G.D2 && acc[e] != 0.f) G.gvol[((size_t)x * G.D1 + y) * G.D2 + z] += acc[e];
-    }
+    add_block8(G.gvol, acc, vx, vy, vz, G.D0, G.D1, G.D2);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1321,11 +1333,7 @@ __global__ __launch_bounds__(FAST ? 256 : 64) __attribute__((amdgpu_waves_per_eu
     }
     if (cum) to_chords();
     permute(cur);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int x = vx + (e >> 2), y = vy + ((e >> 1) & 1), z = vz + (e & 1);
-        if (x < G.D0 && y < G.D1 && z < G.D2 && acc[e] != 0.f) G.gvol[((size_t)x * G.D1 + y) * G.D2 + z] += acc[e];
-    }
+    add_block8(G.gvol, acc, vx, vy, vz, G.D0, G.D1, G.D2);
 #ifdef XVR_GATHER_STATS
     for (int i = 0; i < 8; ++i)
         if (st[i]) atomicAdd(&g_gather_stats[i], st[i]);
