@@ -45,6 +45,12 @@ def main():
     ap.add_argument("--renderers", default="trilinear,siddon")
     ap.add_argument("--out", default=str(Path(__file__).resolve().parent / "_c2c3_parts"))
     ap.add_argument("--pack-only", action="store_true")
+    ap.add_argument("--variant", default="", choices=["", "clip", "nx"],
+                    help="'clip': the trilinear render with the per-ray alpha window SURVEY.md Appendix A recalls for upstream "
+                         "(clip_to_volume = True; bench.py's recalled_knobs) -> tests/golden/c2c3_oracle_batch_clip.npz, keys trilinear_clip_*.  "
+                         "'nx': Siddon under the recalled index map dims = shape + 1 on a 511^3 phantom (an even-sized axis carries the map's "
+                         "structural tie, tests/conftest.py::has_structural_tie) -> c2c3_oracle_batch_nx.npz, keys siddon_nx_*; run it with "
+                         "--dtype float64 AND --dtype float32: the float32 run's pixels and gradients are the test's yardstick")
     ap.add_argument("--dtype", default="float32", choices=["float32", "float64"],
                     help="arithmetic of the oracle run.  Siddon's pose gradient is a sum of jumps of a piecewise-constant integrand over "
                          "65536 rays: on the phantom's sharp ellipsoid surfaces the float32 oracle is 1e-2 from its own float64 run, so the "
@@ -55,7 +61,9 @@ def main():
     out = Path(args.out)
     out.mkdir(parents=True, exist_ok=True)
     lo, hi = (int(x) for x in args.poses.split(":"))
-    renderers = args.renderers.split(",")
+    renderers = args.renderers.split(",") if not args.variant else ["trilinear" if args.variant == "clip" else "siddon"]
+    size = 511 if args.variant == "nx" else SIZE
+    tag = lambda renderer: renderer + ("_" + args.variant if args.variant else "")   # noqa: E731
     if not args.pack_only:
         from oracle.diffdrr_restated import RenderSpec, drr_from_pose
         from xvr_amd.data import make_phantom, read
@@ -63,7 +71,7 @@ def main():
         from xvr_amd.training import get_random_pose
 
         dt = getattr(torch, args.dtype)
-        vol, _ = make_phantom(SIZE, n_ellipsoids=64, seed=0)
+        vol, _ = make_phantom(size, n_ellipsoids=64, seed=0)
         affine = read(vol, orientation="AP").affine.to(dt)
         vol = vol.to(dt)
         g = torch.Generator().manual_seed(0)   # (bench.py::deepfluoro_poses(116, seed=0))
@@ -71,9 +79,10 @@ def main():
                                    generator=g).convert("euler_angles", "ZXY")
         pix = torch.from_numpy(sampled_pixels())
         for renderer in renderers:
-            spec = RenderSpec(renderer=renderer, n_points=N_POINTS)
+            spec = RenderSpec(renderer=renderer, n_points=N_POINTS, clip_to_volume=args.variant == "clip",
+                              norm_dims_offset=1 if args.variant == "nx" else 0)
             for b in range(lo, hi):
-                part = out / (f"{renderer}_{b:03d}.npz" if args.dtype == "float32" else f"{renderer}_{b:03d}_f64.npz")
+                part = out / (f"{tag(renderer)}_{b:03d}.npz" if args.dtype == "float32" else f"{tag(renderer)}_{b:03d}_f64.npz")
                 if part.exists():
                     continue
                 t0 = time.time()
@@ -87,9 +96,9 @@ def main():
                 tiles = im.double().reshape(16, 16, 16, 16).sum(dim=(1, 3))
                 np.savez(part, pixels=im.reshape(-1)[pix].float().numpy(), tiles=tiles.numpy(), imax=im.max().item(), isum=im.double().sum().item(),
                          grad=torch.cat([r.grad, x.grad], dim=-1).double().numpy()[0], rot=rot[b].numpy(), xyz=xyz[b].numpy())
-                print(f"{renderer} pose {b}: {time.time() - t0:.1f} s, max {im.max().item():.3f}", flush=True)
+                print(f"{tag(renderer)} pose {b}: {time.time() - t0:.1f} s, max {im.max().item():.3f}", flush=True)
     packed = {"pixel_index": sampled_pixels()}
-    for renderer in ("trilinear", "siddon"):
+    for renderer in (("trilinear", "siddon") if not args.variant else (tag(renderers[0]),)):
         parts = [out / f"{renderer}_{b:03d}_f64.npz" for b in range(B)]
         if not all(p.exists() for p in parts):
             parts = [out / f"{renderer}_{b:03d}.npz" for b in range(B)]
@@ -105,8 +114,10 @@ def main():
             # the float32 run's gradient next to the float64 one: where the two disagree the gradient is ill-conditioned in float32
             # (Siddon, pose 77: 9e-2 of the largest entry) and the test allows the HIP path as much
             packed[f"{renderer}_grad_f32"] = np.stack([np.load(p)["grad"] for p in f32])
+            if args.variant == "nx":   # (and its pixels: under a non-exact map two float32 evaluations differ by whole segments on some rays)
+                packed[f"{renderer}_pixels_f32"] = np.stack([np.load(p)["pixels"] for p in f32])
     if len(packed) > 1:
-        np.savez_compressed(Path(__file__).resolve().parent / "c2c3_oracle_batch.npz", **packed)
+        np.savez_compressed(Path(__file__).resolve().parent / ("c2c3_oracle_batch.npz" if not args.variant else f"c2c3_oracle_batch_{args.variant}.npz"), **packed)
         print({k: v.shape for k, v in packed.items()})
 
 

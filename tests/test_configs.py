@@ -351,8 +351,9 @@ def test_full_size_trilinear_voxel_gradient_is_bit_reproducible():
 # ----------------------------------------------------------------------------------------------
 # C2 / C3: the WHOLE benchmark batch against the oracle (a fixture: the oracle needs ~20 CPU-minutes for it)
 # ----------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("renderer", ["trilinear", "siddon"])
-def test_benchmark_batch_against_the_oracle_fixture(renderer):
+@pytest.mark.parametrize("renderer,variant", [("trilinear", ""), ("siddon", ""), ("trilinear", "clip")],
+                         ids=["trilinear", "siddon", "trilinear per-ray clip (recalled)"])
+def test_benchmark_batch_against_the_oracle_fixture(renderer, variant):
     """All 116 poses of bench.py's headline batch (512^3 phantom -> 256^2, DeepFluoro pose ranges, seed 0), image and pose gradient,
     against oracle/diffdrr_restated.py -- rendered once on the CPU by tests/golden/make_golden_c2c3.py (every pixel of every pose)
     and committed as 4096 pixels per pose, the sums over all 256 tiles of 16 x 16 pixels per pose, and the gradient of a weighted
@@ -365,14 +366,17 @@ def test_benchmark_batch_against_the_oracle_fixture(renderer):
     from xvr_amd.data import make_phantom, read
     from xvr_amd.drr import DRR
 
-    path = Path(__file__).parent / "golden" / "c2c3_oracle_batch.npz"
-    gold = np.load(path)
+    # (variant "clip": the per-ray alpha window SURVEY.md Appendix A recalls for upstream's trilinear render -- its own fixture file,
+    #  `make_golden_c2c3.py --variant clip`)
+    path = Path(__file__).parent / "golden" / ("c2c3_oracle_batch.npz" if not variant else f"c2c3_oracle_batch_{variant}.npz")
+    gold = {k.replace(f"{renderer}_{variant}_", f"{renderer}_") if variant else k: v for k, v in np.load(path).items()}
     assert f"{renderer}_pixels" in gold, "fixture incomplete: run tests/golden/make_golden_c2c3.py"
     B, H = 116, 256
     # (the phantom as the fixture's generator built it, on the HOST: built on the device, a few hundred voxels on the ellipsoids'
     #  surfaces fall on the other side of `q <= 1` -- fused multiply-adds -- and move the rays through them by 2e-3 of the maximum)
     vol, _ = make_phantom(512, n_ellipsoids=64, seed=0)
-    drr = DRR(read(vol, orientation="AP"), 1020.0, H, 1.08821875, renderer=renderer, reverse_x_axis=False).cuda()
+    drr = DRR(read(vol, orientation="AP"), 1020.0, H, 1.08821875, renderer=renderer, reverse_x_axis=False,
+              **({"clip_to_volume": True} if variant == "clip" else {})).cuda()
     rot0, xyz0 = deepfluoro_poses(B, seed=0).convert("euler_angles", "ZXY")
     assert np.allclose(rot0.numpy(), gold[f"{renderer}_rot"]) and np.allclose(xyz0.numpy(), gold[f"{renderer}_xyz"])
     rot, xyz = rot0.cuda().requires_grad_(True), xyz0.cuda().requires_grad_(True)
