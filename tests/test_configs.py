@@ -44,6 +44,16 @@ def _close_per_ray(a, b, tol, what, outliers=2e-4, outlier_tol=5e-2):
     assert err.max().item() <= outlier_tol, f"{what}: worst entry {err.max().item():.3e} > {outlier_tol:.1e}"
 
 
+@__import__("functools").lru_cache(maxsize=2)
+def _host_phantom(size):
+    """bench.py's phantom built on the HOST, as tests/golden/make_golden_c2c3.py builds it (20 s for 512^3: shared by the fixture tests;
+    built on the device, a few hundred voxels on the ellipsoids' surfaces fall on the other side of `q <= 1` -- fused multiply-adds --
+    and move the rays through them by 2e-3 of the maximum)."""
+    from xvr_amd.data import make_phantom
+
+    return make_phantom(size, n_ellipsoids=64, seed=0)[0]
+
+
 def deepfluoro_poses(batch, seed):
     from xvr_amd.training import get_random_pose
 
@@ -374,7 +384,7 @@ def test_benchmark_batch_against_the_oracle_fixture(renderer, variant):
     B, H = 116, 256
     # (the phantom as the fixture's generator built it, on the HOST: built on the device, a few hundred voxels on the ellipsoids'
     #  surfaces fall on the other side of `q <= 1` -- fused multiply-adds -- and move the rays through them by 2e-3 of the maximum)
-    vol, _ = make_phantom(512, n_ellipsoids=64, seed=0)
+    vol = _host_phantom(512)
     drr = DRR(read(vol, orientation="AP"), 1020.0, H, 1.08821875, renderer=renderer, reverse_x_axis=False,
               **({"clip_to_volume": True} if variant == "clip" else {})).cuda()
     rot0, xyz0 = deepfluoro_poses(B, seed=0).convert("euler_angles", "ZXY")
@@ -429,7 +439,7 @@ def test_benchmark_batch_under_the_recalled_siddon_map_against_the_oracle_fixtur
     gold = np.load(Path(__file__).parent / "golden" / "c2c3_oracle_batch_nx.npz")
     assert "siddon_nx_pixels_f32" in gold and str(gold["siddon_nx_oracle_dtype"]) == "float64", "fixture incomplete: make_golden_c2c3.py --variant nx"
     B, H = 116, 256
-    vol, _ = make_phantom(511, n_ellipsoids=64, seed=0)     # (on the host, as the generator built it)
+    vol = _host_phantom(511)
     drr = DRR(read(vol, orientation="AP"), 1020.0, H, 1.08821875, renderer="siddon", reverse_x_axis=False, norm_dims_offset=1).cuda()
     rot0, xyz0 = deepfluoro_poses(B, seed=0).convert("euler_angles", "ZXY")
     assert np.allclose(rot0.numpy(), gold["siddon_nx_rot"]) and np.allclose(xyz0.numpy(), gold["siddon_nx_xyz"])
