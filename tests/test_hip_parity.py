@@ -1424,7 +1424,8 @@ def test_fuzz_random_configurations_against_the_oracle(seed):
     renderer = "trilinear" if rng.random() < 0.6 else "siddon"
     kw = dict(renderer=renderer, voxel_shift=float(rng.choice([0.0, 0.5])))
     if renderer == "trilinear":
-        kw.update(n_points=1 if seed >= 10000 else int(rng.integers(1, 90)), align_corners=bool(rng.random() < 0.3),
+        # (seeds 10000..10099: a single sample per ray; every other seed -- the suite's 0..199 and tools/fuzz_soak.py's fresh ones -- draws)
+        kw.update(n_points=1 if 10000 <= seed < 10100 else int(rng.integers(1, 90)), align_corners=bool(rng.random() < 0.3),
                   norm_dims_offset=int(rng.choice([0, 0, -1])), step_mode=str(rng.choice(["n_points", "n_minus_1"])),
                   clip_to_volume=bool(rng.random() < 0.25))
         if kw["n_points"] < 2:
@@ -1463,6 +1464,14 @@ def test_fuzz_random_configurations_against_the_oracle(seed):
         assert int(bad.sum()) <= 2, f"grad_target: {int(bad.sum())} rays disagree [{what}]"
         hs, rs = (t.detach().double().cpu() for t in named.pop("grad_source"))
         assert (hs - rs).abs().max() <= 5 * GRAD_TOL * rs.abs().max() + 2.0 * (per_ray * bad).sum(), f"grad_source [{what}]"
+    elif (kw["n_points"] == 1 and kw.get("clip_to_volume") and kw.get("align_corners") and kw.get("norm_dims_offset") == -1
+          and "near" not in kw and not masked):
+        # One sample per ray under the per-ray window sits AT alpha_min, on the face the ray enters through; under this map (a = 1)
+        # that face is a plane of grid nodes, where the interpolant has a kink: every ray's d/d target (and their sum, d/d source) is
+        # one-sided, and two implementations take different sides on a hundred rays at once (tools/fuzz_soak.py, seeds 60139 and
+        # 60857).  Image, voxel gradient and d/d ray length are compared; the two one-sided derivatives are not.
+        named.pop("grad_target")
+        named.pop("grad_source")
     elif not masked:
         # Trilinear: a sample that sits ON a voxel boundary (to the last bit) makes its ray's d/d target one-sided, and the
         # two implementations may take different sides.  One ray in ~100 cases (tools/fuzz_soak.py over 800 fresh seeds found

@@ -274,6 +274,36 @@ def test_slab_march_source_inside_miss_and_hot_voxel():
     _close(got, ref, FWD_TOL, "hot voxel")
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(voxel_shift=0.0), dict(voxel_shift=0.0, align_corners=True), dict(norm_dims_offset=1)],
+                         ids=["exact", "exact, corner convention", "align_corners", "dims = shape + 1"])
+def test_slab_march_rays_with_the_volume_behind_them_render_as_zero(kw):
+    """A source beside a corner of a flat volume and a detector that looks past it: for some rays the volume lies BEHIND the ray --
+    every far plane at a negative alpha, a_hi < a_lo = 0.  Round 5's soak (seed 70034, this geometry) found the march clamping its
+    plane alphas into that reversed interval and crediting a positive "segment" between the two minor planes to whatever voxel the
+    clamped index named: six pixels at 7-31 where the oracle has 0.  The exact map's small launches take the merge walk and never
+    showed it; this test forces the march for every map.  Rays of both kinds share wavefronts."""
+    from oracle.diffdrr_restated import render as oracle_render
+    from xvr_amd.spec import RenderSpec
+
+    spec = RenderSpec(renderer="siddon", **kw)
+    g = torch.Generator().manual_seed(5)
+    vol = torch.rand((22, 11, 6), generator=g) + 0.1
+    src = torch.tensor([9.4953, -2.8751, -17.4703])
+    i, j = torch.meshgrid(torch.arange(30.0), torch.arange(24.0), indexing="ij")
+    d = (torch.tensor([19.384, -1.283, -35.511]) + (i - 8)[..., None] * torch.tensor([-0.64815, 1.16294, -1.11767])
+         + j[..., None] * torch.tensor([-0.2992, 0.21322, 4.21897])).reshape(-1, 3)
+    case = dict(volume=vol, **_rays(src.tolist(), (src + d).tolist()))
+    ref = oracle_render(case["volume"], case["source"], case["target"], case["img"], to_oracle_spec(spec), None)
+    assert (ref > 0).float().mean().item() > 0.05 and (ref == 0).float().mean().item() > 0.2      # both kinds of rays
+    w = torch.rand(1, 1, d.shape[0], generator=g)
+    got, walk = _render(case, spec, 1, w=w, grid_w=24), _render(case, spec, 0, w=w, grid_w=24)
+    missed = (ref == 0) & (walk[0].cpu() == 0)
+    assert bool((got[0].cpu()[missed] == 0).all()), f"{int((got[0].cpu()[missed] != 0).sum())} rays that miss the volume render as non-zero"
+    if not kw.get("norm_dims_offset"):     # (dims + 1 on even sizes: the map's structural tie, compared within the pair elsewhere)
+        _close_but(got[0], ref, FWD_TOL, 4 if kw.get("align_corners") else 0, "image")
+        _close_but(got[2], walk[2], 5 * GRAD_TOL, 8, "d/d target, march against merge walk")
+
+
 def test_slab_march_is_the_default_for_large_one_channel_launches_and_deterministic():
     """A launch of >= 2048 wavefronts with the exact index map takes the slab march by itself (no option), on the bricked copy
     (built at first sight); two runs give the same bits; image and pose gradient of DRR.forward agree with the merge walk's."""

@@ -372,6 +372,12 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, XVR_SLAB_
         off += i0 * strd[i];
         if (R.d[i] != 0.f) ahi = fminf(ahi, (fpfar[i] + ps[i]) * inv_d[i]);   // the loop's own plane arithmetic: no far plane is ever crossed
     }
+    // A ray with the volume BEHIND it (a source inside or beside the volume, the ray pointing away: every far plane at a negative
+    // alpha) leaves a_hi < a_lo = 0.  The loop clamps its plane alphas into [a_end, a_c] then -- the wrong way round -- and the two
+    // minor planes cut a "segment" of positive length out of it, credited with whatever voxel the clamped index names: such rays
+    // rendered as garbage instead of 0 (tools/fuzz_soak.py seed 70034, round 5; the exact map's small launches take the merge walk and
+    // never showed it).  An empty interval is [a_lo, a_lo].
+    ahi = fmaxf(ahi, alo);
     const float ad0 = fabsf(R.d[0]), ad1 = fabsf(R.d[1]), ad2 = fabsf(R.d[2]);
     const int m = (ad0 >= ad1 && ad0 >= ad2) ? 0 : (ad1 >= ad2 ? 1 : 2);
     const int u = m == 2 ? 0 : m + 1, v = 3 - m - u;
