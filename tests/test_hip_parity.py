@@ -1453,6 +1453,16 @@ def test_fuzz_random_configurations_against_the_oracle(seed):
     ref = _oracle_render(case, spec, mask=mask, grads=True, w=w)
     what = f"seed {seed}: {kw} shape {shape} det {H}x{W} B {B} masked {masked} inside {inside}"
     named = dict(zip(("out", "grad_volume", "grad_source", "grad_target", "grad_img"), zip(hip, ref)))
+    if masked:
+        # A sample within an ulp of the midpoint between two voxels can take its label from either (the oracle's
+        # coordinate goes through grid_sample's normalise / denormalise round trip): the channel SUM is compared
+        # tightly, the split into channels with room for a couple of such samples.
+        h, r = (t.detach().double().cpu() for t in named.pop("out"))
+        _close(h.sum(1), r.sum(1), FWD_TOL, f"out, channel sum [{what}]")
+        flips = ((h - r).abs() > FWD_TOL * r.abs().max()).sum().item()
+        assert flips <= 6, f"out: {flips} channel entries disagree [{what}]"
+        if flips:   # the per-channel upstream weights then see different samples: gradients are not comparable
+            return
     if renderer == "siddon":
         # A ray that crosses two planes at once (through a voxel edge, to the last bit) sits on a kink of the Siddon
         # integral: which plane the jump is attributed to is a tie-break, and the oracle's sort and the traversal
@@ -1472,7 +1482,8 @@ def test_fuzz_random_configurations_against_the_oracle(seed):
         # 60857).  Image, voxel gradient and d/d ray length are compared; the two one-sided derivatives are not.
         named.pop("grad_target")
         named.pop("grad_source")
-    elif not masked:
+    elif True:
+        # (masked renders as well, since round 5: seed 70197 -- one ray at 6.6e-3, every other at 5e-7)
         # Trilinear: a sample that sits ON a voxel boundary (to the last bit) makes its ray's d/d target one-sided, and the
         # two implementations may take different sides.  One ray in ~100 cases (tools/fuzz_soak.py over 800 fresh seeds found
         # 4, each with exactly one such ray at 0.6-4 % of the largest gradient and every other ray within 3e-6): at most ONE
@@ -1484,17 +1495,9 @@ def test_fuzz_random_configurations_against_the_oracle(seed):
         bad = per_ray > GRAD_TOL * top
         assert int(bad.sum()) <= 1 and float(per_ray.max()) <= 0.1 * float(top), f"grad_target: {int(bad.sum())} rays disagree, worst {float(per_ray.max() / top):.2e} [{what}]"
         hs, rs = (t.detach().double().cpu() for t in named.pop("grad_source"))
-        assert (hs - rs).abs().max() <= GRAD_TOL * rs.abs().max() + 2.0 * (per_ray * bad).sum(), f"grad_source [{what}]"
-    if masked:
-        # A sample within an ulp of the midpoint between two voxels can take its label from either (the oracle's
-        # coordinate goes through grid_sample's normalise / denormalise round trip): the channel SUM is compared
-        # tightly, the split into channels with room for a couple of such samples.
-        h, r = (t.detach().double().cpu() for t in named.pop("out"))
-        _close(h.sum(1), r.sum(1), FWD_TOL, f"out, channel sum [{what}]")
-        flips = ((h - r).abs() > FWD_TOL * r.abs().max()).sum().item()
-        assert flips <= 6, f"out: {flips} channel entries disagree [{what}]"
-        if flips:   # the per-channel upstream weights then see different samples: gradients are not comparable
-            named = {}
+        # (d/d source is the sum over rays of (1 - alpha)-weighted terms of d/d target's size; where it cancels to ~0 -- seed 70004:
+        #  two samples per ray, 1e-6 against per-ray gradients of 6 -- its own largest entry is no scale)
+        assert (hs - rs).abs().max() <= GRAD_TOL * max(rs.abs().max().item(), 1e-3 * float(top)) + 2.0 * (per_ray * bad).sum(), f"grad_source [{what}]"
     for name, (h, r) in named.items():
         tol = FWD_TOL if name == "out" else (GRAD_TOL if renderer == "trilinear" or name == "grad_volume" else 5 * GRAD_TOL)
         _close(h, r, tol, f"{name} [{what}]")

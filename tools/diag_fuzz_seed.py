@@ -1,0 +1,32 @@
+"""One seed of tests/test_hip_parity.py::test_fuzz_random_configurations_against_the_oracle, with the per-quantity distances the\nassertion hides:  python tools/diag_fuzz_seed.py 70004 70197   (on the GPU box)"""
+import sys, traceback
+from pathlib import Path
+R = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(R)); sys.path.insert(0, str(R / "tests"))
+import torch
+import test_hip_parity as T
+orig = T._hip_render
+keep = {}
+def spy(*a, **k):
+    r = orig(*a, **k); keep["hip"] = r; return r
+T._hip_render = spy
+orig_o = T._oracle_render
+def spy_o(*a, **k):
+    r = orig_o(*a, **k); keep["ref"] = r; return r
+T._oracle_render = spy_o
+for seed in map(int, sys.argv[1:]):
+    try:
+        T.test_fuzz_random_configurations_against_the_oracle(seed)
+        print(seed, "passes")
+    except BaseException as e:
+        print(seed, "FAILED", str(e)[:400])
+    names = ("out", "grad_volume", "grad_source", "grad_target", "grad_img")
+    for n, h, r in zip(names, keep["hip"], keep["ref"]):
+        if h is None or r is None: continue
+        h, r = h.detach().double().cpu(), r.detach().double().cpu()
+        e = (h - r).abs() / r.abs().max().clamp_min(1e-30)
+        print(f"   {n}: max rel err {e.max().item():.2e}; entries beyond 2e-3: {int((e > 2e-3).sum())} of {e.numel()}; scale {r.abs().max().item():.3e}")
+        if n == "grad_target":
+            per = e.amax(dim=-1).reshape(-1)
+            top = per.sort(descending=True)
+            print("      worst rays:", [(int(i), f"{v:.1e}") for v, i in zip(top.values[:5].tolist(), top.indices[:5].tolist())])
