@@ -1,4 +1,5 @@
-"""One seed of tests/test_hip_parity.py::test_fuzz_random_configurations_against_the_oracle, with the per-quantity distances the\nassertion hides:  python tools/diag_fuzz_seed.py 70004 70197   (on the GPU box)"""
+"""One seed of tests/test_hip_parity.py::test_fuzz_random_configurations_against_the_oracle, with the per-quantity distances the
+assertion hides:  python tools/diag_fuzz_seed.py 70004 70197   (on the GPU box)"""
 import sys, traceback
 from pathlib import Path
 R = Path(__file__).resolve().parents[1]
