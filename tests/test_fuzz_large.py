@@ -91,6 +91,12 @@ def _case(seed, n_poses):
     if seed % 3 == 0:
         depth[-1] = float(rng.uniform(0.0, 4.0))                       # this pose's source sits inside the volume
     xyz = tuple((float(rng.uniform(-12, 12)), d, float(rng.uniform(-12, 12))) for d in depth)
+    if seed % 4 == 1 or __import__("os").environ.get("XVR_FUZZ_WILD") == "1":
+        # two poses whose source sits BESIDE the volume, close to it, the detector looking past it: rays that miss, rays that graze a
+        # face, rays with the volume behind them (the class of the slab-march bug round 5's soak found at a small launch, seed 70034)
+        ext = float(max(shape))
+        xyz = xyz[:-2] + tuple((float(rng.choice([-1.0, 1.0]) * rng.uniform(0.4, 1.1) * ext), float(rng.uniform(0.0, 0.6) * ext),
+                                float(rng.choice([-1.0, 1.0]) * rng.uniform(0.2, 0.9) * ext)) for _ in range(2))
     delx = float(rng.uniform(0.25, 1.6)) * 128.0 / max(h, w)
     case = make_case(shape=shape, height=h, width=w, seed=seed, rot=rot, xyz=xyz, delx=delx)
     case["volume"] = _smooth(shape, seed)
