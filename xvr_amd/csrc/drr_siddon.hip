@@ -346,7 +346,17 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(1, XVR_SLAB_
     const unsigned vol_bytes = BRICK ? (unsigned)((A.D0 + 1) >> 1) * (unsigned)nby * (unsigned)nbz * 128u
                                      : (unsigned)A.D0 * (unsigned)A.D1 * (unsigned)A.D2 * 4u;
     const bool live = valid && (R.amax > R.amin);
-    const float alo = live ? R.amin : 0.f;
+    // The interval starts at the slab test's a_min -- or an ulp later, at the alpha the march's OWN plane arithmetic gives the face the ray
+    // enters through, (p + (plane0 - s)) * (1 / d): the ray-driven brick splat (k_siddon_splat) clips a ray against its brick's box with
+    // that expression, the volume's faces included, and forward and backward must agree on the ends of the FIRST segment to the bit as
+    // on every other (a lookup of its midpoint that lands within an ulp of a rounding threshold: tools/fuzz_soak.py seed 120742,
+    // round 5 -- the pair disagreed on one segment of one ray in 3 600 non-exact cases).  a_hi gets the same treatment below.
+    float alo = live ? R.amin : 0.f;
+    if (live) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (R.d[i] != 0.f) alo = fmaxf(alo, ((R.d[i] >= 0.f ? 0.f : (float)D[i]) + (A.sp.plane0[i] - R.s[i])) * (1.f / R.d[i]));
+    }
 
     // per axis: the voxel the ray enters, the next plane in travel direction and the far boundary plane (as floats: exact small
     // integers), plane0 - s, 1 / d, the signed stride
