@@ -9,7 +9,7 @@ import test_hip_parity as T
 orig = T._hip_render
 keep = {}
 def spy(*a, **k):
-    r = orig(*a, **k); keep["hip"] = r; return r
+    r = orig(*a, **k); keep["hip"] = r; keep["case"] = a[0]; return r
 T._hip_render = spy
 orig_o = T._oracle_render
 def spy_o(*a, **k):
@@ -31,3 +31,11 @@ for seed in map(int, sys.argv[1:]):
             per = e.amax(dim=-1).reshape(-1)
             top = per.sort(descending=True)
             print("      worst rays:", [(int(i), f"{v:.1e}") for v, i in zip(top.values[:5].tolist(), top.indices[:5].tolist())])
+    if "case" in keep:
+        c = keep["case"]
+        h_t, r_t = keep["hip"][3].detach().double().cpu(), keep["ref"][3].detach().double().cpu()
+        per = ((h_t - r_t).abs().amax(dim=-1) / r_t.abs().max()).reshape(h_t.shape[0], -1)
+        b, ray = divmod(int(per.argmax()), per.shape[1])
+        s0 = c["source"][b].reshape(-1, 3)[0]; t0 = c["target"][b].reshape(-1, 3)[ray]
+        print(f"      worst ray: pose {b} ray {ray}: source {s0.tolist()} direction {(t0 - s0).tolist()}; out hip {keep['hip'][0][b].reshape(-1)[ray].item():.6f} ref {keep['ref'][0][b].reshape(-1)[ray].item():.6f}"
+              f"; d/d target hip {h_t[b].reshape(-1, 3)[ray].tolist()} ref {r_t[b].reshape(-1, 3)[ray].tolist()}; volume shape {tuple(c['volume'].shape)}")
