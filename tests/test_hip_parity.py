@@ -1614,6 +1614,13 @@ def test_fuzz_voxel_gather_equals_atomic_scatter(seed):
         a, b = grads[0].double().cpu(), grads[1].double().cpu()
         err = (a - b).abs() / b.abs().max().clamp_min(1e-12)
         assert (err > 1e-4).double().mean().item() <= 1e-2 and abs(a.sum().item() - b.sum().item()) <= 1e-4 * b.abs().sum().item(), what
+    elif masked:
+        # (a sample within an ulp of the midpoint between two voxels takes its label -- hence its channel's upstream weight -- from either:
+        #  the forward's flips <= 6 of the oracle fuzz above.  Seed 160227 of round 5's soak: 4 samples per ray, two voxels at 5e-3 of a
+        #  largest gradient of 2e-4, in the ray-major splat, the table gather AND the scatter against the float64 oracle alike)
+        a, b = grads[0].double().cpu(), grads[1].double().cpu()
+        err = (a - b).abs() / b.abs().max().clamp_min(1e-12)
+        assert int((err > 1e-4).sum()) <= 4 and err.max().item() <= 2e-2, f"gather vs scatter, masked [{what}]: {int((err > 1e-4).sum())} voxels, worst {err.max().item():.2e}"
     else:
         _close(grads[0], grads[1], 1e-4, f"gather vs scatter [{what}]")
 
