@@ -169,10 +169,16 @@ def batch_window(source, target, shape, spec: RenderSpec):
     return alphamin[hit].min(), alphamax[hit].max()
 
 
-def trilinear(volume, source, target, img, spec: RenderSpec, mask=None, window=None):
+def trilinear(volume, source, target, img, spec: RenderSpec, mask=None, window=None, label_nudge=None):
     """Trilinear ray-marching.  volume[D0,D1,D2]; source[B,1,3]; target[B,n,3]; img[B,1,n] -> [B,C,n].
     ``window``: the (A, Z) of ``clip_to_volume="batch"`` when the caller has computed it over MORE rays than it passes here
-    (``render`` chunks over rays; the window belongs to the whole call)."""
+    (``render`` chunks over rays; the window belongs to the whole call).
+    ``label_nudge`` = (p0, p1), each broadcastable to [B, n, 3], in voxel-space units: the LABEL of a ray's first sample is looked
+    up at x_0 + p0 and that of its last sample at x_{N-1} + p1 (the interpolated values stay where they are).  Test
+    infrastructure for ``clip_to_volume=True`` with a mask: the first and last sample then sit exactly on a face of the volume,
+    where the nearest-label lookup is decided by the last bit of the position -- a tie no two implementations break alike.  A
+    nudge of a thousandth of a voxel along the face's normal, into or out of the volume, names the side explicitly
+    (tests/conftest.py::resolve_face_ties)."""
     shape = volume.shape
     N = spec.n_points
     alphas = torch.linspace(spec.near, spec.far, N)[None, None].to(volume)
@@ -191,7 +197,14 @@ def trilinear(volume, source, target, img, spec: RenderSpec, mask=None, window=N
         alphas = alphas[..., keep.any(dim=0).any(dim=0)]
     xyzs = _xyzs(alphas, source, target, shape, spec)
     samples = _lookup(volume, xyzs, "bilinear", spec.align_corners)
-    out = _to_channels(samples, volume, mask, xyzs, spec)
+    label_xyzs = xyzs
+    if label_nudge is not None and mask is not None:
+        dims = torch.tensor(list(shape)).to(source) + spec.norm_dims_offset
+        label_xyzs = xyzs.detach().expand(source.shape[0], 1, target.shape[1], xyzs.shape[-2], 3).clone()
+        label_xyzs[:, 0, :, 0] += 2 * torch.as_tensor(label_nudge[0]).to(source) / dims
+        if label_xyzs.shape[-2] > 1:
+            label_xyzs[:, 0, :, -1] += 2 * torch.as_tensor(label_nudge[1]).to(source) / dims
+    out = _to_channels(samples, volume, mask, label_xyzs, spec)
     denom = N if spec.step_mode == "n_points" else N - 1
     scale = img / denom
     if spec.clip_to_volume == "batch":
@@ -234,9 +247,13 @@ def siddon(volume, source, target, img, spec: RenderSpec, mask=None):
     return out * img
 
 
-def render(volume, source, target, img, spec: RenderSpec, mask=None, chunk: int | None = None):
+def render(volume, source, target, img, spec: RenderSpec, mask=None, chunk: int | None = None, label_nudge=None):
     """Dispatch + optional chunking over rays (the materialised [B,n,K,3] grid is huge: SURVEY 3.3)."""
     fn = trilinear if spec.renderer == "trilinear" else siddon
+    if label_nudge is not None:
+        if spec.renderer != "trilinear" or (chunk is not None and target.shape[1] > chunk):
+            raise ValueError("label_nudge: trilinear, unchunked")
+        return trilinear(volume, source, target, img, spec, mask, label_nudge=label_nudge)
     if chunk is None or target.shape[1] <= chunk:
         return fn(volume, source, target, img, spec, mask)
     if spec.renderer == "siddon" and not spec.per_ray_clamp:

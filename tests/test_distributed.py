@@ -66,6 +66,31 @@ def _worker(rank, world, port, B, out_q):
     sl.finish(copy)
     want3 = 2 * torch.arange(30, dtype=torch.float32).reshape(5, 3, 2) + 100.0
     slab_ok = fired and not sl.fired() and torch.equal(g3, want3) and torch.equal(copy, want3)
+    # the contract: a leaf whose .grad is a clone gets the REDUCED tensor put in its place, no copy back; a .grad that is
+    # not None at install time raises; the slabs of a second gradient tensor in one backward make finish raise
+    leaf = torch.zeros(5, 3, 2, requires_grad=True)
+    g4 = (torch.arange(30, dtype=torch.float32).reshape(5, 3, 2) + 100.0 * rank)
+    sl.install(leaf)
+    sl.remove()
+    for i, (a, b) in enumerate(((0, 2), (2, 3), (3, 5))):
+        sl._hook(i, g4[a:b])
+    leaf.grad = g4.clone()                      # what AccumulateGrad does while the slab views hold the tensor
+    sl.finish(leaf.grad)
+    slab_ok = slab_ok and leaf.grad.data_ptr() == g4.data_ptr() and torch.equal(leaf.grad, want3)
+    try:
+        sl.install(leaf)
+        slab_ok = False
+    except RuntimeError as e:
+        slab_ok = slab_ok and ".grad must be None" in str(e)
+    finally:
+        sl.remove()
+    g5, g6 = torch.ones(4, 2, 2) * (rank + 1), torch.ones(4, 2, 2)
+    sl._hook(0, g5[0:2]); sl._hook(1, g5[2:4]); sl._hook(0, g6[0:2])
+    try:
+        sl.finish(g5)
+        slab_ok = False
+    except RuntimeError as e:
+        slab_ok = slab_ok and "two renders" in str(e) and torch.equal(g5, torch.full((4, 2, 2), 3.0)) and not sl.fired()
     score = torch.tensor(0.5 + 0.1 * ((rank * 7) % 3))
     best_score, best_pose, best_rank = xd.multistart_best(score, pose.matrix[lo])
     out_q.put(dict(rank=rank, bounds=(lo, hi), same=torch.allclose(gathered, full, atol=1e-6), ok_async=ok_async,

@@ -214,6 +214,44 @@ def test_golden_fixtures(name):
             assert torch.allclose(g.grad, want, rtol=1e-4, atol=1e-4 * max(1.0, want.abs().max().item())), k
 
 
+@pytest.mark.parametrize("kw", [
+    dict(n_points=38), dict(n_points=32, voxel_shift=0.0, step_mode="n_minus_1"), dict(n_points=45, near=0.13, far=0.96),
+    dict(n_points=48, norm_dims_offset=-1), dict(n_points=47, voxel_shift=0.0, align_corners=True, norm_dims_offset=-1),
+    dict(n_points=1), dict(n_points=2),
+], ids=lambda kw: "-".join(f"{k}={v}" for k, v in kw.items()))
+def test_mask_under_clip_to_volume_the_two_oracles_agree_once_the_face_ties_are_named(kw):
+    """mask x clip_to_volume=True: the first / last sample of every ray sits ON a face of the volume and its label is decided by
+    the last bit of the position -- the float32 torch restatement and the float64 scalar restatement break that tie differently on
+    a sixth of the rays (2-50 % of a pixel).  ``conftest.resolve_face_ties`` names, per ray, which of the four readings
+    (first: inside / padding) x (last: inside / padding) an implementation took; under the named readings the two restatements
+    agree to 2e-5 on EVERY ray -- the machinery the GPU suite uses for the HIP path (no ray skipped, nothing waived)."""
+    from conftest import clip_mask_tie_free, make_case as mk, resolve_face_ties
+    from oracle import scalar
+
+    spec = RenderSpec(renderer="trilinear", clip_to_volume=True, **kw)
+    case = mk(seed=41, height=14, width=18, delx=4.0)
+    assert clip_mask_tie_free(case["volume"].shape, spec.n_points, spec.near, spec.far, spec.voxel_shift, spec.norm_dims_offset, spec.align_corners)
+    args = [case[k] for k in ("volume", "source", "target", "img")]
+    f64 = torch.from_numpy(scalar.render(*args, spec, case["mask"])).float()
+    plain = render(*args, spec, case["mask"])
+    nudge, ref, stats = resolve_face_ties(f64, *args, spec, case["mask"], 2e-5)
+    assert torch.allclose(f64.sum(1), plain.sum(1), rtol=1e-4, atol=1e-4)           # the channel sum never depended on the ties
+    if (spec.near, spec.far) == (0.0, 1.0) and spec.norm_dims_offset == 0:
+        assert (f64 - plain).abs().max() > 1e-3 * plain.abs().max()                 # ... the channels did
+        assert stats["first_out"] + stats["last_out"] > 0
+    assert nudge[0].shape == case["target"].shape and float(nudge[0].abs().max()) == pytest.approx(1e-3)
+
+
+def test_clip_mask_tie_free_names_the_interior_ties():
+    """A ray that enters and leaves through opposite faces of an axis of D voxels puts sample j of n on a voxel boundary whenever
+    D j / (n - 1) is an integer: 24 voxels and 40 samples tie at j = 13, 26 (round 5's golden had exactly that)."""
+    from conftest import clip_mask_tie_free
+
+    assert not clip_mask_tie_free((20, 24, 28), 40) and not clip_mask_tie_free((20, 24, 28), 33)
+    assert clip_mask_tie_free((20, 24, 28), 38) and clip_mask_tie_free((512, 512, 512), 500)      # (499 is prime: the benchmark's C5)
+    assert clip_mask_tie_free((20, 24, 28), 1) and clip_mask_tie_free((20, 24, 28), 2)
+
+
 # ----------------------------------------------------------------------------------------------
 # structural properties that pin the restatement independently of any reference implementation
 # ----------------------------------------------------------------------------------------------

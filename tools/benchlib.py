@@ -60,6 +60,136 @@ def committed_counters(kind, pattern, profiles=None):
     return None
 
 
+
+# ---- what binds the render kernels: floors priced from the committed microbenchmarks and PMC summaries (moved out of bench.py in
+# round 6: the driver's line carries only the dominant kernel's {unit, floor_ms, frac}; the tables go to bench_full.json) ----
+import json
+import sys
+
+ROOT = PROFILES.parent
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s measured copy peak
+HBM_COPY_GBS = 6290.0
+# What actually binds the render kernels (their taps are served by L1 / L2 / LDS, not by HBM): unit costs measured on this
+# chip by the committed microbenchmarks, applied to the live unit count.  floor_ms = the time the launch would take if the
+# binding unit were busy every clock and nothing else cost anything.
+CUS, CLK_GHZ = 256, 2.4
+VALU_CLK = 3.0   # clocks a plain wave64 vector instruction occupies its SIMD (2.9-3.4 measured with 4 wavefronts per SIMD,
+                 # tools/microbench/valu_issue.hip, profiles/r03_microbench_valu_issue.txt; v_pk_*_f32 7.5, v_mad_u64_u32 6.0)
+# candidate units per timed call: (unit, wavefront instructions per 64 units of work, clocks each on the unit's 256 CU-wide or
+# 1024 SIMD-wide resource, source).  The instruction and line counts are NOT literals: they are read at run time from the newest
+# committed PMC summaries (profiles/rNN_{trilinear,siddon}_rocprof_summary.md, written by tools/profile.sh + summarize_profile.py)
+# and divided by the unit count of the very run they were collected under (profiles/rNN_*_bench_under_trace.json), so a kernel
+# edit followed by a profile run re-prices the floors without touching this file (tests/test_bench_contract.py checks the
+# parse against the files).
+# fabric_bandwidth: an L2 miss moves one whole 128-byte line (tools/microbench/fetch_calib.hip, profiles/r04_fetch_calibration.txt);
+# random lines of a working set far beyond the Infinity Cache arrive at 43-46 G lines/s (5.5-5.9 TB/s) -- 0.054 clocks per line for
+# the chip.
+LINE_CLK = CLK_GHZ / 44.5
+# timed call -> (which summary, regex of the kernel instantiation that IS the call's steady state)
+BINDING_KERNELS = {
+    "trilinear_backward": ("trilinear", r"k_trilinear_splat_b16"),
+    "trilinear_forward+jac": ("trilinear", r"k_trilinear_fwd<true, 0, false, [1-9]"),
+    "trilinear_forward": ("trilinear", r"k_trilinear_fwd<false, 0, false, [1-9]"),
+    "siddon_backward": ("siddon", r"k_siddon_gather_vol2"),
+    "siddon_forward+jac": ("siddon", r"k_siddon_slab<true, true(, false)?>"),
+    "siddon_forward": ("siddon", r"k_siddon_slab<false, true(, false)?>"),
+    # the recalled index map (dims = shape + 1): the slab march's NX instantiations and the ray-driven brick splat
+    "siddon_backward@nx": ("siddon_nx", r"k_siddon_splat"),
+    "siddon_forward+jac@nx": ("siddon_nx", r"k_siddon_slab<true, true, true>"),
+    "siddon_forward@nx": ("siddon_nx", r"k_siddon_slab<false, true, true>"),
+}
+_BINDING_CACHE = {}
+
+
+def binding_candidates(base):
+    """[(unit, wavefront instructions per 64 units, clocks each, width, source)] for one timed call, from the committed counters."""
+    if base in _BINDING_CACHE:
+        return _BINDING_CACHE[base]
+    cands = []
+    kind, pattern = BINDING_KERNELS.get(base, (None, None))
+    c = committed_counters(kind, pattern) if kind else None
+    if c:
+        per64 = lambda counter: c[counter] / (c["units"] / 64.0)   # noqa: E731
+        src = f"{c['file']} / units of {c['units_file']}"
+        if base == "trilinear_backward" and "SQ_THREAD_CYCLES_VALU" in c:
+            # tools/microbench/lds_atomics.hip: a ds_add_u32 wavefront instruction costs >= 4.4 LDS clocks however few lanes are
+            # live; 8 per sample; live lanes per vector instruction from the same PMC pass
+            live = c["SQ_THREAD_CYCLES_VALU"] / c["SQ_INSTS_VALU"]
+            cands.append(("lds_atomic_issue", 8 / (live / 64.0), 4.4, CUS, f"profiles/r02_microbench_lds_atomics.txt; {live:.1f} live lanes ({src})"))
+        if base.startswith("trilinear_forward"):
+            # tools/microbench/gather.hip: a 64-lane gather costs ~15 clk per CU on one 128-B line and 10-14 more per further line;
+            # two 16-byte gathers per sample (y-pair copy), ~3 lines by that estimate
+            cands.append(("texture_address", 2, 36.0, CUS, "profiles/r01_microbench_gather_lines.txt"))
+        if base.startswith("siddon_forward+jac") and "TA_BUSY_avr" in c:
+            # clocks the CUs' texture-address units were busy (TA_BUSY_avr: mean over the TA instances), per 64 voxel segments
+            cands.append(("texture_address", 1.0, c["TA_BUSY_avr"] / (c["units"] / 64.0) * CUS, CUS, f"TA_BUSY_avr ({src})"))
+        if "SQ_INSTS_VALU" in c:
+            cands.append(("valu_issue", per64("SQ_INSTS_VALU"), VALU_CLK, 4 * CUS, f"profiles/r03_microbench_valu_issue.txt x SQ_INSTS_VALU ({src})"))
+        if "TCC_EA0_RDREQ_sum" in c:
+            cands.append(("fabric_bandwidth", per64("TCC_EA0_RDREQ_sum"), LINE_CLK, 1, f"profiles/r04_fetch_calibration.txt x TCC_EA0_RDREQ ({src})"))
+    _BINDING_CACHE[base] = cands
+    return cands
+
+
+def binding_floor(tag, units, avg_ms, variant=""):
+    """The unit with the largest floor for one timed call, and every candidate's floor next to it.  ``variant`` "nx": the leg renders
+    under a non-exact Siddon index map (other kernels, other committed profile)."""
+    cands = binding_candidates(tag.split("[")[0] + ("@" + variant if variant else ""))
+    if not cands or not units:
+        return None
+    floors = {}
+    for unit, per64, clk, width, source in cands:
+        floors[unit] = {"floor_ms": units / 64.0 * per64 * clk / width / (CLK_GHZ * 1e9) * 1e3, "clk_per_wave_instr": clk, "source": source}
+    unit = max(floors, key=lambda u: floors[u]["floor_ms"])
+    return {"unit": unit, "floor_ms": floors[unit]["floor_ms"], "frac": floors[unit]["floor_ms"] / avg_ms,
+            "clk_per_wave_instr": floors[unit]["clk_per_wave_instr"], "source": floors[unit]["source"],
+            "floors_ms": {u: v["floor_ms"] for u, v in floors.items()}}
+
+
+# which profiled kernels make up each timed C-ABI call (one call may launch several kernels)
+TRAFFIC_KERNELS = {
+    "trilinear_forward": ["k_trilinear_fwd"],
+    "trilinear_backward": ["k_trilinear_splat_b16", "k_trilinear_gather_tab", "k_gather_prep", "k_gather_cull", "k_trilinear_bwd"],
+    "siddon_forward": ["k_siddon<", "k_siddon_slab"],
+    "siddon_backward": ["k_siddon_gather_vol", "k_gather_prep", "k_gather_cull", "k_siddon<"],
+    "backward_from_jac": ["k_backward_from_jac"],
+}
+
+
+def pmc_traffic(tag, variant=""):
+    """HBM-side bytes per launch of the kernels behind one timed call, from the committed rocprofv3 PMC
+    passes (profiles/traffic.json, written by tools/summarize_profile.py: FETCH_SIZE + WRITE_SIZE, in
+    bytes MOVED: the fetch side is the reported FETCH_SIZE doubled, as calibrated in profiles/r04_fetch_calibration.txt).
+    None when not profiled."""
+    path = ROOT / "profiles" / "traffic.json"
+    if not path.exists():
+        return None
+    try:
+        table = json.loads(path.read_text())
+    except ValueError:
+        return None
+    base = tag.split("[")[0].split("+")[0]
+    keys = TRAFFIC_KERNELS.get(base)
+    if not keys:
+        return None
+    nx = variant == "nx"
+    if base == "siddon_backward":   # (the exact map's voxel gather, or the brick splat of a non-exact one: never both)
+        keys = [k for k in keys if k != "k_siddon_gather_vol"] + ["k_siddon_splat"] if nx else keys
+    fam = {}   # kernel family (name up to its template list) -> traffic of each profiled instantiation that matches
+    for name, v in table.items():
+        if "k_siddon<" in name:   # k_siddon<MODE, ...>: 0 forward, 1 forward + jacobian, 2 backward
+            mode = "2" if base == "siddon_backward" else ("1" if "+jac" in tag else "0")
+            if f"k_siddon<{mode}," not in name:
+                continue
+        if "k_siddon_slab<" in name and (("k_siddon_slab<true" in name) != ("+jac" in tag) or base != "siddon_forward"
+                                         or name.split("k_siddon_slab<")[1].split(">")[0].endswith(", true") != nx):
+            continue
+        if any(k in name for k in keys) and (("fwd<true" in name) == ("+jac" in tag) or "fwd<" not in name):
+            fam.setdefault(name.split("<")[0], []).append(v.get("fetch_bytes", 0.0) + v.get("write_bytes", 0.0))
+    # different kernels of one call add up; instantiations of one kernel (volume layouts) are alternatives: their mean
+    return sum(sum(v) / len(v) for v in fam.values()) if fam else None
+
+
 def _kernel_table(events):
     per = {}
     for name, e0, e1 in events:
@@ -127,7 +257,7 @@ def c4_register(dev, subject, sizes=((256, 0.1360 * 8), (512, 0.1360 * 4)), n_it
     return out
 
 
-def c5_train_step(dev, size=512, B=116, H=256, n=9, warm=3):
+def c5_train_step(dev, size=512, B=116, H=256, n=9, warm=3, drr_kwargs=None):
     """-> {"ms_per_step": wall ms, "phases": {name: ms by HIP events}, "kernels": {...}}"""
     from xvr_amd import renderers
     from xvr_amd.data import make_phantom, read, transform_hu_to_density
@@ -141,7 +271,7 @@ def c5_train_step(dev, size=512, B=116, H=256, n=9, warm=3):
     hu = vol * 1400 - 1000
     del vol
     drr = DRR(read(hu, lab, spacing=(512.0 / size,) * 3, orientation="AP", hu=True), 1020.0, H, 1.08821875 * 256 / H, renderer="trilinear",
-              reverse_x_axis=False).to(dev)
+              reverse_x_axis=False, **(drr_kwargs or {})).to(dev)
     drr.register_buffer("volume", hu)
     transforms = XrayTransforms(H)
     lossfn = PoseRegressionLoss(1020.0).to(dev)
@@ -194,5 +324,5 @@ def c5_train_step(dev, size=512, B=116, H=256, n=9, warm=3):
     total = statistics.median(walls)
     ev, renderers.PROFILER = renderers.PROFILER, None
     return {"ms_per_step": total, "min_median_max_ms": [min(walls), total, max(walls)], "steps": n,
-            "config": f"{size}^3 -> {H}^2, batch {B}, 8 label channels, render side only (no regressor)",
+            "config": f"{size}^3 -> {H}^2, batch {B}, 8 label channels, render side only (no regressor)" + (f", spec {drr_kwargs}" if drr_kwargs else ""),
             "phases": {k: statistics.median(a.elapsed_time(b) for a, b in v) for k, v in marks.items()}, "kernels": _kernel_table(ev)}

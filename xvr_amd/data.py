@@ -67,6 +67,15 @@ class HUDensity:
     def __init__(self, hu: torch.Tensor, stats: torch.Tensor, multiplier: float):
         self.hu, self.stats, self.multiplier = hu, stats, float(multiplier)
         self._dense = None
+        self._hu_version = hu._version      # the statistics belong to THIS content of the tensor
+
+    def check_fresh(self):
+        """The HU tensor must not have been modified in place since ``transform_hu_to_density(..., lazy=True)`` reduced its
+        statistics: the renders' packing pass would apply a map normalised with stale min / max while a fresh ``materialize()``
+        recomputes them -- two different densities from one object.  Raises instead; call ``transform_hu_to_density`` again."""
+        if self.hu._version != self._hu_version:
+            raise RuntimeError("HUDensity: the HU volume was modified in place after transform_hu_to_density(..., lazy=True); its "
+                               "statistics are stale -- map it again")
 
     shape = property(lambda self: self.hu.shape)
     device = property(lambda self: self.hu.device)
@@ -78,6 +87,7 @@ class HUDensity:
         return self.hu.dim()
 
     def materialize(self) -> torch.Tensor:
+        self.check_fresh()
         if self._dense is None:
             self._dense = _hu_to_density_hip(self.hu, self.multiplier)
         return self._dense

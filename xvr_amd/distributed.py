@@ -136,23 +136,45 @@ class SlabAllReduce:
     """The voxel-gradient sum of a fwd+bwd(pose+voxel) step, OVERLAPPED with the backward that produces it: while installed, the
     renderer computes the voxel gradient in ``count`` x slabs (xvr_amd.renderers.VOXEL_GRAD_SLABS, option gather_slab of the library)
     and every finished slab goes into an async all-reduce at once -- RCCL moves slab i over xGMI while the splat works on slab i + 1;
-    only the last slab's collective is exposed.  ``finish(grad)`` waits and makes sure the sums are in ``grad`` (autograd normally
-    adopts the backward's tensor as ``.grad``; if it copied instead, the reduced slabs are copied over)."""
+    only the last slab's collective is exposed.
+
+    Contract (checked): ONE render with a voxel gradient per backward, and the volume's ``.grad`` is ``None`` when the
+    backward starts.  Autograd would otherwise ADD the backward's tensor into the existing ``.grad`` (or a second render's tensor
+    into the first's) on the compute stream while the collectives are still writing it, and the sum would hold whatever the race left.
+    ``install(leaf)`` raises on a ``.grad`` that is not ``None``; slabs of a second gradient tensor make ``finish`` raise (after
+    waiting for what is in flight).  ``finish(grad)`` waits and makes sure the sums are what the caller reads: the slab views
+    (and the pending collectives) hold references to the backward's tensor, so autograd never adopts it as ``.grad`` but clones it
+    -- mid-reduction; the reduced tensor is therefore put in the clone's place (``leaf.grad`` is re-pointed when the leaf was given
+    to ``install``: no copy back; otherwise the reduced slabs are copied over ``grad``)."""
 
     def __init__(self, count: int = 4, force: bool = False):
         self.count, self.force = int(count), force
         self.slabs, self.works = [], []
+        self.leaf, self._base, self._second = None, None, False
 
     def _active(self) -> bool:
         return dist.is_available() and dist.is_initialized() and (_world() > 1 or self.force)
 
     def _hook(self, i, slab):
+        base = slab._base if slab._base is not None else slab
+        if self._base is None:
+            self._base = base
+        elif base.data_ptr() != self._base.data_ptr():
+            self._second = True          # a second render's gradient in the same backward: not reduced, reported by finish()
+            return
         self.slabs.append(slab)
         if self._active():
             self.works.append(dist.all_reduce(slab, op=dist.ReduceOp.SUM, async_op=True))
 
-    def install(self):
+    def install(self, leaf=None):
+        """``leaf``: the volume tensor whose ``.grad`` the backward will fill (optional; lets ``finish`` adopt the reduced tensor
+        instead of copying it back, and lets the ``.grad is None`` half of the contract be checked here)."""
         from . import renderers
+        if leaf is not None and leaf.grad is not None:
+            raise RuntimeError("SlabAllReduce: the volume's .grad must be None when the backward starts (autograd would accumulate into it "
+                               "while the slab all-reduces are in flight); set it to None, or reduce after the backward with "
+                               "allreduce_volume_grad_bucketed")
+        self.leaf = leaf
         renderers.VOXEL_GRAD_SLABS = (self.count, self._hook)
         return self
 
@@ -171,10 +193,18 @@ class SlabAllReduce:
     def finish(self, grad) -> None:
         wait_all(self.works)
         slabs, self.slabs, self.works = self.slabs, [], []
+        base, second, leaf = self._base, self._second, self.leaf
+        self._base, self._second, self.leaf = None, False, None
+        if second:
+            raise RuntimeError("SlabAllReduce: two renders with a voxel gradient in one backward -- only the first one's slabs were "
+                               "reduced and autograd added the second into a tensor the collectives were writing; render once per "
+                               "backward, or reduce after it with allreduce_volume_grad_bucketed")
         if grad is None or not slabs:
             return
-        base = slabs[0]._base if slabs[0]._base is not None else slabs[0]
         if base.data_ptr() != grad.data_ptr():
+            if leaf is not None and leaf.grad is grad and base.shape == grad.shape and base.is_contiguous():
+                leaf.grad = base         # autograd cloned the backward's tensor mid-reduction: the reduced tensor takes its place
+                return
             row = base.stride(0)
             for sl in slabs:
                 x0 = (sl.storage_offset() - base.storage_offset()) // row

@@ -50,11 +50,13 @@ class Registrar:
     def __init__(self, drr: DRR, scales="8", n_itrs="500", parameterization="euler_angles", convention="ZXY",
                  lr_rot=1e-2, lr_xyz=1e0, patience=10, threshold=1e-4, max_n_plateaus=3, crop=0, equalize=False,
                  mncc_patch_size=9, gncc_patch_size=11, sigma=0.0, beta=0.5, verbose=0, use_graph=None, fused=None,
-                 device_loop=None, check_every=8, subtract_background=False, linearize=False, reducefn="max"):
+                 device_loop=None, check_every=8, subtract_background=False, linearize=True, reducefn="max"):
         self.drr = drr
         # what turns the raw pixel array into the registration target (xvr_amd/xray.py; the reference's read_xray options,
-        # /root/reference/src/xvr/registrar/base.py:128-141): `prepare_xray(raw)` applies it, parameters.pt records it.  The
-        # defaults leave an already prepared image (a rendered DRR, a linearised X-ray) as it is but for the crop.
+        # /root/reference/src/xvr/registrar/base.py:128-141): `prepare_xray(raw)` applies it, parameters.pt records it.  Defaults
+        # as every registrar of the reference (linearize=True: registrar/model.py:16, dicom.py:14, fixed.py:20): crop, rescale to
+        # [0, 1] (always), log-linearise.  `run(gt, ...)` takes an image that is ALREADY the target (a rendered DRR, a prepared
+        # X-ray) and applies none of this; only `prepare_xray` does.
         self.xray_preparation = XrayPreparation(trim=int(crop), subtract_background=bool(subtract_background),
                                                 linearize=bool(linearize), frames=reducefn)
         self.scales = scales.split(",") if isinstance(scales, str) else [str(s) for s in scales]

@@ -205,7 +205,8 @@ def _packed_ypair_volume(lib, volume, mask, hu_map=None):
                     else (lib.xvr_drr_ypairs_bytes, lib.xvr_drr_pack_labels_ypairs))
     buf = hit[1] if hit is not None and hit[1].numel() * 4 == nbytes(D0, D1, D2) and hu_map is not None else \
         torch.empty(nbytes(D0, D1, D2) // 4, device=volume.device, dtype=torch.float32)
-    if hu_map is not None:   # (`volume` holds HU: the density map rides in the same pass, data.HUDensity; the step's buffer is reused)
+    if hu_map is not None:   # (`volume` holds HU: the density map rides in the same pass, data.HUDensity; the step's buffer is reused
+        #                          IN PLACE -- safe because every render of it is enqueued on the one stream this pass is enqueued on)
         rc = _timed("pack_hu_labels_ytiles", lib.xvr_drr_pack_hu_labels_ytiles, _ptr(volume), _ptr(mask), _ptr(hu_map.stats),
                     ctypes.c_float(hu_map.multiplier), D0, D1, D2, _ptr(buf), _stream())
     else:
@@ -540,6 +541,7 @@ def render(volume, source, target, img, spec: RenderSpec, mask=None, ray_grid_w:
     volume-touching samples (trilinear) or voxel segments (siddon) to."""
     hu_map = None
     if type(volume).__name__ == "HUDensity":   # (xvr_amd.data.HUDensity: a density that has not been written yet)
+        volume.check_fresh()
         hu_map, volume = volume, volume.hu
     for name, t in (("volume", volume), ("source", source), ("target", target), ("img", img)):
         _check_gpu_f32(name, t)
