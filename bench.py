@@ -506,10 +506,11 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(vol, leg["drr"], leg["rot"], leg["xyz"], leg["spec"], args)
+    if use_dist:   # (before the line: whatever the backend says while it shuts down must not follow it on stdout)
+        dist.barrier()
+        dist.destroy_process_group()
     if rank == 0:
         emit(result, args.full_json)
-    if use_dist:
-        dist.destroy_process_group()
 
 
 def _r(x, digits=5):
@@ -595,7 +596,10 @@ def emit(full, full_json):
     json.loads(line, parse_constant=_no_constants)
     if len(line) >= 8192:
         raise SystemExit(f"bench.py: the JSON line is {len(line)} bytes; the driver needs it below 8 KB")
-    print(line, flush=True)
+    sys.stderr.flush()
+    # (a fresh line whatever a library left unterminated on stdout: the driver reads the LAST line)
+    sys.stdout.write("\n" + line + "\n")
+    sys.stdout.flush()
 
 
 def self_launch(n):

@@ -189,3 +189,35 @@ def resolve_face_ties(out, volume, source, target, img, spec, mask, tol, chunk=N
     worst = ((out - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
     assert worst <= tol, f"masked render under clip_to_volume: a ray matches none of the four face readings (rel {worst:.2e} > {tol:.1e})"
     return nudge, ref, {"first_out": int((pick0 < 0).sum()), "last_out": int((pick1 < 0).sum()), "rays": pick0.numel()}
+
+
+# ----------------------------------------------------------------------------------------------
+# non-exact Siddon index maps across implementations: moved segments, counted two-sidedly and checked to be neighbour swaps
+# (the allowances were floors and factors picked by the party being tested)
+# ----------------------------------------------------------------------------------------------
+def unpaired_moves(a, b, tol):
+    """Voxel gradients ``a``, ``b`` [D0, D1, D2] of two evaluations of a Siddon render under a non-exact index map.  Where two
+    float32 evaluations of rint(a x_mid + b) fall on different sides of a threshold, one segment's whole weight moves between two
+    NEIGHBOURING voxels: the difference field holds +c in one voxel and -c in a neighbour and the sum over any 3 x 3 x 3 box
+    around either is what it was.  -> (entries beyond ``tol`` of the largest |b|, how many of them are NOT explained that way:
+    |box sum| > 5 % of the entry itself).  A wrong weight, a dropped or a doubled segment does not cancel and is counted."""
+    import torch.nn.functional as F
+
+    d = (a.double() - b.double().to(a.device))
+    top = b.abs().max().item()
+    bad = d.abs() > tol * top
+    box = 27.0 * F.avg_pool3d(d[None, None], 3, stride=1, padding=1, count_include_pad=True)[0, 0]
+    unpaired = bad & (box.abs() > 0.05 * d.abs())
+    return int(bad.sum()), int(unpaired.sum())
+
+
+def tie_count_window(n_ref, ratio=1.5, per_move=2.0):
+    """[lo, hi] for the number of entries an implementation may miss the float64 oracle on, given that the float32 ORACLE misses
+    ``n_ref``.  A lookup rint(a x_mid + b) is missed when the evaluation's position error exceeds the lookup's distance from the
+    threshold, and near 0 those distances are uniformly distributed: the expected count is proportional to the mean position
+    error.  torch evaluates alpha = (plane - s) / d (two roundings), the HIP kernels (p + (plane0 - s)) * (1 / d) with an IEEE
+    reciprocal (three): errors within a factor 1.5 of each other either way.  A moved segment shows up in up to ``per_move``
+    entries (two voxels; the two jumps of a ray), so the variance of a count is at most per_move x its mean: 3 sigma on both sides.
+    Two-sided on purpose: far FEWER misses than the float32 oracle's would mean the comparison is not seeing the map at all."""
+    lo, hi = n_ref / ratio, n_ref * ratio
+    return lo - 3.0 * (per_move * max(lo, 1.0)) ** 0.5, hi + 3.0 * (per_move * max(hi, 1.0)) ** 0.5

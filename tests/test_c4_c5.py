@@ -208,11 +208,17 @@ def test_c5_full_size_masked_renders_under_the_per_ray_window():
         L = (target - source).norm(dim=-1).unsqueeze(1)
         s_vox, t_vox = drr.affine_inverse(source), drr.affine_inverse(target)
         chan = drr.reshape_transform(drr.renderer(tmp, s_vox, t_vox, L, mask=drr.mask), B)
+        plain_e = drr.reshape_transform(drr.renderer(tmp, s_vox, t_vox, L), B)
         lazy_img, lazy_mask, lazy_keep = render_samples(drr, transform_hu_to_density(hu, 4.2, lazy=True), drr.mask, drr.affine_inverse, pose)
     assert mask.shape == (B, 8, H, H) and chan.shape == (B, 8, H, H)
     _close(img, plain, 1e-5, "sum of 8 channels vs unmasked render under the window at B = 116")
-    air = plain[:, 0] == 0
-    assert air.any() and (chan.sum(1)[air] == 0).all() and (chan >= 0).all() and torch.equal(air, img[:, 0] == 0)
+    # air stays exactly 0 in every channel -- per ray set: `img` / `plain` come from the fused ray generation, `chan` / `plain_e` from
+    # the explicit detector -> affine sequence, whose rays differ by an ulp (under the window every one of a ray's 500 samples is
+    # inside the volume, so a ray grazing tissue with a 1e-7 weight in one set and none in the other does occur)
+    air, air_e = plain[:, 0] == 0, plain_e[:, 0] == 0
+    assert air.any() and torch.equal(air, img[:, 0] == 0)
+    assert air_e.any() and (chan.sum(1)[air_e] == 0).all() and (chan >= 0).all()
+    assert (air != air_e).float().mean().item() < 1e-4
     assert torch.equal(keep, plain_keep) and 0 < int(keep.sum()) <= B
     assert torch.equal(lazy_img, img) and torch.equal(lazy_mask, mask) and torch.equal(lazy_keep, keep)
     # the window integrates the same line as the whole-segment rule, with every sample inside the volume: the two images agree to

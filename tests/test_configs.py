@@ -257,12 +257,24 @@ def test_full_size_recalled_knob_sets_match_the_oracle(renderer, knobs, size):
             err = (a - b).abs() / b.abs().max()
             return int((err > tol).sum()), err.max().item()
 
-        floor = 8 + int(2.5e-3 * B * 256 * 256)
+        # Round 6: no floor, no factor 2 -- the count is held to a two-sided window around the float32 oracle's
+        # own (conftest.tie_count_window: error-ratio 1.5 from the roundings of the two alpha expressions, 3 sigma), and every
+        # voxel beyond the tolerance must BE what the argument claims: one segment's weight moved to a neighbour, the sum over the
+        # 3 x 3 x 3 box around it conserved (conftest.unpaired_moves).
+        from conftest import tie_count_window, unpaired_moves
         for what, hip, o32, o64, tol in (("forward", out, ref, ref64, 1e-3), ("d/d volume", density.grad, v.grad, v64.grad, GRAD_TOL)):
             (bad, worst), (bad32, _) = beyond(hip, o64, tol), beyond(o32, o64, tol)
-            print(f"dims + 1, 511^3, {what}: beyond {tol:.0e} of the float64 oracle: HIP {bad}, float32 oracle {bad32} (worst HIP entry {worst:.2e})")
-            assert bad <= max(floor, 2 * bad32), f"dims + 1, full-size {what}: {bad} entries beyond {tol:.0e} (float32 oracle: {bad32}; worst {worst:.2e})"
+            lo, hi = tie_count_window(bad32)
+            print(f"dims + 1, 511^3, {what}: beyond {tol:.0e} of the float64 oracle: HIP {bad}, float32 oracle {bad32} (window {lo:.0f}..{hi:.0f}; worst HIP entry {worst:.2e})")
+            assert lo <= bad <= hi, f"dims + 1, full-size {what}: {bad} entries beyond {tol:.0e}, float32 oracle {bad32}: outside {lo:.0f}..{hi:.0f} (worst {worst:.2e})"
             assert worst <= 2e-2 or what != "forward", (what, worst)
+        n_bad, n_unpaired = unpaired_moves(density.grad.detach(), v64.grad.cuda(), GRAD_TOL)
+        n_bad32, n_unpaired32 = unpaired_moves(v.grad.cuda(), v64.grad.cuda(), GRAD_TOL)
+        print(f"dims + 1, 511^3, d/d volume: of {n_bad} voxels beyond {GRAD_TOL:.0e}, {n_unpaired} are not a neighbour swap (float32 oracle: {n_unpaired32} of {n_bad32})")
+        # (two swaps whose boxes overlap leave a residue in each other's box: chance, at the density of the swaps -- the float32
+        #  oracle's own rate is the yardstick, within the same window)
+        assert n_unpaired <= tie_count_window(max(n_unpaired32, 1))[1], (n_unpaired, n_unpaired32, n_bad)
+        assert n_unpaired <= 0.02 * n_bad, (n_unpaired, n_bad)
         g, r = density.grad.double().cpu(), v64.grad
         assert abs(g.sum().item() - r.sum().item()) <= 1e-4 * r.abs().sum().item()
 
@@ -455,7 +467,9 @@ def test_benchmark_batch_under_the_recalled_siddon_map_against_the_oracle_fixtur
     err32 = (ref_px32 - ref_px).abs() / scale
     bad, bad32 = int((err > 1e-3).sum()), int((err32 > 1e-3).sum())
     print(f"dims + 1, 116 poses: sampled pixels beyond 1e-3 of the float64 oracle: HIP {bad}, float32 oracle {bad32} of {err.numel()}; worst {err.max().item():.2e}")
-    assert bad <= max(8 + int(2.5e-3 * err.numel()), 2 * bad32) and err.max().item() <= 2e-2, (bad, bad32, err.max().item())
+    from conftest import tie_count_window
+    lo, hi = tie_count_window(bad32)       # (two-sided, no floor: conftest.tie_count_window)
+    assert lo <= bad <= hi and err.max().item() <= 2e-2, (bad, bad32, (lo, hi), err.max().item())
     tiles = im.double().reshape(B, 16, 16, 16, 16).sum(dim=(2, 4))
     ref_t = torch.from_numpy(gold["siddon_nx_tiles"])
     terr = (tiles - ref_t).abs() / ref_t.abs().max()
@@ -474,6 +488,8 @@ def test_benchmark_batch_under_the_recalled_siddon_map_against_the_oracle_fixtur
         g32 = ((ref32[:, sl] - ref_g[:, sl]).abs() / scale).amax(dim=1)
         print(f"{name}: beyond 5e-3 of the float64 oracle: HIP {int((gerr > 5e-3).sum())} poses (worst {gerr.max().item():.2e}, median {gerr.median().item():.2e}); "
               f"float32 oracle {int((g32 > 5e-3).sum())} (worst {g32.max().item():.2e}, median {g32.median().item():.2e})")
-        assert int((gerr > 5e-3).sum()) <= max(4, 2 * int((g32 > 5e-3).sum())), name
-        assert gerr.max().item() <= max(5e-3, 2.0 * g32.max().item()), name
-        assert gerr.median().item() <= max(1e-3, 2.0 * g32.median().item()), name
+        lo, hi = tie_count_window(int((g32 > 5e-3).sum()))
+        assert lo <= int((gerr > 5e-3).sum()) <= hi, (name, int((gerr > 5e-3).sum()), (lo, hi))
+        # (a pose's error is the sum of its moved segments' jumps: the same factor 1.5 between the two evaluations' error sizes)
+        assert gerr.max().item() <= max(5e-3, 1.5 * g32.max().item()), name
+        assert g32.median().item() / 1.5 <= gerr.median().item() <= max(1e-3, 1.5 * g32.median().item()), name
