@@ -288,6 +288,8 @@ def main():
         return self_launch(args.gpus)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node and --gpus disagree")
+    if rank != 0:   # only rank 0 owns stdout (the launcher merges the ranks' streams): whatever a library prints elsewhere goes to stderr
+        os.dup2(2, 1)
     if args.single_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -597,9 +599,21 @@ def emit(full, full_json):
     if len(line) >= 8192:
         raise SystemExit(f"bench.py: the JSON line is {len(line)} bytes; the driver needs it below 8 KB")
     sys.stderr.flush()
+    flush_c_stdio()
     # (a fresh line whatever a library left unterminated on stdout: the driver reads the LAST line)
     sys.stdout.write("\n" + line + "\n")
     sys.stdout.flush()
+
+
+def flush_c_stdio():
+    """RCCL writes its version banner through C stdio, which is fully buffered when stdout is a pipe and comes out when the PROCESS
+    exits -- behind the JSON line Python flushed long before (seen in round 6: `Librccl path : ...` was the last stdout line of the
+    one-rank RCCL run).  Every rank empties the C buffers right after the group's first collective, and rank 0 again before the line."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
 
 
 def self_launch(n):
@@ -630,6 +644,11 @@ def init_group(backend, dev, world):
         dist.init_process_group("nccl", device_id=dev, **kw_pg)
     else:
         dist.init_process_group(backend, **kw_pg)
+    # the first collective creates the communicator (and makes RCCL say what it has to say): out with it now, on every rank
+    t = torch.zeros(1, device=dev)
+    dist.all_reduce(t)
+    torch.cuda.synchronize()
+    flush_c_stdio()
 
 
 def dry_run_collectives(args):

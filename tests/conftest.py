@@ -198,16 +198,20 @@ def resolve_face_ties(out, volume, source, target, img, spec, mask, tol, chunk=N
 def unpaired_moves(a, b, tol):
     """Voxel gradients ``a``, ``b`` [D0, D1, D2] of two evaluations of a Siddon render under a non-exact index map.  Where two
     float32 evaluations of rint(a x_mid + b) fall on different sides of a threshold, one segment's whole weight moves between two
-    NEIGHBOURING voxels: the difference field holds +c in one voxel and -c in a neighbour and the sum over any 3 x 3 x 3 box
-    around either is what it was.  -> (entries beyond ``tol`` of the largest |b|, how many of them are NOT explained that way:
-    |box sum| > 5 % of the entry itself).  A wrong weight, a dropped or a doubled segment does not cancel and is counted."""
+    NEIGHBOURING voxels: the difference field holds +c in one voxel and -c in a neighbour, and the sum over a box around either is
+    what it was.  -> (entries beyond ``tol`` of the largest |b|, how many of them are NOT explained that way: the box sums of
+    3^3, 5^3 AND 7^3 voxels around the entry all exceed 5 % of the entry itself -- the larger boxes are for chains, u -> v and
+    v -> w next to each other where many rays cross a voxel).  A wrong weight, a dropped or a doubled segment cancels in no box and
+    is counted."""
     import torch.nn.functional as F
 
     d = (a.double() - b.double().to(a.device))
     top = b.abs().max().item()
     bad = d.abs() > tol * top
-    box = 27.0 * F.avg_pool3d(d[None, None], 3, stride=1, padding=1, count_include_pad=True)[0, 0]
-    unpaired = bad & (box.abs() > 0.05 * d.abs())
+    unpaired = bad.clone()
+    for k in (3, 5, 7):
+        box = float(k ** 3) * F.avg_pool3d(d[None, None], k, stride=1, padding=k // 2, count_include_pad=True)[0, 0]
+        unpaired &= box.abs() > 0.05 * d.abs()
     return int(bad.sum()), int(unpaired.sum())
 
 

@@ -1442,6 +1442,7 @@ int xvr_detail::launch_gather(bool siddon, const float* source, const float* tar
         e = hipMemsetAsync(G.flag, 0, 16, (hipStream_t)stream);
         if (e == hipSuccess && G.cmax) e = hipMemsetAsync(G.cmax, 0, (size_t)B * G.cmax_stride * sizeof(unsigned), (hipStream_t)stream);
     }
+    if (e == hipSuccess && sid_splat) e = hipMemsetAsync(G.flag + 16, 0, 8 * sizeof(unsigned), (hipStream_t)stream);   // (k_siddon_splat's per-XCD brick queues)
     if (e != hipSuccess) return fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
     if (!later_slab) {
         hipLaunchKernelGGL(k_gather_prep, dim3((unsigned)((n + WG - 1) / WG), (unsigned)B), dim3(WG), 0,
