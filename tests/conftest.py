@@ -202,13 +202,18 @@ def unpaired_moves(a, b, tol):
     what it was.  -> (entries beyond ``tol`` of the largest |b|, how many of them are NOT explained that way: the box sums of
     3^3, 5^3 AND 7^3 voxels around the entry all exceed 5 % of the entry itself -- the larger boxes are for chains, u -> v and
     v -> w next to each other where many rays cross a voxel).  A wrong weight, a dropped or a doubled segment cancels in no box and
-    is counted."""
+    is counted.  Voxels of the volume's outermost layer are exempt: there the neighbour a segment moves to can be the zero padding
+    outside (the lookup's index -1 or D), and the segment is then dropped by one evaluation only -- the same tie, its partner
+    invisible (seen under align_corners + dims = shape + 1, where the map reaches past the faces)."""
     import torch.nn.functional as F
 
     d = (a.double() - b.double().to(a.device))
     top = b.abs().max().item()
     bad = d.abs() > tol * top
     unpaired = bad.clone()
+    for ax in range(3):
+        unpaired.select(ax, 0).fill_(False)
+        unpaired.select(ax, d.shape[ax] - 1).fill_(False)
     for k in (3, 5, 7):
         box = float(k ** 3) * F.avg_pool3d(d[None, None], k, stride=1, padding=k // 2, count_include_pad=True)[0, 0]
         unpaired &= box.abs() > 0.05 * d.abs()
