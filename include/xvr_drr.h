@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define XVR_DRR_ABI_VERSION 9   /* 9: xvr_drr_pack_hu_labels_ytiles, options siddon_splat / gather_splat = 3 / siddon_slab = 2, pose kind 6 (rotation_10d), non-exact Siddon index maps on the slab march and the brick splat, guard-banded fixed point; 8: volume_layout 3 + xvr_drr_pack_ytiles / _labels_ytiles (tiled y-pair copy), xvr_pose_camera_forward_param / xvr_pose_opt_step_param (device-resident registration for every parameterisation; xvr_pose_opt_state holds 13 parameters), xvr_sim_equalize_* write / take the normalised output, options tile_geom, siddon_slab, siddon_gather_fast; 7: xvr_drr_foreground, xvr_drr_pack_labels_ypairs, xvr_sim_dice_bool, xvr_sim_transform_* (xvr_sim.h), xvr_pose_convert_* (xvr_pose.h); 6: xvr_drr_spec.alpha_window + xvr_drr_alpha_window (clip_to_volume = 2); 5: xvr_drr_set_option / xvr_drr_get_option (the A/B switches are no longer getenv calls per launch); 4: volume_layout 2 + xvr_drr_pack_bricks (siddon forward); 3: xvr_drr_spec.volume_layout + xvr_drr_pack_ypairs; 2: xvr_sim_spec grew, camera-driven forwards, packed labels, xvr_pose.h */
+#define XVR_DRR_ABI_VERSION 10   /* 10: xvr_sim_ncc_registration_step (the tail of a registration iteration in the similarity's launches); 9: xvr_drr_pack_hu_labels_ytiles, options siddon_splat / gather_splat = 3 / siddon_slab = 2, pose kind 6 (rotation_10d), non-exact Siddon index maps on the slab march and the brick splat, guard-banded fixed point; 8: volume_layout 3 + xvr_drr_pack_ytiles / _labels_ytiles (tiled y-pair copy), xvr_pose_camera_forward_param / xvr_pose_opt_step_param (device-resident registration for every parameterisation; xvr_pose_opt_state holds 13 parameters), xvr_sim_equalize_* write / take the normalised output, options tile_geom, siddon_slab, siddon_gather_fast; 7: xvr_drr_foreground, xvr_drr_pack_labels_ypairs, xvr_sim_dice_bool, xvr_sim_transform_* (xvr_sim.h), xvr_pose_convert_* (xvr_pose.h); 6: xvr_drr_spec.alpha_window + xvr_drr_alpha_window (clip_to_volume = 2); 5: xvr_drr_set_option / xvr_drr_get_option (the A/B switches are no longer getenv calls per launch); 4: volume_layout 2 + xvr_drr_pack_bricks (siddon forward); 3: xvr_drr_spec.volume_layout + xvr_drr_pack_ypairs; 2: xvr_sim_spec grew, camera-driven forwards, packed labels, xvr_pose.h */
 
 #define XVR_DRR_OK 0
 #define XVR_DRR_E_ARG (-1)     /* bad argument (null pointer, non-positive size, unsupported combo) */

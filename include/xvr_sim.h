@@ -58,6 +58,33 @@ int xvr_sim_ncc_forward_backward(const float* fixed, const float* fixed_sobel, c
                                  void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * One registration iteration's tail behind the render, in the similarity's own launches (ABI 10; replaces, for Euler angles,
+ * the sequence of /root/reference/src/xvr/registrar/base.py:250-262 -- transform, imagesim, loss.backward(), optimizer.step(),
+ * scheduler.step(loss), the stopping rule -- and the first line of the NEXT iteration, reg() -> camera, base.py:249):
+ *
+ *     xvr_sim_ncc_forward_backward  +  xvr_drr_jac_to_camera_backward  +  xvr_pose_opt_step  +  xvr_pose_camera_forward
+ *
+ * The similarity's last kernel also contracts the image gradient with the render's per-ray jacobian, and the block that
+ * finishes last for a pose takes that pose's optimiser step and writes the camera vector of the updated pose.  Same
+ * expressions, same reduction order: rot, xyz, state, history and cam are bit for bit those of the four separate calls
+ * (tests/test_pose_opt.py).  Three launches fewer per iteration; the image gradient is not stored.
+ *
+ *   fixed, fixed_sobel, moving, spec (pre_transformed = 0), loss, workspace   as xvr_sim_ncc_forward_backward
+ *   grad_scratch [B][H][W]   scratch for the image gradient before its min / max terms (contents undefined afterwards)
+ *   jac  [B][H W][XVR_DRR_JAC_STRIDE]   the forward's per-ray jacobian (xvr_drr_*_forward_camera)
+ *   cam  [B][24]   IN: the camera vector the render used;  OUT: that of the updated pose (unchanged for a pose that is done)
+ *   j2c_workspace   xvr_drr_jac_to_camera_workspace_bytes(B, H, W) bytes, zero-filled once (xvr_drr_jac_to_camera_backward's)
+ *   rot, xyz [B][3], opt_spec, G [24][12], c [24], state [B], history   as xvr_pose_opt_step / xvr_pose_camera_forward
+ */
+struct xvr_pose_opt_spec;
+struct xvr_pose_opt_state;
+int xvr_sim_ncc_registration_step(const float* fixed, const float* fixed_sobel, const float* moving, int B, int H, int W,
+                                  const xvr_sim_spec* spec, float* loss, float* grad_scratch, void* workspace, size_t workspace_bytes,
+                                  const float* jac, float* cam, void* j2c_workspace, size_t j2c_workspace_bytes,
+                                  float* rot, float* xyz, const struct xvr_pose_opt_spec* opt_spec, const float* G, const float* c,
+                                  struct xvr_pose_opt_state* state, float* history, void* stream);
+
+/*
  * The Gaussian pre-blur of GradientNormalizedCrossCorrelation2d(patch, sigma > 0)
  * (/root/reference/src/xvr/registrar/base.py:122): 5 taps exp(-x^2 / (2 sigma^2)), x = -2..2, normalised, separable,
  * reflect padding by 2 -- and its exact transpose (adjoint = 1), which is the blur's backward.  The similarity of a

@@ -219,6 +219,49 @@ def test_device_registration_is_bitwise_reproducible():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("starts", [1, 3], ids=["one start", "three starts as a batch"])
+def test_fused_iteration_tail_is_the_five_call_iteration_bit_for_bit(starts, monkeypatch):
+    """Round 6: for Euler angles + the fused similarity an iteration is render -> ONE call,
+    xvr_sim_ncc_registration_step, whose last kernel also contracts the image gradient with the render's jacobian, takes the
+    optimiser step and writes the next camera vector (include/xvr_sim.h).  It shares every expression and every reduction order with
+    the calls it replaces (csrc/j2c_device.hiph, pose_device.hiph): the trajectories -- poses, similarities, learning rates, every
+    iteration of both pyramid stages, eager and graph-replayed -- are IDENTICAL, not close."""
+    from xvr_amd import pose_opt
+    from xvr_amd.registrar import Registrar
+    vol, _ = make_phantom(64, n_ellipsoids=8, seed=8, device="cuda")
+    drr = DRR(read(vol, spacing=(2.0,) * 3, orientation="AP"), 1020.0, 128, 1.4, renderer="trilinear", reverse_x_axis=False,
+              voxel_shift=0.0).cuda()
+    rot0, xyz0 = torch.tensor([[3.10, 0.05, -0.03]]), torch.tensor([[4.0, 700.0, -6.0]])
+    with torch.no_grad():
+        gt = drr(convert(rot0.cuda(), xyz0.cuda(), parameterization="euler_angles", convention="ZXY"))
+    g = torch.Generator().manual_seed(2)
+    inits = convert(rot0 + (torch.rand(starts, 3, generator=g) - 0.5) * 0.2, xyz0 + (torch.rand(starts, 3, generator=g) - 0.5) * 30.0,
+                    parameterization="euler_angles", convention="ZXY")
+    out = {}
+    for fused in (True, False):
+        monkeypatch.setattr(pose_opt, "FUSED_TAIL", fused)
+        reg = Registrar(drr, scales="2,1", n_itrs="30,20", patience=4, max_n_plateaus=2, device_loop=True)
+        out[fused] = reg.run_batch(gt, inits) if starts > 1 else [reg.run(gt, inits)]
+    for a, b in zip(out[True], out[False]):
+        assert len(a["trajectory"]) > 10
+        assert a["trajectory"] == b["trajectory"] and a["nccs"] == b["nccs"] and a["lrs"] == b["lrs"]
+        assert torch.equal(a["final_pose"].matrix, b["final_pose"].matrix)
+    # the tail really ran (and only where it applies): one timed call instead of four
+    from xvr_amd import renderers
+    monkeypatch.setattr(pose_opt, "FUSED_TAIL", True)
+    renderers.PROFILER = []
+    Registrar(drr, scales="1", n_itrs="6", max_n_plateaus=100, device_loop=True, use_graph=False).run(gt, inits[0])
+    names = {e[0] for e in renderers.PROFILER}
+    renderers.PROFILER = None
+    assert "ncc_registration_step" in names and not names & {"ncc_forward_backward", "jac_to_camera_backward", "pose_opt_step"}, names
+    renderers.PROFILER = []
+    Registrar(drr, scales="1", n_itrs="6", max_n_plateaus=100, device_loop=True, use_graph=False, parameterization="axis_angle").run(gt, inits[0])
+    names = {e[0] for e in renderers.PROFILER}
+    renderers.PROFILER = None
+    assert "ncc_registration_step" not in names and {"ncc_forward_backward", "jac_to_camera_backward", "pose_opt_step"} <= names, names
+
+
+@pytest.mark.gpu
 def test_batched_multistart_matches_one_by_one():
     """Registrar.run_batch: B starts as independent problems in one batch (own optimiser state, own
     standardisation) follow the same trajectories as B separate runs."""

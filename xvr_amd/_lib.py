@@ -11,7 +11,7 @@ import warnings
 
 from .build import LIB, HipccMissing, build_library, is_stale
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 JAC_STRIDE = 8
 ALPHA_WINDOW_FLOATS = 16   # XVR_DRR_ALPHA_WINDOW_FLOATS
 
@@ -105,6 +105,8 @@ EXPORTS = {
     "xvr_drr_alpha_window_backward": ([_P, _P, _P, _P, _P, _I, _I, ctypes.POINTER(CSpec), _P, _P, _P, _P], ctypes.c_int),
     "xvr_sim_workspace_bytes": ([_I, _I, _I], ctypes.c_size_t),
     "xvr_sim_ncc_forward_backward": ([_P, _P, _P, _I, _I, _I, ctypes.POINTER(CSimSpec), _P, _P, _P, ctypes.c_size_t, _P], ctypes.c_int),
+    "xvr_sim_ncc_registration_step": ([_P, _P, _P, _I, _I, _I, ctypes.POINTER(CSimSpec), _P, _P, _P, ctypes.c_size_t,
+                                       _P, _P, _P, ctypes.c_size_t, _P, _P, ctypes.POINTER(CPoseOptSpec), _P, _P, _P, _P, _P], ctypes.c_int),
     "xvr_sim_equalize_workspace_bytes": ([_I, _I], ctypes.c_size_t),
     "xvr_sim_equalize_forward": ([_P, _I, _I, _I, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _P, _P, _P, _P, ctypes.c_size_t, _P],
                                  ctypes.c_int),

@@ -17,6 +17,7 @@ SRC = [PKG / "csrc" / f for f in ("drr_trilinear.hip", "drr_siddon.hip", "drr_ga
                                   "sim_kernels.hip", "volume_kernels.hip", "pose_kernels.hip")]
 HDR = [ROOT / "include" / "xvr_drr.h", ROOT / "include" / "xvr_sim.h", ROOT / "include" / "xvr_pose.h",
        PKG / "csrc" / "drr_common.hiph", PKG / "csrc" / "drr_splat.hiph", PKG / "csrc" / "drr_siddon_splat.hiph",
+       PKG / "csrc" / "j2c_device.hiph", PKG / "csrc" / "pose_device.hiph",
        Path(__file__).resolve()]   # (this file holds the compiler flags: a change of flags makes the library stale too)
 OBJ = PKG / "lib" / "obj"
 LIB = PKG / "lib" / "libxvr_drr.so"

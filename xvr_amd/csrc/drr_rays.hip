@@ -1,6 +1,7 @@
 // MI355X (gfx950) differentiable-DRR kernels: the per-ray side -- pose gradient from the saved jacobian, ray generation
 // from the camera vector and its adjoint, jacobian -> camera in one fixed-order pass.
 #include "drr_common.hiph"
+#include "j2c_device.hiph"
 
 namespace {
 
@@ -159,9 +160,6 @@ template <int RPT>
 __global__ __launch_bounds__(WG) void k_jac_to_cam(const float* __restrict__ jac, const float* __restrict__ gout,
                                                    const float* __restrict__ cam, int H, int W, float* partial,
                                                    unsigned* counter, float* __restrict__ g_cam) {
-    __shared__ float part[24][WG / 64];
-    __shared__ float fin[24][WG + 1];
-    __shared__ bool last;
     const int b = blockIdx.y, n = H * W, nblk = gridDim.x;
     const float* c = cam + 24 * b;
     float acc[24];
@@ -185,72 +183,9 @@ __global__ __launch_bounds__(WG) void k_jac_to_cam(const float* __restrict__ jac
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const int r = (blockIdx.x * RPT + k) * WG + threadIdx.x;
-        if (r < n) {
-            const float g = g_[k];
-            const float4 j0 = j0_[k], j1 = j1_[k];
-            const int i = r / W, j = r - i * W;
-            const float pix[3] = {(float)i, (float)j, 1.f};
-            const float gt[3] = {g * j1.x, g * j1.y, g * j1.z};
-            float w[3], l2 = 0.f;
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                w[a] = fmaf(c[12 + 3 * a], pix[0], fmaf(c[12 + 3 * a + 1], pix[1], c[12 + 3 * a + 2])) - c[21 + a];
-                l2 = fmaf(w[a], w[a], l2);
-            }
-            const float gl = g * j0.x;
-            const float sc = l2 > 0.f ? gl / sqrtf(l2) : 0.f;  // g_L * (unit direction) = sc * w
-            acc[9] += g * j0.y; acc[10] += g * j0.z; acc[11] += g * j0.w;   // d/d s_v = grad_source
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-#pragma unroll
-                for (int m = 0; m < 3; ++m) {
-                    acc[3 * a + m] += gt[a] * pix[m];             // d/d Mv[a][m]
-                    acc[12 + 3 * a + m] += sc * w[a] * pix[m];    // d/d Mw[a][m]
-                }
-                acc[21 + a] += -sc * w[a];                         // d/d s_w[a]
-            }
-        }
+        if (r < n) j2c_accumulate(g_[k], j0_[k], j1_[k], c, r, W, acc);
     }
-#pragma unroll
-    for (int q = 0; q < 24; ++q) {
-        const float tot = wave_sum_f(acc[q]);
-        if ((threadIdx.x & 63) == 0) part[q][threadIdx.x >> 6] = tot;
-    }
-    __syncthreads();
-    // Publishing without a device-wide fence (a release fence writes the XCD's whole L2 back: ~70 ns per
-    // block, serialised -- measured 4x slower than the kernel itself): the partials are stored and
-    // loaded with agent-scope atomics, which go to the level where the 8 XCDs are coherent; the
-    // barrier's wait for outstanding stores orders them before this block's ticket, and the block that
-    // draws the last ticket therefore reads everybody's partials.
-    float* mine = partial + ((size_t)b * nblk + blockIdx.x) * 24;
-    if (threadIdx.x < 24)
-        __hip_atomic_store(mine + threadIdx.x, (part[threadIdx.x][0] + part[threadIdx.x][1]) + (part[threadIdx.x][2] + part[threadIdx.x][3]),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();   // includes s_waitcnt vmcnt(0): the stores above have completed
-    if (threadIdx.x == 0)
-        last = __hip_atomic_fetch_add(counter + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nblk - 1);
-    __syncthreads();
-    if (!last) return;
-    // thread t adds rows t, t + 256, ... (all 24 columns, independent loads), then the 256 per-thread sums
-    // are added column by column in thread order
-    float t24[24];
-#pragma unroll
-    for (int q = 0; q < 24; ++q) t24[q] = 0.f;
-    const float* P = partial + (size_t)b * nblk * 24;
-    for (int k = threadIdx.x; k < nblk; k += WG) {
-#pragma unroll
-        for (int q = 0; q < 24; ++q)
-            t24[q] += __hip_atomic_load(P + (size_t)k * 24 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-#pragma unroll
-    for (int q = 0; q < 24; ++q) fin[q][threadIdx.x] = t24[q];
-    __syncthreads();
-    if (threadIdx.x < 24) {
-        float t = 0.f;
-        for (int k = 0; k < WG; ++k) t += fin[threadIdx.x][k];
-        g_cam[24 * b + threadIdx.x] = t;
-    }
-    if (threadIdx.x == 0) counter[b] = 0;   // ready for the next call
+    j2c_reduce(acc, partial, counter, b, nblk, g_cam + 24 * b);
 }
 
 // =============================================================================================

@@ -18,7 +18,10 @@
 #include <stdio.h>
 
 #include "xvr_drr.h"
+#include "xvr_pose.h"
 #include "xvr_sim.h"
+#include "j2c_device.hiph"
+#include "pose_device.hiph"
 
 extern "C" void xvr_drr_set_last_error(const char* msg);  // drr_api.hip
 
@@ -420,6 +423,89 @@ __global__ __launch_bounds__(TB) void k_sim_minmax_grad(const float* __restrict_
         if (v == mn) add += gmin;
         if (v == mx) add += gmax;
         if (add != 0.f) grad[i] += add;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Round 6: the tail of a registration iteration in ONE launch (xvr_sim_ncc_registration_step).  What four launches did --
+//   k_sim_minmax_grad   the gradient's terms through Standardize's global min / max, and the similarity values
+//   k_jac_to_cam        its contraction with the render's per-ray jacobian, 24 sums per pose in a fixed order (drr_rays.hip)
+//   k_pose_opt_step     chain rule to (rot, xyz), Adam, ReduceLROnPlateau, stopping rule, history row (pose_kernels.hip)
+//   k_pose_camera_fwd   the NEXT iteration's camera vector
+// -- with the same expressions in the same order (j2c_device.hiph, pose_device.hiph): a block takes k_jac_to_cam's rays, adds the
+// min / max terms to the image gradient in passing (never stored: nobody else reads it in the loop), and the block that draws a
+// pose's last ticket finishes that pose.  At 256^2 an iteration is launch- and latency-bound (twelve dependent launches of a few
+// microseconds each): three launches fewer and 0.5 MB less traffic.  Euler angles (kind 0) only.
+// ---------------------------------------------------------------------------------------------
+struct RegTail {
+    const float* jac; float* cam; float* partial; unsigned* counter;                       // jacobian -> camera
+    float* rot; float* xyz; const float* G; const float* c; xvr_pose_opt_state* state; float* history;   // optimiser step, next camera
+    xvr_pose_opt_spec osp;
+};
+
+template <int RPT>
+__global__ __launch_bounds__(TB) void k_sim_reg_tail(const float* __restrict__ m, const SimHeader* hd, xvr_sim_spec sp,
+                                                     const float* __restrict__ grad, const double* __restrict__ acc, int B, int H, int W,
+                                                     float* __restrict__ loss, RegTail T) {
+    static_assert(TB == J2C_WG, "the tail takes k_jac_to_cam's blocks");
+    __shared__ float s_g[24];
+    const int b = blockIdx.y, n = H * W, nblk = gridDim.x;
+    hd += sp.per_image ? b : 0;
+    const float mn = dec(hd->enc_min), mx = dec(hd->enc_max);
+    const float r_ = (mx - mn) + sp.std_eps;
+    const double a = 1.0 / ((double)r_ * sp.std);
+    const float gmin = (float)(-a * hd->smin / (double)max(hd->cnt_min, 1));
+    const float gmax = (float)(-a * hd->smax / (double)max(hd->cnt_max, 1));
+    const float* c = T.cam + 24 * b;
+    float a24[24];
+#pragma unroll
+    for (int q = 0; q < 24; ++q) a24[q] = 0.f;
+    float g_[RPT];
+    float4 j0_[RPT], j1_[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {   // every load of the thread first
+        const int r = (blockIdx.x * RPT + k) * TB + threadIdx.x;
+        g_[k] = 0.f;
+        j0_[k] = j1_[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < n) {
+            const size_t ray = (size_t)b * n + r;
+            const float v = m[ray];
+            float g = grad[ray], add = 0.f;
+            if (v == mn) add += gmin;      // (k_sim_minmax_grad's `grad[i] += add`, where add != 0)
+            if (v == mx) add += gmax;
+            if (add != 0.f) g += add;
+            g_[k] = g;
+            const float4* jp = reinterpret_cast<const float4*>(T.jac + ray * XVR_DRR_JAC_STRIDE);
+            j0_[k] = jp[0];
+            j1_[k] = jp[1];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int r = (blockIdx.x * RPT + k) * TB + threadIdx.x;
+        if (r < n) j2c_accumulate(g_[k], j0_[k], j1_[k], c, r, W, a24);
+    }
+    if (!j2c_reduce(a24, T.partial, T.counter, b, nblk, s_g)) return;
+    // ---- the pose's last block: every ray of pose b is in s_g.  One wavefront finishes the iteration (k_pose_opt_step's body).
+    if (threadIdx.x >= 64) return;
+    const float cur = sim_loss_of(acc + (size_t)b * N_ACC, H, W, sp);
+    float gm[12];
+    wave_gt_g(T.G, s_g, false, gm);
+    xvr_pose_opt_state s = T.state[b];
+    if (threadIdx.x == 0) loss[b] = cur;
+    if (s.done) return;      // (rot / xyz untouched: the camera vector in place is still theirs)
+    float p[6], g[6];
+    for (int i = 0; i < 3; ++i) { p[i] = T.rot[(size_t)b * 3 + i]; p[3 + i] = T.xyz[b * 3 + i]; }
+    Axes ax = {{T.osp.axes[0], T.osp.axes[1], T.osp.axes[2]}};
+    pose_chain(ax, p, p + 3, gm, g, g + 3);
+    // (every lane carries the scalars and takes the same step on its own copy; lane 0 writes the state, lane r < 24 row r of the camera)
+    pose_opt_update(T.osp, 3, p, g, cur, s, threadIdx.x == 0 ? T.history : nullptr, b);
+    float R[9], m12[12];
+    pose_matrix(ax, p, p + 3, R, m12);
+    if (threadIdx.x < 24) T.cam[b * 24 + threadIdx.x] = camera_row(T.G, T.c, m12, threadIdx.x);
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < 3; ++i) { T.rot[(size_t)b * 3 + i] = p[i]; T.xyz[b * 3 + i] = p[3 + i]; }
+        T.state[b] = s;
     }
 }
 
@@ -942,9 +1028,9 @@ size_t xvr_sim_workspace_bytes(int B, int H, int W) {
     return layout(B, H, W, 1, 1).total;
 }
 
-int xvr_sim_ncc_forward_backward(const float* fixed, const float* fixed_sobel, const float* moving, int B, int H, int W,
-                                 const xvr_sim_spec* sp, float* loss, float* grad_moving, void* workspace,
-                                 size_t workspace_bytes, void* stream_) {
+static int ncc_launch(const float* fixed, const float* fixed_sobel, const float* moving, int B, int H, int W,
+                      const xvr_sim_spec* sp, float* loss, float* grad_moving, void* workspace,
+                      size_t workspace_bytes, void* stream_, const RegTail* tail) {
     if (!fixed || !fixed_sobel || !moving || !sp || !loss || !workspace) return sim_fail(XVR_DRR_E_ARG, "null pointer argument");
     if (B <= 0 || H <= 0 || W <= 0) return sim_fail(XVR_DRR_E_ARG, "B, H, W must be positive");
     const int p1 = sp->mncc_patch, p2 = sp->gncc_patch;
@@ -1006,11 +1092,48 @@ int xvr_sim_ncc_forward_backward(const float* fixed, const float* fixed_sobel, c
                        *sp, grad_moving, reinterpret_cast<double*>(ws + L.part_final), tickets + 4 * B);
     const long long want2 = (n_mm + (long long)TB * 4 - 1) / ((long long)TB * 4);
     const unsigned gb = (unsigned)(want2 < 1 ? 1 : (want2 > 1024 ? 1024 : want2));
-    if (grad_moving && !pre) hipLaunchKernelGGL(k_sim_minmax_grad, dim3(gb, groups), dim3(TB), 0, stream, moving, n_mm, hd, *sp, grad_moving, acc, B, H, W, loss);
+    if (tail) {   // the registration step: the min / max terms, jacobian -> camera, the optimiser step and the next camera in one launch
+        const bool batch = (size_t)B * H * W >= ((size_t)1 << 20);   // (k_jac_to_cam's block geometry: the same partial sums)
+        const unsigned per_block = batch ? 4 * TB : TB;
+        const unsigned nblk = (unsigned)(((size_t)hw + per_block - 1) / per_block);
+        if (batch) hipLaunchKernelGGL(k_sim_reg_tail<4>, dim3(nblk, (unsigned)B), dim3(TB), 0, stream, moving, (const SimHeader*)hd, *sp,
+                                      (const float*)grad_moving, (const double*)acc, B, H, W, loss, *tail);
+        else hipLaunchKernelGGL(k_sim_reg_tail<1>, dim3(nblk, (unsigned)B), dim3(TB), 0, stream, moving, (const SimHeader*)hd, *sp,
+                                (const float*)grad_moving, (const double*)acc, B, H, W, loss, *tail);
+    }
+    else if (grad_moving && !pre) hipLaunchKernelGGL(k_sim_minmax_grad, dim3(gb, groups), dim3(TB), 0, stream, moving, n_mm, hd, *sp, grad_moving, acc, B, H, W, loss);
     else hipLaunchKernelGGL(k_sim_loss, dim3((B + 63) / 64), dim3(64), 0, stream, acc, B, H, W, *sp, loss);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return sim_fail(XVR_DRR_E_LAUNCH, hipGetErrorString(e));
     return XVR_DRR_OK;
+}
+
+int xvr_sim_ncc_forward_backward(const float* fixed, const float* fixed_sobel, const float* moving, int B, int H, int W,
+                                 const xvr_sim_spec* sp, float* loss, float* grad_moving, void* workspace,
+                                 size_t workspace_bytes, void* stream_) {
+    return ncc_launch(fixed, fixed_sobel, moving, B, H, W, sp, loss, grad_moving, workspace, workspace_bytes, stream_, nullptr);
+}
+
+int xvr_sim_ncc_registration_step(const float* fixed, const float* fixed_sobel, const float* moving, int B, int H, int W,
+                                  const xvr_sim_spec* sp, float* loss, float* grad_scratch, void* workspace, size_t workspace_bytes,
+                                  const float* jac, float* cam, void* j2c_workspace, size_t j2c_workspace_bytes,
+                                  float* rot, float* xyz, const xvr_pose_opt_spec* ospec, const float* G, const float* c,
+                                  xvr_pose_opt_state* state, float* history, void* stream_) {
+    if (!grad_scratch || !jac || !cam || !j2c_workspace || !rot || !xyz || !ospec || !G || !c || !state)
+        return sim_fail(XVR_DRR_E_ARG, "null pointer argument");
+    if (sp && sp->pre_transformed) return sim_fail(XVR_DRR_E_UNSUPPORTED, "registration step: the similarity of raw renders (pre_transformed = 0)");
+    if (B <= 0 || H <= 0 || W <= 0) return sim_fail(XVR_DRR_E_ARG, "B, H, W must be positive");
+    if (j2c_workspace_bytes < xvr_drr_jac_to_camera_workspace_bytes(B, H, W)) return sim_fail(XVR_DRR_E_ARG, "jacobian -> camera workspace too small");
+    if (reinterpret_cast<uintptr_t>(jac) & 15u) return sim_fail(XVR_DRR_E_ARG, "jac must be 16-byte aligned");
+    for (int i = 0; i < 3; ++i)
+        if (ospec->axes[i] < 0 || ospec->axes[i] > 2) return sim_fail(XVR_DRR_E_ARG, "axes must be 0, 1 or 2");
+    char* jw = static_cast<char*>(j2c_workspace);
+    RegTail T;
+    T.jac = jac; T.cam = cam;
+    T.counter = reinterpret_cast<unsigned*>(jw);
+    T.partial = reinterpret_cast<float*>(jw + al((size_t)B * sizeof(unsigned)));   // (xvr_drr_jac_to_camera_backward's own layout)
+    T.rot = rot; T.xyz = xyz; T.G = G; T.c = c; T.state = state; T.history = history; T.osp = *ospec;
+    return ncc_launch(fixed, fixed_sobel, moving, B, H, W, sp, loss, grad_scratch, workspace, workspace_bytes, stream_, &T);
 }
 
 int xvr_sim_dice_bool(const unsigned char* pred, const unsigned char* truth, int B, int C, int n, float* dice, void* stream_) {

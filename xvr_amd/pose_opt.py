@@ -31,6 +31,7 @@ from .renderers import _ptr, _stream, _timed, make_cspec
 __all__ = ["PoseCamera", "pose_camera", "RegistrationStage", "axes_of"]
 
 MAX_PARAMS = 13   # XVR_POSE_MAX_PARAMS
+FUSED_TAIL = True  # Euler + fused similarity: render -> xvr_sim_ncc_registration_step (False: the five-call iteration, A/B)
 STATE_DTYPE = np.dtype([("m", "f4", MAX_PARAMS), ("v", "f4", MAX_PARAMS), ("lr", "f4", 2), ("seen_lr", "f4"), ("step", "i4"),
                         ("n_bad", "i4"), ("n_plateaus", "i4"), ("done", "i4"), ("iter", "i4"), ("best", "f8")], align=True)
 
@@ -139,21 +140,44 @@ class RegistrationStage:
         self.graph = None
 
     # -- the five calls --------------------------------------------------------------------------
-    def render(self):
-        lib, B, H, W, n, s = self.lib, self.B, self.H, self.W, self.n, _stream()
-        vol = self.drr.density
+    def camera(self):
+        lib, B, s = self.lib, self.B, _stream()
         if self.kind == 0:
             _lib.check(_timed("pose_camera_forward", lib.xvr_pose_camera_forward, _ptr(self.rot), _ptr(self.xyz), B, self.axes,
                               _ptr(self.G), _ptr(self.c), _ptr(self.cam), s), "xvr_pose_camera_forward")
         else:
             _lib.check(_timed("pose_camera_forward", lib.xvr_pose_camera_forward_param, _ptr(self.rot), _ptr(self.xyz), B, self.kind, self.axes,
                               _ptr(self.G), _ptr(self.c), _ptr(self.cam), _ptr(self.pose_jac), s), "xvr_pose_camera_forward_param")
+
+    def render(self, camera: bool = True):
+        lib, B, H, W, n, s = self.lib, self.B, self.H, self.W, self.n, _stream()
+        vol = self.drr.density
+        if camera:
+            self.camera()
         _lib.check(_timed(f"{self.rspec.renderer}_forward+jac", self.render_fn, _ptr(vol), None, *vol.shape, 1, _ptr(self.cam), B, H, W,
                           ctypes.byref(self.cspec), _ptr(self.img), _ptr(self.jac), None, s),
                    f"xvr_drr_{self.rspec.renderer}_forward_camera")
 
+    @property
+    def fused_tail(self) -> bool:
+        """Euler angles + the fused similarity: the iteration is render -> xvr_sim_ncc_registration_step (round 6) -- the
+        similarity's last kernel also does jacobian -> camera, the optimiser step and the NEXT iteration's camera vector; bit for
+        bit the five-call sequence (tests/test_pose_opt.py), three launches fewer.  FUSED_TAIL = False: the five calls (A/B)."""
+        return FUSED_TAIL and self.kind == 0 and self.sim_kind == "fused" and not getattr(self.sim.spec, "pre_transformed", 0)
+
     def iteration(self):
         lib, B, H, W, n = self.lib, self.B, self.H, self.W, self.n
+        if self.fused_tail:
+            # (the camera vector in place belongs to the current (rot, xyz): written by run() before its first iteration and by
+            #  every step's tail afterwards)
+            self.render(camera=False)
+            s, sim = _stream(), self.sim
+            _lib.check(_timed("ncc_registration_step", lib.xvr_sim_ncc_registration_step, _ptr(sim.fixed), _ptr(sim.fixed_sobel), _ptr(self.img),
+                              B, H, W, ctypes.byref(sim.spec), _ptr(self.loss), _ptr(self.g_img), _ptr(sim.workspace), sim.workspace.numel() * 4,
+                              _ptr(self.jac), _ptr(self.cam), _ptr(self.j2c_ws), self.j2c_ws.numel() * 4, _ptr(self.rot), _ptr(self.xyz),
+                              ctypes.byref(self.spec), _ptr(self.G), _ptr(self.c), _ptr(self.state), _ptr(self.history), s),
+                       "xvr_sim_ncc_registration_step")
+            return
         self.render()
         s, sim = _stream(), self.sim
         if self.sim_kind == "chain":
@@ -192,6 +216,8 @@ class RegistrationStage:
         """Up to ``n_itr`` iterations (never more than ``max_iters`` in total); stops at the first check
         after every pose is done.  Returns (state, seconds per iteration of each chunk as a list)."""
         n_itr = min(int(n_itr), self.max_iters - int(self.read_state()["iter"].max()))
+        if self.fused_tail:
+            self.camera()   # (rot / xyz may have been set from outside since the last step; outside the captured iteration)
         times, taken = [], 0
         st = self.read_state()
         while taken < n_itr and not st["done"].all():
