@@ -217,7 +217,16 @@ def unpaired_moves(a, b, tol):
     for k in (3, 5, 7):
         box = float(k ** 3) * F.avg_pool3d(d[None, None], k, stride=1, padding=k // 2, count_include_pad=True)[0, 0]
         unpaired &= box.abs() > 0.05 * d.abs()
+    if int(unpaired.sum()) and UNPAIRED_DETAILS is not None:   # (diagnosis: the unexplained entries and their neighbourhoods)
+        for idx in unpaired.nonzero()[:4].tolist():
+            x, y, z = idx
+            nb = d[max(x - 2, 0):x + 3, max(y - 2, 0):y + 3, max(z - 2, 0):z + 3] / top
+            big = (nb.abs() > 0.1 * tol).nonzero().tolist()
+            UNPAIRED_DETAILS.append((idx, d[x, y, z].item() / top, [(tuple(i), round(nb[tuple(i)].item(), 6)) for i in big]))
     return int(bad.sum()), int(unpaired.sum())
+
+
+UNPAIRED_DETAILS = []
 
 
 def tie_count_window(n_ref, ratio=1.5, per_move=2.0):

@@ -267,7 +267,7 @@ def test_c5_full_size_masked_renders_under_the_per_ray_window():
     for lo in range(0, H * H, 8192):      # rays are independent: the oracle's [B, n, N, 3] grid in slices, gradients accumulate
         sl = slice(lo, lo + 8192)
         o = oracle_render(tmp.cpu(), so, to_[:, sl], Lo[..., sl], to_oracle_spec(spec), lab.cpu(), label_nudge=(nudge[0][:, sl], nudge[1][:, sl]))
-        (o * w.reshape(2, 8, -1)[..., sl]).sum().backward()
+        (o * w.reshape(2, 8, -1)[..., sl]).sum().backward(retain_graph=True)    # (the rays' graph is shared by the slices)
     _close(r.grad, ro.grad, 5e-3, "C5 under clip_to_volume: d / d rotation, per-channel upstream")
     _close(x.grad, xo.grad, 5e-3, "C5 under clip_to_volume: d / d translation, per-channel upstream")
 

@@ -66,8 +66,10 @@ def test_siddon_splat_equals_the_scatter_and_the_oracle(kw, shape, hw, why):
     # ... and every voxel that differs must BE such a move: +c here, -c in a neighbour, the 3 x 3 x 3 box sum conserved
     # (conftest.unpaired_moves) -- a wrong weight, a dropped or a doubled segment would not cancel
     from conftest import unpaired_moves
+    import conftest
+    conftest.UNPAIRED_DETAILS.clear()
     n_bad, n_unpaired = unpaired_moves(splat, scatter, 1e-4)
-    assert n_unpaired <= max(1, n_bad // 20), (why, n_bad, n_unpaired)
+    assert n_unpaired <= max(1, n_bad // 20), (why, n_bad, n_unpaired, conftest.UNPAIRED_DETAILS)
     if hw[0] * hw[1] <= 10000:
         ref = _oracle_render(case, spec, grads=True, w=w)[1]
         assert _differing(splat.cpu(), ref, 2e-3) <= allowed, (why, _differing(splat.cpu(), ref, 2e-3), allowed)

@@ -137,7 +137,7 @@ class RegistrationStage:
         self.state = torch.zeros(B * STATE_DTYPE.itemsize, device=dev, dtype=torch.uint8)
         _lib.check(self.lib.xvr_pose_opt_init(_ptr(self.state), B, float(lr_rot), float(lr_xyz), _stream()),
                    "xvr_pose_opt_init")
-        self.graph = None
+        self.graph, self.graph_len = None, 1
 
     # -- the five calls --------------------------------------------------------------------------
     def camera(self):
@@ -205,12 +205,16 @@ class RegistrationStage:
         """Device -> host copy of the optimiser state (the one sync of a chunk of iterations)."""
         return np.frombuffer(self.state.cpu().numpy().tobytes(), dtype=STATE_DTYPE)
 
-    def capture(self):
-        """Two eager iterations (real ones) to warm allocations and module loading, then capture one."""
+    def capture(self, iterations: int = 1):
+        """Two eager iterations (real ones) to warm allocations and module loading, then capture ``iterations`` of them in ONE graph:
+        a replay costs 10-16 us of host + launch whatever it holds, which is a tenth of a 256^2 iteration once the tail is fused --
+        the block of iterations between two looks at the `done` flag goes out as one replay (iterations past the stopping rule are
+        no-ops on the device, so a block is exactly the loop that checks after every step)."""
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            self.iteration()
-        self.graph = g
+            for _ in range(max(int(iterations), 1)):
+                self.iteration()
+        self.graph, self.graph_len = g, max(int(iterations), 1)
 
     def run(self, n_itr: int, check_every: int = 8, use_graph: bool = True):
         """Up to ``n_itr`` iterations (never more than ``max_iters`` in total); stops at the first check
@@ -225,7 +229,7 @@ class RegistrationStage:
             t0 = time.perf_counter()
             if use_graph and self.graph is None and taken >= 2:
                 try:
-                    self.capture()   # capture enqueues nothing: the k replays below are the iterations
+                    self.capture(check_every)   # capture enqueues nothing: the replays below are the iterations
                 except RuntimeError as e:
                     # capture is an optimisation, never a requirement -- but only for the general similarity path (autograd and
                     # torch ops inside it may refuse a capture); the all-HIP iteration must capture, and anything that is not a
@@ -238,12 +242,13 @@ class RegistrationStage:
                     warnings.warn(f"RegistrationStage: HIP-graph capture failed ({e}); continuing eagerly", RuntimeWarning, stacklevel=2)
                     self.graph, use_graph = None, False
                     torch.cuda.synchronize()
-            for _ in range(k if (self.graph is not None or not use_graph) else min(k, 2 - taken)):
-                if self.graph is not None:
-                    self.graph.replay()
-                else:
+            if self.graph is not None and k == self.graph_len:
+                self.graph.replay()          # the whole block of iterations in one replay
+                taken += k
+            else:                            # (the first two iterations, a last block shorter than the graph, or no graph at all)
+                for _ in range(k if (self.graph is not None or not use_graph) else min(k, 2 - taken)):
                     self.iteration()
-                taken += 1
+                    taken += 1
             before = st["iter"].copy()
             st = self.read_state()
             done_now = int((st["iter"] - before).max())
