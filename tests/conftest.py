@@ -214,9 +214,12 @@ def unpaired_moves(a, b, tol):
     for ax in range(3):
         unpaired.select(ax, 0).fill_(False)
         unpaired.select(ax, d.shape[ax] - 1).fill_(False)
+    # (a box also sums the rounding differences of its other voxels -- fixed-point sums against float atomics: a random walk of
+    #  k^3 steps of the field's typical size, which the median of |d| measures robustly)
+    noise = d.abs().median().item()
     for k in (3, 5, 7):
         box = float(k ** 3) * F.avg_pool3d(d[None, None], k, stride=1, padding=k // 2, count_include_pad=True)[0, 0]
-        unpaired &= box.abs() > 0.05 * d.abs()
+        unpaired &= box.abs() > 0.05 * d.abs() + 4.0 * (k ** 1.5) * noise
     if int(unpaired.sum()) and UNPAIRED_DETAILS is not None:   # (diagnosis: the unexplained entries and their neighbourhoods)
         for idx in unpaired.nonzero()[:4].tolist():
             x, y, z = idx

@@ -18,6 +18,7 @@ for tag in ("trilinear", "pose_only", "siddon", "siddon_nx"):
     for k, v in json.loads((src / "traffic.json").read_text()).items():
         merged.setdefault(k, v)     # (a kernel two legs share keeps the first leg's counters)
 (out / "traffic.json").write_text(json.dumps(merged, indent=1))
-for f in (f"{rd}_bench_final_default.json", f"{rd}_bench_final_siddon.json"):
-    shutil.copy(ROOT / "gpurun_out" / f, out / f)
+for f in (f"{rd}_bench_final_default.json", f"{rd}_bench_final_siddon.json", f"{rd}_bench_full_default.json", f"{rd}_bench_full_siddon.json"):
+    if (ROOT / "gpurun_out" / f).exists():   # (final = the ONE line the driver parses; full = kernel tables, floors, spreads)
+        shutil.copy(ROOT / "gpurun_out" / f, out / f)
 print("profiles/ updated for", rd, "-", len(merged), "kernels in traffic.json")

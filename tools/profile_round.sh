@@ -14,17 +14,22 @@ for t in trilinear pose_only siddon siddon_nx; do
   rm -rf $O/trace $O/pmc_*/ 2>/dev/null
 done
 cd $R
-python bench.py --steps 20 --warmup 5 > gpurun_out/${RD}_bench_final_default.json 2> gpurun_out/${RD}_bench_final_default.err
-python bench.py --steps 20 --warmup 5 --renderer siddon --no-variants > gpurun_out/${RD}_bench_final_siddon.json 2>/dev/null
+# (the driver's own command; the line it parses -> *_bench_final_default.json, the full result -> *_bench_full_default.json)
+python bench.py --steps 20 --warmup 5 --full-json gpurun_out/${RD}_bench_full_default.json > gpurun_out/${RD}_bench_final_default.json 2> /dev/null
+python bench.py --steps 20 --warmup 5 --renderer siddon --no-variants --full-json gpurun_out/${RD}_bench_full_siddon.json > gpurun_out/${RD}_bench_final_siddon.json 2>/dev/null
 python - <<PY
 import json
-d = json.load(open("gpurun_out/${RD}_bench_final_default.json"))
-v = d["variants"]
-print("headline", round(d["ms_per_step"], 3), "ms", round(d["value"], 1), "DRRs/s; roofline frac", round(d["roofline"]["frac"], 3), "binding", d["roofline"].get("binding", {}).get("unit"), round(d["roofline"].get("binding", {}).get("frac", 0), 3))
-print({k: round(x["avg_ms"], 3) for k, x in d["kernels"].items()})
-print("volume changing", round(v["ms_per_step_volume_changing"], 2), "clip", round(v["clip_to_volume_ms_per_step"], 2), "siddon", round(v["siddon_ms_per_step"], 2), "pose-only", v["pose_only_ms_per_step"])
-print("recalled", {k: (round(x["ms_per_step"], 2), round(x["pose_only_ms_per_step"], 2)) for k, x in v["recalled_knobs"].items()})
+line = open("gpurun_out/${RD}_bench_final_default.json").read().strip()
+d = json.loads(line)
+print("the line:", len(line), "bytes")
+print("headline", round(d["ms_per_step"], 3), "ms", round(d["value"], 1), "DRRs/s; clip per ray / clip batch / volume changing:", d["value_clip_per_ray"], d["value_clip_batch"], d["value_volume_changing"])
+print("roofline", d["roofline"])
+print("kernels_ms", d["kernels_ms"])
+print("variants", d["variants"])
+print("cpu", d["cpu_baseline"]["value"], d["cpu_baseline"]["cores"])
+f = json.load(open("gpurun_out/${RD}_bench_full_default.json"))
+v = f["variants"]
 print("c4", {k: {a: round(b, 4) for a, b in x.items() if isinstance(b, float)} for k, x in v["c4_register_ms_per_pose_iteration"].items()})
 print("c5", round(v["c5_train_step_ms"], 2), v["c5_train_step"]["min_median_max_ms"], {k: round(x, 2) for k, x in v["c5_train_step"]["phases"].items()})
-print("cpu", d["cpu_baseline"]["value"], d["cpu_baseline"]["cores"])
+print("c5 under the per-ray clip", round(v["c5_train_step_clip_ms"], 2), v["c5_train_step_clip"]["min_median_max_ms"])
 PY
