@@ -136,6 +136,9 @@ def test_ypair_volume_layout_is_bit_identical(kw, shape, tiles, monkeypatch):
 
     monkeypatch.setattr(renderers, "YPAIR_TILES", tiles)
     monkeypatch.setattr(renderers, "YPAIR_TILES_PACKED", tiles)     # (the label-carrying copy is tiled on request only)
+    # (the "third render" rule is what is exercised here; round 6's first-sight rule for launches of many samples per voxel has
+    #  its own test below)
+    monkeypatch.setattr(renderers, "YPAIR_FIRST_SIGHT_SAMPLES_PER_VOXEL", float("inf"))
     from xvr_amd.renderers import render
     from xvr_amd.spec import RenderSpec
 
@@ -370,6 +373,43 @@ def _face_ties(case, spec, hip_out):
     assert clip_mask_tie_free(case["volume"].shape, spec.n_points, spec.near, spec.far, spec.voxel_shift, spec.norm_dims_offset, spec.align_corners)
     nudge, ref, stats = resolve_face_ties(hip_out, case["volume"], case["source"], case["target"], case["img"], spec, case["mask"], FWD_TOL)
     return nudge, ref, stats
+
+
+def test_large_launch_builds_the_tiled_copy_at_first_sight_and_a_changed_volume_rebuilds_it(monkeypatch):
+    """Round 6: a launch of more than ~10 nominal samples per voxel pays for the tiled y-pair copy at once (0.6 ms at 512^3 against
+    1.7 ms of the forward), so a volume that changes between renders -- voxels being optimised -- renders from the copy too: built
+    at first sight, rebuilt after every in-place change, the same bits as the natural layout, and not built for a launch too small
+    to pay for it."""
+    from xvr_amd import renderers
+    from xvr_amd.renderers import render
+    from xvr_amd.spec import RenderSpec
+
+    spec = RenderSpec(renderer="trilinear", n_points=90)
+    case = make_case(seed=33, shape=(40, 44, 48), height=128, width=128, delx=0.45, rot=((170.0, 10.0, 5.0),) * 4 + ((20.0, -20.0, -8.0),) * 4,
+                     xyz=((5.0, 300.0, -4.0), (-3.0, 200.0, 6.0), (0.0, 30.0, 0.0), (40.0, 250.0, 10.0)) * 2)
+    vol, src, tgt, img = (case[k].cuda() for k in ("volume", "source", "target", "img"))
+    assert 8 * 128 * 128 * 90 > renderers.YPAIR_FIRST_SIGHT_SAMPLES_PER_VOXEL * vol.numel()
+    with torch.no_grad():
+        monkeypatch.setattr(renderers, "YPAIR_LAYOUT", False)
+        natural = render(vol, src, tgt, img, spec, ray_grid_w=128)
+        natural2 = render(vol * 1.5, src, tgt, img, spec, ray_grid_w=128)
+        monkeypatch.setattr(renderers, "YPAIR_LAYOUT", True)
+        renderers.PROFILER = []
+        first = render(vol, src, tgt, img, spec, ray_grid_w=128)
+        assert [e[0] for e in renderers.PROFILER].count("pack_ypairs") == 1      # built at first sight ...
+        assert torch.equal(first, natural)
+        vol.mul_(1.5)                                                              # ... the volume changes in place ...
+        again = render(vol, src, tgt, img, spec, ray_grid_w=128)
+        names = [e[0] for e in renderers.PROFILER]
+        assert names.count("pack_ypairs") == 2 and torch.equal(again, natural2)   # ... and the copy is rebuilt, once per version
+        render(vol, src, tgt, img, spec, ray_grid_w=128)
+        assert [e[0] for e in renderers.PROFILER].count("pack_ypairs") == 2
+        # a launch too thin to pay for the copy keeps the third-render rule
+        big = torch.rand(128, 128, 128, device="cuda")
+        renderers.PROFILER = []
+        render(big, src, tgt, img, spec, ray_grid_w=128)
+        assert "pack_ypairs" not in [e[0] for e in renderers.PROFILER]
+    renderers.PROFILER = None
 
 
 @pytest.mark.parametrize("packed", [True, False], ids=["packed-labels", "mask-lookup"])

@@ -236,9 +236,15 @@ BRICK_LAYOUT = _os.environ.get("XVR_DRR_BRICKS", "1") != "0"
 # the y-pair copy costs 0.54 ms and saves 0.70 of the forward -- 14.75 -> 14.96 ms per step with the splat behind it, no gain --;
 # the bricked copy saves 1.3 ms of the Siddon walk: 21.46 -> 20.51 ms per step when built at first sight)
 LAYOUT_COPY_AFTER = {"ypairs": 2, "bricks": 0}
+# Round 6: on the TILED y-pair copy (round 4) the forward of a large launch is 1.7 ms faster than on the natural layout (C2:
+# 4.76 against 6.48 ms, profiles/r06_trilinear_rocprof_summary.md) and the copy costs 0.6 ms -- the measurement above is of round
+# 2's row layout.  A launch whose saving (~0.45 ms per 1e9 nominal samples) exceeds the copy's cost (0.6 ms per 512^3 voxels) builds
+# it at FIRST sight, i.e. above ~10 samples per voxel: a volume that changes every step (voxels being optimised) then renders from
+# the copy as well -- 14.2 -> ms per step at the benchmark (bench.py's value_volume_changing).
+YPAIR_FIRST_SIGHT_SAMPLES_PER_VOXEL = float(_os.environ.get("XVR_DRR_YPAIRS_FIRST_SIGHT", "10"))
 
 
-def _layout_copy(lib, volume, kind):
+def _layout_copy(lib, volume, kind, first_sight=False):
     """The y-pair (``kind`` = "ypairs") or bricked ("bricks") copy of ``volume``, or None the first LAYOUT_COPY_AFTER[kind]
     times a version of it is seen.  The y-pair copy costs 0.54 ms at 512^3 and saves ~0.7 ms per render: it waits for the third
     render, i.e. for a volume that is rendered again and again unchanged (registration, the benchmark, a fixed CT) -- a volume
@@ -253,7 +259,7 @@ def _layout_copy(lib, volume, kind):
         return hit[1]
     seen = hit[3] + 1 if hit is not None and hit[0] == key else 1
     buf = hit[2] if hit is not None else None
-    if seen <= LAYOUT_COPY_AFTER[kind]:
+    if seen <= LAYOUT_COPY_AFTER[kind] and not first_sight:
         slot[kind] = (key, None, buf, seen)
         return None
     if kind == "ypairs":
@@ -271,9 +277,11 @@ def _layout_copy(lib, volume, kind):
     return buf
 
 
-def _ypair_volume(lib, volume):
-    """-> (copy or None, its volume_layout code: 3 = 2 x 8 tiles, 1 = rows)"""
-    return _layout_copy(lib, volume, "ypairs"), (3 if YPAIR_TILES else 1)
+def _ypair_volume(lib, volume, samples=0):
+    """-> (copy or None, its volume_layout code: 3 = 2 x 8 tiles, 1 = rows).  ``samples``: nominal samples of the launch asking
+    (B n n_points): a launch large enough to pay for the tiled copy gets it at first sight (YPAIR_FIRST_SIGHT_SAMPLES_PER_VOXEL)."""
+    first = YPAIR_TILES and samples > YPAIR_FIRST_SIGHT_SAMPLES_PER_VOXEL * volume.numel()
+    return _layout_copy(lib, volume, "ypairs", first), (3 if YPAIR_TILES else 1)
 
 
 def _brick_volume(lib, volume):
@@ -350,7 +358,7 @@ class _Render(torch.autograd.Function):
             else:
                 vol_f, msk_f = _packed_volume(lib, vol_c, msk_c), None     # labels ride in the taps
         if pairs is None and msk_f is None and _use_ypairs(spec, vol_c, B, n):
-            pairs, pairs_layout = _ypair_volume(lib, vol_f)
+            pairs, pairs_layout = _ypair_volume(lib, vol_f, B * n * spec.n_points)
         bricks = _brick_volume(lib, vol_f) if msk_f is None and _use_bricks(spec, vol_c, B, n, C) else None
         if pairs is not None:
             vol_f = pairs                                              # (of the label-carrying copy when there is one)
@@ -488,7 +496,7 @@ class _RenderFromCamera(torch.autograd.Function):
         lib = _lib.load()
         cam_c, vol_c = cam.contiguous(), volume.contiguous()
         B, n = cam_c.shape[0], H * W
-        pairs, layout = _ypair_volume(lib, vol_c) if _use_ypairs(spec, vol_c, B, n) else (None, 0)
+        pairs, layout = _ypair_volume(lib, vol_c, B * n * spec.n_points) if _use_ypairs(spec, vol_c, B, n) else (None, 0)
         if pairs is None and _use_bricks(spec, vol_c, B, n):
             pairs, layout = _brick_volume(lib, vol_c), 2               # (siddon: the bricked copy takes the same seat)
         if pairs is None:
