@@ -173,10 +173,14 @@ def test_large_siddon_launch_under_the_recalled_index_maps(seed):
 
 
 @pytest.mark.parametrize("seed", range(10))
-def test_large_trilinear_launch_on_the_tiled_copy_against_the_oracle(seed):
+def test_large_trilinear_launch_on_the_tiled_copy_against_the_oracle(seed, monkeypatch):
     from xvr_amd import renderers
     from xvr_amd.renderers import render
     from xvr_amd.spec import RenderSpec
+
+    # (the third-render rule, so that the first two renders are the natural layout's to compare bits with; round 6's first-sight
+    #  rule for launches of many samples per voxel: tests/test_hip_parity.py::test_large_launch_builds_the_tiled_copy_at_first_sight...)
+    monkeypatch.setattr(renderers, "YPAIR_FIRST_SIGHT_SAMPLES_PER_VOXEL", float("inf"))
 
     case, h, w, n_poses = _case(100 + seed, 8 if seed % 2 else 9)
     kw = [dict(), dict(voxel_shift=0.0, step_mode="n_minus_1"), dict(norm_dims_offset=-1), dict(near=0.15, far=0.95)][seed % 4]

@@ -47,6 +47,11 @@ struct SlabRange {
 
 // WIN (clip_to_volume == 2, with the jacobian): also E1 = sum (alpha_k - A) (a d . grad V) -- d out / d (window width) needs it
 // directly; rebuilt from G and H it is a difference of two large sums and loses 2 % in float32
+#ifndef XVR_FWD_MASK_REGS   // 0: per-lane LDS accumulators for any C (the product); 1: up to eight label channels summed in registers --
+                            // round 6 A/B at C5 (tools/ab_mask_regs.sh): 6.47 against 5.87 ms (forward), 7.21 against 6.63 (+ jacobian):
+                            // the eight predicated adds per sample cost more issue slots than the LDS round trip costs latency
+#define XVR_FWD_MASK_REGS 0
+#endif
 template <bool JAC, int MASK, bool CLIP, int YP = 0, bool SLAB = false, bool WIN = false, int SYNC = 0>
 __device__ __forceinline__ void tri_march(const RenderArgs& A, const Ray& R, const KRange K, const int kbeg, const int kend,
                                           const float step, const SpecWin Wn, float* lds, const int tid, TriAcc& acc,
@@ -58,6 +63,10 @@ __device__ __forceinline__ void tri_march(const RenderArgs& A, const Ray& R, con
     float G[3] = {0.f, 0.f, 0.f}, H[3] = {0.f, 0.f, 0.f};
     float E0 = 0.f, E1 = 0.f;
     unsigned cnt = 0;
+#if XVR_FWD_MASK_REGS
+    const bool ch_regs = MASK && A.C <= 8;   // (uniform)
+    float ch[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#endif
     const float adx = A.sp.a[0] * R.d[0], ady = A.sp.a[1] * R.d[1], adz = A.sp.a[2] * R.d[2];
 
     // Two steps per trip: the 8 independent 8-byte gathers of both samples are issued before either
@@ -148,6 +157,14 @@ __device__ __forceinline__ void tri_march(const RenderArgs& A, const Ray& R, con
             const float v = fmaf(t.wx1, r1, t.wx0 * r0);
             ++cnt;
             if (MASK) {
+#if XVR_FWD_MASK_REGS
+                if (ch_regs) {
+                    // (diagnostic build) up to eight channels: the sums stay in registers -- eight predicated adds instead of an LDS
+                    // read-modify-write
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) ch[c] += lab == c ? v : 0.f;
+                } else
+#endif
                 lds[lab * WG + tid] += v;
                 if (JAC) S += v;  // the jacobian saved with a mask is that of the channel SUM
             } else {
@@ -173,6 +190,13 @@ __device__ __forceinline__ void tri_march(const RenderArgs& A, const Ray& R, con
         if (__builtin_amdgcn_ballot_w64(inside) == ~0ull) trip(std::true_type{});
         else trip(std::false_type{});
     }
+#if XVR_FWD_MASK_REGS
+    if (MASK && ch_regs) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (c < A.C) lds[c * WG + tid] += ch[c];
+    }
+#endif
     acc.S = S;
     acc.cnt = cnt;
 #pragma unroll
