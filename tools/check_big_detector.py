@@ -14,16 +14,26 @@ from xvr_amd import renderers  # noqa: E402
 from xvr_amd.renderers import render  # noqa: E402
 from xvr_amd.spec import RenderSpec  # noqa: E402
 
-H, W = 1000, 1100
+# optional: H W depth_mm [only-siddon].  `python tools/check_big_detector.py 3500 3400 60 1`: ONE source INSIDE the volume and 1.19e7 pixels --
+# every brick's footprint is then the whole detector, 2.97e6 pixels per wavefront quarter, beyond what k_siddon_splat's float
+# estimate of (pixel / columns) resolves without its integer correction (fixed in round 6)
+H, W = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1000, 1100)
+DEPTH = float(sys.argv[3]) if len(sys.argv) > 3 else None
+ONLY_SIDDON = len(sys.argv) > 4
 SHAPE = (201, 181, 221)     # (odd sizes: no structural tie under dims = shape + 1, conftest.has_structural_tie -- the splat carries the march's
                             #  plane alphas, the scatter the merge walk's: comparable voxel by voxel only without one)
-case = make_case(seed=3, shape=SHAPE, height=H, width=W, delx=0.25, xyz=((3.0, 420.0, -2.0), (-8.0, 300.0, 5.0)))
+if DEPTH is None:
+    case = make_case(seed=3, shape=SHAPE, height=H, width=W, delx=0.25, xyz=((3.0, 420.0, -2.0), (-8.0, 300.0, 5.0)))
+else:
+    case = make_case(seed=3, shape=SHAPE, height=H, width=W, delx=275.0 / max(H, W), rot=((170.0, 10.0, 5.0),), xyz=((3.0, DEPTH, -2.0),))
+NB = case["source"].shape[0]
 g = torch.Generator().manual_seed(1)
 case["volume"] = torch.rand(SHAPE, generator=g)
-w = torch.rand(2, 1, H * W, generator=g).cuda()
+w = torch.rand(NB, 1, H * W, generator=g).cuda()
 ok = True
-for kw in (dict(renderer="trilinear", n_points=300), dict(renderer="trilinear", n_points=300, clip_to_volume=True), dict(renderer="siddon"),
-           dict(renderer="siddon", norm_dims_offset=1)):
+KWS = (dict(renderer="trilinear", n_points=300), dict(renderer="trilinear", n_points=300, clip_to_volume=True), dict(renderer="siddon"),
+       dict(renderer="siddon", norm_dims_offset=1))
+for kw in (KWS[2:] if ONLY_SIDDON else KWS):
     spec = RenderSpec(**kw)
     res = {}
     for name, grid_w, gather in (("lattice", W, True), ("general", 0, True), ("scatter", W, False)):
