@@ -122,7 +122,8 @@ class RegistrationStage:
                                       float(threshold), 1e-8, int(max_n_plateaus), int(max_iters))
         self.max_iters = int(max_iters)
         self.rspec = drr.renderer.make_spec()
-        self.cspec = make_cspec(tuple(drr.density.shape), self.rspec, self.W)
+        self._vol_version = None
+        self._bind_volume()
         self.render_fn = (self.lib.xvr_drr_trilinear_forward_camera if self.rspec.renderer == "trilinear"
                           else self.lib.xvr_drr_siddon_forward_camera)
         f = dict(device=dev, dtype=torch.float32)
@@ -139,6 +140,27 @@ class RegistrationStage:
                    "xvr_pose_opt_init")
         self.graph, self.graph_len = None, 1
 
+    def _bind_volume(self):
+        """The render-ready copy of the (static) volume a launch of this size marches, as the autograd path chooses it
+        (renderers._RenderFromCamera): the tiled y-pair copy for trilinear launches of >= 2048 wavefronts (512^2: the unsplit kernel
+        on tiles takes 183 us against the split kernel's 198 on the natural layout, profiles/r06_small_batch_tiles.txt), the
+        bricked copy for Siddon where it serves; built once per volume version, at first sight -- a registration renders the same
+        volume hundreds of times."""
+        from . import renderers as R
+        vol = self.drr.density
+        if self._vol_version == (vol.data_ptr(), vol._version):
+            return
+        pairs, layout = None, 0
+        if R._use_ypairs(self.rspec, vol, self.B, self.n):
+            pairs, layout = R._layout_copy(self.lib, vol, "ypairs", first_sight=True), (3 if R.YPAIR_TILES else 1)
+        elif R._use_bricks(self.rspec, vol, self.B, self.n):
+            pairs, layout = R._brick_volume(self.lib, vol), 2
+        self.vol_render = pairs if pairs is not None else vol
+        self.cspec = make_cspec(tuple(vol.shape), self.rspec, self.W, volume_layout=layout if pairs is not None else 0)
+        if self._vol_version is not None:
+            self.graph = None        # (the captured launches hold the old copy's pointer)
+        self._vol_version = (vol.data_ptr(), vol._version)
+
     # -- the five calls --------------------------------------------------------------------------
     def camera(self):
         lib, B, s = self.lib, self.B, _stream()
@@ -154,7 +176,7 @@ class RegistrationStage:
         vol = self.drr.density
         if camera:
             self.camera()
-        _lib.check(_timed(f"{self.rspec.renderer}_forward+jac", self.render_fn, _ptr(vol), None, *vol.shape, 1, _ptr(self.cam), B, H, W,
+        _lib.check(_timed(f"{self.rspec.renderer}_forward+jac", self.render_fn, _ptr(self.vol_render), None, *vol.shape, 1, _ptr(self.cam), B, H, W,
                           ctypes.byref(self.cspec), _ptr(self.img), _ptr(self.jac), None, s),
                    f"xvr_drr_{self.rspec.renderer}_forward_camera")
 
@@ -220,6 +242,7 @@ class RegistrationStage:
         """Up to ``n_itr`` iterations (never more than ``max_iters`` in total); stops at the first check
         after every pose is done.  Returns (state, seconds per iteration of each chunk as a list)."""
         n_itr = min(int(n_itr), self.max_iters - int(self.read_state()["iter"].max()))
+        self._bind_volume()   # (a volume changed in place since the last run gets a fresh copy, and a fresh graph)
         if self.fused_tail:
             self.camera()   # (rot / xyz may have been set from outside since the last step; outside the captured iteration)
         times, taken = [], 0
