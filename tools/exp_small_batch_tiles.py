@@ -30,9 +30,12 @@ for det in (256, 512):
         ts = sorted(a.elapsed_time(b) * 1e3 for name, a, b in ev if name.startswith("trilinear_forward"))
         print(f"{det}^2  {tag:44s} forward + jacobian: median {ts[len(ts) // 2]:7.1f} us  (min {ts[0]:.1f})", flush=True)
 
-    timed("split kernel, natural layout (product)")
-    with _lib.option("fwd_split", 1):
-        timed("unsplit kernel, natural layout")
-        renderers.YPAIR_MIN_WAVEFRONTS = 0
-        timed("unsplit kernel, tiled y-pair copy")
+    for rep in range(2):      # (twice: the order of the variants must not be what is measured)
+        renderers.YPAIR_MIN_WAVEFRONTS = 1 << 30
+        timed("auto split factor, natural layout")
+        with _lib.option("fwd_split", 1):
+            timed("unsplit kernel, natural layout")
+            renderers.YPAIR_MIN_WAVEFRONTS = 0
+            timed("unsplit kernel, tiled y-pair copy")
         renderers.YPAIR_MIN_WAVEFRONTS = 2048
+        timed("product (tiles from 2048 wavefronts)")
