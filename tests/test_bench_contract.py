@@ -200,6 +200,30 @@ def test_bench_two_ranks_strong_scaling_contract(batch):
     assert abs(d["value"] - batch * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
 
 
+def test_the_line_is_rebuilt_from_the_committed_full_result_and_stays_small():
+    """No GPU needed: bench.compact_line applied to the newest committed full result (profiles/rNN_bench_full_default.json, written
+    by the driver's own command on the GPU box) reproduces the committed line's keys, is strict JSON below 8 KB -- round 5's 23 KB
+    line is why BENCH_r05.parsed is null -- and carries only scalars in `variants`."""
+    sys.path.insert(0, str(ROOT))
+    import bench
+
+    fulls = sorted((ROOT / "profiles").glob("r[0-9][0-9]_bench_full_default.json"))
+    assert fulls, "no committed full bench result"
+    full = json.loads(fulls[-1].read_text())
+    line = json.dumps(bench.compact_line(full), allow_nan=False, separators=(",", ":"))
+    assert len(line) < 4096, len(line)
+    d = json.loads(line, parse_constant=_no_constants)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline", "variants", "value_clip_per_ray", "value_clip_batch", "value_volume_changing"):
+        assert key in d, key
+    _scalars_only(d["variants"])
+    assert set(d["roofline"]["binding"]) == {"unit", "floor_ms", "frac"} and d["roofline"]["hbm_physical"]["GBps"] > 0
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+    committed = json.loads((fulls[-1].with_name(fulls[-1].name.replace("_full_", "_final_"))).read_text().strip(), parse_constant=_no_constants)
+    assert set(committed) == set(d) and committed["value"] == d["value"] and committed["variants"].keys() == d["variants"].keys()
+    assert "before the timed region" in d["config"]["workload"]
+
+
 def test_pmc_traffic_reads_the_committed_counter_table():
     """`roofline.traffic` comes from profiles/traffic.json (FETCH_SIZE + WRITE_SIZE per launch of the committed PMC passes):
     the kernels of one timed call add up, the instantiations of one kernel (volume layouts) count once, and Siddon's
