@@ -75,6 +75,9 @@ int xvr_sim_ncc_forward_backward(const float* fixed, const float* fixed_sobel, c
  *   cam  [B][24]   IN: the camera vector the render used;  OUT: that of the updated pose (unchanged for a pose that is done)
  *   j2c_workspace   xvr_drr_jac_to_camera_workspace_bytes(B, H, W) bytes, zero-filled once (xvr_drr_jac_to_camera_backward's)
  *   rot, xyz [B][3], opt_spec, G [24][12], c [24], state [B], history   as xvr_pose_opt_step / xvr_pose_camera_forward
+ *   workspace_armed   0: `workspace` may hold anything (its header and tickets are reset first, one more launch); 1: the caller
+ *                     vouches that the LAST thing that ran on `workspace` was a complete xvr_sim_ncc_* call (tickets back at
+ *                     zero) -- the min / max reduction then writes the header itself and the reset is not launched
  */
 struct xvr_pose_opt_spec;
 struct xvr_pose_opt_state;
@@ -82,7 +85,7 @@ int xvr_sim_ncc_registration_step(const float* fixed, const float* fixed_sobel, 
                                   const xvr_sim_spec* spec, float* loss, float* grad_scratch, void* workspace, size_t workspace_bytes,
                                   const float* jac, float* cam, void* j2c_workspace, size_t j2c_workspace_bytes,
                                   float* rot, float* xyz, const struct xvr_pose_opt_spec* opt_spec, const float* G, const float* c,
-                                  struct xvr_pose_opt_state* state, float* history, void* stream);
+                                  struct xvr_pose_opt_state* state, float* history, int workspace_armed, void* stream);
 
 /*
  * The Gaussian pre-blur of GradientNormalizedCrossCorrelation2d(patch, sigma > 0)

@@ -106,7 +106,7 @@ EXPORTS = {
     "xvr_sim_workspace_bytes": ([_I, _I, _I], ctypes.c_size_t),
     "xvr_sim_ncc_forward_backward": ([_P, _P, _P, _I, _I, _I, ctypes.POINTER(CSimSpec), _P, _P, _P, ctypes.c_size_t, _P], ctypes.c_int),
     "xvr_sim_ncc_registration_step": ([_P, _P, _P, _I, _I, _I, ctypes.POINTER(CSimSpec), _P, _P, _P, ctypes.c_size_t,
-                                       _P, _P, _P, ctypes.c_size_t, _P, _P, ctypes.POINTER(CPoseOptSpec), _P, _P, _P, _P, _P], ctypes.c_int),
+                                       _P, _P, _P, ctypes.c_size_t, _P, _P, ctypes.POINTER(CPoseOptSpec), _P, _P, _P, _P, _I, _P], ctypes.c_int),
     "xvr_sim_equalize_workspace_bytes": ([_I, _I], ctypes.c_size_t),
     "xvr_sim_equalize_forward": ([_P, _I, _I, _I, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _P, _P, _P, _P, ctypes.c_size_t, _P],
                                  ctypes.c_int),

@@ -31,6 +31,7 @@ constexpr int TB = 256;
 constexpr int TILE = 16;      // output tile edge of the patch kernels
 constexpr int MAXP = 15;      // largest supported patch edge
 constexpr int N_ACC = 16;     // doubles per image
+constexpr unsigned MM_BLOCKS_MAX = 256;   // blocks of the min / max reduction per group
 
 
 struct SimHeader {           // first 256 bytes of the workspace
@@ -140,6 +141,67 @@ __global__ __launch_bounds__(TB) void k_sim_minmax(const float* __restrict__ m, 
         }
         atomicMin(&hd->enc_min, enc(lo));
         atomicMax(&hd->enc_max, enc(hi));
+    }
+}
+
+// The same min / max WITHOUT the header's initial state (round 6, the registration step): blocks store their pair, the block that
+// draws the group's last ticket takes the min / max over the pairs -- exact in any order -- and WRITES the header: enc_min, enc_max,
+// and the counts k_sim_prep adds to from zero.  Nothing has to be reset before the call (k_sim_init is not launched: one launch
+// fewer in a chain of a few microseconds each); the ticket goes back to zero.  Needs gridDim.x <= MM_BLOCKS_MAX.
+__global__ __launch_bounds__(TB) void k_sim_minmax_det(const float* __restrict__ m, long long n, SimHeader* hd, float* partial, unsigned* tickets) {
+    __shared__ float plo[TB / 64], phi[TB / 64];
+    __shared__ bool last;
+    float lo = INFINITY, hi = -INFINITY;
+    m += (size_t)blockIdx.y * n;
+    hd += blockIdx.y;
+    partial += (size_t)blockIdx.y * MM_BLOCKS_MAX * 2;
+    for (long long i = (long long)blockIdx.x * TB + threadIdx.x; i < n; i += (long long)gridDim.x * TB) {
+        const float v = m[i];
+        lo = fminf(lo, v);
+        hi = fmaxf(hi, v);
+    }
+    auto block_minmax = [&]() {   // -> thread 0 holds the block's min / max
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = fminf(lo, __shfl_xor(lo, o));
+            hi = fmaxf(hi, __shfl_xor(hi, o));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            plo[threadIdx.x >> 6] = lo;
+            phi[threadIdx.x >> 6] = hi;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int w = 1; w < TB / 64; ++w) {
+                lo = fminf(lo, plo[w]);
+                hi = fmaxf(hi, phi[w]);
+            }
+        }
+    };
+    block_minmax();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(partial + 2 * blockIdx.x, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(partial + 2 * blockIdx.x + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();   // includes s_waitcnt vmcnt(0): the stores above have completed
+    if (threadIdx.x == 0)
+        last = __hip_atomic_fetch_add(tickets + blockIdx.y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    __syncthreads();
+    if (!last) return;
+    lo = INFINITY; hi = -INFINITY;
+    if (threadIdx.x < gridDim.x) {
+        lo = __hip_atomic_load(partial + 2 * threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        hi = __hip_atomic_load(partial + 2 * threadIdx.x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();   // (plo / phi are reused)
+    block_minmax();
+    if (threadIdx.x == 0) {
+        hd->enc_min = enc(lo);
+        hd->enc_max = enc(hi);
+        hd->cnt_min = 0;
+        hd->cnt_max = 0;
+        __hip_atomic_store(tickets + blockIdx.y, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -522,7 +584,7 @@ int sim_fail(int code, const char* msg) {
 size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Layout {
-    size_t acc, tickets, y, gy, m1, m2, Gy, Gg, part_prep, part_patch, part_final, total;
+    size_t acc, tickets, y, gy, m1, m2, Gy, Gg, part_prep, part_patch, part_final, part_mm, total;
 };
 constexpr unsigned PREP_BLOCKS_MAX = 256;
 
@@ -531,7 +593,7 @@ Layout layout(int B, int H, int W, int p1, int p2) {
     const size_t hw = (size_t)H * W;
     size_t o = al((size_t)B * sizeof(SimHeader));   // one header per image (only the first is used unless per_image)
     L.acc = o; o += al((size_t)B * N_ACC * sizeof(double));
-    L.tickets = o; o += al((size_t)(5 * B) * sizeof(unsigned));   // prep [B], patch [3B], final [B]
+    L.tickets = o; o += al((size_t)(6 * B) * sizeof(unsigned));   // prep [B], patch [3B], final [B], min / max [B] (k_sim_minmax_det)
     L.y = o; o += al((size_t)B * hw * 4);   // everything before y is reset by k_sim_init
     L.gy = o; o += al((size_t)B * 2 * hw * 4);
     L.m1 = o; o += al((size_t)4 * B * (size_t)(H - p1 + 1) * (W - p1 + 1) * 4);
@@ -542,6 +604,7 @@ Layout layout(int B, int H, int W, int p1, int p2) {
     L.part_prep = o; o += al((size_t)B * PREP_BLOCKS_MAX * 5 * sizeof(double));
     L.part_patch = o; o += al((size_t)3 * B * tiles * sizeof(double));
     L.part_final = o; o += al((size_t)B * ((hw + TB - 1) / TB) * 2 * sizeof(double));
+    L.part_mm = o; o += al((size_t)B * MM_BLOCKS_MAX * 2 * sizeof(float));
     L.total = o;
     return L;
 }
@@ -1030,7 +1093,7 @@ size_t xvr_sim_workspace_bytes(int B, int H, int W) {
 
 static int ncc_launch(const float* fixed, const float* fixed_sobel, const float* moving, int B, int H, int W,
                       const xvr_sim_spec* sp, float* loss, float* grad_moving, void* workspace,
-                      size_t workspace_bytes, void* stream_, const RegTail* tail) {
+                      size_t workspace_bytes, void* stream_, const RegTail* tail, bool armed = false) {
     if (!fixed || !fixed_sobel || !moving || !sp || !loss || !workspace) return sim_fail(XVR_DRR_E_ARG, "null pointer argument");
     if (B <= 0 || H <= 0 || W <= 0) return sim_fail(XVR_DRR_E_ARG, "B, H, W must be positive");
     const int p1 = sp->mncc_patch, p2 = sp->gncc_patch;
@@ -1053,16 +1116,20 @@ static int ncc_launch(const float* fixed, const float* fixed_sobel, const float*
     const long long n = (long long)B * hw;
 
     const int nwords = (int)(L.y / 4);   // header + accumulators
-    hipLaunchKernelGGL(k_sim_init, dim3((nwords + TB - 1) / TB), dim3(TB), 0, stream, reinterpret_cast<unsigned*>(ws), nwords,
-                       (int)(B * sizeof(SimHeader) / 4));
+    const bool skip_init = armed && !sp->pre_transformed;   // (the caller vouches for zero tickets; the ticketed min / max writes the header)
+    if (!skip_init)
+        hipLaunchKernelGGL(k_sim_init, dim3((nwords + TB - 1) / TB), dim3(TB), 0, stream, reinterpret_cast<unsigned*>(ws), nwords,
+                           (int)(B * sizeof(SimHeader) / 4));
     const bool per_image = sp->per_image != 0;
     const long long n_mm = per_image ? (long long)hw : n;   // elements one min/max group spans
     const unsigned groups = per_image ? (unsigned)B : 1u;
     const long long want = (n_mm + (long long)TB * 16 - 1) / ((long long)TB * 16);
     const unsigned rb = (unsigned)(want < 1 ? 1 : (want > 256 ? 256 : want));
     const bool pre = sp->pre_transformed != 0;   // no Standardize: no min/max, no gradient through them
-    if (!pre) hipLaunchKernelGGL(k_sim_minmax, dim3(rb, groups), dim3(TB), 0, stream, moving, n_mm, hd);
     unsigned* tickets = reinterpret_cast<unsigned*>(ws + L.tickets);
+    if (skip_init) hipLaunchKernelGGL(k_sim_minmax_det, dim3(rb, groups), dim3(TB), 0, stream, moving, n_mm, hd,
+                                      reinterpret_cast<float*>(ws + L.part_mm), tickets + 5 * B);
+    else if (!pre) hipLaunchKernelGGL(k_sim_minmax, dim3(rb, groups), dim3(TB), 0, stream, moving, n_mm, hd);
     // (a batch fills the chip with a quarter of the blocks per image: four pixels per thread, a quarter of the deterministic
     //  reductions -- 0.23 -> ms below at the training loss's 116 images; one image keeps every block it can get)
     unsigned pb = (unsigned)((hw + TB - 1) / TB < (int)PREP_BLOCKS_MAX ? (hw + TB - 1) / TB : PREP_BLOCKS_MAX);
@@ -1118,7 +1185,7 @@ int xvr_sim_ncc_registration_step(const float* fixed, const float* fixed_sobel, 
                                   const xvr_sim_spec* sp, float* loss, float* grad_scratch, void* workspace, size_t workspace_bytes,
                                   const float* jac, float* cam, void* j2c_workspace, size_t j2c_workspace_bytes,
                                   float* rot, float* xyz, const xvr_pose_opt_spec* ospec, const float* G, const float* c,
-                                  xvr_pose_opt_state* state, float* history, void* stream_) {
+                                  xvr_pose_opt_state* state, float* history, int workspace_armed, void* stream_) {
     if (!grad_scratch || !jac || !cam || !j2c_workspace || !rot || !xyz || !ospec || !G || !c || !state)
         return sim_fail(XVR_DRR_E_ARG, "null pointer argument");
     if (sp && sp->pre_transformed) return sim_fail(XVR_DRR_E_UNSUPPORTED, "registration step: the similarity of raw renders (pre_transformed = 0)");
@@ -1133,7 +1200,7 @@ int xvr_sim_ncc_registration_step(const float* fixed, const float* fixed_sobel, 
     T.counter = reinterpret_cast<unsigned*>(jw);
     T.partial = reinterpret_cast<float*>(jw + al((size_t)B * sizeof(unsigned)));   // (xvr_drr_jac_to_camera_backward's own layout)
     T.rot = rot; T.xyz = xyz; T.G = G; T.c = c; T.state = state; T.history = history; T.osp = *ospec;
-    return ncc_launch(fixed, fixed_sobel, moving, B, H, W, sp, loss, grad_scratch, workspace, workspace_bytes, stream_, &T);
+    return ncc_launch(fixed, fixed_sobel, moving, B, H, W, sp, loss, grad_scratch, workspace, workspace_bytes, stream_, &T, workspace_armed != 0);
 }
 
 int xvr_sim_dice_bool(const unsigned char* pred, const unsigned char* truth, int B, int C, int n, float* dice, void* stream_) {

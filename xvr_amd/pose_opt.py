@@ -197,8 +197,12 @@ class RegistrationStage:
             _lib.check(_timed("ncc_registration_step", lib.xvr_sim_ncc_registration_step, _ptr(sim.fixed), _ptr(sim.fixed_sobel), _ptr(self.img),
                               B, H, W, ctypes.byref(sim.spec), _ptr(self.loss), _ptr(self.g_img), _ptr(sim.workspace), sim.workspace.numel() * 4,
                               _ptr(self.jac), _ptr(self.cam), _ptr(self.j2c_ws), self.j2c_ws.numel() * 4, _ptr(self.rot), _ptr(self.xyz),
-                              ctypes.byref(self.spec), _ptr(self.G), _ptr(self.c), _ptr(self.state), _ptr(self.history), s),
+                              ctypes.byref(self.spec), _ptr(self.G), _ptr(self.c), _ptr(self.state), _ptr(self.history),
+                              int(getattr(sim, "_ws_armed", False)), s),
                        "xvr_sim_ncc_registration_step")
+            # (every xvr_sim_ncc_* call leaves its tickets at zero: from the second call on this workspace the header's reset is not
+            #  launched -- the graph is captured at the third iteration, i.e. with the flag set)
+            sim._ws_armed = True
             return
         self.render()
         s, sim = _stream(), self.sim
