@@ -115,6 +115,9 @@ def test_siddon_splat_many_poses_source_inside_and_determinism(B):
     assert torch.equal(a, _voxel_grad(case, spec, w, 30)[1]), "integer sums: same bits whatever order the bricks and the rays were taken in"
     scatter = _voxel_grad(case, spec, w, 30, gather=False)[1]
     assert _differing(a, scatter) <= 8 + int(2.5e-3 * B * 26 * 30), _differing(a, scatter)     # (cross-family ties, see above)
+    from conftest import unpaired_moves
+    n_bad, n_unpaired = unpaired_moves(a, scatter, 1e-4)     # ... each of them a neighbour swap, not a wrong weight
+    assert n_unpaired <= max(1, n_bad // 20), (n_bad, n_unpaired)
 
 
 def test_siddon_splat_zero_and_non_finite_upstream_gradients():
@@ -126,7 +129,11 @@ def test_siddon_splat_zero_and_non_finite_upstream_gradients():
     w0 = w.clone()
     w0[1] = 0.0
     a = _voxel_grad(case, spec, w0, 44)[1]
-    assert _differing(a, _voxel_grad(case, spec, w0, 44, gather=False)[1]) <= 8 + int(2.5e-3 * 40 * 44)
+    sc0 = _voxel_grad(case, spec, w0, 44, gather=False)[1]
+    assert _differing(a, sc0) <= 8 + int(2.5e-3 * 40 * 44)
+    from conftest import unpaired_moves
+    n_bad, n_unpaired = unpaired_moves(a, sc0, 1e-4)
+    assert n_unpaired <= max(1, n_bad // 20), (n_bad, n_unpaired)
     wn = w.clone()
     wn[1, 0, 17] = float("nan")
     bad = _voxel_grad(case, spec, wn, 44)[1]
