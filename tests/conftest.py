@@ -218,7 +218,8 @@ def unpaired_moves(a, b, tol):
     #  k^3 steps of the field's typical size, which the median of |d| measures robustly)
     noise = d.abs().median().item()
     for k in (3, 5, 7):
-        box = float(k ** 3) * F.avg_pool3d(d[None, None], k, stride=1, padding=k // 2, count_include_pad=True)[0, 0]
+        # (zero padding by hand: avg_pool3d refuses a kernel larger than the unpadded input -- a 6-voxel axis and the 7^3 box)
+        box = float(k ** 3) * F.avg_pool3d(F.pad(d[None, None], (k // 2,) * 6), k, stride=1)[0, 0]
         unpaired &= box.abs() > 0.05 * d.abs() + 4.0 * (k ** 1.5) * noise
     if int(unpaired.sum()) and UNPAIRED_DETAILS is not None:   # (diagnosis: the unexplained entries and their neighbourhoods)
         for idx in unpaired.nonzero()[:4].tolist():

@@ -9,7 +9,7 @@ import test_hip_parity as T
 orig = T._hip_render
 keep = {}
 def spy(*a, **k):
-    r = orig(*a, **k); keep["hip"] = r; keep["case"] = a[0]; return r
+    r = orig(*a, **k); keep["hip"] = r; keep["case"] = a[0]; keep["spec"] = a[1]; keep["w"] = k.get("w"); keep["masked"] = k.get("mask") is not None; return r
 T._hip_render = spy
 orig_o = T._oracle_render
 def spy_o(*a, **k):
@@ -39,3 +39,20 @@ for seed in map(int, sys.argv[1:]):
         s0 = c["source"][b].reshape(-1, 3)[0]; t0 = c["target"][b].reshape(-1, 3)[ray]
         print(f"      worst ray: pose {b} ray {ray}: source {s0.tolist()} direction {(t0 - s0).tolist()}; out hip {keep['hip'][0][b].reshape(-1)[ray].item():.6f} ref {keep['ref'][0][b].reshape(-1)[ray].item():.6f}"
               f"; d/d target hip {h_t[b].reshape(-1, 3)[ray].tolist()} ref {r_t[b].reshape(-1, 3)[ray].tolist()}; volume shape {tuple(c['volume'].shape)}")
+        # d/d source against the FLOAT64 oracle, with the float32 oracle beside it, and the sources themselves (a source within
+        # rounding of a voxel plane makes alpha = 0 a crossing: whether the first segment exists is then a tie)
+        try:
+            spec = keep.get("spec")
+            if spec is not None:
+                from conftest import to_oracle_spec
+                from oracle.diffdrr_restated import render as orender
+                d64 = {k: c[k].double().clone().requires_grad_(k != "mask") for k in ("volume", "source", "target", "img")}
+                w = keep["w"].double()
+                (orender(d64["volume"], d64["source"], d64["target"], d64["img"], to_oracle_spec(spec)) * w).sum().backward()
+                g64 = d64["source"].grad
+                gh, g32 = keep["hip"][2].detach().double().cpu(), keep["ref"][2].detach().double().cpu()
+                sc = g64.abs().max()
+                print(f"      d/d source vs FLOAT64 oracle: HIP {((gh - g64).abs().max() / sc).item():.2e}, float32 oracle {((g32 - g64).abs().max() / sc).item():.2e}")
+                print(f"      sources (voxel units): {c['source'].reshape(-1, 3).tolist()}")
+        except BaseException as e2:   # noqa: BLE001
+            print("      (float64 diagnosis failed:", str(e2)[:200], ")")
