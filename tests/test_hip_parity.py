@@ -1594,7 +1594,16 @@ def test_fuzz_random_configurations_against_the_oracle(seed):
             rs = _oracle_render(case, spec, mask=mask, grads=True, w=w0)[2].detach().double().cpu()
             assert (hs - rs).abs().max() <= 5 * GRAD_TOL * rs.abs().max(), f"grad_source, the tie-broken rays left out [{what}]"
         else:
-            assert (hs - rs).abs().max() <= 5 * GRAD_TOL * rs.abs().max() + 2.0 * (per_ray * bad).sum(), f"grad_source [{what}]"
+            if not (hs - rs).abs().max() <= 5 * GRAD_TOL * rs.abs().max() + 2.0 * (per_ray * bad).sum():
+                # d/d source is a sum over rays of terms that blow up where a ray starts next to a plane (a source inside the
+                # volume: (1 - alpha) / alpha with alpha -> 0): the FLOAT32 oracle itself can be percents from its own float64 run
+                # there (soak seed 906996: 3.5e-2, the HIP path 2.9e-8 from the float64 run).  The better reference decides, at the
+                # same tolerance -- not another input.
+                from oracle.diffdrr_restated import render as _orender
+                d64 = {k: case[k].double().clone().requires_grad_(True) for k in ("volume", "source", "target", "img")}
+                (_orender(d64["volume"], d64["source"], d64["target"], d64["img"], to_oracle_spec(spec), mask) * w.double()).sum().backward()
+                r64 = d64["source"].grad
+                assert (hs - r64).abs().max() <= 5 * GRAD_TOL * r64.abs().max(), f"grad_source, against the float64 oracle [{what}]"
     elif (kw["n_points"] == 1 and kw.get("clip_to_volume") and kw.get("align_corners") and kw.get("norm_dims_offset") == -1
           and "near" not in kw and not masked):
         # One sample per ray under the per-ray window sits AT alpha_min, on the face the ray enters through; under this map (a = 1)
