@@ -1802,7 +1802,10 @@ def test_fuzz_drr_module_end_to_end_against_the_oracle(seed):
     out1 = drr(r2.cuda(), t2.cuda(), parameterization=name, **kw)
     assert out1.shape == (B, 1, H, W)
     # (the fp32 round trip matrix -> parameters -> matrix moves the pose by ~1e-6 rad, lever arm ~1 m)
-    _close(out1, ref, 10 * FWD_TOL, f"DRR.forward({name}) [{what}]")
+    # (a detector that barely touches the volume -- soak seeds 130453, 1000148: the largest pixel 1.2e-4 .. 1.5e-2 -- has no scale of
+    #  its own: at least 1e-3 of the ray length times the largest density, as for entry form 2 below)
+    floor1 = 1e-3 * float(vol.max()) * sdd
+    assert (out1.detach().cpu() - ref).abs().max().item() <= 10 * FWD_TOL * max(ref.abs().max().item(), floor1), f"DRR.forward({name}) [{what}]"
     # entry form 2: Euler parameters (one HIP launch to the camera), with the gradient
     r, t = rot.clone().cuda().requires_grad_(), xyz.clone().cuda().requires_grad_()
     out2 = drr(r, t, parameterization="euler_angles", convention="ZXY", **kw)
