@@ -22,4 +22,4 @@ else:
         out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "6", "--warmup", "2", "--no-cpu-baseline"],
                              env=dict(os.environ, **env), capture_output=True, text=True)
         d = json.loads(out.stdout.strip().splitlines()[-1])
-        print(f"{name}: voxel gradient {d['kernels']['trilinear_backward[vol]']['avg_ms']:.3f} ms", flush=True)
+        print(f"{name}: voxel gradient {d['kernels_ms']['trilinear_backward[vol]']:.3f} ms", flush=True)

@@ -25,4 +25,4 @@ else:
         out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--renderer", "siddon", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-variants"],
                              env=dict(os.environ, **env), capture_output=True, text=True)
         d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-        print(f"{names[k]:20s}: voxel gradient {d['kernels']['siddon_backward[vol]']['avg_ms']:.3f} ms", flush=True)
+        print(f"{names[k]:20s}: voxel gradient {d['kernels_ms']['siddon_backward[vol]']:.3f} ms", flush=True)

@@ -20,4 +20,4 @@ else:
         out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--renderer", "siddon", "--no-voxel-grad", "--steps", "6", "--warmup", "2",
                               "--no-cpu-baseline", "--no-variants"], env=dict(os.environ, **env), capture_output=True, text=True)
         d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-        print(f"{name:16s}: forward + jacobian {d['kernels']['siddon_forward+jac']['avg_ms']:.3f} ms", flush=True)
+        print(f"{name:16s}: forward + jacobian {d['kernels_ms']['siddon_forward+jac']:.3f} ms", flush=True)

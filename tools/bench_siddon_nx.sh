@@ -7,7 +7,7 @@ KW='{"norm_dims_offset": 1}'
 show() { python -c "
 import json,sys
 d=json.loads([l for l in sys.stdin if l.startswith('{')][-1])
-print('$1', 'ms/step %.2f' % d['ms_per_step'], {k: round(v['avg_ms'],3) for k,v in d['kernels'].items() if v['avg_ms']>0.05})"; }
+print('$1', 'ms/step %.2f' % d['ms_per_step'], {k: v for k,v in d['kernels_ms'].items() if v>0.05})"; }
 $B --drr-kwargs "$KW" 2>&1 | show "NX default              "
 XVR_DRR_BRICKS_NX=0 $B --drr-kwargs "$KW" 2>&1 | show "NX slab on rows         "
 XVR_DRR_SIDDON_SLAB=2 $B --drr-kwargs "$KW" 2>&1 | show "NX merge walk           "

@@ -16,4 +16,4 @@ else:
             out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-voxel-grad"],
                                  env=env, capture_output=True, text=True)
             d = json.loads(out.stdout.strip().splitlines()[-1])
-            print(f"waves <= {w}, ypairs {yp}: forward+jac {d['kernels']['trilinear_forward+jac']['avg_ms']:.3f} ms", flush=True)
+            print(f"waves <= {w}, ypairs {yp}: forward+jac {d['kernels_ms']['trilinear_forward+jac']:.3f} ms", flush=True)

@@ -29,6 +29,6 @@ else:
                              env=env, capture_output=True, text=True)
         try:
             d = json.loads(out.stdout.strip().splitlines()[-1])
-            print(f"waves {w} rows {t}: step {d['ms_per_step']:.2f} ms, voxel gradient {d['kernels']['trilinear_backward[vol]']['avg_ms']:.3f} ms", flush=True)
+            print(f"waves {w} rows {t}: step {d['ms_per_step']:.2f} ms, voxel gradient {d['kernels_ms']['trilinear_backward[vol]']:.3f} ms", flush=True)
         except Exception as e:  # noqa: BLE001
             print(f"waves {w} rows {t}: failed ({e}) {out.stderr[-300:]}", flush=True)
